@@ -1,0 +1,91 @@
+"""ctypes binding of the gfx950 rasterizer library (C ABI: include/gs_raster.h).
+
+The library is built ahead of time by `make -C easy_gaussian_splatting_amd/csrc`
+(`__graft_entry__.build()` does that) and lives IN-TREE next to this file.  There is no
+fallback: if the shared object is missing or a stage fails, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+import subprocess
+import threading
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsraster.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+GS_TILE = 16
+GS_BUCKET = 64
+GS_REC_FLOATS = 12
+GS_ROW_FLOATS = 12
+
+_lib: Optional[ct.CDLL] = None
+_lock = threading.Lock()
+
+_P = ct.c_void_p
+_I = ct.c_int
+_L = ct.c_int64
+_F = ct.c_float
+_Z = ct.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/gs_raster.h declares
+SIGNATURES = {
+    "gs_version": (_I, []),
+    "gs_last_error": (ct.c_char_p, []),
+    "gs_arch": (ct.c_char_p, []),
+    "gs_bin_groups": (_I, [_L]),
+    "gs_bin_workspace_bytes": (_Z, [_I, _L, _I, _I]),
+    "gs_project_fwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _F,
+                            _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_bin_count": (_I, [_P, _I, _L, _I, _I, _P, _P, _Z, _P, _P, _P, _P]),
+    "gs_bin_emit_sort": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _Z, _P, _L, _L, _P, _P, _P, _P, _P, _P]),
+    "gs_blend_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_project_bwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F,
+                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    proc = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout)
+        print(proc.stderr)
+    if proc.returncode != 0:
+        raise NativeLibraryError("building libgsraster.so failed:\n" + proc.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib() -> ct.CDLL:
+    """Load (once) and return the native library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise NativeLibraryError(
+                        f"{LIB_PATH} is missing: the HIP rasterizer has not been built. Run "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                        f"`make -C {CSRC_DIR}`. There is no CPU fallback.")
+                L = ct.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(L, name)  # AttributeError => header/library mismatch
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().gs_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise NativeLibraryError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,406 @@
+// gs_binning.hip -- tile lists for gfx950 without global atomics and without a global sort.
+//
+// gsplat builds the per-tile lists with a count pass, a cumsum, an emit pass and ONE global
+// 64-bit radix sort over (camera | tile | depth) keys.  Here the tile
+// id is never sorted on: the 160 KB LDS of a CU holds a full per-tile histogram
+// (1080p: 8160 tiles = 32 KB, 4K: 32400 tiles = 127 KB), so the tile partition is a counting
+// sort with LDS atomics only:
+//   bin_hist_kernel     one block per (camera, Gaussian group): LDS histogram over tiles -> matrix
+//   bin_colscan_kernel  per tile: exclusive scan down the group axis (in place), tile totals
+//   bin_tilescan_kernel one block: exclusive scan of tile totals -> isect_offsets, bucket_offsets,
+//                       group bases, {I, n_buckets, max_tile}
+//   bin_emit_kernel     same blocks as hist: per-tile write cursor in LDS (returning ds_add),
+//                       emits (depth bits << 32 | row slot) into its tile's segment
+//   tile_sort_kernel    one block per tile: bitonic sort of the 64-bit keys in LDS -> depth order,
+//                       ties by flatten index (slot order == flatten order), as the stable global
+//                       sort of the reference yields.
+// The "slot" carried in the key's low word is the index of this intersection's gradient row
+// (cum_tiles[f] + k): rows of one Gaussian are contiguous, which lets the backward reduce them
+// with plain coalesced loads instead of float atomics.
+#include "gs_common.h"
+
+namespace gs {
+
+constexpr int kBinThreads = 1024;
+constexpr int kCoopTiles = 32;  // footprints above this are spread over the whole wave
+
+BinLayout bin_layout(int C, int64_t N, int tiles) {
+    BinLayout L;
+    int64_t g = (N + 4095) / 4096;
+    if (g < 1) g = 1;
+    if (g > 256) g = 256;
+    L.groups = (int)g;
+    L.per_group = (N + g - 1) / g;
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    L.hist_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * L.groups * tiles);
+    L.tile_cnt_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * tiles);
+    L.grp_tot_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * L.groups);
+    L.grp_base_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * L.groups);
+    L.total = off;
+    return L;
+}
+
+__device__ __forceinline__ void unpack_bbox(uint2 b, int& x0, int& x1, int& y0, int& y1) {
+    x0 = b.x & 0xffff; x1 = b.x >> 16; y0 = b.y & 0xffff; y1 = b.y >> 16;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBinThreads) void bin_hist_kernel(int64_t N, int tw, int tiles,
+                                                               int64_t per_group,
+                                                               const uint2* __restrict__ bbox,
+                                                               uint32_t* __restrict__ hist_mat,
+                                                               uint32_t* __restrict__ grp_tot) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* hist = lds;               // [tiles]
+    uint32_t* scratch = lds + tiles;    // [32]
+    const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
+    const int64_t g0 = grp * per_group, g1 = min(N, g0 + per_group);
+    uint32_t local = 0;
+    for (int64_t base = g0; base < g1; base += blockDim.x) {
+        const int64_t n = base + threadIdx.x;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        if (n < g1) unpack_bbox(bbox[(int64_t)c * N + n], x0, x1, y0, y1);
+        const int w = x1 - x0, cnt = w * (y1 - y0);
+        local += cnt;
+        if (cnt > 0 && cnt <= kCoopTiles)
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicAdd(&hist[y * tw + x], 1u);
+        unsigned long long big = __ballot(cnt > kCoopTiles);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w, src, 64),
+                      bcnt = __shfl(cnt, src, 64);
+            for (int i = lane_id(); i < bcnt; i += 64) {
+                const int yy = i / bw;
+                atomicAdd(&hist[(by0 + yy) * tw + bx0 + (i - yy * bw)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* out = hist_mat + ((size_t)c * G + grp) * tiles;
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) out[t] = hist[t];
+    // block total
+    uint32_t wsum = wave_reduce_add(local);
+    if (lane_id() == 0) scratch[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += scratch[i];
+        grp_tot[c * G + grp] = s;
+    }
+}
+
+// per (camera, tile): exclusive scan over groups, in place
+__global__ void bin_colscan_kernel(int C, int G, int tiles, uint32_t* __restrict__ hist_mat,
+                                   uint32_t* __restrict__ tile_cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)C * tiles) return;
+    const int c = (int)(i / tiles), t = (int)(i % tiles);
+    uint32_t run = 0;
+    uint32_t* col = hist_mat + (size_t)c * G * tiles + t;
+#pragma unroll 8
+    for (int g = 0; g < G; ++g) {
+        const uint32_t v = col[(size_t)g * tiles];
+        col[(size_t)g * tiles] = run;
+        run += v;
+    }
+    tile_cnt[i] = run;
+}
+
+// single block: scans over tiles and groups
+constexpr int kScanItems = 16;
+__global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
+    int n_tiles_total, int n_groups_total, const uint32_t* __restrict__ tile_cnt,
+    const uint32_t* __restrict__ grp_tot, int32_t* __restrict__ isect_offsets,
+    int32_t* __restrict__ bucket_offsets, uint32_t* __restrict__ grp_base,
+    int64_t* __restrict__ info) {
+    __shared__ unsigned long long scratch[17];
+    unsigned long long carry_i = 0, carry_b = 0;
+    uint32_t max_cnt = 0;
+    const int chunk = kBinThreads * kScanItems;
+    for (int base = 0; base < n_tiles_total; base += chunk) {
+        const int first = base + threadIdx.x * kScanItems;
+        uint32_t v[kScanItems];
+        unsigned long long si = 0, sb = 0;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            v[k] = (first + k < n_tiles_total) ? tile_cnt[first + k] : 0u;
+            si += v[k];
+            sb += (v[k] + GS_BUCKET - 1) / GS_BUCKET;
+            max_cnt = max(max_cnt, v[k]);
+        }
+        // pack both running sums in one 64-bit scan: buckets (<= 2^31/64+tiles) in the high word
+        unsigned long long packed = si | (sb << 36), total;
+        unsigned long long ex = block_excl_scan_add(packed, scratch, &total);
+        unsigned long long ri = carry_i + (ex & ((1ull << 36) - 1)), rb = carry_b + (ex >> 36);
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            if (first + k < n_tiles_total) {
+                isect_offsets[first + k] = (int32_t)ri;
+                bucket_offsets[first + k] = (int32_t)rb;
+            }
+            ri += v[k];
+            rb += (v[k] + GS_BUCKET - 1) / GS_BUCKET;
+        }
+        carry_i += total & ((1ull << 36) - 1);
+        carry_b += total >> 36;
+    }
+    // max over block
+    uint32_t m = max_cnt;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    __shared__ uint32_t smax[16];
+    if (lane_id() == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t mm = 0;
+        for (int i = 0; i < kBinThreads / 64; ++i) mm = max(mm, smax[i]);
+        isect_offsets[n_tiles_total] = (int32_t)carry_i;
+        bucket_offsets[n_tiles_total] = (int32_t)carry_b;
+        info[0] = (int64_t)carry_i; info[1] = (int64_t)carry_b; info[2] = (int64_t)mm; info[3] = 0;
+    }
+    __syncthreads();
+    // group bases (few thousand values at most): serial chunks of kBinThreads
+    unsigned long long gcarry = 0;
+    for (int base = 0; base < n_groups_total; base += kBinThreads) {
+        const int i = base + threadIdx.x;
+        unsigned long long v = i < n_groups_total ? grp_tot[i] : 0ull, total;
+        unsigned long long ex = block_excl_scan_add(v, scratch, &total);
+        if (i < n_groups_total) grp_base[i] = (uint32_t)(gcarry + ex);
+        gcarry += total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
+    int64_t N, int tw, int tiles, int64_t per_group, const uint2* __restrict__ bbox,
+    const float* __restrict__ depths, const uint32_t* __restrict__ hist_mat,
+    const int32_t* __restrict__ isect_offsets, const uint32_t* __restrict__ grp_base,
+    unsigned long long* __restrict__ keys, int32_t* __restrict__ slot_gid,
+    int32_t* __restrict__ cum_tiles) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* cursor = lds;                                    // [tiles]
+    uint32_t* scratch = lds + tiles;                           // [32]
+    const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
+    const uint32_t* mine = hist_mat + ((size_t)c * G + grp) * tiles;
+    const int32_t* toff = isect_offsets + (size_t)c * tiles;
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) cursor[t] = mine[t] + (uint32_t)toff[t];
+    __syncthreads();
+    uint32_t running = grp_base[c * G + grp];
+    const int64_t g0 = grp * per_group, g1 = min(N, g0 + per_group);
+    for (int64_t base = g0; base < g1; base += blockDim.x) {
+        const int64_t n = base + threadIdx.x;
+        const int64_t f = (int64_t)c * N + n;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        if (n < g1) unpack_bbox(bbox[f], x0, x1, y0, y1);
+        const int w = x1 - x0, cnt = w * (y1 - y0);
+        uint32_t total;
+        const uint32_t slot0 = running + block_excl_scan_add((uint32_t)cnt, scratch, &total);
+        running += total;
+        if (n < g1) cum_tiles[f] = (int32_t)slot0;
+        uint32_t dbits = 0;
+        if (cnt > 0) dbits = __float_as_uint(depths[f]);
+        if (cnt > 0 && cnt <= kCoopTiles) {
+            uint32_t k = 0;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x, ++k) {
+                    const uint32_t pos = atomicAdd(&cursor[y * tw + x], 1u);
+                    keys[pos] = ((unsigned long long)dbits << 32) | (slot0 + k);
+                    slot_gid[slot0 + k] = (int32_t)f;
+                }
+        }
+        unsigned long long big = __ballot(cnt > kCoopTiles);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w, src, 64),
+                      bcnt = __shfl(cnt, src, 64);
+            const uint32_t bslot = __shfl((int)slot0, src, 64), bd = __shfl((int)dbits, src, 64);
+            const int32_t bf = (int32_t)(c * N + base) + (src + (threadIdx.x & ~63));
+            for (int i = lane_id(); i < bcnt; i += 64) {
+                const int yy = i / bw;
+                const uint32_t pos = atomicAdd(&cursor[(by0 + yy) * tw + bx0 + (i - yy * bw)], 1u);
+                keys[pos] = ((unsigned long long)bd << 32) | (bslot + i);
+                slot_gid[bslot + i] = bf;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ascending-only bitonic network (first step of each stage mirrors, the rest are half-cleaners);
+// indices >= n behave as +inf and are never touched, so no padding is materialised.
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort_keys(KeyPtr key, int n, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        const int half = k >> 1;
+        for (int idx = threadIdx.x; idx < (P >> 1); idx += blockDim.x) {
+            const int blk = idx / half, off = idx - blk * half;
+            const int a = blk * k + off, b = blk * k + k - 1 - off;
+            if (b < n) {
+                const unsigned long long ka = key[a], kb = key[b];
+                if (ka > kb) { key[a] = kb; key[b] = ka; }
+            }
+        }
+        __syncthreads();
+        for (int j = half >> 1; j > 0; j >>= 1) {
+            for (int idx = threadIdx.x; idx < (P >> 1); idx += blockDim.x) {
+                const int a = ((idx & ~(j - 1)) << 1) | (idx & (j - 1)), b = a + j;
+                if (b < n) {
+                    const unsigned long long ka = key[a], kb = key[b];
+                    if (ka > kb) { key[a] = kb; key[b] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct SortArgs {
+    int tiles, tile_bits, lo_excl, hi_incl;  // this launch sorts tiles with lo_excl < n <= hi_incl
+    const int32_t* isect_offsets;
+    unsigned long long* keys;
+    const int32_t* slot_gid;
+    int64_t* isect_ids;
+    int32_t* flatten_ids;
+    int32_t* slots;
+};
+
+template <bool IN_LDS>
+__global__ void tile_sort_kernel(const SortArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+    const int t = blockIdx.x;
+    const int lo = a.isect_offsets[t], hi = a.isect_offsets[t + 1];
+    const int n = hi - lo;
+    if (n <= a.lo_excl || n > a.hi_incl) return;
+    int P = 1;
+    while (P < n) P <<= 1;
+    unsigned long long* gk = a.keys + lo;
+    if (IN_LDS) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) skeys[i] = gk[i];
+        __syncthreads();
+        bitonic_sort_keys(skeys, n, P);
+    } else {
+        bitonic_sort_keys(gk, n, P);
+    }
+    const int cam = t / a.tiles, tid = t - cam * a.tiles;
+    const long long hi_bits = ((long long)cam << (32 + a.tile_bits)) | ((long long)tid << 32);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long k = IN_LDS ? skeys[i] : gk[i];
+        const uint32_t slot = (uint32_t)k;
+        a.slots[lo + i] = (int32_t)slot;
+        a.flatten_ids[lo + i] = a.slot_gid[slot];
+        a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
+    }
+}
+
+constexpr int kSortSmall = 2048, kSortLarge = 16384;
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" int gs_bin_groups(int64_t N) { return bin_layout(1, N, 1).groups; }
+
+extern "C" size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h) {
+    return bin_layout(C, N, tile_w * tile_h).total;
+}
+
+static int ensure_lds(const void* fn, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        GS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile_h, const uint32_t* bbox,
+                            void* workspace, size_t workspace_bytes, int32_t* isect_offsets,
+                            int32_t* bucket_offsets, int64_t* info_dev, int64_t* info_host) {
+    GS_REQUIRE(C >= 1 && N >= 0 && tile_w > 0 && tile_h > 0, "C>=1, N>=0, positive tile grid");
+    const int tiles = tile_w * tile_h;
+    GS_REQUIRE((size_t)tiles * 4 + 128 <= 160 * 1024, "tile grid too large for the LDS histogram (max 40928 tiles per camera)");
+    GS_REQUIRE((int64_t)C * tiles < (1ll << 31), "too many tiles");
+    const BinLayout L = bin_layout(C, N, tiles);
+    GS_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small (see gs_bin_workspace_bytes)");
+    GS_REQUIRE(isect_offsets && bucket_offsets && info_dev, "null output pointer");
+    GS_REQUIRE(N == 0 || bbox, "null bbox");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    uint32_t* hist = (uint32_t*)(ws + L.hist_off);
+    uint32_t* tile_cnt = (uint32_t*)(ws + L.tile_cnt_off);
+    uint32_t* grp_tot = (uint32_t*)(ws + L.grp_tot_off);
+    uint32_t* grp_base = (uint32_t*)(ws + L.grp_base_off);
+    const size_t lds = sizeof(uint32_t) * ((size_t)tiles + 32);
+    if (int rc = ensure_lds((const void*)bin_hist_kernel, lds)) return rc;
+    hipLaunchKernelGGL(bin_hist_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, tile_w, tiles,
+                       L.per_group, (const uint2*)bbox, hist, grp_tot);
+    GS_LAUNCH_CHECK("bin_hist_kernel");
+    const int64_t ct = (int64_t)C * tiles;
+    hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)((ct + 255) / 256)), dim3(256), 0, st, C, L.groups,
+                       tiles, hist, tile_cnt);
+    GS_LAUNCH_CHECK("bin_colscan_kernel");
+    hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(kBinThreads), 0, st, (int)ct, C * L.groups, tile_cnt,
+                       grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev);
+    GS_LAUNCH_CHECK("bin_tilescan_kernel");
+    if (info_host) {
+        GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        GS_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return GS_OK;
+}
+
+extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, const uint32_t* bbox,
+                                const float* depths, void* workspace, size_t workspace_bytes,
+                                const int32_t* isect_offsets, int64_t n_isects, int64_t max_tile_count,
+                                uint64_t* keys_tmp, int32_t* slot_gid, int32_t* cum_tiles,
+                                int64_t* isect_ids, int32_t* flatten_ids, int32_t* slots) {
+    GS_REQUIRE(C >= 1 && N >= 0 && tile_w > 0 && tile_h > 0, "C>=1, N>=0, positive tile grid");
+    const int tiles = tile_w * tile_h;
+    const BinLayout L = bin_layout(C, N, tiles);
+    GS_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small (see gs_bin_workspace_bytes)");
+    GS_REQUIRE(n_isects >= 0 && n_isects < (1ll << 31), "intersection count must fit int32");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(bbox && depths && isect_offsets && cum_tiles, "null pointer");
+    GS_REQUIRE(n_isects == 0 || (keys_tmp && slot_gid && isect_ids && flatten_ids && slots), "null intersection buffer");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const uint32_t* hist = (const uint32_t*)(ws + L.hist_off);
+    const uint32_t* grp_base = (const uint32_t*)(ws + L.grp_base_off);
+    const size_t lds = sizeof(uint32_t) * ((size_t)tiles + 32);
+    if (int rc = ensure_lds((const void*)bin_emit_kernel, lds)) return rc;
+    hipLaunchKernelGGL(bin_emit_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, tile_w, tiles,
+                       L.per_group, (const uint2*)bbox, depths, hist, isect_offsets, grp_base,
+                       (unsigned long long*)keys_tmp, slot_gid, cum_tiles);
+    GS_LAUNCH_CHECK("bin_emit_kernel");
+    if (n_isects == 0) return GS_OK;
+    SortArgs a;
+    a.tiles = tiles;
+    int tb = 0;
+    for (int v = tiles; v > 0; v >>= 1) ++tb;
+    a.tile_bits = tb;
+    a.isect_offsets = isect_offsets; a.keys = (unsigned long long*)keys_tmp; a.slot_gid = slot_gid;
+    a.isect_ids = isect_ids; a.flatten_ids = flatten_ids; a.slots = slots;
+    const unsigned grid = (unsigned)(C * tiles);
+    // size classes: <=2048 entries (16 KB LDS, 256 threads), <=16384 (128 KB LDS, 1024 threads),
+    // beyond that an in-place global-memory network (rare: pathological scenes only)
+    a.lo_excl = 0; a.hi_incl = kSortSmall;
+    hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(256), sizeof(uint64_t) * kSortSmall, st, a);
+    GS_LAUNCH_CHECK("tile_sort_kernel<small>");
+    if (max_tile_count > kSortSmall) {
+        a.lo_excl = kSortSmall; a.hi_incl = kSortLarge;
+        const size_t big_lds = sizeof(uint64_t) * kSortLarge;
+        if (int rc = ensure_lds((const void*)tile_sort_kernel<true>, big_lds)) return rc;
+        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(1024), big_lds, st, a);
+        GS_LAUNCH_CHECK("tile_sort_kernel<large>");
+    }
+    if (max_tile_count > kSortLarge) {
+        a.lo_excl = kSortLarge; a.hi_incl = 0x7fffffff;
+        hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(grid), dim3(1024), 0, st, a);
+        GS_LAUNCH_CHECK("tile_sort_kernel<global>");
+    }
+    return GS_OK;
+}

@@ -1,0 +1,95 @@
+// gs_common.h -- internal helpers shared by the gfx950 translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gs_raster.h"
+
+namespace gs {
+
+void set_error(const char* fmt, ...);
+
+#define GS_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            gs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,   \
+                          __LINE__);                                                         \
+            return GS_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define GS_LAUNCH_CHECK(name)                                                                \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) {                                                              \
+            gs::set_error("launch of %s failed: %s", name, hipGetErrorString(_e));           \
+            return GS_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define GS_REQUIRE(cond, msg)                                                                \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            gs::set_error("invalid argument: %s (%s)", msg, #cond);                          \
+            return GS_ERR_ARG;                                                               \
+        }                                                                                    \
+    } while (0)
+
+constexpr int kWave = 64;
+
+// Workspace layout of the binning stage (all offsets in bytes, 256-B aligned).
+struct BinLayout {
+    int groups;          // Gaussian groups per camera
+    int64_t per_group;   // Gaussians per group
+    size_t hist_off;     // u32 [C*groups][tiles]   per-group tile histogram -> per-group tile base
+    size_t tile_cnt_off; // u32 [C*tiles]
+    size_t grp_tot_off;  // u32 [C*groups]          intersections emitted by each group
+    size_t grp_base_off; // u32 [C*groups]          exclusive scan of the above
+    size_t total;
+};
+BinLayout bin_layout(int C, int64_t N, int tiles);
+
+// ---- wavefront helpers (wave = 64 lanes on gfx950) ----
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan_add(T v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_add(T v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Block-wide exclusive scan for blockDim.x <= 1024 (16 waves).  `scratch` >= 17 entries of T.
+template <typename T>
+__device__ __forceinline__ T block_excl_scan_add(T v, T* scratch, T* total) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    T incl = wave_incl_scan_add(v);
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        T w = lane < nw ? scratch[lane] : T(0);
+        T wi = wave_incl_scan_add(w);
+        if (lane < nw) scratch[lane] = wi - w;
+        if (lane == nw - 1) scratch[16] = wi;
+    }
+    __syncthreads();
+    T res = incl - v + scratch[wave];
+    *total = scratch[16];
+    __syncthreads();
+    return res;
+}
+
+}  // namespace gs

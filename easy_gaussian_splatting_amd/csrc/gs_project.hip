@@ -1,0 +1,369 @@
+// gs_project.hip -- per-Gaussian stages for gfx950:
+//   project_fwd_kernel : P-fwd + SH-fwd fused (one pass over means/quats/scales/shs)
+//   project_bwd_kernel : gradient-row reduction + SH-bwd + P-bwd fused (no atomics)
+// Both are HBM-streaming kernels.  The [N,K,3] SH block (192 B per Gaussian at SH3) is moved
+// through LDS with coalesced 16-byte accesses and read per thread at an odd row stride
+// (3K+1 dwords) so the per-thread walk over its own row is bank-conflict free.
+#include "gs_common.h"
+#include "gs_math.h"
+
+namespace gs {
+
+constexpr int kProjThreads = 256;
+
+struct ProjFwdArgs {
+    int C, K, colors_per_camera, W, H, tw, th;
+    int64_t N;
+    float eps2d, near_p, far_p, radius_clip;
+    const float *means, *quats, *scales, *opacities, *colors_in, *viewmats, *Ks;
+    int32_t* radii;
+    float *means2d, *depths, *conics, *colors_out;
+    float4* rec;
+    uint2* bbox;
+    int32_t* tiles_per_gauss;
+};
+
+// dynamic LDS carve (dwords): [0,32) camera | [32, 32+256) visibility | SH tile 256*(3K+1)
+__device__ __forceinline__ void load_camera(const float* viewmats, const float* Ks, int c, int W,
+                                            int H, float* lds_cam, Camera& cam) {
+    if (threadIdx.x == 0) {
+        Camera tmp;
+        make_camera(viewmats + 16 * c, Ks + 9 * c, W, H, tmp);
+        const float* src = reinterpret_cast<const float*>(&tmp);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(Camera) / 4); ++i) lds_cam[i] = src[i];
+    }
+    __syncthreads();
+    float* dst = reinterpret_cast<float*>(&cam);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Camera) / 4); ++i) dst[i] = lds_cam[i];
+}
+
+// Cooperative global -> LDS copy of the first `ka3` floats of every visible Gaussian's SH row.
+__device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int64_t n0, int rows,
+                                              int K, int ka3, const int* vis, float* tile) {
+    const int row_f = 3 * K, stride = row_f + 1;
+    const float* src = shs + n0 * row_f;
+    if (ka3 == row_f && (row_f & 3) == 0) {
+        const int per_row = row_f >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        for (int e = threadIdx.x; e < rows * per_row; e += blockDim.x) {
+            const int g = e / per_row, q = e - g * per_row;
+            if (vis[g]) {
+                const float4 v = src4[e];
+                float* d = tile + g * stride + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < rows * ka3; e += blockDim.x) {
+            const int g = e / ka3, o = e - g * ka3;
+            if (vis[g]) tile[g * stride + o] = src[(int64_t)g * row_f + o];
+        }
+    }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds_cam = smem;
+    int* vis_s = reinterpret_cast<int*>(smem + 32);
+    float* tile = smem + 32 + kProjThreads;
+
+    const int c = blockIdx.y;
+    const int64_t n0 = (int64_t)blockIdx.x * kProjThreads;
+    const int64_t n = n0 + threadIdx.x;
+    const int64_t f = (int64_t)c * a.N + n;
+    const bool in_range = n < a.N;
+    Camera cam;
+    load_camera(a.viewmats, a.Ks, c, a.W, a.H, lds_cam, cam);
+
+    Splat2D s;
+    s.radius = 0; s.mx = s.my = s.depth = s.A = s.B = s.C = 0.f;
+    float mean[3] = {0.f, 0.f, 0.f};
+    if (in_range) {
+        mean[0] = a.means[3 * n]; mean[1] = a.means[3 * n + 1]; mean[2] = a.means[3 * n + 2];
+        const float4 q4 = reinterpret_cast<const float4*>(a.quats)[n];
+        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float scale[3] = {a.scales[3 * n], a.scales[3 * n + 1], a.scales[3 * n + 2]};
+        s = project_gaussian(mean, quat, scale, cam, a.W, a.H, a.eps2d, a.near_p, a.far_p, a.radius_clip);
+    }
+    const bool vis = s.radius > 0;
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    if (vis) tile_rect(s.mx, s.my, s.radius, GS_TILE, a.tw, a.th, x0, x1, y0, y1);
+    const int cnt = (x1 - x0) * (y1 - y0);
+    if (in_range) {
+        a.radii[f] = s.radius;
+        reinterpret_cast<float2*>(a.means2d)[f] = make_float2(s.mx, s.my);
+        a.depths[f] = s.depth;
+        a.conics[3 * f] = s.A; a.conics[3 * f + 1] = s.B; a.conics[3 * f + 2] = s.C;
+        a.bbox[f] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+        a.tiles_per_gauss[f] = cnt;
+    }
+
+    float rgb[3] = {0.5f, 0.5f, 0.5f};
+    if (DEG >= 0) {
+        vis_s[threadIdx.x] = vis ? 1 : 0;
+        const int any_vis = __syncthreads_or(vis ? 1 : 0);
+        if (any_vis) {
+            const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
+            constexpr int ka3 = 3 * (DEG + 1) * (DEG + 1);
+            stage_sh_rows(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+            __syncthreads();
+            if (vis) {
+                float ux, uy, uz;
+                view_dir(mean, cam, ux, uy, uz);
+                sh_to_rgb(DEG < 0 ? 0 : DEG, tile + threadIdx.x * (3 * a.K + 1), ux, uy, uz, rgb);
+            }
+        }
+    } else if (in_range) {
+        const float* src = a.colors_in + 3 * (a.colors_per_camera ? f : n);
+        rgb[0] = src[0]; rgb[1] = src[1]; rgb[2] = src[2];
+    }
+    if (in_range) {
+        a.colors_out[3 * f] = rgb[0]; a.colors_out[3 * f + 1] = rgb[1]; a.colors_out[3 * f + 2] = rgb[2];
+        if (vis) {
+            float4* r = a.rec + 3 * f;
+            r[0] = make_float4(s.mx, s.my, s.A, s.B);
+            r[1] = make_float4(s.C, a.opacities[n], rgb[0], rgb[1]);
+            r[2] = make_float4(rgb[2], s.depth, (float)s.radius, 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ProjBwdArgs {
+    int C, cam, K, colors_per_camera, W, H, accumulate;
+    int64_t N;
+    float eps2d, near_p, far_p;
+    const float *means, *quats, *scales, *colors_in, *viewmats, *Ks, *colors_post;
+    const int32_t *radii, *tiles_per_gauss, *cum_tiles;
+    const float4* rows;
+    float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_means2d_abs, *v_means2d,
+        *v_conics, *v_colors_post;
+};
+
+struct RowSum {
+    float v[12];
+};
+
+__device__ __forceinline__ void row_add(RowSum& s, const float4* __restrict__ r) {
+    const float4 a = r[0], b = r[1], c = r[2];
+    s.v[0] += a.x; s.v[1] += a.y; s.v[2] += a.z; s.v[3] += a.w;
+    s.v[4] += b.x; s.v[5] += b.y; s.v[6] += b.z; s.v[7] += b.w;
+    s.v[8] += c.x; s.v[9] += c.y; s.v[10] += c.z;
+}
+
+constexpr int kCoopRows = 48;  // Gaussians with more rows than this are summed by the whole wave
+
+template <int DEG>
+__global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds_cam = smem;
+    int* vis_s = reinterpret_cast<int*>(smem + 32);
+    float* tile = smem + 32 + kProjThreads;
+
+    const int c = a.cam;
+    const int64_t n0 = (int64_t)blockIdx.x * kProjThreads;
+    const int64_t n = n0 + threadIdx.x;
+    const int64_t f = (int64_t)c * a.N + n;
+    const bool in_range = n < a.N;
+    Camera cam;
+    load_camera(a.viewmats, a.Ks, c, a.W, a.H, lds_cam, cam);
+
+    const bool vis = in_range && a.radii[f] > 0;
+    const int cnt = vis ? a.tiles_per_gauss[f] : 0;
+    const int base = vis ? a.cum_tiles[f] : 0;
+
+    // ---- 1. sum this Gaussian's gradient rows (contiguous, written once each by blend_bwd)
+    RowSum s;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s.v[i] = 0.f;
+    if (cnt <= kCoopRows)
+        for (int r = 0; r < cnt; ++r) row_add(s, a.rows + 3 * (int64_t)(base + r));
+    unsigned long long big = __ballot(cnt > kCoopRows);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bcnt = __shfl(cnt, src, 64), bbase = __shfl(base, src, 64);
+        RowSum p;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) p.v[i] = 0.f;
+        for (int r = lane_id(); r < bcnt; r += 64) row_add(p, a.rows + 3 * (int64_t)(bbase + r));
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const float t = wave_reduce_add(p.v[i]);
+            if (lane_id() == src) s.v[i] = t;
+        }
+    }
+
+    // ---- 2. colour path
+    float v_mean[3] = {0.f, 0.f, 0.f}, v_quat[4] = {0.f, 0.f, 0.f, 0.f}, v_scale[3] = {0.f, 0.f, 0.f};
+    float mean[3] = {0.f, 0.f, 0.f};
+    if (in_range) { mean[0] = a.means[3 * n]; mean[1] = a.means[3 * n + 1]; mean[2] = a.means[3 * n + 2]; }
+    const float v_rgb[3] = {s.v[8], s.v[9], s.v[10]};
+    if (DEG >= 0) {
+        const int row_f = 3 * a.K, stride = row_f + 1;
+        constexpr int ka3 = 3 * (DEG + 1) * (DEG + 1);
+        vis_s[threadIdx.x] = vis ? 1 : 0;
+        __syncthreads();
+        const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
+        stage_sh_rows(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+        __syncthreads();
+        float* my = tile + threadIdx.x * stride;
+        if (vis) {
+            float ux, uy, uz;
+            const float dn = view_dir(mean, cam, ux, uy, uz);
+            float rgb[3] = {a.colors_post[3 * f], a.colors_post[3 * f + 1], a.colors_post[3 * f + 2]};
+            sh_vjp(DEG < 0 ? 0 : DEG, my, rgb, v_rgb, ux, uy, uz, dn, my, v_mean, false);
+            for (int o = ka3; o < row_f; ++o) my[o] = 0.f;
+        } else if (in_range) {
+            for (int o = 0; o < row_f; ++o) my[o] = 0.f;
+        }
+        __syncthreads();
+        // dense write-out of v_shs[n0 : n0+rows, :, :]
+        float* dst = a.v_colors + n0 * row_f;
+        if ((row_f & 3) == 0) {
+            const int per_row = row_f >> 2;
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            for (int e = threadIdx.x; e < rows * per_row; e += blockDim.x) {
+                const int g = e / per_row, q = e - g * per_row;
+                const float* sp = tile + g * stride + 4 * q;
+                float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                if (a.accumulate) { const float4 o = dst4[e]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                dst4[e] = v;
+            }
+        } else {
+            for (int e = threadIdx.x; e < rows * row_f; e += blockDim.x) {
+                const int g = e / row_f, o = e - g * row_f;
+                float v = tile[g * stride + o];
+                if (a.accumulate) v += dst[e];
+                dst[e] = v;
+            }
+        }
+    } else if (in_range) {
+        if (a.colors_per_camera) {
+            float* d = a.v_colors + 3 * f;
+            d[0] = v_rgb[0]; d[1] = v_rgb[1]; d[2] = v_rgb[2];
+        } else {
+            float* d = a.v_colors + 3 * n;
+            if (a.accumulate) { d[0] += v_rgb[0]; d[1] += v_rgb[1]; d[2] += v_rgb[2]; }
+            else { d[0] = v_rgb[0]; d[1] = v_rgb[1]; d[2] = v_rgb[2]; }
+        }
+    }
+
+    // ---- 3. projection VJP
+    if (vis) {
+        const float4 q4 = reinterpret_cast<const float4*>(a.quats)[n];
+        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float scale[3] = {a.scales[3 * n], a.scales[3 * n + 1], a.scales[3 * n + 2]};
+        ProjChain p;
+        if (project_chain(mean, quat, scale, cam, a.eps2d, a.near_p, a.far_p, p))
+            project_vjp(scale, cam, p, s.v[0], s.v[1], s.v[4], s.v[5], s.v[6], 0.f, v_mean, v_quat, v_scale);
+    }
+    if (in_range) {
+        float* vm = a.v_means + 3 * n; float* vq = a.v_quats + 4 * n; float* vs = a.v_scales + 3 * n;
+        if (a.accumulate) {
+            vm[0] += v_mean[0]; vm[1] += v_mean[1]; vm[2] += v_mean[2];
+            vq[0] += v_quat[0]; vq[1] += v_quat[1]; vq[2] += v_quat[2]; vq[3] += v_quat[3];
+            vs[0] += v_scale[0]; vs[1] += v_scale[1]; vs[2] += v_scale[2];
+            a.v_opacities[n] += s.v[7];
+        } else {
+            vm[0] = v_mean[0]; vm[1] = v_mean[1]; vm[2] = v_mean[2];
+            vq[0] = v_quat[0]; vq[1] = v_quat[1]; vq[2] = v_quat[2]; vq[3] = v_quat[3];
+            vs[0] = v_scale[0]; vs[1] = v_scale[1]; vs[2] = v_scale[2];
+            a.v_opacities[n] = s.v[7];
+        }
+        reinterpret_cast<float2*>(a.v_means2d_abs)[f] = make_float2(s.v[2], s.v[3]);
+        if (a.v_means2d) reinterpret_cast<float2*>(a.v_means2d)[f] = make_float2(s.v[0], s.v[1]);
+        if (a.v_conics) { a.v_conics[3 * f] = s.v[4]; a.v_conics[3 * f + 1] = s.v[5]; a.v_conics[3 * f + 2] = s.v[6]; }
+        if (a.v_colors_post) { a.v_colors_post[3 * f] = v_rgb[0]; a.v_colors_post[3 * f + 1] = v_rgb[1]; a.v_colors_post[3 * f + 2] = v_rgb[2]; }
+    }
+}
+
+static size_t proj_lds_bytes(int K, int degree) {
+    return sizeof(float) * (32 + kProjThreads + (degree >= 0 ? (size_t)kProjThreads * (3 * K + 1) : 0));
+}
+
+}  // namespace gs
+
+using namespace gs;
+
+extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
+                              const float* quats, const float* scales, const float* opacities,
+                              const float* colors_in, int colors_per_camera, const float* viewmats,
+                              const float* Ks, int width, int height, float eps2d, float near_plane,
+                              float far_plane, float radius_clip, int32_t* radii, float* means2d,
+                              float* depths, float* conics, float* colors_out, float* rec,
+                              uint32_t* bbox, int32_t* tiles_per_gauss) {
+    GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
+    GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
+    GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
+    GS_REQUIRE((width + GS_TILE - 1) / GS_TILE < 65536 && (height + GS_TILE - 1) / GS_TILE < 65536, "tile grid must fit 16 bits per axis");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(means && quats && scales && opacities && colors_in && viewmats && Ks, "null input pointer");
+    GS_REQUIRE(radii && means2d && depths && conics && colors_out && rec && bbox && tiles_per_gauss, "null output pointer");
+    ProjFwdArgs a;
+    a.C = C; a.N = N; a.K = K; a.colors_per_camera = colors_per_camera; a.W = width; a.H = height;
+    a.tw = (width + GS_TILE - 1) / GS_TILE; a.th = (height + GS_TILE - 1) / GS_TILE;
+    a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane; a.radius_clip = radius_clip;
+    a.means = means; a.quats = quats; a.scales = scales; a.opacities = opacities; a.colors_in = colors_in;
+    a.viewmats = viewmats; a.Ks = Ks; a.radii = radii; a.means2d = means2d; a.depths = depths;
+    a.conics = conics; a.colors_out = colors_out; a.rec = reinterpret_cast<float4*>(rec);
+    a.bbox = reinterpret_cast<uint2*>(bbox); a.tiles_per_gauss = tiles_per_gauss;
+    dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads), (unsigned)C);
+    const size_t lds = proj_lds_bytes(K, sh_degree);
+    hipStream_t st = (hipStream_t)stream;
+    switch (sh_degree) {
+        case 0: hipLaunchKernelGGL(project_fwd_kernel<0>, grid, dim3(kProjThreads), lds, st, a); break;
+        case 1: hipLaunchKernelGGL(project_fwd_kernel<1>, grid, dim3(kProjThreads), lds, st, a); break;
+        case 2: hipLaunchKernelGGL(project_fwd_kernel<2>, grid, dim3(kProjThreads), lds, st, a); break;
+        case 3: hipLaunchKernelGGL(project_fwd_kernel<3>, grid, dim3(kProjThreads), lds, st, a); break;
+        default: hipLaunchKernelGGL(project_fwd_kernel<-1>, grid, dim3(kProjThreads), lds, st, a); break;
+    }
+    GS_LAUNCH_CHECK("project_fwd_kernel");
+    return GS_OK;
+}
+
+extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
+                              const float* quats, const float* scales, const float* colors_in,
+                              int colors_per_camera, const float* viewmats, const float* Ks, int width,
+                              int height, float eps2d, float near_plane, float far_plane,
+                              const int32_t* radii, const float* colors_post,
+                              const int32_t* tiles_per_gauss, const int32_t* cum_tiles,
+                              const float* rows, float* v_means, float* v_quats, float* v_scales,
+                              float* v_opacities, float* v_colors, float* v_means2d_abs,
+                              float* v_means2d, float* v_conics, float* v_colors_post) {
+    GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
+    GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
+    GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(means && quats && scales && colors_in && viewmats && Ks && radii && colors_post && tiles_per_gauss && cum_tiles, "null input pointer");
+    GS_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_colors && v_means2d_abs, "null output pointer");
+    ProjBwdArgs a;
+    a.C = C; a.N = N; a.K = K; a.colors_per_camera = colors_per_camera; a.W = width; a.H = height;
+    a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
+    a.means = means; a.quats = quats; a.scales = scales; a.colors_in = colors_in; a.viewmats = viewmats;
+    a.Ks = Ks; a.colors_post = colors_post; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss;
+    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows);
+    a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_opacities = v_opacities;
+    a.v_colors = v_colors; a.v_means2d_abs = v_means2d_abs; a.v_means2d = v_means2d;
+    a.v_conics = v_conics; a.v_colors_post = v_colors_post;
+    dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
+    const size_t lds = proj_lds_bytes(K, sh_degree);
+    hipStream_t st = (hipStream_t)stream;
+    // One launch per camera: launch c accumulates onto launch c-1 (same thread owns Gaussian n in
+    // every launch, stream order serialises them) -> deterministic sum over cameras, no atomics.
+    for (int c = 0; c < C; ++c) {
+        a.cam = c; a.accumulate = c > 0;
+        switch (sh_degree) {
+            case 0: hipLaunchKernelGGL(project_bwd_kernel<0>, grid, dim3(kProjThreads), lds, st, a); break;
+            case 1: hipLaunchKernelGGL(project_bwd_kernel<1>, grid, dim3(kProjThreads), lds, st, a); break;
+            case 2: hipLaunchKernelGGL(project_bwd_kernel<2>, grid, dim3(kProjThreads), lds, st, a); break;
+            case 3: hipLaunchKernelGGL(project_bwd_kernel<3>, grid, dim3(kProjThreads), lds, st, a); break;
+            default: hipLaunchKernelGGL(project_bwd_kernel<-1>, grid, dim3(kProjThreads), lds, st, a); break;
+        }
+        GS_LAUNCH_CHECK("project_bwd_kernel");
+    }
+    return GS_OK;
+}

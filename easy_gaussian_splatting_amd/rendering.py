@@ -1,0 +1,287 @@
+"""`rasterization()` -- the drop-in for `gsplat.rendering.rasterization` on MI355X.
+
+Mirrors the gsplat 1.0.0 signature that /root/reference/model/gaussian.py:353-367 calls
+(`packed=False, absgrad=True, sh_degree=active_sh_degree, backgrounds=[1,3]`) and the two side
+channels the reference reads afterwards (`meta["means2d"].absgrad`, `meta["radii"]`,
+/root/reference/model/gaussian.py:188-197, 371-372).  All arithmetic runs in the hand-written
+gfx950 kernels behind the C ABI of include/gs_raster.h; PyTorch only owns the memory, the
+stream and the autograd graph edge.  There is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as _ct
+import math
+import weakref
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _native as nat
+
+_TILE = nat.GS_TILE
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _Holder:
+    """Carries non-tensor state between `rasterization()` and the autograd node without making
+    the node own its own output (the weak reference lets backward attach `.absgrad` to the very
+    tensor object that was handed out in `meta`)."""
+
+    __slots__ = ("meta", "means2d_ref", "absgrad", "debug")
+
+    def __init__(self, absgrad: bool):
+        self.meta: Dict = {}
+        self.means2d_ref = None
+        self.absgrad = absgrad
+        self.debug: Optional[Dict] = None
+
+
+def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, cfg, need_grad):
+    """Runs P/SH-fwd, binning, per-tile sort and B-fwd.  Returns (outputs, saved-state dict)."""
+    L = nat.lib()
+    dev = means.device
+    C, N = viewmats.shape[0], means.shape[0]
+    W, H = cfg["width"], cfg["height"]
+    sh_degree = cfg["sh_degree"]
+    tw, th = math.ceil(W / _TILE), math.ceil(H / _TILE)
+    tiles = tw * th
+    st = _stream(dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+
+    if sh_degree is None:
+        deg, K = -1, 0
+        per_cam = 1 if colors.dim() == 3 else 0
+    else:
+        deg, K, per_cam = int(sh_degree), colors.shape[1], 0
+
+    radii = torch.empty((C, N), **i32)
+    means2d = torch.empty((C, N, 2), **f32)
+    depths = torch.empty((C, N), **f32)
+    conics = torch.empty((C, N, 3), **f32)
+    colors_post = torch.empty((C, N, 3), **f32)
+    rec = torch.empty((C * N, nat.GS_REC_FLOATS), **f32)
+    bbox = torch.empty((C * N, 2), **i32)
+    tiles_per_gauss = torch.empty((C, N), **i32)
+    nat.check(L.gs_project_fwd(st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+                               _ptr(colors), per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
+                               cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"], _ptr(radii),
+                               _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(colors_post), _ptr(rec),
+                               _ptr(bbox), _ptr(tiles_per_gauss)), "gs_project_fwd")
+
+    ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
+    workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    isect_offsets = torch.empty((C * tiles + 1,), **i32)
+    bucket_offsets = torch.empty((C * tiles + 1,), **i32)
+    info_dev = torch.empty((4,), dtype=torch.int64, device=dev)
+    info_host = (_ct.c_int64 * 4)()
+    nat.check(L.gs_bin_count(st, C, N, tw, th, _ptr(bbox), _ptr(workspace), ws_bytes, _ptr(isect_offsets),
+                             _ptr(bucket_offsets), _ptr(info_dev), info_host), "gs_bin_count")
+    n_isects, n_buckets, max_tile = int(info_host[0]), int(info_host[1]), int(info_host[2])
+
+    cap = max(n_isects, 1)
+    keys_tmp = torch.empty((cap,), dtype=torch.int64, device=dev)
+    slot_gid = torch.empty((cap,), **i32)
+    cum_tiles = torch.empty((C * N,), **i32)
+    isect_ids = torch.empty((cap,), dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty((cap,), **i32)
+    slots = torch.empty((cap,), **i32)
+    nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, _ptr(bbox), _ptr(depths), _ptr(workspace), ws_bytes,
+                                 _ptr(isect_offsets), n_isects, max_tile, _ptr(keys_tmp), _ptr(slot_gid),
+                                 _ptr(cum_tiles), _ptr(isect_ids), _ptr(flatten_ids), _ptr(slots)),
+              "gs_bin_emit_sort")
+
+    render_colors = torch.empty((C, H, W, 3), **f32)
+    render_alphas = torch.empty((C, H, W, 1), **f32)
+    last_ids = torch.empty((C, H, W), **i32)
+    tile_used = torch.empty((C * tiles,), **i32)
+    ckpt = bucket_tile = None
+    if need_grad:
+        ckpt = torch.empty((max(n_buckets, 1), 256, 4), **f32)
+        bucket_tile = torch.empty((max(n_buckets, 1),), **i32)
+    nat.check(L.gs_blend_fwd(st, C, W, H, _ptr(rec), _ptr(backgrounds), _ptr(isect_offsets),
+                             _ptr(bucket_offsets), _ptr(flatten_ids), _ptr(render_colors),
+                             _ptr(render_alphas), _ptr(last_ids), _ptr(tile_used), _ptr(ckpt),
+                             _ptr(bucket_tile)), "gs_blend_fwd")
+
+    meta = {
+        "camera_ids": None, "gaussian_ids": None,
+        "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
+        "opacities": opacities[None, :].expand(C, N),
+        "tile_width": tw, "tile_height": th, "tiles_per_gauss": tiles_per_gauss,
+        "isect_ids": isect_ids[:n_isects], "flatten_ids": flatten_ids[:n_isects],
+        "isect_offsets": isect_offsets[: C * tiles].view(C, th, tw),
+        "width": W, "height": H, "tile_size": _TILE, "n_cameras": C,
+    }
+    state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, n_isects=n_isects, n_buckets=n_buckets,
+                 radii=radii, colors_post=colors_post, rec=rec, tiles_per_gauss=tiles_per_gauss,
+                 cum_tiles=cum_tiles, isect_offsets=isect_offsets, bucket_offsets=bucket_offsets,
+                 flatten_ids=flatten_ids, slots=slots, last_ids=last_ids, tile_used=tile_used,
+                 ckpt=ckpt, bucket_tile=bucket_tile)
+    return render_colors, render_alphas, meta, state
+
+
+
+class _Rasterize(torch.autograd.Function):
+    """One autograd node for the whole path (P-fwd .. B-fwd | B-bwd .. P-bwd)."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, cfg, holder):
+        need_grad = any(ctx.needs_input_grad[:5])
+        render_colors, render_alphas, meta, state = _forward_stages(
+            means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, cfg, need_grad)
+        holder.meta = meta
+        ctx.cfg, ctx.holder, ctx.state = cfg, holder, state
+        if need_grad:
+            ctx.save_for_backward(means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas)
+        return render_colors, render_alphas
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alphas):
+        L = nat.lib()
+        means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas = ctx.saved_tensors
+        s, cfg, holder = ctx.state, ctx.cfg, ctx.holder
+        dev = means.device
+        st = _stream(dev)
+        C, N, K = s["C"], s["N"], s["K"]
+        W, H = cfg["width"], cfg["height"]
+        f32 = dict(dtype=torch.float32, device=dev)
+        v_rc = v_render_colors.contiguous()
+        v_ra = None if v_render_alphas is None else v_render_alphas.contiguous()
+        rows = torch.empty((max(s["n_isects"], 1), nat.GS_ROW_FLOATS), **f32)
+        nat.check(L.gs_blend_bwd(st, C, W, H, _ptr(s["rec"]), _ptr(s["isect_offsets"]),
+                                 _ptr(s["bucket_offsets"]), _ptr(s["flatten_ids"]), _ptr(s["slots"]),
+                                 s["n_buckets"], _ptr(s["bucket_tile"]), _ptr(s["tile_used"]),
+                                 _ptr(s["ckpt"]), _ptr(render_colors), _ptr(render_alphas),
+                                 _ptr(s["last_ids"]), _ptr(v_rc), _ptr(v_ra), _ptr(rows)), "gs_blend_bwd")
+        v_means = torch.empty((N, 3), **f32)
+        v_quats = torch.empty((N, 4), **f32)
+        v_scales = torch.empty((N, 3), **f32)
+        v_opac = torch.empty((N,), **f32)
+        v_colors = torch.empty(colors.shape, **f32)
+        v_abs = torch.empty((C, N, 2), **f32)
+        dbg = holder.debug
+        v_m2 = v_cn = v_cp = None
+        if dbg is not None:
+            v_m2 = torch.empty((C, N, 2), **f32)
+            v_cn = torch.empty((C, N, 3), **f32)
+            v_cp = torch.empty((C, N, 3), **f32)
+        nat.check(L.gs_project_bwd(st, C, N, K, s["deg"], _ptr(means), _ptr(quats), _ptr(scales), _ptr(colors),
+                                   s["per_cam"], _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
+                                   cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
+                                   _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
+                                   _ptr(rows), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
+                                   _ptr(v_colors), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp)),
+                  "gs_project_bwd")
+        if dbg is not None:
+            dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp, rows=rows)
+        if holder.absgrad and holder.means2d_ref is not None:
+            m2 = holder.means2d_ref()
+            if m2 is not None:
+                m2.absgrad = v_abs
+        ni = ctx.needs_input_grad
+        return (v_means if ni[0] else None, v_quats if ni[1] else None, v_scales if ni[2] else None,
+                v_opac if ni[3] else None, v_colors if ni[4] else None, None, None, None, None, None)
+
+
+def rasterization(
+    means: Tensor,  # [N, 3]
+    quats: Tensor,  # [N, 4]  wxyz, need not be normalised
+    scales: Tensor,  # [N, 3]
+    opacities: Tensor,  # [N]
+    colors: Tensor,  # [N, K, 3] SH coefficients (sh_degree given) or [N, 3] / [C, N, 3]
+    viewmats: Tensor,  # [C, 4, 4] world -> camera
+    Ks: Tensor,  # [C, 3, 3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    channel_chunk: int = 32,
+    _debug: Optional[Dict] = None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Rasterize 3D Gaussians to images; same tensor signature and return value as
+    `gsplat.rendering.rasterization` (gsplat 1.0.0).
+
+    Returns `(render_colors [C,H,W,3], render_alphas [C,H,W,1], meta)`.  `meta["means2d"]`
+    receives the attribute `.absgrad` ([C,N,2]) during backward when `absgrad=True`;
+    `meta["radii"]` is int32 [C,N] with `> 0` marking visible Gaussians.
+
+    Only the configuration the reference exercises is implemented natively; anything else raises
+    `NotImplementedError` instead of silently computing something different.
+    """
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    assert means.shape == (N, 3), means.shape
+    assert quats.shape == (N, 4), quats.shape
+    assert scales.shape == (N, 3), scales.shape
+    assert opacities.shape == (N,), opacities.shape
+    assert viewmats.shape == (C, 4, 4), viewmats.shape
+    assert Ks.shape == (C, 3, 3), Ks.shape
+    assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
+    if sh_degree is None:
+        assert (colors.dim() == 2 and colors.shape[0] == N) or (
+            colors.dim() == 3 and colors.shape[:2] == (C, N)), colors.shape
+        if colors.shape[-1] != 3:
+            raise NotImplementedError("only 3-channel colours are implemented on the HIP path")
+    else:
+        assert colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3, colors.shape
+        assert (sh_degree + 1) ** 2 <= colors.shape[1], colors.shape
+        if sh_degree > 3 or colors.shape[1] > 16:
+            raise NotImplementedError("SH degree > 3 is not implemented")
+    if backgrounds is not None:
+        assert backgrounds.shape == (C, 3), backgrounds.shape
+    if packed:
+        raise NotImplementedError("packed=True is not implemented (the reference passes packed=False)")
+    if render_mode != "RGB":
+        raise NotImplementedError("only render_mode='RGB' is implemented")
+    if rasterize_mode != "classic":
+        raise NotImplementedError("only rasterize_mode='classic' is implemented")
+    if tile_size != _TILE:
+        raise NotImplementedError(f"only tile_size={_TILE} is implemented")
+    if sparse_grad:
+        raise NotImplementedError("sparse_grad requires packed=True")
+    if not means.is_cuda:
+        raise RuntimeError("rasterization() runs on the GPU only: tensors must live on a HIP device "
+                           "(there is no CPU fallback in this package)")
+    nat.lib()  # fail loudly here if the extension is missing
+
+    def prep(t: Tensor) -> Tensor:
+        if t.dtype != torch.float32:
+            raise TypeError(f"expected float32 tensors, got {t.dtype}")
+        if t.device != means.device:
+            raise RuntimeError("all tensors must be on the same device")
+        return t.contiguous()
+
+    means_c, quats_c, scales_c, opac_c, colors_c = map(prep, (means, quats, scales, opacities, colors))
+    viewmats_c, Ks_c = prep(viewmats), prep(Ks)
+    bg_c = None if backgrounds is None else prep(backgrounds)
+    cfg = dict(width=int(width), height=int(height), near_plane=float(near_plane),
+               far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d),
+               sh_degree=sh_degree)
+    holder = _Holder(absgrad)
+    holder.debug = _debug
+    with torch.cuda.device(means.device):
+        render_colors, render_alphas = _Rasterize.apply(means_c, quats_c, scales_c, opac_c, colors_c,
+                                                        viewmats_c, Ks_c, bg_c, cfg, holder)
+    meta = holder.meta
+    holder.meta = {}
+    holder.means2d_ref = weakref.ref(meta["means2d"])
+    return render_colors, render_alphas, meta

@@ -1,0 +1,131 @@
+/*
+ * gs_raster.h -- C ABI of the MI355X (gfx950) Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for the ONE call the reference makes into its rasterizer:
+ *
+ *     from gsplat.rendering import rasterization            (/root/reference/model/gaussian.py:8)
+ *     rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height,
+ *                   sh_degree=..., backgrounds=..., absgrad=True, packed=False)
+ *                                                           (/root/reference/model/gaussian.py:353-367)
+ *
+ * gsplat 1.0.0 reaches its CUDA kernels through per-stage torch ops; each entry point below is
+ * the stage a binding for this path would call instead (stage names: SURVEY.md section 2.2).
+ * Plain pointers and sizes only: every pointer is a DEVICE pointer unless its name ends in
+ * `_host`; `stream` is a hipStream_t passed as void*.  All tensors are dense row-major fp32 /
+ * int32 / int64.  Every function returns 0 on success and a negative code on failure, in which
+ * case gs_last_error() (thread-local) describes it.  Nothing is allocated inside; the caller owns
+ * all memory (ownership contract: SURVEY.md section 8b).  Entry points may be called from any
+ * host thread.
+ *
+ * Index vocabulary: C cameras, N Gaussians, K stored SH coefficients per Gaussian, flatten id
+ * f = c*N + n, tiles = tile_w*tile_h (16x16 pixel tiles), I = number of (tile, Gaussian)
+ * intersections, bucket = 64 consecutive entries of one tile's depth-sorted list.
+ */
+#ifndef GS_RASTER_H_
+#define GS_RASTER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_TILE 16           /* tile edge in pixels (gsplat default tile_size=16) */
+#define GS_BUCKET 64         /* entries per bucket = one wavefront */
+#define GS_REC_FLOATS 12     /* packed per-(camera,Gaussian) blend record */
+#define GS_ROW_FLOATS 12     /* per-intersection gradient row written by gs_blend_bwd */
+
+#define GS_OK 0
+#define GS_ERR_ARG (-1)
+#define GS_ERR_HIP (-2)
+#define GS_ERR_UNSUPPORTED (-3)
+
+/* Library identity / diagnostics. */
+int gs_version(void);
+const char* gs_last_error(void);
+const char* gs_arch(void); /* "gfx950" */
+
+/* Number of Gaussian groups per camera used by the binning kernels, and the bytes of scratch
+ * `workspace` gs_bin_count / gs_bin_emit_sort need for (C, N, tiles). */
+int gs_bin_groups(int64_t N);
+size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h);
+
+/* P-fwd + SH-fwd fused (replaces gsplat fully_fused_projection + spherical_harmonics +
+ * clamp_min(rgb+0.5, 0); call site /root/reference/model/gaussian.py:353-367).
+ * sh_degree >= 0: `colors_in` is shs[N,K,3];  sh_degree < 0: `colors_in` is already
+ * post-activation colour, [N,3] (colors_per_camera=0) or [C,N,3] (=1).
+ * Outputs: radii[C,N] i32 (0 = culled), means2d[C,N,2], depths[C,N], conics[C,N,3],
+ * colors_out[C,N,3], rec[C*N*12] (mx,my,A,B | C,opacity,r,g | b,depth,radius,0),
+ * bbox[C*N*2] u32 (x0 | x1<<16, y0 | y1<<16; tile rectangle, min inclusive / max exclusive),
+ * tiles_per_gauss[C,N] i32. */
+int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
+                   const float* quats, const float* scales, const float* opacities,
+                   const float* colors_in, int colors_per_camera, const float* viewmats,
+                   const float* Ks, int width, int height, float eps2d, float near_plane,
+                   float far_plane, float radius_clip, int32_t* radii, float* means2d,
+                   float* depths, float* conics, float* colors_out, float* rec, uint32_t* bbox,
+                   int32_t* tiles_per_gauss);
+
+/* I-count (replaces the counting half of gsplat isect_tiles + its cumsum and
+ * isect_offset_encode).  Writes isect_offsets[C*tiles+1] (exclusive; last = I),
+ * bucket_offsets[C*tiles+1] (exclusive scan of ceil(count/64)), info_dev[4] =
+ * {I, n_buckets, max entries in one tile, 0}.  If info_host != NULL the four values are copied
+ * there and the stream is synchronised (the one host sync of the exact mode). */
+int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile_h, const uint32_t* bbox,
+                 void* workspace, size_t workspace_bytes, int32_t* isect_offsets,
+                 int32_t* bucket_offsets, int64_t* info_dev, int64_t* info_host);
+
+/* I-emit + per-tile depth sort (replaces the emitting half of isect_tiles and the global
+ * cub::DeviceRadixSort).  Needs the workspace as left by gs_bin_count.  keys_tmp[I] u64 and
+ * slot_gid[I] i32 are scratch.  Outputs: cum_tiles[C*N] (exclusive scan of tiles_per_gauss =
+ * first gradient-row slot of each flatten id), isect_ids[I] i64 (cam | tile | depth bits, sorted),
+ * flatten_ids[I] i32 (sorted), slots[I] i32 (gradient-row slot of each sorted entry). */
+int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, const uint32_t* bbox,
+                     const float* depths, void* workspace, size_t workspace_bytes,
+                     const int32_t* isect_offsets, int64_t n_isects, int64_t max_tile_count,
+                     uint64_t* keys_tmp, int32_t* slot_gid, int32_t* cum_tiles, int64_t* isect_ids,
+                     int32_t* flatten_ids, int32_t* slots);
+
+/* B-fwd (replaces gsplat rasterize_to_pixels forward).  backgrounds[C,3] may be NULL.
+ * Outputs render_colors[C,H,W,3], render_alphas[C,H,W,1], last_ids[C,H,W] i32 (absolute sorted
+ * index of the last contributor, -1 if none), tile_used[C*tiles] i32 (buckets actually walked).
+ * When ckpt != NULL (training) also writes ckpt[n_buckets*256*4] (per bucket, per pixel: T and
+ * accumulated rgb at the bucket's start) and bucket_tile[n_buckets]. */
+int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
+                 const float* backgrounds, const int32_t* isect_offsets,
+                 const int32_t* bucket_offsets, const int32_t* flatten_ids, float* render_colors,
+                 float* render_alphas, int32_t* last_ids, int32_t* tile_used, float* ckpt,
+                 int32_t* bucket_tile);
+
+/* B-bwd (replaces rasterize_to_pixels backward incl. absgrad).  One wavefront per bucket; writes
+ * one 12-float row per intersection at rows[slots[i]*12]:
+ * (v_mx, v_my, |v_mx|, |v_my|, v_A, v_B, v_C, v_opacity, v_r, v_g, v_b, 0).  No atomics.
+ * v_render_alphas may be NULL. */
+int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
+                 const int32_t* isect_offsets, const int32_t* bucket_offsets,
+                 const int32_t* flatten_ids, const int32_t* slots, int64_t n_buckets,
+                 const int32_t* bucket_tile, const int32_t* tile_used, const float* ckpt,
+                 const float* render_colors, const float* render_alphas, const int32_t* last_ids,
+                 const float* v_render_colors, const float* v_render_alphas, float* rows);
+
+/* Row reduction + SH-bwd + P-bwd fused (replaces the atomics of the blend backward,
+ * spherical_harmonics backward and fully_fused_projection backward).  Sums each Gaussian's rows
+ * [cum_tiles[f], cum_tiles[f]+tiles_per_gauss[f]) and pushes the result through the colour and
+ * projection VJPs.  Outputs (all fully written): v_means[N,3], v_quats[N,4], v_scales[N,3],
+ * v_opacities[N], v_colors: v_shs[N,K,3] (sh_degree>=0) or v_colors[N,3]/[C,N,3];
+ * v_means2d_abs[C,N,2] (the `.absgrad` side channel, /root/reference/model/gaussian.py:191).
+ * Optional (may be NULL): v_means2d[C,N,2], v_conics[C,N,3], v_colors_post[C,N,3]. */
+int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
+                   const float* quats, const float* scales, const float* colors_in,
+                   int colors_per_camera, const float* viewmats, const float* Ks, int width,
+                   int height, float eps2d, float near_plane, float far_plane,
+                   const int32_t* radii, const float* colors_post, const int32_t* tiles_per_gauss,
+                   const int32_t* cum_tiles, const float* rows, float* v_means, float* v_quats,
+                   float* v_scales, float* v_opacities, float* v_colors, float* v_means2d_abs,
+                   float* v_means2d, float* v_conics, float* v_colors_post);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS_RASTER_H_ */
