@@ -35,8 +35,24 @@ struct Camera {
 struct Splat2D {
     float mx, my, depth;
     float A, B, C;   // conic
+    float cxx, cyy;  // diagonal of the blurred 2-D covariance (for opacity-aware extents)
     int radius;      // 0 => culled
 };
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// Half-extents (pixels) of the region where opacity * exp(-sigma) can reach 1/255: the level set
+// sigma = ln(255 * opacity) of a Gaussian with covariance diag entries (cxx, cyy) spans
+// +-sqrt(2 tau cxx) in x.  Inflated slightly so that it is a strict superset of what the blend's
+// own per-pixel test accepts; negative when the Gaussian can never pass the test.
+GS_HD void alpha_extent(float opacity, float cxx, float cyy, float& ex, float& ey) {
+    const float v = 255.0f * opacity;
+    if (!(v > 1.0f)) { ex = -1.f; ey = -1.f; return; }
+    const float tau2 = 2.0f * (logf(v) + 0.01f);
+    ex = sqrtf(tau2 * cxx) * 1.0005f + 0.02f;
+    ey = sqrtf(tau2 * cyy) * 1.0005f + 0.02f;
+}
 
 // Intermediates the VJP needs again; recomputed in backward rather than stored.
 struct ProjChain {
@@ -112,7 +128,7 @@ GS_HD Splat2D project_gaussian(const float* mean, const float* quat, const float
                                const Camera& cam, int W, int H, float eps2d, float near_p,
                                float far_p, float radius_clip) {
     Splat2D s;
-    s.mx = s.my = s.depth = s.A = s.B = s.C = 0.f;
+    s.mx = s.my = s.depth = s.A = s.B = s.C = s.cxx = s.cyy = 0.f;
     s.radius = 0;
     ProjChain p;
     if (!project_chain(mean, quat, scale, cam, eps2d, near_p, far_p, p)) return s;
@@ -126,6 +142,7 @@ GS_HD Splat2D project_gaussian(const float* mean, const float* quat, const float
     const float rdet = 1.0f / p.det;
     s.mx = mx; s.my = my; s.depth = p.z;
     s.A = p.c * rdet; s.B = -p.b * rdet; s.C = p.a * rdet;
+    s.cxx = p.a; s.cyy = p.c;
     s.radius = (int)radius;
     return s;
 }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
     load_camera(a.viewmats, a.Ks, c, a.W, a.H, lds_cam, cam);
 
     Splat2D s;
-    s.radius = 0; s.mx = s.my = s.depth = s.A = s.B = s.C = 0.f;
+    s.radius = 0; s.mx = s.my = s.depth = s.A = s.B = s.C = s.cxx = s.cyy = 0.f;
     float mean[3] = {0.f, 0.f, 0.f};
     if (in_range) {
         mean[0] = a.means[3 * n]; mean[1] = a.means[3 * n + 1]; mean[2] = a.means[3 * n + 2];
@@ -123,10 +123,14 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
     if (in_range) {
         a.colors_out[3 * f] = rgb[0]; a.colors_out[3 * f + 1] = rgb[1]; a.colors_out[3 * f + 2] = rgb[2];
         if (vis) {
+            // blend record: conic pre-scaled so the kernels evaluate exp2(-(hA dx^2 + B dx dy + hC dy^2))
+            const float op = a.opacities[n];
+            float ex, ey;
+            alpha_extent(op, s.cxx, s.cyy, ex, ey);
             float4* r = a.rec + 3 * f;
-            r[0] = make_float4(s.mx, s.my, s.A, s.B);
-            r[1] = make_float4(s.C, a.opacities[n], rgb[0], rgb[1]);
-            r[2] = make_float4(rgb[2], s.depth, (float)s.radius, 0.f);
+            r[0] = make_float4(s.mx, s.my, 0.5f * kLog2e * s.A, kLog2e * s.B);
+            r[1] = make_float4(0.5f * kLog2e * s.C, op, rgb[0], rgb[1]);
+            r[2] = make_float4(rgb[2], ex, ey, 0.f);
         }
     }
 }

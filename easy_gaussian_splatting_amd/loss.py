@@ -1,0 +1,62 @@
+"""L1 + (1 - SSIM) as the reference's train step uses it
+(/root/reference/model/gaussian.py:415-453, lambda_ssim = 0.2 in configs/*.yaml:46).
+
+The reference takes SSIM from torchmetrics (`StructuralSimilarityIndexMeasure(data_range=1.0)`),
+which is not installed here; `ssim()` restates that metric in plain torch: 11x11 Gaussian window
+(sigma 1.5), reflect padding, K1=0.01, K2=0.03, mean over the un-padded interior.  Plain torch on
+purpose: the loss produces `v_render_colors` for the hot path, it is not part of it
+(SURVEY.md section 8f-1 lists a fused HIP version as "next").
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+
+def _gaussian_window(size: int, sigma: float, device, dtype) -> Tensor:
+    x = torch.arange(size, device=device, dtype=dtype) - (size - 1) / 2.0
+    g = torch.exp(-(x / sigma) ** 2 / 2)
+    return g / g.sum()
+
+
+def ssim(preds: Tensor, target: Tensor, data_range: float = 1.0, kernel_size: int = 11,
+         sigma: float = 1.5, k1: float = 0.01, k2: float = 0.03) -> Tensor:
+    """preds/target: [B, C, H, W] -> scalar mean SSIM."""
+    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
+    ch = preds.shape[1]
+    pad = (kernel_size - 1) // 2
+    g = _gaussian_window(kernel_size, sigma, preds.device, preds.dtype)
+    kern_h = g.view(1, 1, -1, 1).expand(ch * 5, 1, -1, 1).contiguous()
+    kern_w = g.view(1, 1, 1, -1).expand(ch * 5, 1, 1, -1).contiguous()
+    p = F.pad(preds, (pad, pad, pad, pad), mode="reflect")
+    t = F.pad(target, (pad, pad, pad, pad), mode="reflect")
+    stack = torch.cat([p, t, p * p, t * t, p * t], dim=1)  # [B, 5C, H+2p, W+2p]
+    out = F.conv2d(F.conv2d(stack, kern_h, groups=ch * 5), kern_w, groups=ch * 5)
+    mu_p, mu_t, e_pp, e_tt, e_pt = out.split(ch, dim=1)
+    s_pp = e_pp - mu_p * mu_p
+    s_tt = e_tt - mu_t * mu_t
+    s_pt = e_pt - mu_p * mu_t
+    num = (2 * mu_p * mu_t + c1) * (2 * s_pt + c2)
+    den = (mu_p * mu_p + mu_t * mu_t + c1) * (s_pp + s_tt + c2)
+    full = num / den
+    full = full[..., pad:-pad, pad:-pad]
+    return full.mean()
+
+
+class LossComputer:
+    def __init__(self, lambda_ssim: float = 0.2):
+        self.lambda_ssim = lambda_ssim
+
+    def get_loss_dict(self, render_img: Tensor, gt_img: Tensor, mask: Tensor = None) -> Dict[str, Tensor]:
+        if mask is not None:
+            m = mask.unsqueeze(2)
+            render_img = m * gt_img + (1.0 - m) * render_img
+        l1 = F.l1_loss(render_img, gt_img)
+        r = render_img.permute(2, 0, 1)[None]
+        g = gt_img.permute(2, 0, 1)[None]
+        ssim_loss = 1.0 - ssim(g, r)
+        total = (1.0 - self.lambda_ssim) * l1 + self.lambda_ssim * ssim_loss
+        return {"l1": l1, "ssim": ssim_loss, "total": total}

@@ -30,6 +30,36 @@ def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# Optional per-stage device timing (bench.py only): when `_prof` is a dict, every native stage call
+# is bracketed by HIP events recorded on the stream the kernels are launched on.
+_prof: Optional[Dict] = None
+
+
+def _stage(name: str, device, thunk):
+    if _prof is None:
+        return thunk()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stream = torch.cuda.current_stream(device)
+    s.record(stream)
+    r = thunk()
+    e.record(stream)
+    _prof.setdefault(name, []).append((s, e))
+    return r
+
+
+def profile_stages(enable: bool) -> Optional[Dict]:
+    """Start (True) or stop (False) stage timing; stopping returns {stage: [ms, ...]}."""
+    global _prof
+    if enable:
+        _prof = {}
+        return None
+    out, _prof = _prof, None
+    if out is None:
+        return None
+    torch.cuda.synchronize()
+    return {k: [s.elapsed_time(e) for s, e in v] for k, v in out.items()}
+
+
 class _Holder:
     """Carries non-tensor state between `rasterization()` and the autograd node without making
     the node own its own output (the weak reference lets backward attach `.absgrad` to the very
@@ -71,11 +101,11 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
     rec = torch.empty((C * N, nat.GS_REC_FLOATS), **f32)
     bbox = torch.empty((C * N, 2), **i32)
     tiles_per_gauss = torch.empty((C, N), **i32)
-    nat.check(L.gs_project_fwd(st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+    _stage("gs_project_fwd", dev, lambda: nat.check(L.gs_project_fwd(st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
                                _ptr(colors), per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
                                cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"], _ptr(radii),
                                _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(colors_post), _ptr(rec),
-                               _ptr(bbox), _ptr(tiles_per_gauss)), "gs_project_fwd")
+                               _ptr(bbox), _ptr(tiles_per_gauss)), "gs_project_fwd"))
 
     ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
     workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
@@ -83,8 +113,8 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
     bucket_offsets = torch.empty((C * tiles + 1,), **i32)
     info_dev = torch.empty((4,), dtype=torch.int64, device=dev)
     info_host = (_ct.c_int64 * 4)()
-    nat.check(L.gs_bin_count(st, C, N, tw, th, _ptr(bbox), _ptr(workspace), ws_bytes, _ptr(isect_offsets),
-                             _ptr(bucket_offsets), _ptr(info_dev), info_host), "gs_bin_count")
+    _stage("gs_bin_count", dev, lambda: nat.check(L.gs_bin_count(st, C, N, tw, th, _ptr(bbox), _ptr(workspace), ws_bytes, _ptr(isect_offsets),
+                             _ptr(bucket_offsets), _ptr(info_dev), info_host), "gs_bin_count"))
     n_isects, n_buckets, max_tile = int(info_host[0]), int(info_host[1]), int(info_host[2])
 
     cap = max(n_isects, 1)
@@ -94,23 +124,21 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
     isect_ids = torch.empty((cap,), dtype=torch.int64, device=dev)
     flatten_ids = torch.empty((cap,), **i32)
     slots = torch.empty((cap,), **i32)
-    nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, _ptr(bbox), _ptr(depths), _ptr(workspace), ws_bytes,
+    _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, _ptr(bbox), _ptr(depths), _ptr(workspace), ws_bytes,
                                  _ptr(isect_offsets), n_isects, max_tile, _ptr(keys_tmp), _ptr(slot_gid),
-                                 _ptr(cum_tiles), _ptr(isect_ids), _ptr(flatten_ids), _ptr(slots)),
-              "gs_bin_emit_sort")
+                                 _ptr(cum_tiles), _ptr(isect_ids), _ptr(flatten_ids), _ptr(slots)), "gs_bin_emit_sort"))
 
     render_colors = torch.empty((C, H, W, 3), **f32)
     render_alphas = torch.empty((C, H, W, 1), **f32)
-    last_ids = torch.empty((C, H, W), **i32)
     tile_used = torch.empty((C * tiles,), **i32)
     ckpt = bucket_tile = None
     if need_grad:
         ckpt = torch.empty((max(n_buckets, 1), 256, 4), **f32)
         bucket_tile = torch.empty((max(n_buckets, 1),), **i32)
-    nat.check(L.gs_blend_fwd(st, C, W, H, _ptr(rec), _ptr(backgrounds), _ptr(isect_offsets),
+    _stage("gs_blend_fwd", dev, lambda: nat.check(L.gs_blend_fwd(st, C, W, H, _ptr(rec), _ptr(backgrounds), _ptr(isect_offsets),
                              _ptr(bucket_offsets), _ptr(flatten_ids), _ptr(render_colors),
-                             _ptr(render_alphas), _ptr(last_ids), _ptr(tile_used), _ptr(ckpt),
-                             _ptr(bucket_tile)), "gs_blend_fwd")
+                             _ptr(render_alphas), _ptr(tile_used), _ptr(ckpt),
+                             _ptr(bucket_tile)), "gs_blend_fwd"))
 
     meta = {
         "camera_ids": None, "gaussian_ids": None,
@@ -124,7 +152,7 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
     state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, n_isects=n_isects, n_buckets=n_buckets,
                  radii=radii, colors_post=colors_post, rec=rec, tiles_per_gauss=tiles_per_gauss,
                  cum_tiles=cum_tiles, isect_offsets=isect_offsets, bucket_offsets=bucket_offsets,
-                 flatten_ids=flatten_ids, slots=slots, last_ids=last_ids, tile_used=tile_used,
+                 flatten_ids=flatten_ids, slots=slots, tile_used=tile_used,
                  ckpt=ckpt, bucket_tile=bucket_tile)
     return render_colors, render_alphas, meta, state
 
@@ -157,11 +185,11 @@ class _Rasterize(torch.autograd.Function):
         v_rc = v_render_colors.contiguous()
         v_ra = None if v_render_alphas is None else v_render_alphas.contiguous()
         rows = torch.empty((max(s["n_isects"], 1), nat.GS_ROW_FLOATS), **f32)
-        nat.check(L.gs_blend_bwd(st, C, W, H, _ptr(s["rec"]), _ptr(s["isect_offsets"]),
+        _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, _ptr(s["rec"]), _ptr(s["isect_offsets"]),
                                  _ptr(s["bucket_offsets"]), _ptr(s["flatten_ids"]), _ptr(s["slots"]),
                                  s["n_buckets"], _ptr(s["bucket_tile"]), _ptr(s["tile_used"]),
                                  _ptr(s["ckpt"]), _ptr(render_colors), _ptr(render_alphas),
-                                 _ptr(s["last_ids"]), _ptr(v_rc), _ptr(v_ra), _ptr(rows)), "gs_blend_bwd")
+                                 _ptr(v_rc), _ptr(v_ra), _ptr(rows)), "gs_blend_bwd"))
         v_means = torch.empty((N, 3), **f32)
         v_quats = torch.empty((N, 4), **f32)
         v_scales = torch.empty((N, 3), **f32)
@@ -174,13 +202,12 @@ class _Rasterize(torch.autograd.Function):
             v_m2 = torch.empty((C, N, 2), **f32)
             v_cn = torch.empty((C, N, 3), **f32)
             v_cp = torch.empty((C, N, 3), **f32)
-        nat.check(L.gs_project_bwd(st, C, N, K, s["deg"], _ptr(means), _ptr(quats), _ptr(scales), _ptr(colors),
+        _stage("gs_project_bwd", dev, lambda: nat.check(L.gs_project_bwd(st, C, N, K, s["deg"], _ptr(means), _ptr(quats), _ptr(scales), _ptr(colors),
                                    s["per_cam"], _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
                                    cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
                                    _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
                                    _ptr(rows), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
-                                   _ptr(v_colors), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp)),
-                  "gs_project_bwd")
+                                   _ptr(v_colors), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp)), "gs_project_bwd"))
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp, rows=rows)
         if holder.absgrad and holder.means2d_ref is not None:

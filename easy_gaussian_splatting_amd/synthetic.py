@@ -1,0 +1,57 @@
+"""Seeded synthetic scenes for the parity tests and the bench (generator of SURVEY.md section 8d).
+
+All arrays are float32 numpy; the same arrays feed the oracle (CPU) and the HIP path (GPU).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+
+
+def look_at_circle(n_views: int, dist: float, dtype=np.float32) -> np.ndarray:
+    """World->camera matrices: view 0 is [I | (0,0,dist)]; the others orbit the y axis."""
+    out = []
+    for v in range(n_views):
+        ang = 2.0 * math.pi * v / max(n_views, 1)
+        c, s = math.cos(ang), math.sin(ang)
+        R = np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]], dtype=np.float64)
+        V = np.eye(4)
+        V[:3, :3] = R
+        V[2, 3] = dist
+        out.append(V)
+    return np.stack(out).astype(dtype)
+
+
+def make_scene(n: int, width: int, height: int, sh_degree: int = 3, n_views: int = 1, seed: int = 42,
+               extent=(2.0, 2.0, 2.0), scale_range=(0.01, 0.1), dist: float = 5.0, k_store: int = None,
+               white_bg: bool = True) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    K_store = (sh_degree + 1) ** 2 if k_store is None else k_store
+    means = (rng.random((n, 3)) * 2 - 1) * np.asarray(extent)
+    scales = np.exp(rng.uniform(math.log(scale_range[0]), math.log(scale_range[1]), (n, 3)))
+    quats = rng.standard_normal((n, 4))
+    opac = 1.0 / (1.0 + np.exp(-rng.standard_normal(n) * 1.5))
+    shs = np.zeros((n, K_store, 3))
+    shs[:, 0] = rng.uniform(-1.77, 1.77, (n, 3))
+    if K_store > 1:
+        shs[:, 1:] = rng.standard_normal((n, K_store - 1, 3)) * 0.1
+    f = width / (2.0 * math.tan(math.radians(30.0)))
+    K = np.array([[f, 0, width / 2.0], [0, f, height / 2.0], [0, 0, 1]])
+    Ks = np.tile(K[None], (n_views, 1, 1))
+    bg = np.ones((n_views, 3)) if white_bg else np.zeros((n_views, 3))
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return dict(means=f32(means), quats=f32(quats), scales=f32(scales), opacities=f32(opac), shs=f32(shs),
+                viewmats=look_at_circle(n_views, dist), Ks=f32(Ks), backgrounds=f32(bg),
+                width=width, height=height, sh_degree=sh_degree)
+
+
+# BASELINE.json configs (synthetic stand-ins at the stated N / HxW)
+def config_s1(seed=42):
+    return make_scene(10_000, 256, 256, sh_degree=0, seed=seed, extent=(2, 2, 2), scale_range=(0.01, 0.1), dist=5.0)
+
+
+def config_bench_1m(seed=42, n=1_000_000, n_views=1):
+    return make_scene(n, 1920, 1080, sh_degree=3, n_views=n_views, seed=seed, extent=(4, 2.25, 4),
+                      scale_range=(0.003, 0.03), dist=8.0, white_bg=False)

@@ -56,7 +56,8 @@ size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h);
  * sh_degree >= 0: `colors_in` is shs[N,K,3];  sh_degree < 0: `colors_in` is already
  * post-activation colour, [N,3] (colors_per_camera=0) or [C,N,3] (=1).
  * Outputs: radii[C,N] i32 (0 = culled), means2d[C,N,2], depths[C,N], conics[C,N,3],
- * colors_out[C,N,3], rec[C*N*12] (mx,my,A,B | C,opacity,r,g | b,depth,radius,0),
+ * colors_out[C,N,3], rec[C*N*12] (mx, my, A*log2e/2, B*log2e | C*log2e/2, opacity, r, g |
+ * b, ext_x, ext_y, 0: conic pre-scaled for exp2, opacity-aware half extents in pixels),
  * bbox[C*N*2] u32 (x0 | x1<<16, y0 | y1<<16; tile rectangle, min inclusive / max exclusive),
  * tiles_per_gauss[C,N] i32. */
 int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
@@ -88,15 +89,15 @@ int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, con
                      int32_t* flatten_ids, int32_t* slots);
 
 /* B-fwd (replaces gsplat rasterize_to_pixels forward).  backgrounds[C,3] may be NULL.
- * Outputs render_colors[C,H,W,3], render_alphas[C,H,W,1], last_ids[C,H,W] i32 (absolute sorted
- * index of the last contributor, -1 if none), tile_used[C*tiles] i32 (buckets actually walked).
- * When ckpt != NULL (training) also writes ckpt[n_buckets*256*4] (per bucket, per pixel: T and
- * accumulated rgb at the bucket's start) and bucket_tile[n_buckets]. */
+ * Outputs render_colors[C,H,W,3], render_alphas[C,H,W,1], tile_used[C*tiles] i32 (buckets actually
+ * walked before every pixel of the tile saturated).  When ckpt != NULL (training) also writes
+ * ckpt[n_buckets*256*4] (per bucket, per pixel: transmittance T -- negative once the pixel is
+ * saturated or outside the image -- and accumulated rgb at the bucket's start) and
+ * bucket_tile[n_buckets]. */
 int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                  const float* backgrounds, const int32_t* isect_offsets,
                  const int32_t* bucket_offsets, const int32_t* flatten_ids, float* render_colors,
-                 float* render_alphas, int32_t* last_ids, int32_t* tile_used, float* ckpt,
-                 int32_t* bucket_tile);
+                 float* render_alphas, int32_t* tile_used, float* ckpt, int32_t* bucket_tile);
 
 /* B-bwd (replaces rasterize_to_pixels backward incl. absgrad).  One wavefront per bucket; writes
  * one 12-float row per intersection at rows[slots[i]*12]:
@@ -106,7 +107,7 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
                  const int32_t* isect_offsets, const int32_t* bucket_offsets,
                  const int32_t* flatten_ids, const int32_t* slots, int64_t n_buckets,
                  const int32_t* bucket_tile, const int32_t* tile_used, const float* ckpt,
-                 const float* render_colors, const float* render_alphas, const int32_t* last_ids,
+                 const float* render_colors, const float* render_alphas,
                  const float* v_render_colors, const float* v_render_alphas, float* rows);
 
 /* Row reduction + SH-bwd + P-bwd fused (replaces the atomics of the blend backward,

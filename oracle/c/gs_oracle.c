@@ -368,6 +368,45 @@ int gso_blend_fwd(int C, int N, int W, int H, int tile, const real* means2d, con
     return 0;
 }
 
+/* Per-pixel distance to the blend's discontinuities (alpha >= 1/255 test, T <= 1e-4 early-out,
+ * sigma >= 0 test): min over the pairs the forward visits of the RELATIVE gap to the threshold.
+ * Pixels with a tiny margin can legitimately flip a contributor under 1-ulp arithmetic
+ * differences; parity tests use this to separate them from real errors. */
+int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, const real* conics,
+                     const real* opac, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                     int64_t I, real* margin) {
+    int tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile;
+    (void)N;
+#pragma omp parallel for schedule(dynamic, 64) collapse(2)
+    for (int c = 0; c < C; c++)
+        for (long pix = 0; pix < (long)H * W; pix++) {
+            int i = (int)(pix / W), j = (int)(pix % W);
+            long t = ((long)c * th + i / tile) * tw + j / tile;
+            int64_t lo = isect_offsets[t];
+            int64_t hi = (t + 1 < (long)C * tw * th) ? isect_offsets[t + 1] : I;
+            real px = j + (real)0.5, py = i + (real)0.5;
+            real T = 1, m = 1;
+            for (int64_t k = lo; k < hi; k++) {
+                int32_t g = flatten_ids[k];
+                real dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                real sigma = (real)0.5 * (conics[3 * g] * dx * dx + conics[3 * g + 2] * dy * dy) + conics[3 * g + 1] * dx * dy;
+                real alpha = opac[g] * REXP(-sigma);
+                if (alpha > ALPHA_MAX) alpha = ALPHA_MAX;
+                real ma = RABS(alpha - ALPHA_MIN) / ALPHA_MIN;
+                if (ma < m) m = ma;
+                if (RABS(sigma) < m && opac[g] >= ALPHA_MIN) m = RABS(sigma);
+                if (sigma < 0 || alpha < ALPHA_MIN) continue;
+                real Tn = T * (1 - alpha);
+                real mt = RABS(Tn - T_MIN) / T_MIN;
+                if (mt < m) m = mt;
+                if (Tn <= T_MIN) break;
+                T = Tn;
+            }
+            margin[(long)c * H * W + pix] = m;
+        }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ A.5 */
 static inline void atomic_add(real* p, real v) {
 #pragma omp atomic

@@ -91,6 +91,20 @@ def render(means, quats, scales, opacities, colors, viewmats, Ks, width, height,
                              eps2d=eps2d, near_plane=near_plane, far_plane=far_plane))
 
 
+def blend_margin(fwd: Dict[str, np.ndarray]) -> np.ndarray:
+    """[C,H,W] relative distance of every pixel to the nearest blend discontinuity (see
+    gso_blend_margin); small values mark pixels where a 1-ulp difference may flip a contributor."""
+    inp = fwd["_inputs"]
+    dtype = fwd["means2d"].dtype
+    L = _lib(dtype)
+    C, N = fwd["radii"].shape
+    W, H = inp["width"], inp["height"]
+    out = np.ones((C, H, W), dtype)
+    L.gso_blend_margin(C, N, W, H, inp["tile_size"], _p(fwd["means2d"]), _p(fwd["conics"]), _p(fwd["opacities"]),
+                       _p(fwd["isect_offsets"]), _p(fwd["flatten_ids"]), ct.c_int64(fwd["n_isects"]), _p(out))
+    return out
+
+
 def backward(fwd: Dict[str, np.ndarray], v_render_colors, v_render_alphas=None) -> Dict[str, np.ndarray]:
     """A.5 + A.6: gradients wrt means, quats, scales, opacities, colors(shs) plus the 2-D
     intermediates and absgrad, for upstream grads of the returned image / alpha."""

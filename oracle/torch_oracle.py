@@ -406,10 +406,10 @@ def naive_blend_autograd(means2d, conics, colors, opacities, backgrounds, width,
                     dy = m2[g, 1] - (i + 0.5)
                     sigma = 0.5 * (cn[g, 0] * dx * dx + cn[g, 2] * dy * dy) + cn[g, 1] * dx * dy
                     alpha = torch.clamp_max(op[g] * torch.exp(-sigma), ALPHA_MAX)
-                    if float(sigma) < 0 or float(alpha) < ALPHA_MIN:
+                    if float(sigma.detach()) < 0 or float(alpha.detach()) < ALPHA_MIN:
                         continue
                     Tn = T * (1 - alpha)
-                    if float(Tn) <= T_MIN:
+                    if float(Tn.detach()) <= T_MIN:
                         break
                     acc = acc + cl[g] * alpha * T
                     T = Tn

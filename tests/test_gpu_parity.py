@@ -1,0 +1,320 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on identical seeded
+inputs, against the committed golden fixtures, and -- at BASELINE.json's full size -- through
+size-independent properties.  Tolerances (BASELINE.json north_star): forward RGB <= 1e-4 abs,
+gradients <= 1e-3 relative (to the largest reference magnitude of each tensor).
+
+The blend has three discontinuities (alpha >= 1/255, T <= 1e-4, sigma >= 0).  A pixel whose
+fp64 oracle run passes within a relative 1e-4 of one of them may legitimately flip a contributor
+under fp32 arithmetic; such pixels (oracle.c_oracle.blend_margin) are excluded from the strict
+1e-4 bound, must stay rare, and are still bounded by one flipped contributor's weight.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as CO
+from scenes import config_bench_1m, config_s1, make_scene
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FWD_ATOL = 1e-4
+GRAD_RTOL = 1e-3
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def to_dev(sc):
+    return {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev()) for k, v in sc.items() if isinstance(v, np.ndarray) and v.dtype.kind == "f"}
+
+
+def run_hip(sc, bwd=True, seed=0, use_bg=True, dbg=None):
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    t = to_dev(sc)
+    ins = [t[k].clone().requires_grad_(bwd) for k in ("means", "quats", "scales", "opacities", "shs")]
+    img, alpha, meta = rasterization(*ins, t["viewmats"], t["Ks"], int(sc["width"]), int(sc["height"]),
+                                     sh_degree=int(sc["sh_degree"]), packed=False,
+                                     backgrounds=t["backgrounds"] if use_bg else None, absgrad=True, _debug=dbg)
+    out = dict(img=img, alpha=alpha, meta=meta, ins=ins)
+    if bwd:
+        g = torch.Generator().manual_seed(seed)
+        vc, va = torch.randn(img.shape, generator=g), torch.randn(alpha.shape, generator=g)
+        out["vc"], out["va"] = vc.numpy().astype(np.float64), va.numpy().astype(np.float64)
+        out["grads"] = torch.autograd.grad((img * vc.to(dev())).sum() + (alpha * va.to(dev())).sum(), ins)
+    torch.cuda.synchronize()
+    return out
+
+
+def run_oracle(sc, use_bg=True, dtype=np.float64):
+    return CO.render(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["shs"], sc["viewmats"], sc["Ks"],
+                     int(sc["width"]), int(sc["height"]), sh_degree=int(sc["sh_degree"]),
+                     backgrounds=sc["backgrounds"] if use_bg else None, dtype=dtype)
+
+
+def check_forward(hip, fw, max_razor_frac=1e-2):
+    meta = hip["meta"]
+    radii = meta["radii"].cpu().numpy()
+    mism = radii != fw["radii"]
+    assert mism.mean() <= 1e-4, f"radii mismatch fraction {mism.mean()}"
+    same = ~mism
+    assert np.abs(meta["means2d"].cpu().numpy() - fw["means2d"])[same].max(initial=0) < 2e-3
+    assert np.abs(meta["depths"].cpu().numpy() - fw["depths"])[same].max(initial=0) < 1e-4
+    con = meta["conics"].cpu().numpy()
+    assert (np.abs(con - fw["conics"]) / (np.abs(fw["conics"]) + 1e-2))[same].max(initial=0) < 2e-3
+    exact_lists = (not mism.any()) and np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), fw["tiles_per_gauss"])
+    if exact_lists:  # integer / index work must then be bit-exact
+        assert np.array_equal(meta["isect_offsets"].cpu().numpy(), fw["isect_offsets"])
+        assert np.array_equal(meta["flatten_ids"].cpu().numpy(), fw["flatten_ids"])
+    err = np.abs(hip["img"].detach().cpu().numpy() - fw["render_colors"]).max(-1)
+    aerr = np.abs(hip["alpha"].detach().cpu().numpy() - fw["render_alphas"])[..., 0]
+    razor = CO.blend_margin(fw) < 1e-4
+    strict = ~razor
+    if not exact_lists:  # a flipped radius / tile rectangle changes a few lists; those pixels are razor-edge too
+        strict &= err < 10 * FWD_ATOL
+        assert (err >= 10 * FWD_ATOL).mean() < 1e-3
+    assert razor.mean() <= max_razor_frac
+    assert err[strict].max(initial=0) <= FWD_ATOL, f"forward RGB err {err[strict].max()}"
+    assert aerr[strict].max(initial=0) <= FWD_ATOL, f"forward alpha err {aerr[strict].max()}"
+    cmax = max(1.0, float(fw["colors"].max()))
+    assert err.max(initial=0) <= 4.0 / 255.0 * cmax, "even a flipped contributor is bounded by ~its weight"
+    return exact_lists
+
+
+def check_backward(hip, fw, rtol=GRAD_RTOL):
+    bw = CO.backward(fw, hip["vc"], hip["va"])
+    for name, g in zip(["v_means", "v_quats", "v_scales", "v_opacities", "v_colors"], hip["grads"]):
+        ref = bw[name]
+        scale = np.abs(ref).max() + 1e-30
+        rel = np.abs(g.cpu().numpy() - ref).max() / scale
+        assert rel <= rtol, f"{name}: rel err {rel}"
+    ag = hip["meta"]["means2d"].absgrad.cpu().numpy()
+    assert np.abs(ag - bw["v_means2d_abs"]).max() <= rtol * (np.abs(bw["v_means2d_abs"]).max() + 1e-30)
+    return bw
+
+
+SCENES = {
+    "tiny_sh3": dict(n=50, width=40, height=24, sh_degree=3, seed=1, scale_range=(0.05, 0.4), dist=4.0),
+    "ragged_sh2_2views": dict(n=2000, width=100, height=70, sh_degree=2, seed=2, k_store=16, n_views=2, scale_range=(0.02, 0.3), dist=4.0),
+    "odd_n_sh1_k4": dict(n=1237, width=333, height=77, sh_degree=1, seed=3, k_store=4, scale_range=(0.02, 0.3), dist=4.0, white_bg=False),
+    "sh0_k1": dict(n=4000, width=128, height=128, sh_degree=0, seed=4, scale_range=(0.01, 0.2), dist=4.0),
+    "sh0_of_k16_3views": dict(n=900, width=64, height=48, sh_degree=0, seed=5, k_store=16, n_views=3, scale_range=(0.03, 0.3), dist=4.0),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_forward_backward_parity_small(name):
+    sc = make_scene(**SCENES[name])
+    hip, fw = run_hip(sc), run_oracle(sc)
+    check_forward(hip, fw)
+    check_backward(hip, fw)
+
+
+def test_config_s1_parity():
+    """BASELINE.json configs[0]: 10k random Gaussians, 256x256, SH degree 0."""
+    sc = config_s1()
+    hip, fw = run_hip(sc), run_oracle(sc)
+    check_forward(hip, fw)
+    check_backward(hip, fw)
+
+
+def test_no_background_and_no_alpha_grad():
+    sc = make_scene(600, 80, 60, sh_degree=3, seed=6, scale_range=(0.03, 0.3), dist=4.0)
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    t = to_dev(sc)
+    ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+    img, alpha, meta = rasterization(*ins, t["viewmats"], t["Ks"], 80, 60, sh_degree=3, packed=False, absgrad=True)
+    vc = torch.randn(img.shape, generator=torch.Generator().manual_seed(0))
+    grads = torch.autograd.grad((img * vc.to(dev())).sum(), ins)  # alpha unused -> v_alphas is None/zero
+    fw = run_oracle(sc, use_bg=False)
+    hip = dict(img=img, alpha=alpha, meta=meta, grads=grads, vc=vc.numpy().astype(np.float64), va=np.zeros(alpha.shape))
+    check_forward(hip, fw)
+    check_backward(hip, fw)
+
+
+def test_post_activation_colours_path():
+    """sh_degree=None: colours are used as given, [N,3] and [C,N,3]."""
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    sc = make_scene(500, 64, 64, sh_degree=0, seed=8, n_views=2, scale_range=(0.03, 0.3), dist=4.0)
+    t = to_dev(sc)
+    rng = np.random.default_rng(0)
+    for shape in ((500, 3), (2, 500, 3)):
+        cols = rng.random(shape).astype(np.float32)
+        c_t = torch.from_numpy(cols).to(dev()).requires_grad_(True)
+        base = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
+        img, alpha, meta = rasterization(*base, c_t, t["viewmats"], t["Ks"], 64, 64, sh_degree=None, packed=False,
+                                         backgrounds=t["backgrounds"], absgrad=True)
+        vc = torch.randn(img.shape, generator=torch.Generator().manual_seed(1))
+        grads = torch.autograd.grad((img * vc.to(dev())).sum(), base + [c_t])
+        fw = CO.render(sc["means"], sc["quats"], sc["scales"], sc["opacities"], cols, sc["viewmats"], sc["Ks"], 64, 64,
+                       sh_degree=None, backgrounds=sc["backgrounds"], dtype=np.float64)
+        bw = CO.backward(fw, vc.numpy().astype(np.float64))
+        assert np.abs(img.detach().cpu().numpy() - fw["render_colors"]).max() < 5e-3
+        ref_c = bw["v_colors"] if len(shape) == 3 else bw["v_colors"].sum(0)
+        assert grads[4].shape == c_t.shape
+        assert np.abs(grads[4].cpu().numpy() - ref_c).max() <= GRAD_RTOL * np.abs(ref_c).max()
+        assert np.abs(grads[0].cpu().numpy() - bw["v_means"]).max() <= GRAD_RTOL * np.abs(bw["v_means"]).max()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_golden_fixtures(tag):
+    """Committed oracle fixtures (tests/golden/make_golden.py): every integer output bit-exact,
+    image and gradients within the north_star tolerances."""
+    z = dict(np.load(os.path.join(GOLD, f"oracle_scene_{tag}.npz")))
+    sc = {k: z[k] for k in ("means", "quats", "scales", "opacities", "shs", "viewmats", "Ks", "backgrounds")}
+    sc.update(width=int(z["width"]), height=int(z["height"]), sh_degree=int(z["sh_degree"]))
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    t = to_dev(sc)
+    ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+    img, alpha, meta = rasterization(*ins, t["viewmats"], t["Ks"], sc["width"], sc["height"], sh_degree=sc["sh_degree"],
+                                     packed=False, backgrounds=t["backgrounds"], absgrad=True)
+    for k in ("radii", "tiles_per_gauss", "flatten_ids", "isect_offsets"):
+        assert np.array_equal(meta[k].cpu().numpy(), z[k]), k
+    assert np.array_equal(meta["isect_ids"].cpu().numpy() >> 32, z["isect_ids"] >> 32)  # camera|tile part
+    assert np.abs(img.detach().cpu().numpy() - z["render_colors"]).max() <= FWD_ATOL
+    assert np.abs(alpha.detach().cpu().numpy() - z["render_alphas"]).max() <= FWD_ATOL
+    vc = torch.from_numpy(z["v_render_colors"]).float().to(dev()); va = torch.from_numpy(z["v_render_alphas"]).float().to(dev())
+    grads = torch.autograd.grad((img * vc).sum() + (alpha * va).sum(), ins)
+    for g, k in zip(grads, ("v_means", "v_quats", "v_scales", "v_opacities", "v_shs")):
+        assert np.abs(g.cpu().numpy() - z[k]).max() <= GRAD_RTOL * np.abs(z[k]).max(), k
+    assert np.abs(meta["means2d"].absgrad.cpu().numpy() - z["absgrad"]).max() <= GRAD_RTOL * np.abs(z["absgrad"]).max()
+
+
+def test_empty_and_invisible_inputs():
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    d = dev()
+    V = torch.eye(4, device=d)[None]; K = torch.tensor([[50.0, 0, 16], [0, 50.0, 16], [0, 0, 1]], device=d)[None]
+    bg = torch.tensor([[0.25, 0.5, 0.75]], device=d)
+    # N = 0
+    z = lambda *s: torch.zeros(*s, device=d)
+    img, alpha, meta = rasterization(z(0, 3), z(0, 4), z(0, 3), z(0), z(0, 16, 3), V, K, 32, 32, sh_degree=3, packed=False, backgrounds=bg)
+    assert torch.allclose(img, bg.expand(1, 32, 32, 3).contiguous()) and float(alpha.abs().max()) == 0.0
+    assert meta["flatten_ids"].numel() == 0 and meta["radii"].shape == (1, 0)
+    # everything behind the camera: zero visible, gradients exist and are zero
+    means = torch.tensor([[0.0, 0, -2.0], [0.1, 0, -3.0]], device=d, requires_grad=True)
+    quats = torch.ones(2, 4, device=d, requires_grad=True); scales = torch.full((2, 3), 0.1, device=d, requires_grad=True)
+    op = torch.full((2,), 0.5, device=d, requires_grad=True); sh = torch.zeros(2, 16, 3, device=d, requires_grad=True)
+    img, alpha, meta = rasterization(means, quats, scales, op, sh, V, K, 32, 32, sh_degree=3, packed=False, backgrounds=bg, absgrad=True)
+    assert int((meta["radii"] > 0).sum()) == 0 and torch.allclose(img, bg.expand(1, 32, 32, 3).contiguous())
+    img.sum().backward()
+    for p in (means, quats, scales, op, sh):
+        assert p.grad is not None and float(p.grad.abs().max()) == 0.0
+    assert float(meta["means2d"].absgrad.abs().max()) == 0.0
+
+
+def test_large_tile_lists_hit_every_sort_class():
+    """Tiles with > 2048 (LDS large class) and > 16384 (global-memory class) entries, and Gaussians
+    that cover every tile (wave-cooperative binning and row-reduction paths)."""
+    rng = np.random.default_rng(0)
+    n = 20000
+    sc = make_scene(n, 64, 48, sh_degree=0, seed=12, scale_range=(0.2, 0.6), dist=4.0, extent=(0.3, 0.3, 0.5))
+    sc["opacities"] = (rng.random(n) * 0.02 + 0.004).astype(np.float32)  # faint: lists are walked to the end
+    hip, fw = run_hip(sc), run_oracle(sc)
+    counts = np.diff(np.append(fw["isect_offsets"].reshape(-1), fw["n_isects"]))
+    assert counts.max() > 16384 and fw["tiles_per_gauss"].max() == 12
+    assert check_forward(hip, fw, max_razor_frac=0.5)  # lists must match exactly (bit-exact sort)
+    check_backward(hip, fw)
+    sc2 = make_scene(3000, 64, 48, sh_degree=0, seed=13, scale_range=(0.2, 0.6), dist=4.0, extent=(0.3, 0.3, 0.5))
+    hip2, fw2 = run_hip(sc2), run_oracle(sc2)
+    c2 = np.diff(np.append(fw2["isect_offsets"].reshape(-1), fw2["n_isects"]))
+    assert 2048 < c2.max() <= 16384
+    assert check_forward(hip2, fw2, max_razor_frac=0.5)
+    check_backward(hip2, fw2)
+
+
+def test_depth_ties_break_by_index():
+    """Equal depths in one tile: order must follow the flatten index (stable-sort contract A.3)."""
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    d = dev()
+    n = 200
+    means = torch.zeros(n, 3, device=d); means[:, 2] = 2.0
+    means[:, 0] = torch.linspace(-0.05, 0.05, n, device=d)
+    V = torch.eye(4, device=d)[None]; K = torch.tensor([[40.0, 0, 8], [0, 40.0, 8], [0, 0, 1]], device=d)[None]
+    img, alpha, meta = rasterization(means, torch.ones(n, 4, device=d), torch.full((n, 3), 0.05, device=d),
+                                     torch.full((n,), 0.1, device=d), torch.rand(n, 3, device=d), V, K, 16, 16,
+                                     sh_degree=None, packed=False)
+    ids = meta["flatten_ids"].cpu().numpy()
+    assert len(ids) == n and np.array_equal(ids, np.arange(n))
+
+
+def test_full_size_properties():
+    """BASELINE.json metric workload (1 M Gaussians, 1920x1080, SH3): size-independent properties."""
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    sc = config_bench_1m()
+    t = to_dev(sc)
+    W, H = sc["width"], sc["height"]
+    args = [t[k] for k in ("means", "quats", "scales", "opacities", "shs")]
+    img, alpha, meta = rasterization(*args, t["viewmats"], t["Ks"], W, H, sh_degree=3, packed=False, backgrounds=t["backgrounds"])
+    assert torch.isfinite(img).all() and float(alpha.min()) >= 0.0 and float(alpha.max()) <= 1.0
+    # list structure: offsets monotone, every run sorted by depth then index, I == sum tiles_per_gauss
+    I = meta["flatten_ids"].numel()
+    assert I == int(meta["tiles_per_gauss"].sum())
+    offs = meta["isect_offsets"].reshape(-1).long()
+    assert bool((offs[1:] >= offs[:-1]).all()) and int(offs[0]) == 0
+    keys = meta["isect_ids"]
+    assert bool((keys[1:] >= keys[:-1]).all()), "(tile | depth) keys must be globally non-decreasing"
+    same = keys[1:] == keys[:-1]
+    fid = meta["flatten_ids"].long()
+    assert bool((fid[1:][same] > fid[:-1][same]).all()), "ties ordered by flatten index"
+    # every listed Gaussian is visible and its depth matches the key's low word
+    assert bool((meta["radii"].reshape(-1)[fid] > 0).all())
+    dbits = meta["depths"].reshape(-1)[fid].view(torch.int32).long()
+    assert bool(((keys & 0xFFFFFFFF) == dbits).all())
+    # permutation invariance of the image (sum order inside a pixel is depth order -> identical lists)
+    perm = torch.randperm(args[0].shape[0], generator=torch.Generator().manual_seed(0)).to(dev())
+    img_p, alpha_p, _ = rasterization(*[a[perm].contiguous() for a in args], t["viewmats"], t["Ks"], W, H, sh_degree=3,
+                                      packed=False, backgrounds=t["backgrounds"])
+    assert float((img - img_p).abs().max()) <= 4.0 / 255.0 * 2  # only exact depth ties can reorder
+    assert float((img - img_p).abs().mean()) < 1e-6
+    # linearity of the backward in the upstream gradient + determinism (no atomics anywhere)
+    ins = [a.clone().requires_grad_(True) for a in args]
+    img2, _, meta2 = rasterization(*ins, t["viewmats"], t["Ks"], W, H, sh_degree=3, packed=False, backgrounds=t["backgrounds"], absgrad=True)
+    g = torch.Generator().manual_seed(3)
+    v1, v2 = torch.randn(img2.shape, generator=g).to(dev()) / (W * H), torch.randn(img2.shape, generator=g).to(dev()) / (W * H)
+    g1 = torch.autograd.grad((img2 * v1).sum(), ins, retain_graph=True)
+    g2 = torch.autograd.grad((img2 * v2).sum(), ins, retain_graph=True)
+    g12 = torch.autograd.grad((img2 * (v1 + v2)).sum(), ins, retain_graph=True)
+    g12b = torch.autograd.grad((img2 * (v1 + v2)).sum(), ins)
+    for a, b, c, cb in zip(g1, g2, g12, g12b):
+        assert torch.equal(c, cb), "backward must be bitwise reproducible"
+        assert float((a + b - c).abs().max()) <= 2e-3 * float(c.abs().max()) + 1e-12
+    assert meta2["means2d"].absgrad.shape == (1, args[0].shape[0], 2)
+
+
+def test_model_forward_and_statistics_mirror():
+    """Rows a-1/a-2/a-3: GaussianModel.forward(data) / update_statistics against the oracle."""
+    from easy_gaussian_splatting_amd.model import GaussianModel
+    sc = make_scene(3000, 160, 96, sh_degree=3, seed=7, scale_range=(0.02, 0.2), dist=4.0)
+    d = dev()
+    T = lambda a: torch.from_numpy(a).to(d)
+    op = np.clip(sc["opacities"], 1e-4, 1 - 1e-4)
+    m = GaussianModel(means=T(sc["means"]), log_scales=torch.log(T(sc["scales"])), quats=T(sc["quats"]),
+                      sh_0=T(sc["shs"])[:, :1].contiguous(), sh_rest=T(sc["shs"])[:, 1:].contiguous(),
+                      logit_opacities=T(np.log(op / (1 - op)).astype(np.float32)), sh_degree=3, white_background=True).to(d)
+    data = {"w2c": T(sc["viewmats"][0]), "K": T(sc["Ks"][0]), "width": 160, "height": 96}
+    out = m(data)
+    assert out["render_img"].shape == (96, 160, 3) and out["batch_xys"].shape == (1, 3000, 2) and out["batch_radii"].shape == (1, 3000)
+    fw = CO.render(sc["means"], sc["quats"], sc["scales"], op, sc["shs"], sc["viewmats"], sc["Ks"], 160, 96, sh_degree=3,
+                   backgrounds=np.ones((1, 3), np.float32), dtype=np.float64)
+    ref_img = np.clip(fw["render_colors"][0], 0, 1)
+    err = np.abs(out["render_img"].detach().cpu().numpy() - ref_img)
+    assert (err > 1e-4).mean() < 1e-3
+    vc = torch.randn(out["render_img"].shape, generator=torch.Generator().manual_seed(2))
+    (out["render_img"] * vc.to(d)).sum().backward()
+    m.update_statistics(data, out)
+    vcl = vc.numpy().astype(np.float64) * ((fw["render_colors"][0] > 0) & (fw["render_colors"][0] < 1))
+    bw = CO.backward(fw, vcl[None])
+    vis = fw["radii"][0] > 0
+    exp_g = np.where(vis, np.linalg.norm(bw["v_means2d_abs"][0], axis=-1) * 160, 0)
+    assert np.abs(m.grad_norm_accum.cpu().numpy() - exp_g).max() <= 2e-3 * exp_g.max()
+    assert np.array_equal(m.collecting_counts.cpu().numpy() > 0, vis)
+    assert np.allclose(m.max_radii.cpu().numpy(), np.where(vis, fw["radii"][0] / 160.0, 0))
+    # parameter gradients flow through exp / sigmoid / cat to all six leaves
+    for name in m.param_names:
+        assert getattr(m, name).grad is not None
+    ref_vls = bw["v_scales"] * sc["scales"]  # d exp(log_s)
+    assert np.abs(m.log_scales.grad.cpu().numpy() - ref_vls).max() <= 2e-3 * np.abs(ref_vls).max()
