@@ -46,11 +46,53 @@ def ssim(preds: Tensor, target: Tensor, data_range: float = 1.0, kernel_size: in
     return full.mean()
 
 
+class _FusedL1SSIM(torch.autograd.Function):
+    """HIP path (csrc/gs_loss.hip): two stencil kernels forward, one backward, no atomics."""
+
+    @staticmethod
+    def forward(ctx, render_img: Tensor, gt_img: Tensor, mask, lambda_ssim: float):
+        from . import _native as nat
+        L = nat.lib()
+        H, W = render_img.shape[:2]
+        dev = render_img.device
+        r, g = render_img.contiguous(), gt_img.contiguous()
+        m = None if mask is None else mask.contiguous()
+        ws = torch.empty((int(L.gs_loss_workspace_floats(H, W)),), dtype=torch.float32, device=dev)
+        out = torch.empty((3,), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        nat.check(L.gs_l1_ssim_fwd(st, H, W, float(lambda_ssim), r.data_ptr(), g.data_ptr(),
+                                   None if m is None else m.data_ptr(), ws.data_ptr(), out.data_ptr()), "gs_l1_ssim_fwd")
+        ctx.save_for_backward(r, g, ws) if m is None else ctx.save_for_backward(r, g, ws, m)
+        ctx.lam = float(lambda_ssim)
+        total, l1, ssim_loss = out[2], out[0], out[1]
+        ctx.mark_non_differentiable(l1, ssim_loss)
+        return total, l1, ssim_loss
+
+    @staticmethod
+    def backward(ctx, v_total, _v_l1, _v_ssim):
+        from . import _native as nat
+        L = nat.lib()
+        saved = ctx.saved_tensors
+        r, g, ws = saved[:3]
+        m = saved[3] if len(saved) > 3 else None
+        H, W = r.shape[:2]
+        v_render = torch.empty_like(r)
+        vt = v_total.contiguous().float()
+        st = torch.cuda.current_stream(r.device).cuda_stream
+        nat.check(L.gs_l1_ssim_bwd(st, H, W, ctx.lam, r.data_ptr(), g.data_ptr(), None if m is None else m.data_ptr(),
+                                   ws.data_ptr(), vt.data_ptr(), v_render.data_ptr()), "gs_l1_ssim_bwd")
+        return v_render, None, None, None
+
+
 class LossComputer:
-    def __init__(self, lambda_ssim: float = 0.2):
+    def __init__(self, lambda_ssim: float = 0.2, fused: bool = True):
         self.lambda_ssim = lambda_ssim
+        self.fused = fused
 
     def get_loss_dict(self, render_img: Tensor, gt_img: Tensor, mask: Tensor = None) -> Dict[str, Tensor]:
+        if self.fused and render_img.is_cuda and render_img.dtype == torch.float32:
+            total, l1, ssim_loss = _FusedL1SSIM.apply(render_img, gt_img, mask, self.lambda_ssim)
+            return {"l1": l1, "ssim": ssim_loss, "total": total}
         if mask is not None:
             m = mask.unsqueeze(2)
             render_img = m * gt_img + (1.0 - m) * render_img

@@ -126,6 +126,20 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    float* v_scales, float* v_opacities, float* v_colors, float* v_means2d_abs,
                    float* v_means2d, float* v_conics, float* v_colors_post);
 
+/* ---- "next" row f-1: the loss that feeds v_render_colors ----
+ * Fused L1 + (1 - SSIM) of /root/reference/model/gaussian.py:415-453 (torchmetrics SSIM:
+ * 11x11 Gaussian window sigma 1.5, K1 0.01, K2 0.03, data_range 1, mean over the interior).
+ * render / gt are [H,W,3]; mask [H,W] may be NULL (render := mask*gt + (1-mask)*render).
+ * workspace holds gs_loss_workspace_floats(H,W) floats and carries the SSIM derivative maps from
+ * the forward to the backward.  out3 = {l1, 1-ssim, (1-lambda)*l1 + lambda*(1-ssim)}.
+ * v_total: device scalar d(loss)/d(out3[2]);  v_render[H,W,3] is fully written. */
+size_t gs_loss_workspace_floats(int height, int width);
+int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_ssim, const float* render,
+                   const float* gt, const float* mask, float* workspace, float* out3);
+int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const float* render,
+                   const float* gt, const float* mask, const float* workspace,
+                   const float* v_total, float* v_render);
+
 #ifdef __cplusplus
 }
 #endif
