@@ -4,26 +4,31 @@
 // owns the pixel at that position in each of the tile's four 8x8 QUADRANTS.  The tile's
 // depth-sorted list is walked in buckets of 64 entries: each lane gathers one packed 48-byte
 // record, tests its opacity-aware extent against the four quadrants and the wave ballots the
-// results into four 64-bit scalar masks.  The inner loop then runs on scalar control flow only:
-// it visits just the entries that can touch the tile at all (s_ff1 over the OR of the masks),
-// reads the record back at a wave-uniform LDS address (broadcast) and evaluates only the
-// quadrants whose bit is set.  The per-pixel arithmetic is straight-line predicated code
-// (v_cndmask, no divergent branches).  A single wave needs no workgroup barrier and leaves the
-// tile with one ballot once all 256 pixels are saturated.
+// results into four 64-bit scalar masks (a quadrant whose 64 pixels are all saturated drops out).
+// The inner loop then runs on scalar control flow only: it visits just the entries that can touch
+// the tile at all (s_ff1 over the OR of the masks), reads the record back at a wave-uniform LDS
+// address (broadcast) and evaluates only the quadrants whose bit is set.  The per-pixel
+// arithmetic is straight-line predicated code (v_cndmask, no divergent branches).
 //
-// Backward: ONE wavefront per bucket, GAUSSIAN-parallel.  Lane l owns entry l of the bucket and
-// keeps its eleven gradient sums in registers while the tile's 256 pixels stream through the
-// wave as a systolic pipeline: at step t lane l treats pixel t-l, receives that pixel's running
-// (transmittance T, P = prefix colour . v_colour) from lane l-1 through one DPP wave_shr:1 each
-// and hands it on.  Lane 0 is fed from the per-bucket checkpoint the forward wrote (T < 0 marks
-// a pixel that is already saturated or outside the image).  There are no cross-lane reductions
-// and no atomics: each lane finally stores its 48-byte gradient row, and gs_project_bwd sums the
-// (contiguous) rows of every Gaussian.  Buckets are independent work units of identical size,
-// which also removes the heavy-tailed per-tile load imbalance of a pixel-parallel backward
-// (SURVEY.md section 7 "hard parts").
+// In training mode the forward also emits, per quadrant, the COMPACTED depth-ordered sublist of
+// the entries that touch it (ranks from popcounts of the ballots), a checkpoint of the quadrant's
+// 64 pixel states (T, accumulated rgb) every 64 sublist entries, and one work-unit descriptor per
+// such 64-entry "quadrant bucket".
 //
-// Forward and backward evaluate alpha, w = alpha*T and T' = T - w with the same instruction
-// sequence, so the backward re-derives the forward's contributor set exactly (no last_ids).
+// Backward: GAUSSIAN-parallel, no cross-lane reductions, no atomics.  A wavefront runs four
+// independent 16-lane systolic pipelines (one DPP row each); a pipeline owns one quadrant bucket:
+// lane r keeps entries 4r..4r+3 and their 4x11 gradient sums in registers while the quadrant's 64
+// pixels stream through -- at step s lane r treats pixel s-r against its four entries in depth
+// order, receives that pixel's running (T, P = prefix colour . v_colour) from lane r-1 through
+// one DPP row_shr:1 each and hands it on; lane 0 is fed from the checkpoint.  79 steps cover
+// 64 pixels x 64 entries (19 % pipeline fill instead of the 100 % a 64-lane pipeline would pay on
+// 64 pixels), and only (entry, quadrant) pairs the forward actually walked are ever evaluated.
+// Each lane finally stores 48-byte gradient rows at rows[slot*4 + quadrant]; gs_project_bwd sums
+// the rows of every Gaussian (contiguous slots) with plain coalesced loads.
+//
+// Forward and backward evaluate alpha, w = alpha*T and T' = fma(-alpha, T, T) with the same
+// instruction sequence on the same inputs, so the backward re-derives the forward's contributor
+// set exactly (no last_ids).
 //
 // Semantics: SURVEY.md Appendix A.4 / A.5 (gsplat 1.0.0 rasterize_to_pixels fwd/bwd).
 #include "gs_common.h"
@@ -35,10 +40,15 @@ struct BlendFwdArgs {
     int C, W, H, tw, tiles;
     const float4* rec;
     const float* bg;
-    const int32_t *isect_offsets, *bucket_offsets, *flatten_ids;
+    const int32_t *isect_offsets, *bucket_offsets, *flatten_ids, *slots;
     float *out_colors, *out_alphas;
-    int32_t *tile_used, *bucket_tile;
-    float4* ckpt;
+    // training-mode outputs
+    float4* ckpt;          // [4*n_buckets][64]  quadrant-bucket checkpoints
+    int32_t* qlist;        // [4*I]              per tile: 4 sublists of capacity len(tile)
+    int32_t* qcnt;         // [C*tiles*4]        sublist lengths
+    uint8_t* qmask;        // [I] by slot        which quadrant rows of an intersection exist
+    int32_t* unit_counter; // [1]
+    int2* unit_desc;       // [4*n_buckets]      (tile*4+quadrant, bucket index within the sublist)
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -71,31 +81,28 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
     const int px0 = x0 + (lane & 7), py0 = y0 + (lane >> 3);   // quadrant 0 pixel; +8 for the others
     const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f, fx1 = fx0 + 8.f, fy1 = fy0 + 8.f;
     const int lo = a.isect_offsets[t], hi = a.isect_offsets[t + 1];
-    const int nb = (hi - lo + GS_BUCKET - 1) / GS_BUCKET;
+    const int len = hi - lo;
+    const int nb = (len + GS_BUCKET - 1) / GS_BUCKET;
     const int bucket0 = a.bucket_offsets[t];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     float T[4], cr[4], cg[4], cb[4];
     bool done[4];
+    int cnt[4] = {0, 0, 0, 0};   // wave-uniform sublist lengths
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         T[k] = 1.f; cr[k] = cg[k] = cb[k] = 0.f;
         done[k] = !((px0 + 8 * (k & 1)) < a.W && (py0 + 8 * (k >> 1)) < a.H);
     }
-    if (CKPT)
-        for (int b = lane; b < nb; b += 64) a.bucket_tile[bucket0 + b] = t;
     // pixel-centre bounds of the four quadrants
     const float qxlo[2] = {(float)x0 + 0.5f, (float)x0 + 8.5f}, qxhi[2] = {(float)x0 + 7.5f, (float)x0 + 15.5f};
     const float qylo[2] = {(float)y0 + 0.5f, (float)y0 + 8.5f}, qyhi[2] = {(float)y0 + 7.5f, (float)y0 + 15.5f};
 
-    int used = 0;
     for (int b = 0; b < nb; ++b) {
-        if (__all(done[0] && done[1] && done[2] && done[3])) break;
-        used = b + 1;
-        if (CKPT) {
-            float4* ck = a.ckpt + (size_t)(bucket0 + b) * 256;
+        bool qa[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ck[k * 64 + lane] = make_float4(done[k] ? -1.f : T[k], cr[k], cg[k], cb[k]);
-        }
+        for (int k = 0; k < 4; ++k) qa[k] = !__all(done[k]);
+        if (!(qa[0] || qa[1] || qa[2] || qa[3])) break;
         const int first = lo + b * GS_BUCKET;
         const int m = min(GS_BUCKET, hi - first);
         bool hx[2] = {false, false}, hy[2] = {false, false};
@@ -110,24 +117,69 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
                 hy[h] = ey >= 0.f && q0.y + ey >= qylo[h] && q0.y - ey <= qyhi[h];
             }
         }
-        const unsigned long long m0 = __ballot(hx[0] && hy[0]), m1 = __ballot(hx[1] && hy[0]),
-                                 m2 = __ballot(hx[0] && hy[1]), m3 = __ballot(hx[1] && hy[1]);
+        const bool bit[4] = {qa[0] && hx[0] && hy[0], qa[1] && hx[1] && hy[0], qa[2] && hx[0] && hy[1], qa[3] && hx[1] && hy[1]};
+        unsigned long long mq[4];
+        int jstar[4] = {-1, -1, -1, -1}, kbstar[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mq[k] = __ballot(bit[k]);
+        if (CKPT) {
+            int mybits = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rank = __popcll(mq[k] & lt_mask);
+                if (bit[k]) {
+                    a.qlist[(size_t)4 * lo + (size_t)k * len + cnt[k] + rank] = first + lane;
+                    mybits |= 1 << k;
+                }
+                // the sublist entry that opens a new 64-entry quadrant bucket (at most one per bucket)
+                const int need = (GS_BUCKET - (cnt[k] & (GS_BUCKET - 1))) & (GS_BUCKET - 1);
+                const unsigned long long bs = __ballot(bit[k] && rank == need);
+                if (bs) { jstar[k] = __builtin_ctzll(bs); kbstar[k] = (cnt[k] + need) / GS_BUCKET; }
+            }
+            if (lane < m) a.qmask[a.slots[first + lane]] = (uint8_t)mybits;
+        }
         __syncthreads();
-        for (unsigned long long rem = m0 | m1 | m2 | m3; rem; rem &= rem - 1) {
+        for (unsigned long long rem = mq[0] | mq[1] | mq[2] | mq[3]; rem; rem &= rem - 1) {
             const int j = __builtin_ctzll(rem);
             const float4 q0 = srec[j * 3], q1 = srec[j * 3 + 1], q2 = srec[j * 3 + 2];
             const float dxa = q0.x - fx0, dxb = q0.x - fx1, dya = q0.y - fy0, dyb = q0.y - fy1;
             const float sxa = q0.z * dxa * dxa, sxb = q0.z * dxb * dxb;   // hA dx^2
             const float bxa = q0.w * dxa, bxb = q0.w * dxb;               // B dx
             const float op = q1.y, r = q1.z, g = q1.w, bl = q2.x;
-            if ((m0 >> j) & 1) blend_pair(fmaf(dya, fmaf(q1.x, dya, bxa), sxa), op, r, g, bl, T[0], cr[0], cg[0], cb[0], done[0]);
-            if ((m1 >> j) & 1) blend_pair(fmaf(dya, fmaf(q1.x, dya, bxb), sxb), op, r, g, bl, T[1], cr[1], cg[1], cb[1], done[1]);
-            if ((m2 >> j) & 1) blend_pair(fmaf(dyb, fmaf(q1.x, dyb, bxa), sxa), op, r, g, bl, T[2], cr[2], cg[2], cb[2], done[2]);
-            if ((m3 >> j) & 1) blend_pair(fmaf(dyb, fmaf(q1.x, dyb, bxb), sxb), op, r, g, bl, T[3], cr[3], cg[3], cb[3], done[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((mq[k] >> j) & 1) {
+                    if (CKPT && j == jstar[k])
+                        a.ckpt[((size_t)4 * bucket0 + (size_t)k * nb + kbstar[k]) * 64 + lane] =
+                            make_float4(done[k] ? -1.f : T[k], cr[k], cg[k], cb[k]);
+                    const float dy = (k >> 1) ? dyb : dya;
+                    const float sigma = fmaf(dy, fmaf(q1.x, dy, (k & 1) ? bxb : bxa), (k & 1) ? sxb : sxa);
+                    blend_pair(sigma, op, r, g, bl, T[k], cr[k], cg[k], cb[k], done[k]);
+                }
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt[k] += __popcll(mq[k]);
         __syncthreads();
     }
-    if (lane == 0) a.tile_used[t] = used;
+    if (CKPT) {
+        // publish sublist lengths and one work unit per 64-entry quadrant bucket
+        int nu[4], tot = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { nu[k] = (cnt[k] + GS_BUCKET - 1) / GS_BUCKET; tot += nu[k]; }
+        if (lane < 4) a.qcnt[4 * t + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
+        int base = 0;
+        if (tot > 0) {
+            if (lane == 0) base = atomicAdd(a.unit_counter, tot);
+            base = __builtin_amdgcn_readfirstlane(base);
+            int off = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                for (int u = lane; u < nu[k]; u += 64) a.unit_desc[base + off + u] = make_int2(4 * t + k, u);
+                off += nu[k];
+            }
+        }
+    }
     float bgr = 0.f, bgg = 0.f, bgb = 0.f;
     if (a.bg) { bgr = a.bg[3 * cam]; bgg = a.bg[3 * cam + 1]; bgb = a.bg[3 * cam + 2]; }
 #pragma unroll
@@ -146,132 +198,156 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct BlendBwdArgs {
     int C, W, H, tw, tiles;
-    int64_t n_buckets;
     const float4* rec;
-    const int32_t *isect_offsets, *bucket_offsets, *flatten_ids, *slots, *bucket_tile, *tile_used;
+    const int32_t *isect_offsets, *bucket_offsets, *flatten_ids, *slots, *qlist, *qcnt, *unit_counter;
+    const int2* unit_desc;
     const float4* ckpt;
     const float *out_colors, *out_alphas, *v_colors, *v_alphas;
-    float4* rows;
+    float4* rows;   // [I*4][3]
 };
 
 constexpr int kBwdWaves = 4;
+constexpr int kRowLanes = 16;                       // one DPP row = one pipeline
+constexpr int kPerLane = GS_BUCKET / kRowLanes;     // 4 entries per lane
+constexpr int kBwdSteps = 64 + kRowLanes - 1;       // 79
 
-__device__ __forceinline__ float dpp_wave_shr1(float v) {
-    // lane l receives lane l-1's value; lane 0 keeps its own (overwritten by the caller)
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+__device__ __forceinline__ float dpp_row_shr1(float v) {
+    // lane r of each 16-lane row receives lane r-1's value; lane 0 keeps its own
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float readlane_f(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+
+struct PixRec {   // 48 B per pixel in LDS
+    float4 d0;    // v_r, v_g, v_b, E
+    float4 ck;    // checkpoint T, r, g, b
+    float2 d1;    // pixel centre
+    float2 pad;
+};
+
+struct EntryState {
+    float mx, my, hA, Bc, hC, op, colr, colg, colb, At, Bt, Ct;
+    float s_mx, s_my, s_ax, s_ay, s_A, s_B, s_C, s_vs, s_r, s_g, s_b;
+    bool has;
+};
+
+__device__ __forceinline__ void bwd_pair(EntryState& e, const bool act, const float4 d0, const float2 d1,
+                                         float& T, float& P) {
+    const float dx = e.mx - d1.x, dy = e.my - d1.y;
+    const float sigma = fmaf(dy, fmaf(e.hC, dy, e.Bc * dx), e.hA * dx * dx);   // same op sequence as the forward
+    const float vis = fast_exp2(-sigma);
+    const float ov = e.op * vis;
+    const float alpha = fminf(kAlphaMax, ov);
+    const bool ok = act && e.has && T > 0.f && sigma >= 0.f && alpha >= kAlphaMin;
+    const float w = alpha * T;
+    const float Tn = fmaf(-alpha, T, T);   // identical to the forward's update
+    const bool stop = ok && Tn <= kTMin;
+    const bool contrib = ok && !stop;
+    const float cv = e.colr * d0.x + e.colg * d0.y + e.colb * d0.z;
+    const float Pn = fmaf(w, cv, P);
+    const float ra = fast_rcp(1.f - alpha);
+    const float v_alpha = fmaf(T, cv, ra * (d0.w + Pn));
+    const float wm = contrib ? w : 0.f;
+    e.s_r = fmaf(wm, d0.x, e.s_r); e.s_g = fmaf(wm, d0.y, e.s_g); e.s_b = fmaf(wm, d0.z, e.s_b);
+    const float vs = (contrib && ov <= kAlphaMax) ? -ov * v_alpha : 0.f;   // d loss / d sigma
+    const float hx = vs * dx, hy = vs * dy;
+    e.s_A = fmaf(hx, dx, e.s_A); e.s_B = fmaf(hx, dy, e.s_B); e.s_C = fmaf(hy, dy, e.s_C);
+    const float gx = fmaf(e.At, hx, e.Bt * hy), gy = fmaf(e.Bt, hx, e.Ct * hy);
+    e.s_mx += gx; e.s_my += gy; e.s_ax += fabsf(gx); e.s_ay += fabsf(gy);
+    e.s_vs += vs;
+    T = contrib ? Tn : (stop ? -1.f : T);
+    P = contrib ? Pn : P;
 }
 
 __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBwdArgs a) {
-    // per wave: 256 pixels x 2 float4 = 8 KB : (v_r, v_g, v_b, E) and (px, py, -, -)
-    __shared__ float4 spix_all[kBwdWaves][256 * 2];
+    __shared__ PixRec spix_all[kBwdWaves][4][64];   // 12 KB per wave
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t B = (int64_t)blockIdx.x * kBwdWaves + wave;
-    if (B >= a.n_buckets) return;  // wave-uniform; no workgroup barriers below
-    float4* spix = spix_all[wave];
+    const int row = lane >> 4, r = lane & (kRowLanes - 1);
+    const int n_units = a.unit_counter[0];
+    const int unit = ((int)blockIdx.x * kBwdWaves + wave) * 4 + row;
+    if (((int)blockIdx.x * kBwdWaves + wave) * 4 >= n_units) return;   // wave-uniform
+    const bool valid = unit < n_units;
+    PixRec* spix = spix_all[wave][row];
 
-    const int t = a.bucket_tile[B];
-    const int b = (int)(B - a.bucket_offsets[t]);
-    const int lo = a.isect_offsets[t] + b * GS_BUCKET, hi = a.isect_offsets[t + 1];
-    const int m = min(GS_BUCKET, hi - lo);
-    const bool has = lane < m;
-    const int idx = lo + lane;
-    const int slot = has ? a.slots[idx] : 0;
-    if (b >= a.tile_used[t]) {  // the forward never reached this bucket: all-zero rows
-        if (has) {
-            float4* r = a.rows + 3 * (size_t)slot;
-            r[0] = r[1] = r[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-    }
+    int tq = 0, kb = 0;
+    if (valid) { const int2 d = a.unit_desc[unit]; tq = d.x; kb = d.y; }
+    const int t = tq >> 2, q = tq & 3;
+    const int lo = a.isect_offsets[t], len = a.isect_offsets[t + 1] - lo;
+    const int nb = (len + GS_BUCKET - 1) / GS_BUCKET, bucket0 = a.bucket_offsets[t];
+    const int n_in = valid ? min(GS_BUCKET, a.qcnt[tq] - kb * GS_BUCKET) : 0;
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
     const int tyi = tt / a.tw, txi = tt - tyi * a.tw;
+    const int qx0 = txi * GS_TILE + 8 * (q & 1), qy0 = tyi * GS_TILE + 8 * (q >> 1);
 
-    float4 ck[4];
+    // stage the quadrant's 64 pixels: 4 per lane
+    const float4* ckp = a.ckpt + ((size_t)4 * bucket0 + (size_t)q * nb + kb) * 64;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int p = k * 64 + lane;
-        const int px = txi * GS_TILE + (lane & 7) + 8 * (k & 1), py = tyi * GS_TILE + (lane >> 3) + 8 * (k >> 1);
-        float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 d1 = make_float4((float)px + 0.5f, (float)py + 0.5f, 0.f, 0.f);
-        if (px < a.W && py < a.H) {
+    for (int i = 0; i < 4; ++i) {
+        const int p = r + kRowLanes * i;
+        const int px = qx0 + (p & 7), py = qy0 + (p >> 3);
+        PixRec pr;
+        pr.d0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        pr.ck = make_float4(-1.f, 0.f, 0.f, 0.f);
+        pr.d1 = make_float2((float)px + 0.5f, (float)py + 0.5f);
+        pr.pad = make_float2(0.f, 0.f);
+        if (valid && px < a.W && py < a.H) {
             const size_t o = ((size_t)cam * a.H + py) * a.W + px;
             const float vr = a.v_colors[3 * o], vg = a.v_colors[3 * o + 1], vb = a.v_colors[3 * o + 2];
             const float Tf = 1.f - a.out_alphas[o];
             const float va = a.v_alphas ? a.v_alphas[o] : 0.f;
             // E = T_final * v_alpha - render_colour . v_colour  (background terms cancel)
             const float E = Tf * va - (a.out_colors[3 * o] * vr + a.out_colors[3 * o + 1] * vg + a.out_colors[3 * o + 2] * vb);
-            d0 = make_float4(vr, vg, vb, E);
+            pr.d0 = make_float4(vr, vg, vb, E);
+            pr.ck = ckp[p];
         }
-        spix[p * 2] = d0; spix[p * 2 + 1] = d1;
-        ck[k] = a.ckpt[(size_t)B * 256 + p];
+        spix[p] = pr;
+    }
+
+    EntryState e[kPerLane];
+    int slot[kPerLane];
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) {
+        const int en = kPerLane * r + i;
+        e[i].has = en < n_in;
+        slot[i] = 0;
+        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+        if (e[i].has) {
+            const int idx = a.qlist[(size_t)4 * lo + (size_t)q * len + kb * GS_BUCKET + en];
+            slot[i] = a.slots[idx];
+            const float4* rp = a.rec + 3 * (size_t)a.flatten_ids[idx];
+            q0 = rp[0]; q1 = rp[1]; q2 = rp[2];
+        }
+        e[i].mx = q0.x; e[i].my = q0.y; e[i].hA = q0.z; e[i].Bc = q0.w; e[i].hC = q1.x; e[i].op = q1.y;
+        e[i].colr = q1.z; e[i].colg = q1.w; e[i].colb = q2.x;
+        // true conic entries for the mean gradient (the record stores them scaled by log2(e))
+        e[i].At = 2.f * kLn2 * q0.z; e[i].Bt = kLn2 * q0.w; e[i].Ct = 2.f * kLn2 * q1.x;
+        e[i].s_mx = e[i].s_my = e[i].s_ax = e[i].s_ay = e[i].s_A = e[i].s_B = e[i].s_C = e[i].s_vs = 0.f;
+        e[i].s_r = e[i].s_g = e[i].s_b = 0.f;
     }
     __builtin_amdgcn_wave_barrier();
 
-    float mx = 0.f, my = 0.f, hA = 0.f, Bc = 0.f, hC = 0.f, op = 0.f, colr = 0.f, colg = 0.f, colb = 0.f;
-    if (has) {
-        const float4* r = a.rec + 3 * (size_t)a.flatten_ids[idx];
-        const float4 q0 = r[0], q1 = r[1], q2 = r[2];
-        mx = q0.x; my = q0.y; hA = q0.z; Bc = q0.w; hC = q1.x; op = q1.y; colr = q1.z; colg = q1.w; colb = q2.x;
-    }
-    // true conic entries for the mean gradient (the record stores them scaled by log2(e))
-    const float At = 2.f * kLn2 * hA, Bt = kLn2 * Bc, Ct = 2.f * kLn2 * hC;
-    float s_mx = 0.f, s_my = 0.f, s_ax = 0.f, s_ay = 0.f, s_A = 0.f, s_B = 0.f, s_C = 0.f, s_vs = 0.f,
-          s_r = 0.f, s_g = 0.f, s_b = 0.f;
     float T_out = -1.f, P_out = 0.f;
-
-    auto step = [&](const int tstep, const bool inject, const float4 ckv, const int src_lane) {
-        float T_in = dpp_wave_shr1(T_out), P_in = dpp_wave_shr1(P_out);
-        const int p = tstep - lane;
-        const bool act = has && (unsigned)p < 256u;
-        const int pc = min(max(p, 0), 255);
-        const float4 d0 = spix[pc * 2], d1 = spix[pc * 2 + 1];
-        if (inject) {
-            const float cT = readlane_f(ckv.x, src_lane), cR = readlane_f(ckv.y, src_lane),
-                        cG = readlane_f(ckv.z, src_lane), cB = readlane_f(ckv.w, src_lane);
-            const float P0 = cR * d0.x + cG * d0.y + cB * d0.z;
-            T_in = lane == 0 ? cT : T_in;
-            P_in = lane == 0 ? P0 : P_in;
-        }
-        const float dx = mx - d1.x, dy = my - d1.y;
-        const float sigma = fmaf(dy, fmaf(hC, dy, Bc * dx), hA * dx * dx);   // same op sequence as the forward
-        const float vis = fast_exp2(-sigma);
-        const float ov = op * vis;
-        const float alpha = fminf(kAlphaMax, ov);
-        const bool ok = act && T_in > 0.f && sigma >= 0.f && alpha >= kAlphaMin;
-        const float w = alpha * T_in;
-        const float Tn = fmaf(-alpha, T_in, T_in);   // identical to the forward's update
-        const bool stop = ok && Tn <= kTMin;
-        const bool contrib = ok && !stop;
-        const float cv = colr * d0.x + colg * d0.y + colb * d0.z;
-        const float Pn = fmaf(w, cv, P_in);
-        const float ra = fast_rcp(1.f - alpha);
-        const float v_alpha = fmaf(T_in, cv, ra * (d0.w + Pn));
-        const float wm = contrib ? w : 0.f;
-        s_r = fmaf(wm, d0.x, s_r); s_g = fmaf(wm, d0.y, s_g); s_b = fmaf(wm, d0.z, s_b);
-        const float vs = (contrib && ov <= kAlphaMax) ? -ov * v_alpha : 0.f;   // d loss / d sigma
-        const float hx = vs * dx, hy = vs * dy;
-        s_A = fmaf(hx, dx, s_A); s_B = fmaf(hx, dy, s_B); s_C = fmaf(hy, dy, s_C);
-        const float gx = fmaf(At, hx, Bt * hy), gy = fmaf(Bt, hx, Ct * hy);
-        s_mx += gx; s_my += gy; s_ax += fabsf(gx); s_ay += fabsf(gy);
-        s_vs += vs;
-        T_out = contrib ? Tn : (stop ? -1.f : T_in);
-        P_out = contrib ? Pn : P_in;
-    };
+    for (int s = 0; s < kBwdSteps; ++s) {
+        float T = dpp_row_shr1(T_out), P = dpp_row_shr1(P_out);
+        const int p = s - r;
+        const bool act = (unsigned)p < 64u;
+        const PixRec* pp = spix + min(max(p, 0), 63);
+        const float4 d0 = pp->d0, ck = pp->ck;
+        const float2 d1 = pp->d1;
+        if (r == 0) { T = ck.x; P = ck.y * d0.x + ck.z * d0.y + ck.w * d0.z; }
 #pragma unroll
-    for (int seg = 0; seg < 4; ++seg)
-        for (int tl = 0; tl < 64; ++tl) step(seg * 64 + tl, true, ck[seg], tl);
-    for (int tl = 0; tl < 63; ++tl) step(256 + tl, false, ck[0], 0);
+        for (int i = 0; i < kPerLane; ++i) bwd_pair(e[i], act, d0, d1, T, P);
+        T_out = T; P_out = P;
+    }
 
-    if (has) {
-        float4* r = a.rows + 3 * (size_t)slot;
-        // v_opacity = sum vis * v_alpha = -sum(vs) / opacity   (vs = -opacity*vis*v_alpha)
-        const float v_op = op > 0.f ? -s_vs / op : 0.f;
-        r[0] = make_float4(s_mx, s_my, s_ax, s_ay);
-        r[1] = make_float4(0.5f * s_A, s_B, 0.5f * s_C, v_op);
-        r[2] = make_float4(s_r, s_g, s_b, 0.f);
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) {
+        if (e[i].has) {
+            float4* rp = a.rows + 3 * ((size_t)slot[i] * 4 + q);
+            // v_opacity = sum vis * v_alpha = -sum(vs) / opacity   (vs = -opacity*vis*v_alpha)
+            const float v_op = e[i].op > 0.f ? -e[i].s_vs / e[i].op : 0.f;
+            rp[0] = make_float4(e[i].s_mx, e[i].s_my, e[i].s_ax, e[i].s_ay);
+            rp[1] = make_float4(0.5f * e[i].s_A, e[i].s_B, 0.5f * e[i].s_C, v_op);
+            rp[2] = make_float4(e[i].s_r, e[i].s_g, e[i].s_b, 0.f);
+        }
     }
 }
 
@@ -282,23 +358,31 @@ using namespace gs;
 extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                             const float* backgrounds, const int32_t* isect_offsets,
                             const int32_t* bucket_offsets, const int32_t* flatten_ids,
-                            float* render_colors, float* render_alphas, int32_t* tile_used,
-                            float* ckpt, int32_t* bucket_tile) {
-    GS_REQUIRE(C >= 1 && width > 0 && height > 0, "C>=1 and positive image size");
-    GS_REQUIRE(isect_offsets && bucket_offsets && render_colors && render_alphas && tile_used, "null pointer");
-    GS_REQUIRE((ckpt == nullptr) == (bucket_tile == nullptr), "ckpt and bucket_tile go together");
+                            const int32_t* slots, int64_t n_isects, float* render_colors,
+                            float* render_alphas, float* ckpt, int32_t* qlist, int32_t* qcnt,
+                            uint8_t* qmask, int32_t* unit_counter, int32_t* unit_desc) {
+    GS_REQUIRE(C >= 1 && width > 0 && height > 0 && n_isects >= 0, "C>=1, positive image size, n_isects>=0");
+    GS_REQUIRE(isect_offsets && bucket_offsets && render_colors && render_alphas, "null pointer");
+    const bool train = ckpt != nullptr;
+    GS_REQUIRE(!train || (qlist && qcnt && qmask && unit_counter && unit_desc && slots), "training mode needs every list output");
     BlendFwdArgs a;
     a.C = C; a.W = width; a.H = height;
     a.tw = (width + GS_TILE - 1) / GS_TILE;
     a.tiles = a.tw * ((height + GS_TILE - 1) / GS_TILE);
     a.rec = reinterpret_cast<const float4*>(rec); a.bg = backgrounds; a.isect_offsets = isect_offsets;
-    a.bucket_offsets = bucket_offsets; a.flatten_ids = flatten_ids; a.out_colors = render_colors;
-    a.out_alphas = render_alphas; a.tile_used = tile_used;
-    a.bucket_tile = bucket_tile; a.ckpt = reinterpret_cast<float4*>(ckpt);
+    a.bucket_offsets = bucket_offsets; a.flatten_ids = flatten_ids; a.slots = slots;
+    a.out_colors = render_colors; a.out_alphas = render_alphas;
+    a.ckpt = reinterpret_cast<float4*>(ckpt); a.qlist = qlist; a.qcnt = qcnt; a.qmask = qmask;
+    a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int2*>(unit_desc);
     const unsigned grid = (unsigned)(C * a.tiles);
     hipStream_t st = (hipStream_t)stream;
-    if (ckpt) hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(grid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(grid), dim3(64), 0, st, a);
+    if (train) {
+        GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));
+        if (n_isects > 0) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
+        hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(grid), dim3(64), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(grid), dim3(64), 0, st, a);
+    }
     GS_LAUNCH_CHECK("blend_fwd_kernel");
     return GS_OK;
 }
@@ -306,24 +390,28 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
 extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
                             const int32_t* isect_offsets, const int32_t* bucket_offsets,
                             const int32_t* flatten_ids, const int32_t* slots, int64_t n_buckets,
-                            const int32_t* bucket_tile, const int32_t* tile_used, const float* ckpt,
-                            const float* render_colors, const float* render_alphas,
-                            const float* v_render_colors, const float* v_render_alphas, float* rows) {
+                            const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_counter,
+                            const int32_t* unit_desc, const float* ckpt, const float* render_colors,
+                            const float* render_alphas, const float* v_render_colors,
+                            const float* v_render_alphas, float* rows) {
     GS_REQUIRE(C >= 1 && width > 0 && height > 0 && n_buckets >= 0, "C>=1, positive image size, n_buckets>=0");
     if (n_buckets == 0) return GS_OK;
-    GS_REQUIRE(rec && isect_offsets && bucket_offsets && flatten_ids && slots && bucket_tile && tile_used && ckpt, "null list pointer");
+    GS_REQUIRE(rec && isect_offsets && bucket_offsets && flatten_ids && slots && qlist && qcnt && unit_counter && unit_desc && ckpt, "null list pointer");
     GS_REQUIRE(render_colors && render_alphas && v_render_colors && rows, "null image pointer");
     BlendBwdArgs a;
     a.C = C; a.W = width; a.H = height;
     a.tw = (width + GS_TILE - 1) / GS_TILE;
     a.tiles = a.tw * ((height + GS_TILE - 1) / GS_TILE);
-    a.n_buckets = n_buckets; a.rec = reinterpret_cast<const float4*>(rec);
+    a.rec = reinterpret_cast<const float4*>(rec);
     a.isect_offsets = isect_offsets; a.bucket_offsets = bucket_offsets; a.flatten_ids = flatten_ids;
-    a.slots = slots; a.bucket_tile = bucket_tile; a.tile_used = tile_used;
+    a.slots = slots; a.qlist = qlist; a.qcnt = qcnt; a.unit_counter = unit_counter;
+    a.unit_desc = reinterpret_cast<const int2*>(unit_desc);
     a.ckpt = reinterpret_cast<const float4*>(ckpt); a.out_colors = render_colors;
     a.out_alphas = render_alphas; a.v_colors = v_render_colors; a.v_alphas = v_render_alphas;
     a.rows = reinterpret_cast<float4*>(rows);
-    const unsigned grid = (unsigned)((n_buckets + kBwdWaves - 1) / kBwdWaves);
+    // upper bound on work units: 4 quadrant sublists per tile, each at most as long as the tile list
+    const int64_t max_units = 4 * n_buckets;
+    const unsigned grid = (unsigned)((max_units + 4 * kBwdWaves - 1) / (4 * kBwdWaves));
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(kBwdWaves * 64), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("blend_bwd_kernel");
     return GS_OK;

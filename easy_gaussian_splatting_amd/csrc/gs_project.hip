@@ -142,7 +142,8 @@ struct ProjBwdArgs {
     float eps2d, near_p, far_p;
     const float *means, *quats, *scales, *colors_in, *viewmats, *Ks, *colors_post;
     const int32_t *radii, *tiles_per_gauss, *cum_tiles;
-    const float4* rows;
+    const float4* rows;      // [I*4][3]: one row per (intersection slot, tile quadrant)
+    const uint8_t* qmask;    // [I] by slot: which of the four quadrant rows exist
     float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_means2d_abs, *v_means2d,
         *v_conics, *v_colors_post;
 };
@@ -151,11 +152,19 @@ struct RowSum {
     float v[12];
 };
 
-__device__ __forceinline__ void row_add(RowSum& s, const float4* __restrict__ r) {
-    const float4 a = r[0], b = r[1], c = r[2];
-    s.v[0] += a.x; s.v[1] += a.y; s.v[2] += a.z; s.v[3] += a.w;
-    s.v[4] += b.x; s.v[5] += b.y; s.v[6] += b.z; s.v[7] += b.w;
-    s.v[8] += c.x; s.v[9] += c.y; s.v[10] += c.z;
+// adds the existing quadrant rows of one intersection slot (fixed order -> reproducible sums)
+__device__ __forceinline__ void row_add(RowSum& s, const float4* __restrict__ rows, const uint8_t* __restrict__ qmask, int64_t slot) {
+    const int bits = qmask[slot];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (bits & (1 << q)) {
+            const float4* r = rows + 3 * (slot * 4 + q);
+            const float4 a = r[0], b = r[1], c = r[2];
+            s.v[0] += a.x; s.v[1] += a.y; s.v[2] += a.z; s.v[3] += a.w;
+            s.v[4] += b.x; s.v[5] += b.y; s.v[6] += b.z; s.v[7] += b.w;
+            s.v[8] += c.x; s.v[9] += c.y; s.v[10] += c.z;
+        }
+    }
 }
 
 constexpr int kCoopRows = 48;  // Gaussians with more rows than this are summed by the whole wave
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
 #pragma unroll
     for (int i = 0; i < 12; ++i) s.v[i] = 0.f;
     if (cnt <= kCoopRows)
-        for (int r = 0; r < cnt; ++r) row_add(s, a.rows + 3 * (int64_t)(base + r));
+        for (int r = 0; r < cnt; ++r) row_add(s, a.rows, a.qmask, (int64_t)(base + r));
     unsigned long long big = __ballot(cnt > kCoopRows);
     while (big) {
         const int src = __ffsll((long long)big) - 1;
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         RowSum p;
 #pragma unroll
         for (int i = 0; i < 12; ++i) p.v[i] = 0.f;
-        for (int r = lane_id(); r < bcnt; r += 64) row_add(p, a.rows + 3 * (int64_t)(bbase + r));
+        for (int r = lane_id(); r < bcnt; r += 64) row_add(p, a.rows, a.qmask, (int64_t)(bbase + r));
 #pragma unroll
         for (int i = 0; i < 11; ++i) {
             const float t = wave_reduce_add(p.v[i]);
@@ -335,21 +344,21 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
                               int height, float eps2d, float near_plane, float far_plane,
                               const int32_t* radii, const float* colors_post,
                               const int32_t* tiles_per_gauss, const int32_t* cum_tiles,
-                              const float* rows, float* v_means, float* v_quats, float* v_scales,
+                              const float* rows, const uint8_t* qmask, float* v_means, float* v_quats, float* v_scales,
                               float* v_opacities, float* v_colors, float* v_means2d_abs,
                               float* v_means2d, float* v_conics, float* v_colors_post) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
     GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
     GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
     if (N == 0) return GS_OK;
-    GS_REQUIRE(means && quats && scales && colors_in && viewmats && Ks && radii && colors_post && tiles_per_gauss && cum_tiles, "null input pointer");
+    GS_REQUIRE(means && quats && scales && colors_in && viewmats && Ks && radii && colors_post && tiles_per_gauss && cum_tiles && rows && qmask, "null input pointer");
     GS_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_colors && v_means2d_abs, "null output pointer");
     ProjBwdArgs a;
     a.C = C; a.N = N; a.K = K; a.colors_per_camera = colors_per_camera; a.W = width; a.H = height;
     a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
     a.means = means; a.quats = quats; a.scales = scales; a.colors_in = colors_in; a.viewmats = viewmats;
     a.Ks = Ks; a.colors_post = colors_post; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss;
-    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows);
+    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.qmask = qmask;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_opacities = v_opacities;
     a.v_colors = v_colors; a.v_means2d_abs = v_means2d_abs; a.v_means2d = v_means2d;
     a.v_conics = v_conics; a.v_colors_post = v_colors_post;

@@ -130,15 +130,19 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
 
     render_colors = torch.empty((C, H, W, 3), **f32)
     render_alphas = torch.empty((C, H, W, 1), **f32)
-    tile_used = torch.empty((C * tiles,), **i32)
-    ckpt = bucket_tile = None
-    if need_grad:
-        ckpt = torch.empty((max(n_buckets, 1), 256, 4), **f32)
-        bucket_tile = torch.empty((max(n_buckets, 1),), **i32)
+    ckpt = qlist = qcnt = qmask = unit_counter = unit_desc = None
+    if need_grad:  # what the Gaussian-parallel backward consumes (see include/gs_raster.h)
+        nbk = max(n_buckets, 1)
+        ckpt = torch.empty((4 * nbk, 64, 4), **f32)
+        qlist = torch.empty((4 * cap,), **i32)
+        qcnt = torch.empty((C * tiles * 4,), **i32)
+        qmask = torch.empty((cap,), dtype=torch.uint8, device=dev)
+        unit_counter = torch.empty((1,), **i32)
+        unit_desc = torch.empty((4 * nbk, 2), **i32)
     _stage("gs_blend_fwd", dev, lambda: nat.check(L.gs_blend_fwd(st, C, W, H, _ptr(rec), _ptr(backgrounds), _ptr(isect_offsets),
-                             _ptr(bucket_offsets), _ptr(flatten_ids), _ptr(render_colors),
-                             _ptr(render_alphas), _ptr(tile_used), _ptr(ckpt),
-                             _ptr(bucket_tile)), "gs_blend_fwd"))
+                             _ptr(bucket_offsets), _ptr(flatten_ids), _ptr(slots), n_isects, _ptr(render_colors),
+                             _ptr(render_alphas), _ptr(ckpt), _ptr(qlist), _ptr(qcnt), _ptr(qmask),
+                             _ptr(unit_counter), _ptr(unit_desc)), "gs_blend_fwd"))
 
     meta = {
         "camera_ids": None, "gaussian_ids": None,
@@ -152,8 +156,8 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
     state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, n_isects=n_isects, n_buckets=n_buckets,
                  radii=radii, colors_post=colors_post, rec=rec, tiles_per_gauss=tiles_per_gauss,
                  cum_tiles=cum_tiles, isect_offsets=isect_offsets, bucket_offsets=bucket_offsets,
-                 flatten_ids=flatten_ids, slots=slots, tile_used=tile_used,
-                 ckpt=ckpt, bucket_tile=bucket_tile)
+                 flatten_ids=flatten_ids, slots=slots, ckpt=ckpt, qlist=qlist, qcnt=qcnt, qmask=qmask,
+                 unit_counter=unit_counter, unit_desc=unit_desc)
     return render_colors, render_alphas, meta, state
 
 
@@ -184,11 +188,11 @@ class _Rasterize(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         v_rc = v_render_colors.contiguous()
         v_ra = None if v_render_alphas is None else v_render_alphas.contiguous()
-        rows = torch.empty((max(s["n_isects"], 1), nat.GS_ROW_FLOATS), **f32)
+        rows = torch.empty((max(s["n_isects"], 1) * 4, nat.GS_ROW_FLOATS), **f32)
         _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, _ptr(s["rec"]), _ptr(s["isect_offsets"]),
                                  _ptr(s["bucket_offsets"]), _ptr(s["flatten_ids"]), _ptr(s["slots"]),
-                                 s["n_buckets"], _ptr(s["bucket_tile"]), _ptr(s["tile_used"]),
-                                 _ptr(s["ckpt"]), _ptr(render_colors), _ptr(render_alphas),
+                                 s["n_buckets"], _ptr(s["qlist"]), _ptr(s["qcnt"]), _ptr(s["unit_counter"]),
+                                 _ptr(s["unit_desc"]), _ptr(s["ckpt"]), _ptr(render_colors), _ptr(render_alphas),
                                  _ptr(v_rc), _ptr(v_ra), _ptr(rows)), "gs_blend_bwd"))
         v_means = torch.empty((N, 3), **f32)
         v_quats = torch.empty((N, 4), **f32)
@@ -206,7 +210,7 @@ class _Rasterize(torch.autograd.Function):
                                    s["per_cam"], _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
                                    cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
                                    _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
-                                   _ptr(rows), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
+                                   _ptr(rows), _ptr(s["qmask"]), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
                                    _ptr(v_colors), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp)), "gs_project_bwd"))
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp, rows=rows)

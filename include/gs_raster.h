@@ -89,42 +89,53 @@ int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, con
                      int32_t* flatten_ids, int32_t* slots);
 
 /* B-fwd (replaces gsplat rasterize_to_pixels forward).  backgrounds[C,3] may be NULL.
- * Outputs render_colors[C,H,W,3], render_alphas[C,H,W,1], tile_used[C*tiles] i32 (buckets actually
- * walked before every pixel of the tile saturated).  When ckpt != NULL (training) also writes
- * ckpt[n_buckets*256*4] (per bucket, per pixel: transmittance T -- negative once the pixel is
- * saturated or outside the image -- and accumulated rgb at the bucket's start) and
- * bucket_tile[n_buckets]. */
+ * Outputs render_colors[C,H,W,3], render_alphas[C,H,W,1].  One wavefront per 16x16 tile, each
+ * lane owning one pixel of each 8x8 quadrant.  Inference: pass ckpt = NULL (and NULL for every
+ * list output).  Training (ckpt != NULL) additionally emits what gs_blend_bwd consumes:
+ *   qlist[4*I] i32      per tile four compacted, depth-ordered quadrant sublists (sublist k of tile
+ *                       t lives at 4*lo_t + k*len_t; entries are indices into the sorted lists)
+ *   qcnt[C*tiles*4]     sublist lengths
+ *   ckpt[4*n_buckets*64*4] f32  per 64-entry quadrant bucket: the quadrant's 64 pixel states
+ *                       (T -- negative once saturated / outside the image -- and accumulated rgb)
+ *   qmask[I] u8         by gradient-row slot: which quadrant rows of an intersection exist
+ *   unit_counter[1], unit_desc[4*n_buckets*2] i32   work units (tile*4+quadrant, bucket) */
 int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                  const float* backgrounds, const int32_t* isect_offsets,
-                 const int32_t* bucket_offsets, const int32_t* flatten_ids, float* render_colors,
-                 float* render_alphas, int32_t* tile_used, float* ckpt, int32_t* bucket_tile);
+                 const int32_t* bucket_offsets, const int32_t* flatten_ids, const int32_t* slots,
+                 int64_t n_isects, float* render_colors, float* render_alphas, float* ckpt,
+                 int32_t* qlist, int32_t* qcnt, uint8_t* qmask, int32_t* unit_counter,
+                 int32_t* unit_desc);
 
-/* B-bwd (replaces rasterize_to_pixels backward incl. absgrad).  One wavefront per bucket; writes
- * one 12-float row per intersection at rows[slots[i]*12]:
- * (v_mx, v_my, |v_mx|, |v_my|, v_A, v_B, v_C, v_opacity, v_r, v_g, v_b, 0).  No atomics.
+/* B-bwd (replaces rasterize_to_pixels backward incl. absgrad).  Gaussian-parallel: four 16-lane
+ * systolic pipelines per wavefront, one 64-entry quadrant bucket each; no atomics.  Writes one
+ * 12-float row per (intersection, quadrant) at rows[(slots[i]*4 + quadrant)*12]:
+ * (v_mx, v_my, |v_mx|, |v_my|, v_A, v_B, v_C, v_opacity, v_r, v_g, v_b, 0); rows[I*4*12].
  * v_render_alphas may be NULL. */
 int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
                  const int32_t* isect_offsets, const int32_t* bucket_offsets,
                  const int32_t* flatten_ids, const int32_t* slots, int64_t n_buckets,
-                 const int32_t* bucket_tile, const int32_t* tile_used, const float* ckpt,
-                 const float* render_colors, const float* render_alphas,
-                 const float* v_render_colors, const float* v_render_alphas, float* rows);
+                 const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_counter,
+                 const int32_t* unit_desc, const float* ckpt, const float* render_colors,
+                 const float* render_alphas, const float* v_render_colors,
+                 const float* v_render_alphas, float* rows);
 
 /* Row reduction + SH-bwd + P-bwd fused (replaces the atomics of the blend backward,
  * spherical_harmonics backward and fully_fused_projection backward).  Sums each Gaussian's rows
- * [cum_tiles[f], cum_tiles[f]+tiles_per_gauss[f]) and pushes the result through the colour and
- * projection VJPs.  Outputs (all fully written): v_means[N,3], v_quats[N,4], v_scales[N,3],
- * v_opacities[N], v_colors: v_shs[N,K,3] (sh_degree>=0) or v_colors[N,3]/[C,N,3];
- * v_means2d_abs[C,N,2] (the `.absgrad` side channel, /root/reference/model/gaussian.py:191).
+ * (slots [cum_tiles[f], cum_tiles[f]+tiles_per_gauss[f]), the quadrant rows qmask marks) and
+ * pushes the result through the colour and projection VJPs.  Outputs (all fully written):
+ * v_means[N,3], v_quats[N,4], v_scales[N,3], v_opacities[N], v_colors: v_shs[N,K,3]
+ * (sh_degree>=0) or v_colors[N,3]/[C,N,3]; v_means2d_abs[C,N,2] (the `.absgrad` side channel,
+ * /root/reference/model/gaussian.py:191).
  * Optional (may be NULL): v_means2d[C,N,2], v_conics[C,N,3], v_colors_post[C,N,3]. */
 int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* colors_in,
                    int colors_per_camera, const float* viewmats, const float* Ks, int width,
                    int height, float eps2d, float near_plane, float far_plane,
                    const int32_t* radii, const float* colors_post, const int32_t* tiles_per_gauss,
-                   const int32_t* cum_tiles, const float* rows, float* v_means, float* v_quats,
-                   float* v_scales, float* v_opacities, float* v_colors, float* v_means2d_abs,
-                   float* v_means2d, float* v_conics, float* v_colors_post);
+                   const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
+                   float* v_means, float* v_quats, float* v_scales, float* v_opacities,
+                   float* v_colors, float* v_means2d_abs, float* v_means2d, float* v_conics,
+                   float* v_colors_post);
 
 /* ---- "next" row f-1: the loss that feeds v_render_colors ----
  * Fused L1 + (1 - SSIM) of /root/reference/model/gaussian.py:415-453 (torchmetrics SSIM:
