@@ -159,6 +159,20 @@ GS_HD void tile_rect(float mx, float my, int radius, int tile, int tw, int th, i
     y0 = (int)fminf(fmaxf(fy0, 0.f), (float)th); y1 = (int)fminf(fmaxf(fy1, 0.f), (float)th);
 }
 
+// Shrinks a tile rectangle to the tiles that contain at least one pixel centre (j + 0.5) with
+// |mx - (j+0.5)| <= ex and |my - (i+0.5)| <= ey; empties it when there is none.
+GS_HD void tile_rect_tight(float mx, float my, float ex, float ey, int W, int H, int tile, int& x0,
+                           int& x1, int& y0, int& y1) {
+    if (ex < 0.f || ey < 0.f) { x1 = x0; y1 = y0; return; }
+    const float jlo = fmaxf(ceilf(mx - ex - 0.5f), 0.f), jhi = fminf(floorf(mx + ex - 0.5f), (float)(W - 1));
+    const float ilo = fmaxf(ceilf(my - ey - 0.5f), 0.f), ihi = fminf(floorf(my + ey - 0.5f), (float)(H - 1));
+    if (jlo > jhi || ilo > ihi) { x1 = x0; y1 = y0; return; }
+    const int tx0 = (int)jlo / tile, tx1 = (int)jhi / tile + 1, ty0 = (int)ilo / tile, ty1 = (int)ihi / tile + 1;
+    x0 = x0 > tx0 ? x0 : tx0; x1 = x1 < tx1 ? x1 : tx1;
+    y0 = y0 > ty0 ? y0 : ty0; y1 = y1 < ty1 ? y1 : ty1;
+    if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; }
+}
+
 // ---------------------------------------------------------------------------------- SH
 constexpr float kC0 = 0.2820947917738781f;
 constexpr float kC1 = 0.4886025119029199f;

@@ -12,7 +12,7 @@ namespace gs {
 constexpr int kProjThreads = 256;
 
 struct ProjFwdArgs {
-    int C, K, colors_per_camera, W, H, tw, th;
+    int C, K, colors_per_camera, W, H, tw, th, tight;
     int64_t N;
     float eps2d, near_p, far_p, radius_clip;
     const float *means, *quats, *scales, *opacities, *colors_in, *viewmats, *Ks;
@@ -90,7 +90,15 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
     }
     const bool vis = s.radius > 0;
     int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-    if (vis) tile_rect(s.mx, s.my, s.radius, GS_TILE, a.tw, a.th, x0, x1, y0, y1);
+    float op = 0.f, ex = -1.f, ey = -1.f;
+    if (vis) {
+        tile_rect(s.mx, s.my, s.radius, GS_TILE, a.tw, a.th, x0, x1, y0, y1);
+        op = a.opacities[n];
+        alpha_extent(op, s.cxx, s.cyy, ex, ey);
+        // tight mode: keep only the tiles of the 3-sigma rectangle that hold a pixel centre where
+        // alpha can reach 1/255 (the blend skips every other pixel anyway: identical image)
+        if (a.tight) tile_rect_tight(s.mx, s.my, ex, ey, a.W, a.H, GS_TILE, x0, x1, y0, y1);
+    }
     const int cnt = (x1 - x0) * (y1 - y0);
     if (in_range) {
         a.radii[f] = s.radius;
@@ -124,9 +132,6 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
         a.colors_out[3 * f] = rgb[0]; a.colors_out[3 * f + 1] = rgb[1]; a.colors_out[3 * f + 2] = rgb[2];
         if (vis) {
             // blend record: conic pre-scaled so the kernels evaluate exp2(-(hA dx^2 + B dx dy + hC dy^2))
-            const float op = a.opacities[n];
-            float ex, ey;
-            alpha_extent(op, s.cxx, s.cyy, ex, ey);
             float4* r = a.rec + 3 * f;
             r[0] = make_float4(s.mx, s.my, 0.5f * kLog2e * s.A, kLog2e * s.B);
             r[1] = make_float4(0.5f * kLog2e * s.C, op, rgb[0], rgb[1]);
@@ -306,8 +311,8 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
                               const float* quats, const float* scales, const float* opacities,
                               const float* colors_in, int colors_per_camera, const float* viewmats,
                               const float* Ks, int width, int height, float eps2d, float near_plane,
-                              float far_plane, float radius_clip, int32_t* radii, float* means2d,
-                              float* depths, float* conics, float* colors_out, float* rec,
+                              float far_plane, float radius_clip, int tile_culling, int32_t* radii,
+                              float* means2d, float* depths, float* conics, float* colors_out, float* rec,
                               uint32_t* bbox, int32_t* tiles_per_gauss) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
     GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
@@ -320,6 +325,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.C = C; a.N = N; a.K = K; a.colors_per_camera = colors_per_camera; a.W = width; a.H = height;
     a.tw = (width + GS_TILE - 1) / GS_TILE; a.th = (height + GS_TILE - 1) / GS_TILE;
     a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane; a.radius_clip = radius_clip;
+    a.tight = tile_culling != 0;
     a.means = means; a.quats = quats; a.scales = scales; a.opacities = opacities; a.colors_in = colors_in;
     a.viewmats = viewmats; a.Ks = Ks; a.radii = radii; a.means2d = means2d; a.depths = depths;
     a.conics = conics; a.colors_out = colors_out; a.rec = reinterpret_cast<float4*>(rec);

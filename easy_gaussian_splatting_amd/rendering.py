@@ -103,7 +103,7 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
     tiles_per_gauss = torch.empty((C, N), **i32)
     _stage("gs_project_fwd", dev, lambda: nat.check(L.gs_project_fwd(st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
                                _ptr(colors), per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
-                               cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"], _ptr(radii),
+                               cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"], cfg["tile_culling"], _ptr(radii),
                                _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(colors_post), _ptr(rec),
                                _ptr(bbox), _ptr(tiles_per_gauss)), "gs_project_fwd"))
 
@@ -247,6 +247,7 @@ def rasterization(
     rasterize_mode: str = "classic",
     channel_chunk: int = 32,
     _debug: Optional[Dict] = None,
+    _tile_culling: str = "tight",
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize 3D Gaussians to images; same tensor signature and return value as
     `gsplat.rendering.rasterization` (gsplat 1.0.0).
@@ -257,6 +258,12 @@ def rasterization(
 
     Only the configuration the reference exercises is implemented natively; anything else raises
     `NotImplementedError` instead of silently computing something different.
+
+    `_tile_culling="tight"` (default) drops, from gsplat's 3-sigma tile rectangle of each Gaussian,
+    the tiles in which no pixel can reach alpha >= 1/255; the image, alphas, radii, means2d and all
+    gradients are unaffected, only the internal lists (`tiles_per_gauss`, `isect_ids`,
+    `flatten_ids`, `isect_offsets`) become a render-equivalent subset.  `"gsplat"` reproduces the
+    reference's lists exactly.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -306,7 +313,7 @@ def rasterization(
     bg_c = None if backgrounds is None else prep(backgrounds)
     cfg = dict(width=int(width), height=int(height), near_plane=float(near_plane),
                far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d),
-               sh_degree=sh_degree)
+               sh_degree=sh_degree, tile_culling={"gsplat": 0, "tight": 1}[_tile_culling])
     holder = _Holder(absgrad)
     holder.debug = _debug
     with torch.cuda.device(means.device):

@@ -59,13 +59,16 @@ size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h);
  * colors_out[C,N,3], rec[C*N*12] (mx, my, A*log2e/2, B*log2e | C*log2e/2, opacity, r, g |
  * b, ext_x, ext_y, 0: conic pre-scaled for exp2, opacity-aware half extents in pixels),
  * bbox[C*N*2] u32 (x0 | x1<<16, y0 | y1<<16; tile rectangle, min inclusive / max exclusive),
- * tiles_per_gauss[C,N] i32. */
+ * tiles_per_gauss[C,N] i32.
+ * tile_culling: 0 = gsplat's 3-sigma square (A.3; lists identical to the reference's), 1 = that
+ * rectangle intersected with the opacity-aware extent (tiles in which no pixel can reach
+ * alpha >= 1/255 are dropped; the rendered image and all gradients are unchanged). */
 int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* opacities,
                    const float* colors_in, int colors_per_camera, const float* viewmats,
                    const float* Ks, int width, int height, float eps2d, float near_plane,
-                   float far_plane, float radius_clip, int32_t* radii, float* means2d,
-                   float* depths, float* conics, float* colors_out, float* rec, uint32_t* bbox,
+                   float far_plane, float radius_clip, int tile_culling, int32_t* radii,
+                   float* means2d, float* depths, float* conics, float* colors_out, float* rec, uint32_t* bbox,
                    int32_t* tiles_per_gauss);
 
 /* I-count (replaces the counting half of gsplat isect_tiles + its cumsum and

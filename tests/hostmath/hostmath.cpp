@@ -67,3 +67,19 @@ int hm_backward(int C, int N, int K, int degree, const float* means, const float
     return 0;
 }
 }
+
+// opacity-aware extents + tight tile rectangle (same source the projection kernel uses)
+extern "C" int hm_extents(int n, const float* opac, const float* cxx, const float* cyy, const float* mx,
+                          const float* my, const int32_t* radius, int W, int H, int tile, float* ex, float* ey,
+                          int32_t* rect_gsplat, int32_t* rect_tight) {
+    const int tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile;
+    for (int i = 0; i < n; ++i) {
+        gs::alpha_extent(opac[i], cxx[i], cyy[i], ex[i], ey[i]);
+        int x0, x1, y0, y1;
+        gs::tile_rect(mx[i], my[i], radius[i], tile, tw, th, x0, x1, y0, y1);
+        rect_gsplat[4 * i] = x0; rect_gsplat[4 * i + 1] = x1; rect_gsplat[4 * i + 2] = y0; rect_gsplat[4 * i + 3] = y1;
+        gs::tile_rect_tight(mx[i], my[i], ex[i], ey[i], W, H, tile, x0, x1, y0, y1);
+        rect_tight[4 * i] = x0; rect_tight[4 * i + 1] = x1; rect_tight[4 * i + 2] = y0; rect_tight[4 * i + 3] = y1;
+    }
+    return 0;
+}

@@ -33,13 +33,14 @@ def to_dev(sc):
     return {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev()) for k, v in sc.items() if isinstance(v, np.ndarray) and v.dtype.kind == "f"}
 
 
-def run_hip(sc, bwd=True, seed=0, use_bg=True, dbg=None):
+def run_hip(sc, bwd=True, seed=0, use_bg=True, dbg=None, culling="gsplat"):
     from easy_gaussian_splatting_amd.rendering import rasterization
     t = to_dev(sc)
     ins = [t[k].clone().requires_grad_(bwd) for k in ("means", "quats", "scales", "opacities", "shs")]
     img, alpha, meta = rasterization(*ins, t["viewmats"], t["Ks"], int(sc["width"]), int(sc["height"]),
                                      sh_degree=int(sc["sh_degree"]), packed=False,
-                                     backgrounds=t["backgrounds"] if use_bg else None, absgrad=True, _debug=dbg)
+                                     backgrounds=t["backgrounds"] if use_bg else None, absgrad=True, _debug=dbg,
+                                     _tile_culling=culling)
     out = dict(img=img, alpha=alpha, meta=meta, ins=ins)
     if bwd:
         g = torch.Generator().manual_seed(seed)
@@ -56,7 +57,7 @@ def run_oracle(sc, use_bg=True, dtype=np.float64):
                      backgrounds=sc["backgrounds"] if use_bg else None, dtype=dtype)
 
 
-def check_forward(hip, fw, max_razor_frac=1e-2):
+def check_forward(hip, fw, max_razor_frac=1e-2, lists=True):
     meta = hip["meta"]
     radii = meta["radii"].cpu().numpy()
     mism = radii != fw["radii"]
@@ -66,8 +67,8 @@ def check_forward(hip, fw, max_razor_frac=1e-2):
     assert np.abs(meta["depths"].cpu().numpy() - fw["depths"])[same].max(initial=0) < 1e-4
     con = meta["conics"].cpu().numpy()
     assert (np.abs(con - fw["conics"]) / (np.abs(fw["conics"]) + 1e-2))[same].max(initial=0) < 2e-3
-    exact_lists = (not mism.any()) and np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), fw["tiles_per_gauss"])
-    if exact_lists:  # integer / index work must then be bit-exact
+    exact_lists = (not mism.any()) and (not lists or np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), fw["tiles_per_gauss"]))
+    if exact_lists and lists:  # integer / index work must then be bit-exact
         assert np.array_equal(meta["isect_offsets"].cpu().numpy(), fw["isect_offsets"])
         assert np.array_equal(meta["flatten_ids"].cpu().numpy(), fw["flatten_ids"])
     err = np.abs(hip["img"].detach().cpu().numpy() - fw["render_colors"]).max(-1)
@@ -106,12 +107,26 @@ SCENES = {
 }
 
 
+@pytest.mark.parametrize("culling", ["gsplat", "tight"])
 @pytest.mark.parametrize("name", list(SCENES))
-def test_forward_backward_parity_small(name):
+def test_forward_backward_parity_small(name, culling):
     sc = make_scene(**SCENES[name])
-    hip, fw = run_hip(sc), run_oracle(sc)
-    check_forward(hip, fw)
+    hip, fw = run_hip(sc, culling=culling), run_oracle(sc)
+    check_forward(hip, fw, lists=culling == "gsplat")
     check_backward(hip, fw)
+
+
+def test_tight_culling_is_render_equivalent_subset():
+    """Default tight tile culling: lists are a subset of gsplat's, image and gradients identical."""
+    sc = make_scene(6000, 200, 150, sh_degree=1, seed=31, k_store=4, scale_range=(0.01, 0.3), dist=4.0)
+    sc["opacities"] = np.random.default_rng(5).uniform(0.002, 1.0, 6000).astype(np.float32)  # some below 1/255
+    a, b = run_hip(sc, culling="gsplat"), run_hip(sc, culling="tight")
+    ta, tb = a["meta"]["tiles_per_gauss"], b["meta"]["tiles_per_gauss"]
+    assert bool((tb <= ta).all()) and int(tb.sum()) < int(ta.sum())
+    assert torch.equal(a["meta"]["radii"], b["meta"]["radii"]) and torch.equal(a["meta"]["means2d"], b["meta"]["means2d"])
+    assert torch.equal(a["img"], b["img"]) and torch.equal(a["alpha"], b["alpha"]), "bitwise identical image"
+    for ga, gb in zip(a["grads"], b["grads"]):
+        assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max())
 
 
 def test_config_s1_parity():
@@ -171,7 +186,7 @@ def test_golden_fixtures(tag):
     t = to_dev(sc)
     ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
     img, alpha, meta = rasterization(*ins, t["viewmats"], t["Ks"], sc["width"], sc["height"], sh_degree=sc["sh_degree"],
-                                     packed=False, backgrounds=t["backgrounds"], absgrad=True)
+                                     packed=False, backgrounds=t["backgrounds"], absgrad=True, _tile_culling="gsplat")
     for k in ("radii", "tiles_per_gauss", "flatten_ids", "isect_offsets"):
         assert np.array_equal(meta[k].cpu().numpy(), z[k]), k
     assert np.array_equal(meta["isect_ids"].cpu().numpy() >> 32, z["isect_ids"] >> 32)  # camera|tile part
@@ -236,7 +251,7 @@ def test_depth_ties_break_by_index():
     V = torch.eye(4, device=d)[None]; K = torch.tensor([[40.0, 0, 8], [0, 40.0, 8], [0, 0, 1]], device=d)[None]
     img, alpha, meta = rasterization(means, torch.ones(n, 4, device=d), torch.full((n, 3), 0.05, device=d),
                                      torch.full((n,), 0.1, device=d), torch.rand(n, 3, device=d), V, K, 16, 16,
-                                     sh_degree=None, packed=False)
+                                     sh_degree=None, packed=False, _tile_culling="gsplat")
     ids = meta["flatten_ids"].cpu().numpy()
     assert len(ids) == n and np.array_equal(ids, np.arange(n))
 

@@ -65,3 +65,39 @@ def test_projection_sh_forward_and_vjp(hm, deg, C, K):
                    _p(f32(vc)), _p(h_means), _p(h_quats), _p(h_scales), _p(h_shs))
     for name, a, b in (("means", h_means, v_means), ("quats", h_quats, v_quats), ("scales", h_scales, v_scales), ("shs", h_shs, v_shs)):
         assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max(), name  # north_star: grads within 1e-3 rel
+
+
+def test_opacity_aware_extent_is_conservative(hm):
+    """Every pixel the blend could accept (alpha >= 1/255, evaluated in fp64) lies inside the
+    extent box, and inside a tile the tight rectangle keeps."""
+    rng = np.random.default_rng(3)
+    n, W, H = 400, 160, 120
+    mx, my = rng.uniform(-10, W + 10, n), rng.uniform(-10, H + 10, n)
+    sx, sy = rng.uniform(0.6, 12, n), rng.uniform(0.6, 12, n)
+    rho = rng.uniform(-0.95, 0.95, n)
+    cxx, cyy, cxy = sx * sx, sy * sy, rho * sx * sy
+    opac = np.concatenate([rng.uniform(0.0, 0.01, n // 4), rng.uniform(0.01, 1.0, n - n // 4)])
+    det = cxx * cyy - cxy * cxy
+    A, B, Cc = cyy / det, -cxy / det, cxx / det
+    lam = 0.5 * (cxx + cyy) + np.sqrt(np.maximum(0.01, (0.5 * (cxx + cyy)) ** 2 - det))
+    radius = np.ceil(3 * np.sqrt(lam)).astype(np.int32)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    ex, ey = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    rg, rt = np.zeros((n, 4), np.int32), np.zeros((n, 4), np.int32)
+    hm.hm_extents(n, _p(f32(opac)), _p(f32(cxx)), _p(f32(cyy)), _p(f32(mx)), _p(f32(my)), _p(radius), W, H, 16,
+                  _p(ex), _p(ey), _p(rg), _p(rt))
+    jj, ii = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)
+    checked = 0
+    for g in range(n):
+        dx, dy = mx[g] - jj, my[g] - ii
+        sigma = 0.5 * (A[g] * dx * dx + Cc[g] * dy * dy) + B[g] * dx * dy
+        hit = opac[g] * np.exp(-sigma) >= (1 / 255.0) * (1 - 1e-6)
+        # restrict to gsplat's own tile rectangle (what the reference would list at all)
+        tx, ty = (jj // 16).astype(int), (ii // 16).astype(int)
+        hit &= (tx >= rg[g, 0]) & (tx < rg[g, 1]) & (ty >= rg[g, 2]) & (ty < rg[g, 3])
+        assert rt[g, 0] >= rg[g, 0] and rt[g, 1] <= rg[g, 1] and rt[g, 2] >= rg[g, 2] and rt[g, 3] <= rg[g, 3]
+        if hit.any():
+            checked += 1
+            assert np.abs(dx[hit]).max() <= ex[g] and np.abs(dy[hit]).max() <= ey[g]
+            assert ((tx[hit] >= rt[g, 0]) & (tx[hit] < rt[g, 1]) & (ty[hit] >= rt[g, 2]) & (ty[hit] < rt[g, 3])).all()
+    assert checked > n // 3
