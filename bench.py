@@ -51,6 +51,18 @@ def build_workload(n_gauss: int, n_views: int, device):
     return sc, model
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
+    command (profiles/r01_pmc_traffic.json, produced by tools/pmc_summary.py with the gfx950
+    FETCH_SIZE x2 correction of MI355X_MICROARCH.md); None when no such profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("traffic_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(sc, sample_n: int):
     """Oracle (C + OpenMP, all host cores) on the first `sample_n` Gaussians of the same workload:
     one rasterization forward + backward.  Reported baseline only."""
@@ -162,16 +174,25 @@ def main():
                                                  data["w2c"][None], data["K"][None], W, H,
                                                  sh_degree=model.active_sh_degree, packed=False,
                                                  backgrounds=model.BACKGROUND[None], absgrad=True)
+            _, _, meta_ref = rendering.rasterization(model.means, model.quats, model.scales, model.opacities, model.shs,
+                                                     data["w2c"][None], data["K"][None], W, H,
+                                                     sh_degree=model.active_sh_degree, packed=False,
+                                                     backgrounds=model.BACKGROUND[None], _tile_culling="gsplat")
         n_isects = int(meta["flatten_ids"].shape[0])
+        # I of the reference's own lists (gsplat's 3-sigma rectangles): the unit SURVEY.md 8d's
+        # byte model counts; the default tight culling walks a render-equivalent subset of it
+        n_isects_ref = int(meta_ref["flatten_ids"].shape[0])
         n_vis = int((meta["radii"] > 0).sum().item())
         # algorithmic bytes per launch: SURVEY.md section 8d
-        alg = {"gs_blend_fwd": 40 * n_isects + 20 * H * W, "gs_blend_bwd": 40 * n_isects + 24 * H * W + 88 * n_isects}
+        alg = {"gs_blend_fwd": 40 * n_isects_ref + 20 * H * W,
+               "gs_blend_bwd": 40 * n_isects_ref + 24 * H * W + 88 * n_isects_ref}
         dom = max(alg, key=lambda k: stage_ms.get(k, 0.0))
         t_ms = stage_ms.get(dom, float("nan"))
         achieved = alg[dom] / (t_ms * 1e-3) / 1e9 if t_ms == t_ms and t_ms > 0 else None
         roofline = {"bound": "hbm", "kernel": {"gs_blend_fwd": "blend_fwd_kernel", "gs_blend_bwd": "blend_bwd_kernel"}[dom],
                     "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": pmc_traffic(roof_kernel := {"gs_blend_fwd": "blend_fwd_kernel", "gs_blend_bwd": "blend_bwd_kernel"}[dom]),
                     "algorithmic_bytes": alg[dom], "avg_launch_ms": None if t_ms != t_ms else round(t_ms, 4)}
         result = {
             "metric": "train iters/sec + forward render fps, 1M Gaussians @ 1080p",
@@ -184,7 +205,8 @@ def main():
             "forward_ms": round(1e3 * fwd_elapsed / args.steps, 4),
             "config": {"workload": f"{args.gaussians} Gaussians, {W}x{H}, SH degree {sc['sh_degree']}, "
                                    "1 view per GPU per step, full train step (fwd + L1/SSIM + bwd + stats + Adam)",
-                       "n_visible": n_vis, "n_isects": n_isects, "parallelism": f"view-dp{world}"},
+                       "n_visible": n_vis, "n_isects": n_isects, "n_isects_gsplat_lists": n_isects_ref,
+                       "parallelism": f"view-dp{world}"},
             "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
             "roofline": roofline,
         }
