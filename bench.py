@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=250_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -99,12 +99,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        # "nccl" is RCCL on ROCm.  GS_BENCH_BACKEND=gloo only exists to exercise this code path with
+        # several ranks on a 1-GPU box (RCCL refuses two ranks on one device); never used for numbers.
+        backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     n_views = max(8, world)
     sc, model = build_workload(args.gaussians, n_views, device)

@@ -44,7 +44,7 @@ struct BlendFwdArgs {
     float *out_colors, *out_alphas;
     // training-mode outputs
     float4* ckpt;          // [4*n_buckets][64]  quadrant-bucket checkpoints
-    int32_t* qlist;        // [4*I]              per tile: 4 sublists of capacity len(tile)
+    int2* qlist;           // [4*I] (flatten id, row slot): per tile 4 sublists of capacity len(tile)
     int32_t* qcnt;         // [C*tiles*4]        sublist lengths
     uint8_t* qmask;        // [I] by slot        which quadrant rows of an intersection exist
     int32_t* unit_counter; // [1]
@@ -106,8 +106,11 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
         const int first = lo + b * GS_BUCKET;
         const int m = min(GS_BUCKET, hi - first);
         bool hx[2] = {false, false}, hy[2] = {false, false};
+        int my_gid = 0, my_slot = 0;
         if (lane < m) {
-            const float4* r = a.rec + 3 * (size_t)a.flatten_ids[first + lane];
+            my_gid = a.flatten_ids[first + lane];
+            if (CKPT) my_slot = a.slots[first + lane];
+            const float4* r = a.rec + 3 * (size_t)my_gid;
             const float4 q0 = r[0], q1 = r[1], q2 = r[2];
             srec[lane * 3] = q0; srec[lane * 3 + 1] = q1; srec[lane * 3 + 2] = q2;
             const float ex = q2.y, ey = q2.z;   // negative when alpha can never reach 1/255
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
             for (int k = 0; k < 4; ++k) {
                 const int rank = __popcll(mq[k] & lt_mask);
                 if (bit[k]) {
-                    a.qlist[(size_t)4 * lo + (size_t)k * len + cnt[k] + rank] = first + lane;
+                    a.qlist[(size_t)4 * lo + (size_t)k * len + cnt[k] + rank] = make_int2(my_gid, my_slot);
                     mybits |= 1 << k;
                 }
                 // the sublist entry that opens a new 64-entry quadrant bucket (at most one per bucket)
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
                 const unsigned long long bs = __ballot(bit[k] && rank == need);
                 if (bs) { jstar[k] = __builtin_ctzll(bs); kbstar[k] = (cnt[k] + need) / GS_BUCKET; }
             }
-            if (lane < m) a.qmask[a.slots[first + lane]] = (uint8_t)mybits;
+            if (lane < m) a.qmask[my_slot] = (uint8_t)mybits;
         }
         __syncthreads();
         for (unsigned long long rem = mq[0] | mq[1] | mq[2] | mq[3]; rem; rem &= rem - 1) {
@@ -199,8 +202,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
 struct BlendBwdArgs {
     int C, W, H, tw, tiles;
     const float4* rec;
-    const int32_t *isect_offsets, *bucket_offsets, *flatten_ids, *slots, *qlist, *qcnt, *unit_counter;
-    const int2* unit_desc;
+    const int32_t *isect_offsets, *bucket_offsets, *qcnt, *unit_counter;
+    const int2 *qlist, *unit_desc;
     const float4* ckpt;
     const float *out_colors, *out_alphas, *v_colors, *v_alphas;
     float4* rows;   // [I*4][3]
@@ -216,11 +219,9 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
 }
 
-struct PixRec {   // 48 B per pixel in LDS
+struct PixRec {   // 32 B per pixel in LDS (+ 8 B pixel centre in a second array)
     float4 d0;    // v_r, v_g, v_b, E
     float4 ck;    // checkpoint T, r, g, b
-    float2 d1;    // pixel centre
-    float2 pad;
 };
 
 struct EntryState {
@@ -258,7 +259,8 @@ __device__ __forceinline__ void bwd_pair(EntryState& e, const bool act, const fl
 }
 
 __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBwdArgs a) {
-    __shared__ PixRec spix_all[kBwdWaves][4][64];   // 12 KB per wave
+    __shared__ PixRec spix_all[kBwdWaves][4][64];   // 8 KB per wave
+    __shared__ float2 sctr_all[kBwdWaves][4][64];   // 2 KB per wave: pixel centres
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane >> 4, r = lane & (kRowLanes - 1);
     const int n_units = a.unit_counter[0];
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
     if (((int)blockIdx.x * kBwdWaves + wave) * 4 >= n_units) return;   // wave-uniform
     const bool valid = unit < n_units;
     PixRec* spix = spix_all[wave][row];
+    float2* sctr = sctr_all[wave][row];
 
     int tq = 0, kb = 0;
     if (valid) { const int2 d = a.unit_desc[unit]; tq = d.x; kb = d.y; }
@@ -286,8 +289,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         PixRec pr;
         pr.d0 = make_float4(0.f, 0.f, 0.f, 0.f);
         pr.ck = make_float4(-1.f, 0.f, 0.f, 0.f);
-        pr.d1 = make_float2((float)px + 0.5f, (float)py + 0.5f);
-        pr.pad = make_float2(0.f, 0.f);
+        sctr[p] = make_float2((float)px + 0.5f, (float)py + 0.5f);
         if (valid && px < a.W && py < a.H) {
             const size_t o = ((size_t)cam * a.H + py) * a.W + px;
             const float vr = a.v_colors[3 * o], vg = a.v_colors[3 * o + 1], vb = a.v_colors[3 * o + 2];
@@ -310,9 +312,9 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         slot[i] = 0;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
         if (e[i].has) {
-            const int idx = a.qlist[(size_t)4 * lo + (size_t)q * len + kb * GS_BUCKET + en];
-            slot[i] = a.slots[idx];
-            const float4* rp = a.rec + 3 * (size_t)a.flatten_ids[idx];
+            const int2 gs = a.qlist[(size_t)4 * lo + (size_t)q * len + kb * GS_BUCKET + en];
+            slot[i] = gs.y;
+            const float4* rp = a.rec + 3 * (size_t)gs.x;
             q0 = rp[0]; q1 = rp[1]; q2 = rp[2];
         }
         e[i].mx = q0.x; e[i].my = q0.y; e[i].hA = q0.z; e[i].Bc = q0.w; e[i].hC = q1.x; e[i].op = q1.y;
@@ -329,9 +331,9 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         float T = dpp_row_shr1(T_out), P = dpp_row_shr1(P_out);
         const int p = s - r;
         const bool act = (unsigned)p < 64u;
-        const PixRec* pp = spix + min(max(p, 0), 63);
-        const float4 d0 = pp->d0, ck = pp->ck;
-        const float2 d1 = pp->d1;
+        const int pc = min(max(p, 0), 63);
+        const float4 d0 = spix[pc].d0, ck = spix[pc].ck;
+        const float2 d1 = sctr[pc];
         if (r == 0) { T = ck.x; P = ck.y * d0.x + ck.z * d0.y + ck.w * d0.z; }
 #pragma unroll
         for (int i = 0; i < kPerLane; ++i) bwd_pair(e[i], act, d0, d1, T, P);
@@ -372,7 +374,7 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     a.rec = reinterpret_cast<const float4*>(rec); a.bg = backgrounds; a.isect_offsets = isect_offsets;
     a.bucket_offsets = bucket_offsets; a.flatten_ids = flatten_ids; a.slots = slots;
     a.out_colors = render_colors; a.out_alphas = render_alphas;
-    a.ckpt = reinterpret_cast<float4*>(ckpt); a.qlist = qlist; a.qcnt = qcnt; a.qmask = qmask;
+    a.ckpt = reinterpret_cast<float4*>(ckpt); a.qlist = reinterpret_cast<int2*>(qlist); a.qcnt = qcnt; a.qmask = qmask;
     a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int2*>(unit_desc);
     const unsigned grid = (unsigned)(C * a.tiles);
     hipStream_t st = (hipStream_t)stream;
@@ -389,22 +391,22 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
 
 extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
                             const int32_t* isect_offsets, const int32_t* bucket_offsets,
-                            const int32_t* flatten_ids, const int32_t* slots, int64_t n_buckets,
+                            int64_t n_buckets,
                             const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_counter,
                             const int32_t* unit_desc, const float* ckpt, const float* render_colors,
                             const float* render_alphas, const float* v_render_colors,
                             const float* v_render_alphas, float* rows) {
     GS_REQUIRE(C >= 1 && width > 0 && height > 0 && n_buckets >= 0, "C>=1, positive image size, n_buckets>=0");
     if (n_buckets == 0) return GS_OK;
-    GS_REQUIRE(rec && isect_offsets && bucket_offsets && flatten_ids && slots && qlist && qcnt && unit_counter && unit_desc && ckpt, "null list pointer");
+    GS_REQUIRE(rec && isect_offsets && bucket_offsets && qlist && qcnt && unit_counter && unit_desc && ckpt, "null list pointer");
     GS_REQUIRE(render_colors && render_alphas && v_render_colors && rows, "null image pointer");
     BlendBwdArgs a;
     a.C = C; a.W = width; a.H = height;
     a.tw = (width + GS_TILE - 1) / GS_TILE;
     a.tiles = a.tw * ((height + GS_TILE - 1) / GS_TILE);
     a.rec = reinterpret_cast<const float4*>(rec);
-    a.isect_offsets = isect_offsets; a.bucket_offsets = bucket_offsets; a.flatten_ids = flatten_ids;
-    a.slots = slots; a.qlist = qlist; a.qcnt = qcnt; a.unit_counter = unit_counter;
+    a.isect_offsets = isect_offsets; a.bucket_offsets = bucket_offsets;
+    a.qlist = reinterpret_cast<const int2*>(qlist); a.qcnt = qcnt; a.unit_counter = unit_counter;
     a.unit_desc = reinterpret_cast<const int2*>(unit_desc);
     a.ckpt = reinterpret_cast<const float4*>(ckpt); a.out_colors = render_colors;
     a.out_alphas = render_alphas; a.v_colors = v_render_colors; a.v_alphas = v_render_alphas;

@@ -134,7 +134,7 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
     if need_grad:  # what the Gaussian-parallel backward consumes (see include/gs_raster.h)
         nbk = max(n_buckets, 1)
         ckpt = torch.empty((4 * nbk, 64, 4), **f32)
-        qlist = torch.empty((4 * cap,), **i32)
+        qlist = torch.empty((4 * cap, 2), **i32)
         qcnt = torch.empty((C * tiles * 4,), **i32)
         qmask = torch.empty((cap,), dtype=torch.uint8, device=dev)
         unit_counter = torch.empty((1,), **i32)
@@ -190,8 +190,7 @@ class _Rasterize(torch.autograd.Function):
         v_ra = None if v_render_alphas is None else v_render_alphas.contiguous()
         rows = torch.empty((max(s["n_isects"], 1) * 4, nat.GS_ROW_FLOATS), **f32)
         _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, _ptr(s["rec"]), _ptr(s["isect_offsets"]),
-                                 _ptr(s["bucket_offsets"]), _ptr(s["flatten_ids"]), _ptr(s["slots"]),
-                                 s["n_buckets"], _ptr(s["qlist"]), _ptr(s["qcnt"]), _ptr(s["unit_counter"]),
+                                 _ptr(s["bucket_offsets"]), s["n_buckets"], _ptr(s["qlist"]), _ptr(s["qcnt"]), _ptr(s["unit_counter"]),
                                  _ptr(s["unit_desc"]), _ptr(s["ckpt"]), _ptr(render_colors), _ptr(render_alphas),
                                  _ptr(v_rc), _ptr(v_ra), _ptr(rows)), "gs_blend_bwd"))
         v_means = torch.empty((N, 3), **f32)

@@ -95,8 +95,8 @@ int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, con
  * Outputs render_colors[C,H,W,3], render_alphas[C,H,W,1].  One wavefront per 16x16 tile, each
  * lane owning one pixel of each 8x8 quadrant.  Inference: pass ckpt = NULL (and NULL for every
  * list output).  Training (ckpt != NULL) additionally emits what gs_blend_bwd consumes:
- *   qlist[4*I] i32      per tile four compacted, depth-ordered quadrant sublists (sublist k of tile
- *                       t lives at 4*lo_t + k*len_t; entries are indices into the sorted lists)
+ *   qlist[4*I*2] i32    per tile four compacted, depth-ordered quadrant sublists of (flatten id,
+ *                       gradient-row slot) pairs (sublist k of tile t starts at pair 4*lo_t + k*len_t)
  *   qcnt[C*tiles*4]     sublist lengths
  *   ckpt[4*n_buckets*64*4] f32  per 64-entry quadrant bucket: the quadrant's 64 pixel states
  *                       (T -- negative once saturated / outside the image -- and accumulated rgb)
@@ -115,8 +115,7 @@ int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
  * (v_mx, v_my, |v_mx|, |v_my|, v_A, v_B, v_C, v_opacity, v_r, v_g, v_b, 0); rows[I*4*12].
  * v_render_alphas may be NULL. */
 int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
-                 const int32_t* isect_offsets, const int32_t* bucket_offsets,
-                 const int32_t* flatten_ids, const int32_t* slots, int64_t n_buckets,
+                 const int32_t* isect_offsets, const int32_t* bucket_offsets, int64_t n_buckets,
                  const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_counter,
                  const int32_t* unit_desc, const float* ckpt, const float* render_colors,
                  const float* render_alphas, const float* v_render_colors,
