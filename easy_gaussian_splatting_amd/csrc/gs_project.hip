@@ -15,7 +15,7 @@ struct ProjFwdArgs {
     int C, K, colors_per_camera, W, H, tw, th, tight;
     int64_t N;
     float eps2d, near_p, far_p, radius_clip;
-    const float *means, *quats, *scales, *opacities, *colors_in, *viewmats, *Ks;
+    const float *means, *quats, *scales, *opacities, *colors_in, *sh_rest, *viewmats, *Ks;
     int32_t* radii;
     float *means2d, *depths, *conics, *colors_out;
     float4* rec;
@@ -59,6 +59,46 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int
         for (int e = threadIdx.x; e < rows * ka3; e += blockDim.x) {
             const int g = e / ka3, o = e - g * ka3;
             if (vis[g]) tile[g * stride + o] = src[(int64_t)g * row_f + o];
+        }
+    }
+}
+
+// Split parameter layout of the reference model (sh_0[N,1,3] and sh_rest[N,K-1,3] are separate
+// nn.Parameters, /root/reference/model/gaussian.py:49-50, concatenated on every forward at :105-107):
+// staging straight from the two tensors removes that cat (and the split of its gradient).
+__device__ __forceinline__ void stage_sh_rows_split(const float* __restrict__ sh0, const float* __restrict__ shr,
+                                                    int64_t n0, int rows, int K, int ka3, const int* vis, float* tile) {
+    const int row_f = 3 * K, stride = row_f + 1, rest_f = row_f - 3, kr = ka3 - 3;
+    for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
+        const int g = e / 3;
+        if (vis[g]) tile[g * stride + (e - 3 * g)] = sh0[n0 * 3 + e];
+    }
+    if (kr <= 0) return;
+    const float* src = shr + n0 * rest_f;
+    const int total = rows * rest_f;
+    if (kr == rest_f) {  // whole rows needed: one contiguous, 16-byte aligned stream for the block
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        for (int e4 = threadIdx.x; e4 < (total >> 2); e4 += blockDim.x) {
+            const int e = e4 << 2;
+            const int g0 = e / rest_f, g1 = (e + 3) / rest_f;
+            if (vis[g0] || vis[g1]) {
+                const float4 v = src4[e4];
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int g = (e + i) / rest_f, o = (e + i) - g * rest_f;
+                    if (vis[g]) tile[g * stride + 3 + o] = vv[i];
+                }
+            }
+        }
+        for (int e = (total & ~3) + threadIdx.x; e < total; e += blockDim.x) {
+            const int g = e / rest_f, o = e - g * rest_f;
+            if (vis[g]) tile[g * stride + 3 + o] = src[e];
+        }
+    } else {
+        for (int e = threadIdx.x; e < rows * kr; e += blockDim.x) {
+            const int g = e / kr, o = e - g * kr;
+            if (vis[g]) tile[g * stride + 3 + o] = src[(int64_t)g * rest_f + o];
         }
     }
 }
@@ -116,7 +156,8 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
         if (any_vis) {
             const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
             constexpr int ka3 = 3 * (DEG + 1) * (DEG + 1);
-            stage_sh_rows(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+            if (a.sh_rest) stage_sh_rows_split(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);
+            else stage_sh_rows(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
             __syncthreads();
             if (vis) {
                 float ux, uy, uz;
@@ -145,11 +186,11 @@ struct ProjBwdArgs {
     int C, cam, K, colors_per_camera, W, H, accumulate;
     int64_t N;
     float eps2d, near_p, far_p;
-    const float *means, *quats, *scales, *colors_in, *viewmats, *Ks, *colors_post;
+    const float *means, *quats, *scales, *colors_in, *sh_rest, *viewmats, *Ks, *colors_post;
     const int32_t *radii, *tiles_per_gauss, *cum_tiles;
     const float4* rows;      // [I*4][3]: one row per (intersection slot, tile quadrant)
     const uint8_t* qmask;    // [I] by slot: which of the four quadrant rows exist
-    float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_means2d_abs, *v_means2d,
+    float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_sh_rest, *v_means2d_abs, *v_means2d,
         *v_conics, *v_colors_post;
 };
 
@@ -226,7 +267,8 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         vis_s[threadIdx.x] = vis ? 1 : 0;
         __syncthreads();
         const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
-        stage_sh_rows(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+        if (a.sh_rest) stage_sh_rows_split(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);
+        else stage_sh_rows(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
         __syncthreads();
         float* my = tile + threadIdx.x * stride;
         if (vis) {
@@ -240,6 +282,35 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         }
         __syncthreads();
         // dense write-out of v_shs[n0 : n0+rows, :, :]
+        if (a.v_sh_rest) {  // split layout: v_sh_0[N,1,3] and v_sh_rest[N,K-1,3]
+            const int rest_f = row_f - 3, total = rows * rest_f;
+            float* d0 = a.v_colors + n0 * 3;
+            for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
+                const int g = e / 3;
+                float v = tile[g * stride + (e - 3 * g)];
+                if (a.accumulate) v += d0[e];
+                d0[e] = v;
+            }
+            float* dr = a.v_sh_rest + n0 * rest_f;
+            float4* dr4 = reinterpret_cast<float4*>(dr);
+            for (int e4 = threadIdx.x; e4 < (total >> 2); e4 += blockDim.x) {
+                float vv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = (e4 << 2) + i, g = e / rest_f;
+                    vv[i] = tile[g * stride + 3 + (e - g * rest_f)];
+                }
+                float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                if (a.accumulate) { const float4 o = dr4[e4]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                dr4[e4] = v;
+            }
+            for (int e = (total & ~3) + threadIdx.x; e < total; e += blockDim.x) {
+                const int g = e / rest_f;
+                float v = tile[g * stride + 3 + (e - g * rest_f)];
+                if (a.accumulate) v += dr[e];
+                dr[e] = v;
+            }
+        } else {
         float* dst = a.v_colors + n0 * row_f;
         if ((row_f & 3) == 0) {
             const int per_row = row_f >> 2;
@@ -258,6 +329,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
                 if (a.accumulate) v += dst[e];
                 dst[e] = v;
             }
+        }
         }
     } else if (in_range) {
         if (a.colors_per_camera) {
@@ -309,9 +381,10 @@ using namespace gs;
 
 extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                               const float* quats, const float* scales, const float* opacities,
-                              const float* colors_in, int colors_per_camera, const float* viewmats,
-                              const float* Ks, int width, int height, float eps2d, float near_plane,
-                              float far_plane, float radius_clip, int tile_culling, int32_t* radii,
+                              const float* colors_in, const float* sh_rest, int colors_per_camera,
+                              const float* viewmats, const float* Ks, int width, int height,
+                              float eps2d, float near_plane, float far_plane, float radius_clip,
+                              int tile_culling, int32_t* radii,
                               float* means2d, float* depths, float* conics, float* colors_out, float* rec,
                               uint32_t* bbox, int32_t* tiles_per_gauss) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
@@ -327,6 +400,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane; a.radius_clip = radius_clip;
     a.tight = tile_culling != 0;
     a.means = means; a.quats = quats; a.scales = scales; a.opacities = opacities; a.colors_in = colors_in;
+    a.sh_rest = sh_degree >= 0 ? sh_rest : nullptr;
     a.viewmats = viewmats; a.Ks = Ks; a.radii = radii; a.means2d = means2d; a.depths = depths;
     a.conics = conics; a.colors_out = colors_out; a.rec = reinterpret_cast<float4*>(rec);
     a.bbox = reinterpret_cast<uint2*>(bbox); a.tiles_per_gauss = tiles_per_gauss;
@@ -346,12 +420,13 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
 
 extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                               const float* quats, const float* scales, const float* colors_in,
-                              int colors_per_camera, const float* viewmats, const float* Ks, int width,
+                              const float* sh_rest, int colors_per_camera, const float* viewmats,
+                              const float* Ks, int width,
                               int height, float eps2d, float near_plane, float far_plane,
                               const int32_t* radii, const float* colors_post,
                               const int32_t* tiles_per_gauss, const int32_t* cum_tiles,
                               const float* rows, const uint8_t* qmask, float* v_means, float* v_quats, float* v_scales,
-                              float* v_opacities, float* v_colors, float* v_means2d_abs,
+                              float* v_opacities, float* v_colors, float* v_sh_rest, float* v_means2d_abs,
                               float* v_means2d, float* v_conics, float* v_colors_post) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
     GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
@@ -363,6 +438,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.C = C; a.N = N; a.K = K; a.colors_per_camera = colors_per_camera; a.W = width; a.H = height;
     a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
     a.means = means; a.quats = quats; a.scales = scales; a.colors_in = colors_in; a.viewmats = viewmats;
+    a.sh_rest = sh_degree >= 0 ? sh_rest : nullptr; a.v_sh_rest = a.sh_rest ? v_sh_rest : nullptr;
     a.Ks = Ks; a.colors_post = colors_post; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss;
     a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.qmask = qmask;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_opacities = v_opacities;

@@ -23,7 +23,7 @@ from .rendering import rasterization
 class GaussianModel(nn.Module):
     def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, sh_0: Tensor, sh_rest: Tensor,
                  logit_opacities: Tensor, sh_degree: int, sh_degree_interval: int = 0,
-                 white_background: bool = False):
+                 white_background: bool = False, fuse_sh_cat: bool = True):
         super().__init__()
         self.means = nn.Parameter(means.float())  # [N, 3]
         self.log_scales = nn.Parameter(log_scales.float())  # [N, 3]
@@ -37,6 +37,9 @@ class GaussianModel(nn.Module):
         self.register_buffer("max_radii", torch.zeros(n), persistent=False)
         self.optimizer: Optional[torch.optim.Optimizer] = None
         self.MAX_SH_DEGREE = sh_degree
+        # hand sh_0 / sh_rest to the rasterizer separately instead of materialising `self.shs`
+        # (saves the [N,K,3] cat and the split of its gradient every step; same values)
+        self.fuse_sh_cat = fuse_sh_cat
         self.active_sh_degree = 0 if sh_degree_interval != 0 else sh_degree
         self.BACKGROUND = nn.Parameter(torch.full((3,), 1.0 if white_background else 0.0), requires_grad=False)
 
@@ -75,7 +78,7 @@ class GaussianModel(nn.Module):
             quats=self.quats,
             scales=self.scales,
             opacities=self.opacities,
-            colors=self.shs,
+            colors=(self.sh_0, self.sh_rest) if self.fuse_sh_cat else self.shs,
             sh_degree=self.active_sh_degree,
             viewmats=w2c[None],
             Ks=data["K"][None],

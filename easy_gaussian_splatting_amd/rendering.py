@@ -74,7 +74,7 @@ class _Holder:
         self.debug: Optional[Dict] = None
 
 
-def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, cfg, need_grad):
+def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, need_grad):
     """Runs P/SH-fwd, binning, per-tile sort and B-fwd.  Returns (outputs, saved-state dict)."""
     L = nat.lib()
     dev = means.device
@@ -91,7 +91,8 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
         deg, K = -1, 0
         per_cam = 1 if colors.dim() == 3 else 0
     else:
-        deg, K, per_cam = int(sh_degree), colors.shape[1], 0
+        deg, per_cam = int(sh_degree), 0
+        K = colors.shape[1] + (0 if colors_rest is None else colors_rest.shape[1])
 
     radii = torch.empty((C, N), **i32)
     means2d = torch.empty((C, N, 2), **f32)
@@ -102,7 +103,7 @@ def _forward_stages(means, quats, scales, opacities, colors, viewmats, Ks, backg
     bbox = torch.empty((C * N, 2), **i32)
     tiles_per_gauss = torch.empty((C, N), **i32)
     _stage("gs_project_fwd", dev, lambda: nat.check(L.gs_project_fwd(st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
-                               _ptr(colors), per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
+                               _ptr(colors), _ptr(colors_rest), per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
                                cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"], cfg["tile_culling"], _ptr(radii),
                                _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(colors_post), _ptr(rec),
                                _ptr(bbox), _ptr(tiles_per_gauss)), "gs_project_fwd"))
@@ -166,20 +167,23 @@ class _Rasterize(torch.autograd.Function):
     """One autograd node for the whole path (P-fwd .. B-fwd | B-bwd .. P-bwd)."""
 
     @staticmethod
-    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, cfg, holder):
-        need_grad = any(ctx.needs_input_grad[:5])
+    def forward(ctx, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, holder):
+        need_grad = any(ctx.needs_input_grad[:6])
         render_colors, render_alphas, meta, state = _forward_stages(
-            means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, cfg, need_grad)
+            means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, need_grad)
         holder.meta = meta
         ctx.cfg, ctx.holder, ctx.state = cfg, holder, state
+        ctx.split = colors_rest is not None
         if need_grad:
-            ctx.save_for_backward(means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas)
+            extra = (colors_rest,) if ctx.split else ()
+            ctx.save_for_backward(means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas, *extra)
         return render_colors, render_alphas
 
     @staticmethod
     def backward(ctx, v_render_colors, v_render_alphas):
         L = nat.lib()
-        means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas = ctx.saved_tensors
+        means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas = ctx.saved_tensors[:8]
+        colors_rest = ctx.saved_tensors[8] if ctx.split else None
         s, cfg, holder = ctx.state, ctx.cfg, ctx.holder
         dev = means.device
         st = _stream(dev)
@@ -198,6 +202,7 @@ class _Rasterize(torch.autograd.Function):
         v_scales = torch.empty((N, 3), **f32)
         v_opac = torch.empty((N,), **f32)
         v_colors = torch.empty(colors.shape, **f32)
+        v_rest = torch.empty(colors_rest.shape, **f32) if ctx.split else None
         v_abs = torch.empty((C, N, 2), **f32)
         dbg = holder.debug
         v_m2 = v_cn = v_cp = None
@@ -206,11 +211,11 @@ class _Rasterize(torch.autograd.Function):
             v_cn = torch.empty((C, N, 3), **f32)
             v_cp = torch.empty((C, N, 3), **f32)
         _stage("gs_project_bwd", dev, lambda: nat.check(L.gs_project_bwd(st, C, N, K, s["deg"], _ptr(means), _ptr(quats), _ptr(scales), _ptr(colors),
-                                   s["per_cam"], _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
+                                   _ptr(colors_rest), s["per_cam"], _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
                                    cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
                                    _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
                                    _ptr(rows), _ptr(s["qmask"]), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
-                                   _ptr(v_colors), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp)), "gs_project_bwd"))
+                                   _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp)), "gs_project_bwd"))
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp, rows=rows)
         if holder.absgrad and holder.means2d_ref is not None:
@@ -219,7 +224,8 @@ class _Rasterize(torch.autograd.Function):
                 m2.absgrad = v_abs
         ni = ctx.needs_input_grad
         return (v_means if ni[0] else None, v_quats if ni[1] else None, v_scales if ni[2] else None,
-                v_opac if ni[3] else None, v_colors if ni[4] else None, None, None, None, None, None)
+                v_opac if ni[3] else None, v_colors if ni[4] else None, v_rest if (ctx.split and ni[5]) else None,
+                None, None, None, None, None)
 
 
 def rasterization(
@@ -227,7 +233,7 @@ def rasterization(
     quats: Tensor,  # [N, 4]  wxyz, need not be normalised
     scales: Tensor,  # [N, 3]
     opacities: Tensor,  # [N]
-    colors: Tensor,  # [N, K, 3] SH coefficients (sh_degree given) or [N, 3] / [C, N, 3]
+    colors,  # Tensor [N, K, 3] SH coefficients (sh_degree given) or [N, 3] / [C, N, 3]; or (sh_0, sh_rest)
     viewmats: Tensor,  # [C, 4, 4] world -> camera
     Ks: Tensor,  # [C, 3, 3]
     width: int,
@@ -266,6 +272,15 @@ def rasterization(
     """
     N = means.shape[0]
     C = viewmats.shape[0]
+    # Extension over gsplat: `colors=(sh_0[N,1,3], sh_rest[N,K-1,3])` hands over the reference model's
+    # two SH parameters (/root/reference/model/gaussian.py:49-50) without the per-forward torch.cat.
+    colors_rest = None
+    if isinstance(colors, (tuple, list)):
+        assert sh_degree is not None and len(colors) == 2, "a (sh_0, sh_rest) pair needs sh_degree"
+        colors, colors_rest = colors
+        assert colors.shape == (N, 1, 3) and colors_rest.dim() == 3 and colors_rest.shape[0] == N and colors_rest.shape[2] == 3
+        if colors_rest.shape[1] == 0:
+            colors_rest = None
     assert means.shape == (N, 3), means.shape
     assert quats.shape == (N, 4), quats.shape
     assert scales.shape == (N, 3), scales.shape
@@ -280,8 +295,9 @@ def rasterization(
             raise NotImplementedError("only 3-channel colours are implemented on the HIP path")
     else:
         assert colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3, colors.shape
-        assert (sh_degree + 1) ** 2 <= colors.shape[1], colors.shape
-        if sh_degree > 3 or colors.shape[1] > 16:
+        k_store = colors.shape[1] + (0 if colors_rest is None else colors_rest.shape[1])
+        assert (sh_degree + 1) ** 2 <= k_store, (colors.shape, k_store)
+        if sh_degree > 3 or k_store > 16:
             raise NotImplementedError("SH degree > 3 is not implemented")
     if backgrounds is not None:
         assert backgrounds.shape == (C, 3), backgrounds.shape
@@ -308,6 +324,7 @@ def rasterization(
         return t.contiguous()
 
     means_c, quats_c, scales_c, opac_c, colors_c = map(prep, (means, quats, scales, opacities, colors))
+    rest_c = None if colors_rest is None else prep(colors_rest)
     viewmats_c, Ks_c = prep(viewmats), prep(Ks)
     bg_c = None if backgrounds is None else prep(backgrounds)
     cfg = dict(width=int(width), height=int(height), near_plane=float(near_plane),
@@ -316,7 +333,7 @@ def rasterization(
     holder = _Holder(absgrad)
     holder.debug = _debug
     with torch.cuda.device(means.device):
-        render_colors, render_alphas = _Rasterize.apply(means_c, quats_c, scales_c, opac_c, colors_c,
+        render_colors, render_alphas = _Rasterize.apply(means_c, quats_c, scales_c, opac_c, colors_c, rest_c,
                                                         viewmats_c, Ks_c, bg_c, cfg, holder)
     meta = holder.meta
     holder.meta = {}

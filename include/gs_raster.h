@@ -53,8 +53,11 @@ size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h);
 
 /* P-fwd + SH-fwd fused (replaces gsplat fully_fused_projection + spherical_harmonics +
  * clamp_min(rgb+0.5, 0); call site /root/reference/model/gaussian.py:353-367).
- * sh_degree >= 0: `colors_in` is shs[N,K,3];  sh_degree < 0: `colors_in` is already
- * post-activation colour, [N,3] (colors_per_camera=0) or [C,N,3] (=1).
+ * sh_degree >= 0: `colors_in` is shs[N,K,3] and sh_rest is NULL, or -- the reference model's own
+ * parameter layout (/root/reference/model/gaussian.py:49-50, cat at :105-107) -- `colors_in` is
+ * sh_0[N,1,3] and `sh_rest` is [N,K-1,3] (no concatenated copy is ever made).
+ * sh_degree < 0: `colors_in` is already post-activation colour, [N,3] (colors_per_camera=0) or
+ * [C,N,3] (=1); sh_rest is ignored.
  * Outputs: radii[C,N] i32 (0 = culled), means2d[C,N,2], depths[C,N], conics[C,N,3],
  * colors_out[C,N,3], rec[C*N*12] (mx, my, A*log2e/2, B*log2e | C*log2e/2, opacity, r, g |
  * b, ext_x, ext_y, 0: conic pre-scaled for exp2, opacity-aware half extents in pixels),
@@ -65,9 +68,9 @@ size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h);
  * alpha >= 1/255 are dropped; the rendered image and all gradients are unchanged). */
 int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* opacities,
-                   const float* colors_in, int colors_per_camera, const float* viewmats,
-                   const float* Ks, int width, int height, float eps2d, float near_plane,
-                   float far_plane, float radius_clip, int tile_culling, int32_t* radii,
+                   const float* colors_in, const float* sh_rest, int colors_per_camera,
+                   const float* viewmats, const float* Ks, int width, int height, float eps2d,
+                   float near_plane, float far_plane, float radius_clip, int tile_culling, int32_t* radii,
                    float* means2d, float* depths, float* conics, float* colors_out, float* rec, uint32_t* bbox,
                    int32_t* tiles_per_gauss);
 
@@ -126,18 +129,19 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
  * (slots [cum_tiles[f], cum_tiles[f]+tiles_per_gauss[f]), the quadrant rows qmask marks) and
  * pushes the result through the colour and projection VJPs.  Outputs (all fully written):
  * v_means[N,3], v_quats[N,4], v_scales[N,3], v_opacities[N], v_colors: v_shs[N,K,3]
- * (sh_degree>=0) or v_colors[N,3]/[C,N,3]; v_means2d_abs[C,N,2] (the `.absgrad` side channel,
+ * (sh_degree>=0; with the split layout v_colors is v_sh_0[N,1,3] and v_sh_rest[N,K-1,3]) or
+ * v_colors[N,3]/[C,N,3]; v_means2d_abs[C,N,2] (the `.absgrad` side channel,
  * /root/reference/model/gaussian.py:191).
  * Optional (may be NULL): v_means2d[C,N,2], v_conics[C,N,3], v_colors_post[C,N,3]. */
 int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* colors_in,
-                   int colors_per_camera, const float* viewmats, const float* Ks, int width,
-                   int height, float eps2d, float near_plane, float far_plane,
+                   const float* sh_rest, int colors_per_camera, const float* viewmats,
+                   const float* Ks, int width, int height, float eps2d, float near_plane, float far_plane,
                    const int32_t* radii, const float* colors_post, const int32_t* tiles_per_gauss,
                    const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities,
-                   float* v_colors, float* v_means2d_abs, float* v_means2d, float* v_conics,
-                   float* v_colors_post);
+                   float* v_colors, float* v_sh_rest, float* v_means2d_abs, float* v_means2d,
+                   float* v_conics, float* v_colors_post);
 
 /* ---- "next" row f-1: the loss that feeds v_render_colors ----
  * Fused L1 + (1 - SSIM) of /root/reference/model/gaussian.py:415-453 (torchmetrics SSIM:

@@ -333,3 +333,27 @@ def test_model_forward_and_statistics_mirror():
         assert getattr(m, name).grad is not None
     ref_vls = bw["v_scales"] * sc["scales"]  # d exp(log_s)
     assert np.abs(m.log_scales.grad.cpu().numpy() - ref_vls).max() <= 2e-3 * np.abs(ref_vls).max()
+
+
+@pytest.mark.parametrize("deg,K", [(3, 16), (1, 16), (2, 9), (0, 4), (0, 1)])
+def test_split_sh_parameters_equal_concatenated(deg, K):
+    """colors=(sh_0, sh_rest) (the reference model's parameter layout) == colors=cat(sh_0, sh_rest)."""
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    sc = make_scene(3001, 150, 90, sh_degree=deg, seed=17, k_store=K, scale_range=(0.02, 0.2), dist=4.0)
+    t = to_dev(sc)
+    base = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
+    shs = t["shs"].clone().requires_grad_(True)
+    sh0 = t["shs"][:, :1].clone().contiguous().requires_grad_(True)
+    shr = t["shs"][:, 1:].clone().contiguous().requires_grad_(True)
+    kw = dict(sh_degree=deg, packed=False, backgrounds=t["backgrounds"], absgrad=True)
+    img_a, al_a, _ = rasterization(*base, shs, t["viewmats"], t["Ks"], 150, 90, **kw)
+    img_b, al_b, _ = rasterization(*base, (sh0, shr), t["viewmats"], t["Ks"], 150, 90, **kw)
+    assert torch.equal(img_a, img_b) and torch.equal(al_a, al_b)
+    vc = torch.randn(img_a.shape, generator=torch.Generator().manual_seed(0)).to(dev())
+    ga = torch.autograd.grad((img_a * vc).sum(), base + [shs])
+    gb = torch.autograd.grad((img_b * vc).sum(), base + [sh0, shr], allow_unused=(K == 1))
+    for x, y in zip(ga[:4], gb[:4]):
+        assert torch.equal(x, y)
+    assert torch.equal(ga[4][:, :1], gb[4])
+    if K > 1:
+        assert torch.equal(ga[4][:, 1:], gb[5])
