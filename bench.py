@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP Adam")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,8 +125,12 @@ def main():
     gt_img = torch.nn.functional.interpolate(gt_img.permute(2, 0, 1)[None], size=(H, W), mode="bilinear",
                                              align_corners=False)[0].permute(1, 2, 0).contiguous()
     mask = torch.zeros((H, W), device=device)
-    optimizer = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused=True)
-    bucket = GradBucket(model.parameters())
+    if args.torch_adam:
+        optimizer = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused=True)
+        bucket = GradBucket(model.parameters())
+    else:  # one HIP kernel per step over flat buffers; its gradient buffer is the all-reduce bucket
+        optimizer = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused="hip")
+        bucket = optimizer.bucket
     loss_computer = LossComputer(lambda_ssim=0.2)
 
     def train_step():
@@ -135,7 +140,7 @@ def main():
         model.update_statistics(data, out)
         bucket.all_reduce_mean()
         optimizer.step()
-        bucket.zero_()
+        optimizer.zero_grad() if not args.torch_adam else bucket.zero_()
         return out
 
     def barrier():

@@ -115,7 +115,10 @@ class GaussianModel(nn.Module):
 
 def build_optimizers(model: GaussianModel, means_lr: float, log_scales_lr: float, quats_lr: float,
                      sh_0_lr: float, sh_rest_lr: float, logit_opacities_lr: float,
-                     fused: Optional[bool] = None) -> torch.optim.Optimizer:
+                     fused=None) -> torch.optim.Optimizer:
+    """One Adam, six named groups (reference signature).  `fused`: None/False/True go to
+    `torch.optim.Adam(fused=...)`; "hip" selects optim.FusedAdam (one HIP kernel per step over flat
+    buffers, gradients cleared in the same pass)."""
     params = [
         {"params": [model.means], "lr": means_lr, "name": "means"},
         {"params": [model.log_scales], "lr": log_scales_lr, "name": "log_scales"},
@@ -124,7 +127,11 @@ def build_optimizers(model: GaussianModel, means_lr: float, log_scales_lr: float
         {"params": [model.sh_rest], "lr": sh_rest_lr, "name": "sh_rest"},
         {"params": [model.logit_opacities], "lr": logit_opacities_lr, "name": "logit_opacities"},
     ]
-    kw = {} if fused is None else {"fused": fused}
-    optimizer = torch.optim.Adam(params, **kw)
+    if fused == "hip":
+        from .optim import FusedAdam
+        optimizer = FusedAdam(params)
+    else:
+        kw = {} if fused is None else {"fused": fused}
+        optimizer = torch.optim.Adam(params, **kw)
     model.register_optimizer(optimizer)
     return optimizer

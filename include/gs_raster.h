@@ -157,6 +157,16 @@ int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const
                    const float* gt, const float* mask, const float* workspace,
                    const float* v_total, float* v_render);
 
+/* ---- "next" row f-2: fused Adam over flat buffers (one torch.optim.Adam with six groups in the
+ * reference, /root/reference/model/gaussian.py:389-412; defaults: no weight decay / amsgrad).
+ * params, grads, exp_avg, exp_avg_sq: flat fp32 device buffers of n elements (n and every group
+ * boundary multiples of 4).  group_ends_host[g] = exclusive end of group g, group_lrs_host[g] its
+ * learning rate (HOST arrays).  step counts from 1.  zero_grad != 0 also clears grads. */
+int gs_adam_step(void* stream, int64_t n, float* params, float* grads, float* exp_avg,
+                 float* exp_avg_sq, int n_groups, const int64_t* group_ends_host,
+                 const float* group_lrs_host, float beta1, float beta2, float eps, int64_t step,
+                 int zero_grad);
+
 #ifdef __cplusplus
 }
 #endif
