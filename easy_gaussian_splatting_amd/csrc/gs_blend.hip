@@ -120,7 +120,22 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
                 hy[h] = ey >= 0.f && q0.y + ey >= qylo[h] && q0.y - ey <= qyhi[h];
             }
         }
-        const bool bit[4] = {qa[0] && hx[0] && hy[0], qa[1] && hx[1] && hy[0], qa[2] && hx[0] && hy[1], qa[3] && hx[1] && hy[1]};
+        bool bit[4] = {qa[0] && hx[0] && hy[0], qa[1] && hx[1] && hy[0], qa[2] && hx[0] && hy[1], qa[3] && hx[1] && hy[1]};
+        if (bit[0] || bit[1] || bit[2] || bit[3]) {
+            // exact test: the smallest exponent over the quadrant's pixel-centre rectangle must allow
+            // alpha >= 1/255, i.e. min sigma' <= log2(255 * opacity)  (conservative margin; the
+            // per-pixel test in blend_pair stays authoritative)
+            const float4 q0 = srec[lane * 3], q1 = srec[lane * 3 + 1];
+            const float tau = __log2f(255.f * q1.y) + 0.02f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (bit[k]) {
+                    const float ms = quad_min_on_rect(q0.z, q0.w, q1.x, qxlo[k & 1] - q0.x, qxhi[k & 1] - q0.x,
+                                                      qylo[k >> 1] - q0.y, qyhi[k >> 1] - q0.y);
+                    bit[k] = ms <= tau + 1e-4f * fabsf(tau);
+                }
+            }
+        }
         unsigned long long mq[4];
         int jstar[4] = {-1, -1, -1, -1}, kbstar[4] = {0, 0, 0, 0};
 #pragma unroll

@@ -159,6 +159,28 @@ GS_HD void tile_rect(float mx, float my, int radius, int tile, int tw, int th, i
     y0 = (int)fminf(fmaxf(fy0, 0.f), (float)th); y1 = (int)fminf(fmaxf(fy1, 0.f), (float)th);
 }
 
+// Minimum of the positive-definite form a dx^2 + b dx dy + c dy^2 over the axis-aligned
+// rectangle [dx0,dx1] x [dy0,dy1] (offsets from the Gaussian's centre): 0 when the centre is
+// inside, otherwise attained on an edge, where the form is a 1-D parabola in the free coordinate.
+GS_HD float quad_min_on_rect(float a, float b, float c, float dx0, float dx1, float dy0, float dy1) {
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return 0.f;
+    const float hbc = -0.5f * b / c, hba = -0.5f * b / a;
+    float m = 3.0e38f;
+    {   // vertical edges: dx fixed, minimise over dy
+        const float X0 = dx0, X1 = dx1;
+        const float t0 = fminf(fmaxf(hbc * X0, dy0), dy1), t1 = fminf(fmaxf(hbc * X1, dy0), dy1);
+        m = fminf(m, a * X0 * X0 + t0 * (b * X0 + c * t0));
+        m = fminf(m, a * X1 * X1 + t1 * (b * X1 + c * t1));
+    }
+    {   // horizontal edges: dy fixed, minimise over dx
+        const float Y0 = dy0, Y1 = dy1;
+        const float t0 = fminf(fmaxf(hba * Y0, dx0), dx1), t1 = fminf(fmaxf(hba * Y1, dx0), dx1);
+        m = fminf(m, c * Y0 * Y0 + t0 * (b * Y0 + a * t0));
+        m = fminf(m, c * Y1 * Y1 + t1 * (b * Y1 + a * t1));
+    }
+    return m;
+}
+
 // Shrinks a tile rectangle to the tiles that contain at least one pixel centre (j + 0.5) with
 // |mx - (j+0.5)| <= ex and |my - (i+0.5)| <= ey; empties it when there is none.
 GS_HD void tile_rect_tight(float mx, float my, float ex, float ey, int W, int H, int tile, int& x0,

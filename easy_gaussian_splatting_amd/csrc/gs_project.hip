@@ -40,8 +40,12 @@ __device__ __forceinline__ void load_camera(const float* viewmats, const float* 
 }
 
 // Cooperative global -> LDS copy of the first `ka3` floats of every visible Gaussian's SH row.
+// KC > 0 fixes K at compile time (K = 16 is the reference's SH3 layout) so the per-element
+// row/offset divisions become multiply-shifts; KC = 0 keeps K a run-time value.
+template <int KC>
 __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int64_t n0, int rows,
-                                              int K, int ka3, const int* vis, float* tile) {
+                                              int Krt, int ka3, const int* vis, float* tile) {
+    const int K = KC > 0 ? KC : Krt;
     const int row_f = 3 * K, stride = row_f + 1;
     const float* src = shs + n0 * row_f;
     if (ka3 == row_f && (row_f & 3) == 0) {
@@ -66,8 +70,10 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int
 // Split parameter layout of the reference model (sh_0[N,1,3] and sh_rest[N,K-1,3] are separate
 // nn.Parameters, /root/reference/model/gaussian.py:49-50, concatenated on every forward at :105-107):
 // staging straight from the two tensors removes that cat (and the split of its gradient).
+template <int KC>
 __device__ __forceinline__ void stage_sh_rows_split(const float* __restrict__ sh0, const float* __restrict__ shr,
-                                                    int64_t n0, int rows, int K, int ka3, const int* vis, float* tile) {
+                                                    int64_t n0, int rows, int Krt, int ka3, const int* vis, float* tile) {
+    const int K = KC > 0 ? KC : Krt;
     const int row_f = 3 * K, stride = row_f + 1, rest_f = row_f - 3, kr = ka3 - 3;
     for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
         const int g = e / 3;
@@ -156,8 +162,13 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
         if (any_vis) {
             const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
             constexpr int ka3 = 3 * (DEG + 1) * (DEG + 1);
-            if (a.sh_rest) stage_sh_rows_split(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);
-            else stage_sh_rows(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+            if (a.sh_rest) {
+                if (a.K == 16) stage_sh_rows_split<16>(a.colors_in, a.sh_rest, n0, rows, 16, ka3, vis_s, tile);
+                else stage_sh_rows_split<0>(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);
+            } else {
+                if (a.K == 16) stage_sh_rows<16>(a.colors_in, n0, rows, 16, ka3, vis_s, tile);
+                else stage_sh_rows<0>(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+            }
             __syncthreads();
             if (vis) {
                 float ux, uy, uz;
@@ -267,8 +278,13 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         vis_s[threadIdx.x] = vis ? 1 : 0;
         __syncthreads();
         const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
-        if (a.sh_rest) stage_sh_rows_split(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);
-        else stage_sh_rows(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+        if (a.sh_rest) {
+            if (a.K == 16) stage_sh_rows_split<16>(a.colors_in, a.sh_rest, n0, rows, 16, ka3, vis_s, tile);
+            else stage_sh_rows_split<0>(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);
+        } else {
+            if (a.K == 16) stage_sh_rows<16>(a.colors_in, n0, rows, 16, ka3, vis_s, tile);
+            else stage_sh_rows<0>(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+        }
         __syncthreads();
         float* my = tile + threadIdx.x * stride;
         if (vis) {
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         __syncthreads();
         // dense write-out of v_shs[n0 : n0+rows, :, :]
         if (a.v_sh_rest) {  // split layout: v_sh_0[N,1,3] and v_sh_rest[N,K-1,3]
-            const int rest_f = row_f - 3, total = rows * rest_f;
+            const int rest_f = a.K == 16 ? 45 : row_f - 3, total = rows * rest_f;
             float* d0 = a.v_colors + n0 * 3;
             for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
                 const int g = e / 3;
