@@ -41,14 +41,15 @@ BinLayout bin_layout(int C, int64_t N, int tiles) {
     return L;
 }
 
-__device__ __forceinline__ void unpack_bbox(uint2 b, int& x0, int& x1, int& y0, int& y1) {
+// footprint word layout written by project_fwd_kernel: x0 | x1<<16, y0 | y1<<16, tile mask, count
+__device__ __forceinline__ void unpack_bbox(uint4 b, int& x0, int& x1, int& y0, int& y1) {
     x0 = b.x & 0xffff; x1 = b.x >> 16; y0 = b.y & 0xffff; y1 = b.y >> 16;
 }
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBinThreads) void bin_hist_kernel(int64_t N, int tw, int tiles,
                                                                int64_t per_group,
-                                                               const uint2* __restrict__ bbox,
+                                                               const uint4* __restrict__ bbox,
                                                                uint32_t* __restrict__ hist_mat,
                                                                uint32_t* __restrict__ grp_tot) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -62,13 +63,16 @@ __global__ __launch_bounds__(kBinThreads) void bin_hist_kernel(int64_t N, int tw
     for (int64_t base = g0; base < g1; base += blockDim.x) {
         const int64_t n = base + threadIdx.x;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-        if (n < g1) unpack_bbox(bbox[(int64_t)c * N + n], x0, x1, y0, y1);
-        const int w = x1 - x0, cnt = w * (y1 - y0);
+        uint4 fp = make_uint4(0u, 0u, 0u, 0u);
+        if (n < g1) { fp = bbox[(int64_t)c * N + n]; unpack_bbox(fp, x0, x1, y0, y1); }
+        const int w = x1 - x0, rect = w * (y1 - y0), cnt = (int)fp.w;
         local += cnt;
-        if (cnt > 0 && cnt <= kCoopTiles)
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) atomicAdd(&hist[y * tw + x], 1u);
-        unsigned long long big = __ballot(cnt > kCoopTiles);
+        if (rect <= kCoopTiles)   // small footprints: one bit per tile of the rectangle
+            for (uint32_t mb = fp.z; mb; mb &= mb - 1) {
+                const int i = __ffs((int)mb) - 1, yy = i / w;
+                atomicAdd(&hist[(y0 + yy) * tw + x0 + (i - yy * w)], 1u);
+            }
+        unsigned long long big = __ballot(rect > kCoopTiles);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
-    int64_t N, int tw, int tiles, int64_t per_group, const uint2* __restrict__ bbox,
+    int64_t N, int tw, int tiles, int64_t per_group, const uint4* __restrict__ bbox,
     const float* __restrict__ depths, const uint32_t* __restrict__ hist_mat,
     const int32_t* __restrict__ isect_offsets, const uint32_t* __restrict__ grp_base,
     unsigned long long* __restrict__ keys, int32_t* __restrict__ slot_gid,
@@ -196,24 +200,25 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
         const int64_t n = base + threadIdx.x;
         const int64_t f = (int64_t)c * N + n;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-        if (n < g1) unpack_bbox(bbox[f], x0, x1, y0, y1);
-        const int w = x1 - x0, cnt = w * (y1 - y0);
+        uint4 fp = make_uint4(0u, 0u, 0u, 0u);
+        if (n < g1) { fp = bbox[f]; unpack_bbox(fp, x0, x1, y0, y1); }
+        const int w = x1 - x0, rect = w * (y1 - y0), cnt = (int)fp.w;
         uint32_t total;
         const uint32_t slot0 = running + block_excl_scan_add((uint32_t)cnt, scratch, &total);
         running += total;
         if (n < g1) cum_tiles[f] = (int32_t)slot0;
         uint32_t dbits = 0;
         if (cnt > 0) dbits = __float_as_uint(depths[f]);
-        if (cnt > 0 && cnt <= kCoopTiles) {
+        if (rect <= kCoopTiles) {
             uint32_t k = 0;
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x, ++k) {
-                    const uint32_t pos = atomicAdd(&cursor[y * tw + x], 1u);
-                    keys[pos] = ((unsigned long long)dbits << 32) | (slot0 + k);
-                    slot_gid[slot0 + k] = (int32_t)f;
-                }
+            for (uint32_t mb = fp.z; mb; mb &= mb - 1, ++k) {
+                const int i = __ffs((int)mb) - 1, yy = i / w;
+                const uint32_t pos = atomicAdd(&cursor[(y0 + yy) * tw + x0 + (i - yy * w)], 1u);
+                keys[pos] = ((unsigned long long)dbits << 32) | (slot0 + k);
+                slot_gid[slot0 + k] = (int32_t)f;
+            }
         }
-        unsigned long long big = __ballot(cnt > kCoopTiles);
+        unsigned long long big = __ballot(rect > kCoopTiles);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
@@ -337,7 +342,7 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
     const size_t lds = sizeof(uint32_t) * ((size_t)tiles + 32);
     if (int rc = ensure_lds((const void*)bin_hist_kernel, lds)) return rc;
     hipLaunchKernelGGL(bin_hist_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, tile_w, tiles,
-                       L.per_group, (const uint2*)bbox, hist, grp_tot);
+                       L.per_group, (const uint4*)bbox, hist, grp_tot);
     GS_LAUNCH_CHECK("bin_hist_kernel");
     const int64_t ct = (int64_t)C * tiles;
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)((ct + 255) / 256)), dim3(256), 0, st, C, L.groups,
@@ -373,7 +378,7 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     const size_t lds = sizeof(uint32_t) * ((size_t)tiles + 32);
     if (int rc = ensure_lds((const void*)bin_emit_kernel, lds)) return rc;
     hipLaunchKernelGGL(bin_emit_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, tile_w, tiles,
-                       L.per_group, (const uint2*)bbox, depths, hist, isect_offsets, grp_base,
+                       L.per_group, (const uint4*)bbox, depths, hist, isect_offsets, grp_base,
                        (unsigned long long*)keys_tmp, slot_gid, cum_tiles);
     GS_LAUNCH_CHECK("bin_emit_kernel");
     if (n_isects == 0) return GS_OK;

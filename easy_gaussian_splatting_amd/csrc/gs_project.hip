@@ -19,7 +19,7 @@ struct ProjFwdArgs {
     int32_t* radii;
     float *means2d, *depths, *conics, *colors_out;
     float4* rec;
-    uint2* bbox;
+    uint4* bbox;
     int32_t* tiles_per_gauss;
 };
 
@@ -145,13 +145,27 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
         // alpha can reach 1/255 (the blend skips every other pixel anyway: identical image)
         if (a.tight) tile_rect_tight(s.mx, s.my, ex, ey, a.W, a.H, GS_TILE, x0, x1, y0, y1);
     }
-    const int cnt = (x1 - x0) * (y1 - y0);
+    // tile footprint: rectangle + (for rectangles of <= 32 tiles) a row-major bit per tile
+    const int rw = x1 - x0, rect_tiles = rw * (y1 - y0);
+    uint32_t tmask = rect_tiles >= 32 ? 0xffffffffu : ((1u << rect_tiles) - 1u);
+    if (a.tight && rect_tiles > 0 && rect_tiles <= 32) {
+        // exact test per tile: some pixel centre of the tile must allow alpha >= 1/255
+        const float tau = __log2f(255.f * op) + 0.02f, lim = tau + 1e-4f * fabsf(tau);
+        const float qa = 0.5f * kLog2e * s.A, qb = kLog2e * s.B, qc = 0.5f * kLog2e * s.C;
+        tmask = 0u;
+        for (int i = 0; i < rect_tiles; ++i) {
+            const int ty = y0 + i / rw, tx = x0 + (i - (i / rw) * rw);
+            const float dx0 = (float)(tx * GS_TILE) + 0.5f - s.mx, dy0 = (float)(ty * GS_TILE) + 0.5f - s.my;
+            if (quad_min_on_rect(qa, qb, qc, dx0, dx0 + (float)(GS_TILE - 1), dy0, dy0 + (float)(GS_TILE - 1)) <= lim) tmask |= 1u << i;
+        }
+    }
+    const int cnt = rect_tiles <= 32 ? __popc(tmask) : rect_tiles;
     if (in_range) {
         a.radii[f] = s.radius;
         reinterpret_cast<float2*>(a.means2d)[f] = make_float2(s.mx, s.my);
         a.depths[f] = s.depth;
         a.conics[3 * f] = s.A; a.conics[3 * f + 1] = s.B; a.conics[3 * f + 2] = s.C;
-        a.bbox[f] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+        a.bbox[f] = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), tmask, (uint32_t)cnt);
         a.tiles_per_gauss[f] = cnt;
     }
 
@@ -419,7 +433,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.sh_rest = sh_degree >= 0 ? sh_rest : nullptr;
     a.viewmats = viewmats; a.Ks = Ks; a.radii = radii; a.means2d = means2d; a.depths = depths;
     a.conics = conics; a.colors_out = colors_out; a.rec = reinterpret_cast<float4*>(rec);
-    a.bbox = reinterpret_cast<uint2*>(bbox); a.tiles_per_gauss = tiles_per_gauss;
+    a.bbox = reinterpret_cast<uint4*>(bbox); a.tiles_per_gauss = tiles_per_gauss;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads), (unsigned)C);
     const size_t lds = proj_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;

@@ -100,7 +100,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     conics = torch.empty((C, N, 3), **f32)
     colors_post = torch.empty((C, N, 3), **f32)
     rec = torch.empty((C * N, nat.GS_REC_FLOATS), **f32)
-    bbox = torch.empty((C * N, 2), **i32)
+    bbox = torch.empty((C * N, 4), **i32)
     tiles_per_gauss = torch.empty((C, N), **i32)
     _stage("gs_project_fwd", dev, lambda: nat.check(L.gs_project_fwd(st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
                                _ptr(colors), _ptr(colors_rest), per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
