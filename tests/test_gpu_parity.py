@@ -175,7 +175,7 @@ def test_post_activation_colours_path():
         assert np.abs(grads[0].cpu().numpy() - bw["v_means"]).max() <= GRAD_RTOL * np.abs(bw["v_means"]).max()
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_golden_fixtures(tag):
     """Committed oracle fixtures (tests/golden/make_golden.py): every integer output bit-exact,
     image and gradients within the north_star tolerances."""
@@ -357,3 +357,31 @@ def test_split_sh_parameters_equal_concatenated(deg, K):
     assert torch.equal(ga[4][:, :1], gb[4])
     if K > 1:
         assert torch.equal(ga[4][:, 1:], gb[5])
+
+
+def test_concurrent_host_threads_on_separate_streams():
+    """Boundary contract: entry points are callable from any Python thread (the
+    reference viewer renders from per-client threads, /root/reference/viewer/viewer.py:23-27)."""
+    import threading
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    scenes = [make_scene(4000 + 500 * i, 200, 120, sh_degree=3, seed=40 + i, scale_range=(0.02, 0.2), dist=4.0) for i in range(4)]
+    tens = [to_dev(s) for s in scenes]
+
+    def render(i, out):
+        t = tens[i]
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for _ in range(5):
+                img, _, _ = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"], t["Ks"],
+                                          200, 120, sh_degree=3, packed=False, backgrounds=t["backgrounds"])
+            torch.cuda.current_stream().synchronize()
+        out[i] = img
+
+    ref = {}
+    for i in range(4):
+        render(i, ref)
+    got = {}
+    threads = [threading.Thread(target=render, args=(i, got)) for i in range(4)]
+    [th.start() for th in threads]
+    [th.join() for th in threads]
+    for i in range(4):
+        assert torch.equal(ref[i], got[i])

@@ -156,7 +156,7 @@ def test_reference_conventions_fixture():
     np.testing.assert_allclose(z["rotmats"][i], [[-2 / 3, 2 / 15, 11 / 15], [2 / 3, -1 / 3, 2 / 3], [1 / 3, 14 / 15, 2 / 15]], atol=1e-12)
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_c_oracle_reproduces_golden_scenes(tag):
     z = np.load(os.path.join(GOLD, f"oracle_scene_{tag}.npz"))
     for dtype, tol in ((np.float64, 1e-11), (np.float32, 2e-5)):
