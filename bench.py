@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from easy_gaussian_splatting_amd import rendering  # noqa: E402
-from easy_gaussian_splatting_amd.distributed import GradBucket, is_distributed  # noqa: E402
+from easy_gaussian_splatting_amd.distributed import GradBucket, all_reduce_param_grads  # noqa: E402
 from easy_gaussian_splatting_amd.loss import LossComputer  # noqa: E402
 from easy_gaussian_splatting_amd.model import GaussianModel, build_optimizers  # noqa: E402
 from easy_gaussian_splatting_amd.synthetic import config_bench_1m  # noqa: E402
@@ -128,9 +128,9 @@ def main():
     if args.torch_adam:
         optimizer = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused=True)
         bucket = GradBucket(model.parameters())
-    else:  # one HIP kernel per step over flat buffers; its gradient buffer is the all-reduce bucket
+    else:  # one HIP kernel per step over flat params/moments; gradients are autograd's own tensors
         optimizer = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused="hip")
-        bucket = optimizer.bucket
+        bucket = None
     loss_computer = LossComputer(lambda_ssim=0.2)
 
     def train_step():
@@ -138,9 +138,14 @@ def main():
         loss = loss_computer.get_loss_dict(out["render_img"], gt_img, mask)["total"]
         loss.backward()
         model.update_statistics(data, out)
-        bucket.all_reduce_mean()
-        optimizer.step()
-        optimizer.zero_grad() if not args.torch_adam else bucket.zero_()
+        if bucket is not None:
+            bucket.all_reduce_mean()
+            optimizer.step()
+            bucket.zero_()
+        else:
+            all_reduce_param_grads(model.parameters())
+            optimizer.step()
+            optimizer.zero_grad()
         return out
 
     def barrier():

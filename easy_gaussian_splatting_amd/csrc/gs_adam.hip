@@ -1,33 +1,35 @@
 // gs_adam.hip -- fused multi-group Adam step for gfx950 ("next" row):
 // the reference drives ONE torch.optim.Adam with six named parameter groups
 // (/root/reference/model/gaussian.py:389-412, default betas/eps, no weight decay, no amsgrad).
-// With all parameters, gradients and both moments living in four flat fp32 buffers (the gradient
-// one is the RCCL bucket of distributed.py) the whole step is a single HBM-streaming kernel:
-// 16 B/lane loads of p, g, m, v; stores of p, m, v and -- optionally -- the zeroed gradient,
-// 28-32 B per element instead of several launches per group.  Same arithmetic as torch's
+// Parameters and both moments live in three flat fp32 buffers (segments padded to 16-byte quads);
+// the gradients stay where autograd put them (one tensor per segment, no accumulate-into-bucket
+// pass, no zero-fill pass).  The whole step is a single HBM-streaming kernel: 16 B/lane loads of
+// p, g, m, v and stores of p, m, v -- 28 B per element.  Same arithmetic as torch's
 // `_single_tensor_adam`:  denom = sqrt(v)/sqrt(1-beta2^t) + eps;  p -= (lr/(1-beta1^t)) * m/denom.
+// A segment whose gradient pointer is NULL is skipped entirely (torch skips `p.grad is None`).
 #include "gs_common.h"
 
 namespace gs {
 
 constexpr int kMaxSeg = 8;
 struct AdamArgs {
-    int64_t n4;                 // number of float4 quads
-    float4 *p, *g, *m, *v;
+    int64_t n4;                   // number of float4 quads in the flat buffers
+    float4 *p, *m, *v;
     int nseg;
-    int64_t seg_end4[kMaxSeg];  // exclusive end of each group, in quads
-    float step_size[kMaxSeg];   // lr / (1 - beta1^t)
+    int64_t seg_begin4[kMaxSeg];  // first quad of each segment
+    int64_t seg_end4[kMaxSeg];    // exclusive end, in quads
+    int64_t seg_len[kMaxSeg];     // un-padded element count (length of the gradient tensor)
+    const float* g[kMaxSeg];      // gradient tensor of each segment (may be null)
+    float step_size[kMaxSeg];     // lr / (1 - beta1^t)
     float beta1, beta2, eps, inv_sqrt_bc2;
-    int zero_grad;
 };
 
-__device__ __forceinline__ float adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
-                                       float isbc2, float ss) {
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
+                                      float isbc2, float ss) {
     m = fmaf(b1, m, (1.f - b1) * g);
     v = fmaf(b2, v, (1.f - b2) * g * g);
     const float denom = sqrtf(v) * isbc2 + eps;
     p = p - ss * (m / denom);
-    return p;
 }
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
@@ -35,15 +37,24 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
         int s = 0;
 #pragma unroll
         for (int k = 0; k < kMaxSeg - 1; ++k) s += (k < a.nseg - 1 && i >= a.seg_end4[k]) ? 1 : 0;
+        const float* gp = a.g[s];
+        if (gp == nullptr) continue;
+        const int64_t e = (i - a.seg_begin4[s]) << 2;   // element index inside the segment
+        const int64_t len = a.seg_len[s];
+        float4 g;
+        if (e + 4 <= len) {
+            g = *reinterpret_cast<const float4*>(gp + e);
+        } else {  // the segment's padded tail
+            g.x = e < len ? gp[e] : 0.f; g.y = e + 1 < len ? gp[e + 1] : 0.f;
+            g.z = e + 2 < len ? gp[e + 2] : 0.f; g.w = 0.f;
+        }
         const float ss = a.step_size[s];
         float4 p = a.p[i], m = a.m[i], v = a.v[i];
-        const float4 g = a.g[i];
         adam1(p.x, g.x, m.x, v.x, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
         adam1(p.y, g.y, m.y, v.y, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
         adam1(p.z, g.z, m.z, v.z, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
         adam1(p.w, g.w, m.w, v.w, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
         a.p[i] = p; a.m[i] = m; a.v[i] = v;
-        if (a.zero_grad) a.g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -51,29 +62,35 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
 
 using namespace gs;
 
-extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* grads, float* exp_avg,
-                            float* exp_avg_sq, int n_groups, const int64_t* group_ends_host,
-                            const float* group_lrs_host, float beta1, float beta2, float eps, int64_t step,
-                            int zero_grad) {
+extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
+                            int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
+                            const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
+                            float beta2, float eps, int64_t step) {
     GS_REQUIRE(n >= 0 && (n & 3) == 0, "flat length must be a multiple of 4 (pad the buffers)");
-    GS_REQUIRE(n_groups >= 1 && n_groups <= kMaxSeg, "1..8 parameter groups");
+    GS_REQUIRE(n_segments >= 1 && n_segments <= kMaxSeg, "1..8 segments");
     GS_REQUIRE(step >= 1, "step counts from 1");
     if (n == 0) return GS_OK;
-    GS_REQUIRE(params && grads && exp_avg && exp_avg_sq && group_ends_host && group_lrs_host, "null pointer");
+    GS_REQUIRE(params && exp_avg && exp_avg_sq && seg_ends_host && seg_lens_host && seg_grads_host && seg_lrs_host, "null pointer");
     AdamArgs a;
     a.n4 = n >> 2;
-    a.p = reinterpret_cast<float4*>(params); a.g = reinterpret_cast<float4*>(grads);
+    a.p = reinterpret_cast<float4*>(params);
     a.m = reinterpret_cast<float4*>(exp_avg); a.v = reinterpret_cast<float4*>(exp_avg_sq);
-    a.nseg = n_groups;
+    a.nseg = n_segments;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    for (int k = 0; k < kMaxSeg; ++k) { a.seg_end4[k] = a.n4; a.step_size[k] = 0.f; }
-    for (int k = 0; k < n_groups; ++k) {
-        GS_REQUIRE((group_ends_host[k] & 3) == 0, "group boundaries must be multiples of 4 elements");
-        a.seg_end4[k] = group_ends_host[k] >> 2;
-        a.step_size[k] = (float)((double)group_lrs_host[k] / bc1);
+    for (int k = 0; k < kMaxSeg; ++k) { a.seg_begin4[k] = a.n4; a.seg_end4[k] = a.n4; a.seg_len[k] = 0; a.g[k] = nullptr; a.step_size[k] = 0.f; }
+    int64_t begin = 0;
+    for (int k = 0; k < n_segments; ++k) {
+        GS_REQUIRE((seg_ends_host[k] & 3) == 0 && seg_ends_host[k] >= begin && seg_ends_host[k] <= n, "segment ends must be ascending multiples of 4 within n");
+        GS_REQUIRE(seg_lens_host[k] >= 0 && seg_lens_host[k] <= seg_ends_host[k] - begin, "segment length exceeds its padded extent");
+        GS_REQUIRE(((uintptr_t)seg_grads_host[k] & 15) == 0, "gradient tensors must be 16-byte aligned");
+        a.seg_begin4[k] = begin >> 2;
+        a.seg_end4[k] = seg_ends_host[k] >> 2;
+        a.seg_len[k] = seg_lens_host[k];
+        a.g[k] = seg_grads_host[k];
+        a.step_size[k] = (float)((double)seg_lrs_host[k] / bc1);
+        begin = seg_ends_host[k];
     }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    a.zero_grad = zero_grad;
     const int64_t want = (a.n4 + 255) / 256;
     const unsigned grid = (unsigned)(want < 256 * 16 ? want : 256 * 16);
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

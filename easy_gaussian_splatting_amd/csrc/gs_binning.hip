@@ -106,11 +106,18 @@ __global__ void bin_colscan_kernel(int C, int G, int tiles, uint32_t* __restrict
     const int c = (int)(i / tiles), t = (int)(i % tiles);
     uint32_t run = 0;
     uint32_t* col = hist_mat + (size_t)c * G * tiles + t;
-#pragma unroll 8
-    for (int g = 0; g < G; ++g) {
-        const uint32_t v = col[(size_t)g * tiles];
-        col[(size_t)g * tiles] = run;
-        run += v;
+    // the scan is in place, so loads are batched by hand ahead of the stores (the compiler must
+    // otherwise serialise each load behind the previous, possibly aliasing, store)
+    constexpr int kBatch = 16;
+    for (int g0 = 0; g0 < G; g0 += kBatch) {
+        uint32_t v[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) v[k] = (g0 + k < G) ? col[(size_t)(g0 + k) * tiles] : 0u;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (g0 + k < G) col[(size_t)(g0 + k) * tiles] = run;
+            run += v[k];
+        }
     }
     tile_cnt[i] = run;
 }

@@ -61,6 +61,21 @@ class GradBucket:
         return None
 
 
+def all_reduce_param_grads(params: Iterable[torch.nn.Parameter], group=None) -> None:
+    """Mean of `.grad` over ranks without a staging bucket: one async all-reduce per parameter
+    tensor, largest first (sh_rest is 76 % of the bytes at SH3), then one wait and the 1/world scale.
+    Used with optim.FusedAdam, whose gradients are the rasterizer's own output tensors."""
+    if not is_distributed():
+        return
+    world = dist.get_world_size(group)
+    grads = sorted((p.grad for p in params if p.requires_grad and p.grad is not None), key=lambda g: -g.numel())
+    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True) for g in grads]
+    for w in works:
+        w.wait()
+    for g in grads:
+        g.div_(world)
+
+
 def all_reduce_statistics(grad_norm: Tensor, counts: Tensor, max_radii: Tensor, group=None) -> None:
     """Sum / sum / max over ranks of the three per-Gaussian statistics of
     /root/reference/model/gaussian.py:188-197 so every replica takes identical densification

@@ -3,9 +3,10 @@
 `/root/reference/model/gaussian.py:389-412` builds ONE `torch.optim.Adam` with six named groups
 (`means, log_scales, quats, sh_0, sh_rest, logit_opacities`), default betas/eps.  `FusedAdam`
 keeps that interface (`param_groups[i]["name"]`, `["lr"]` -- what `update_learning_rate`,
-`model/gaussian.py:121-128`, edits) but stores parameters, gradients and both moments in four flat
-fp32 buffers, so one step is ONE HBM-streaming HIP kernel (csrc/gs_adam.hip) that can also clear
-the gradients, and the gradient buffer doubles as the RCCL all-reduce bucket of `distributed.py`.
+`model/gaussian.py:121-128`, edits) but stores parameters and both moments in three flat fp32
+buffers, so one step is ONE HBM-streaming HIP kernel (csrc/gs_adam.hip).  Gradients stay exactly
+where autograd put them: with `.grad` left `None` before `backward()` the rasterizer's own output
+tensors become the `.grad`s without an accumulate pass, and `zero_grad()` just drops them.
 """
 from __future__ import annotations
 
@@ -14,41 +15,37 @@ from typing import Dict, List
 
 import torch
 
-from .distributed import GradBucket
-
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params: List[Dict], betas=(0.9, 0.999), eps: float = 1e-8, zero_grad_in_step: bool = True):
+    def __init__(self, params: List[Dict], betas=(0.9, 0.999), eps: float = 1e-8):
         defaults = dict(lr=1e-3, betas=betas, eps=eps)
         super().__init__(params, defaults)
-        self.zero_grad_in_step = zero_grad_in_step
-        plist = [p for g in self.param_groups for p in g["params"]]
-        if not plist:
+        self._plist = [(g, p) for g in self.param_groups for p in g["params"]]
+        if not self._plist:
             raise ValueError("no parameters")
-        dev, dt = plist[0].device, plist[0].dtype
+        if len(self._plist) > 8:
+            raise NotImplementedError("FusedAdam handles up to 8 parameter tensors (the reference has 6)")
+        dev, dt = self._plist[0][1].device, self._plist[0][1].dtype
         if dt != torch.float32:
             raise TypeError("FusedAdam handles float32 parameters")
-        # layout: groups back to back, each padded to a multiple of 4 elements (16-byte quads)
+        # layout: one segment per parameter tensor, each padded to a multiple of 4 elements
         self._ends: List[int] = []
+        self._lens: List[int] = []
         offs, off = [], 0
-        for g in self.param_groups:
-            for p in g["params"]:
-                offs.append(off)
-                off += p.numel()
-            off = (off + 3) // 4 * 4
+        for _, p in self._plist:
+            offs.append(off)
+            self._lens.append(p.numel())
+            off = (off + p.numel() + 3) // 4 * 4
             self._ends.append(off)
-        total = off
-        self.flat_param = torch.zeros(total, dtype=dt, device=dev)
-        self.flat_grad = torch.zeros(total, dtype=dt, device=dev)
-        self.exp_avg = torch.zeros(total, dtype=dt, device=dev)
-        self.exp_avg_sq = torch.zeros(total, dtype=dt, device=dev)
+        self.flat_param = torch.zeros(off, dtype=dt, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=dt, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=dt, device=dev)
         with torch.no_grad():
-            for p, o in zip(plist, offs):
+            for (_, p), o in zip(self._plist, offs):
                 n = p.numel()
                 self.flat_param[o:o + n].copy_(p.detach().reshape(-1))
-                p.data = self.flat_param[o:o + n].view_as(p)       # parameters become views
-                p.grad = self.flat_grad[o:o + n].view_as(p)        # autograd accumulates into the bucket
-        self.bucket = GradBucket.from_flat(self.flat_grad, plist)
+                p.data = self.flat_param[o:o + n].view_as(p)   # parameters become views of the flat buffer
+                p.grad = None
         self._step = 0
 
     @torch.no_grad()
@@ -58,19 +55,28 @@ class FusedAdam(torch.optim.Optimizer):
         from . import _native as nat
         L = nat.lib()
         self._step += 1
-        ng = len(self.param_groups)
-        ends = (ct.c_int64 * ng)(*self._ends)
-        lrs = (ct.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
+        ns = len(self._plist)
+        grads = []
+        for _, p in self._plist:
+            g = p.grad
+            if g is not None and (not g.is_contiguous() or g.dtype != torch.float32):
+                g = g.contiguous().float()
+            grads.append(g)   # keep alive until the launch is queued
+        ends = (ct.c_int64 * ns)(*self._ends)
+        lens = (ct.c_int64 * ns)(*self._lens)
+        gptr = (ct.c_void_p * ns)(*[None if g is None else g.data_ptr() for g in grads])
+        lrs = (ct.c_float * ns)(*[float(grp["lr"]) for grp, _ in self._plist])
         b1, b2 = self.defaults["betas"]
-        st = torch.cuda.current_stream(self.flat_param.device).cuda_stream
-        with torch.cuda.device(self.flat_param.device):
-            nat.check(L.gs_adam_step(st, self.flat_param.numel(), self.flat_param.data_ptr(), self.flat_grad.data_ptr(),
-                                     self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), ng, ends, lrs,
-                                     float(b1), float(b2), float(self.defaults["eps"]), self._step,
-                                     1 if self.zero_grad_in_step else 0), "gs_adam_step")
+        dev = self.flat_param.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            nat.check(L.gs_adam_step(st, self.flat_param.numel(), self.flat_param.data_ptr(), self.exp_avg.data_ptr(),
+                                     self.exp_avg_sq.data_ptr(), ns, ends, lens, gptr, lrs, float(b1), float(b2),
+                                     float(self.defaults["eps"]), self._step), "gs_adam_step")
 
-    def zero_grad(self, set_to_none: bool = False):
-        # gradients are views into the flat bucket and must stay attached; the step already cleared
-        # them when zero_grad_in_step is on
-        if not self.zero_grad_in_step:
-            self.flat_grad.zero_()
+    def zero_grad(self, set_to_none: bool = True):
+        for _, p in self._plist:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()

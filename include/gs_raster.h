@@ -161,13 +161,15 @@ int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const
 
 /* ---- "next" row f-2: fused Adam over flat buffers (one torch.optim.Adam with six groups in the
  * reference, /root/reference/model/gaussian.py:389-412; defaults: no weight decay / amsgrad).
- * params, grads, exp_avg, exp_avg_sq: flat fp32 device buffers of n elements (n and every group
- * boundary multiples of 4).  group_ends_host[g] = exclusive end of group g, group_lrs_host[g] its
- * learning rate (HOST arrays).  step counts from 1.  zero_grad != 0 also clears grads. */
-int gs_adam_step(void* stream, int64_t n, float* params, float* grads, float* exp_avg,
-                 float* exp_avg_sq, int n_groups, const int64_t* group_ends_host,
-                 const float* group_lrs_host, float beta1, float beta2, float eps, int64_t step,
-                 int zero_grad);
+ * params, exp_avg, exp_avg_sq: flat fp32 device buffers of n elements holding n_segments parameter
+ * tensors back to back, each padded to a multiple of 4 elements.  HOST arrays per segment:
+ * seg_ends_host (exclusive padded end), seg_lens_host (true element count), seg_grads_host (device
+ * pointer of that tensor's contiguous, 16-byte aligned gradient; NULL = skip the segment, as torch
+ * skips `p.grad is None`), seg_lrs_host.  step counts from 1. */
+int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
+                 int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
+                 const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
+                 float beta2, float eps, int64_t step);
 
 #ifdef __cplusplus
 }

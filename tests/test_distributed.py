@@ -48,7 +48,7 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
-    from easy_gaussian_splatting_amd.distributed import GradBucket, all_reduce_statistics, shard_views
+    from easy_gaussian_splatting_amd.distributed import GradBucket, all_reduce_param_grads, all_reduce_statistics, shard_views
     sc = _scene()
     params = _params(sc)
     bucket = GradBucket(params)
@@ -58,7 +58,13 @@ def _worker(rank, world, port, out_dir):
     loss, meta = _view_loss(params, sc, views, target)
     loss.backward()
     assert params[0].grad.data_ptr() == bucket.flat.data_ptr()  # autograd accumulated into the bucket
+    loose = [torch.nn.Parameter(p.detach().clone()) for p in params]   # bucket-free variant
+    for q, p in zip(loose, params):
+        q.grad = p.grad.detach().clone()
     bucket.all_reduce_mean()
+    all_reduce_param_grads(loose)
+    for q, p in zip(loose, params):
+        assert torch.equal(q.grad, p.grad)
     radii = meta["radii"][0].double() / max(sc["width"], sc["height"])
     vis = radii > 0
     g = torch.where(vis, meta["means2d"].absgrad[0].norm(dim=-1), torch.zeros_like(radii))

@@ -32,9 +32,11 @@ def test_fused_adam_matches_torch_adam(n):
             grad = torch.randn(getattr(a, name).shape, generator=g).to(dev) * (10.0 ** (it - 2))
             pa, pb = getattr(a, name), getattr(b, name)
             pa.grad = grad.clone()
-            pb.grad.copy_(grad)          # FusedAdam's grads are views into its flat bucket
+            pb.grad = grad.clone() if not (it == 4 and name == "quats") else None   # a skipped tensor
+            if it == 4 and name == "quats":
+                pa.grad = None
         oa.step(); ob.step(); oa.zero_grad(); ob.zero_grad()
-        assert float(ob.flat_grad.abs().max()) == 0.0
+        assert all(getattr(b, name).grad is None for name in b.param_names)
     for name in a.param_names:
         pa, pb = getattr(a, name).detach().cpu().numpy(), getattr(b, name).detach().cpu().numpy()
         assert np.abs(pa - pb).max() <= 2e-6 * max(1.0, np.abs(pa).max()), name
