@@ -49,14 +49,27 @@ __device__ __forceinline__ void stage_sh_rows(const float* __restrict__ shs, int
     const int row_f = 3 * K, stride = row_f + 1;
     const float* src = shs + n0 * row_f;
     if (ka3 == row_f && (row_f & 3) == 0) {
-        const int per_row = row_f >> 2;
+        // All of a thread's (<= 12) 16-byte loads are issued before the first LDS write: a single
+        // loop "load, then store to LDS" makes hipcc wait for each load before the next is issued
+        // (the LDS store may alias the visibility flags it reads), i.e. 12 serial HBM round trips.
+        const int per_row = row_f >> 2, total4 = rows * per_row;
         const float4* src4 = reinterpret_cast<const float4*>(src);
-        for (int e = threadIdx.x; e < rows * per_row; e += blockDim.x) {
-            const int g = e / per_row, q = e - g * per_row;
-            if (vis[g]) {
-                const float4 v = src4[e];
-                float* d = tile + g * stride + 4 * q;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        constexpr int kMaxQ = 12;   // K <= 16 -> at most 48 floats = 12 quads per Gaussian
+        float4 v[kMaxQ];
+        bool ld[kMaxQ];
+#pragma unroll
+        for (int q = 0; q < kMaxQ; ++q) {
+            const int e = threadIdx.x + q * kProjThreads;
+            ld[q] = e < total4 && vis[e / per_row];
+            if (ld[q]) v[q] = src4[e];
+        }
+#pragma unroll
+        for (int q = 0; q < kMaxQ; ++q) {
+            if (ld[q]) {
+                const int e = threadIdx.x + q * kProjThreads;
+                const int g = e / per_row, o = e - g * per_row;
+                float* d = tile + g * stride + 4 * o;
+                d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
             }
         }
     } else {
@@ -84,12 +97,21 @@ __device__ __forceinline__ void stage_sh_rows_split(const float* __restrict__ sh
     const int total = rows * rest_f;
     if (kr == rest_f) {  // whole rows needed: one contiguous, 16-byte aligned stream for the block
         const float4* src4 = reinterpret_cast<const float4*>(src);
-        for (int e4 = threadIdx.x; e4 < (total >> 2); e4 += blockDim.x) {
-            const int e = e4 << 2;
-            const int g0 = e / rest_f, g1 = (e + 3) / rest_f;
-            if (vis[g0] || vis[g1]) {
-                const float4 v = src4[e4];
-                const float vv[4] = {v.x, v.y, v.z, v.w};
+        constexpr int kMaxQ = 12;   // <= 45 floats per Gaussian -> at most 12 quads per thread
+        const int total4 = total >> 2;
+        float4 v[kMaxQ];
+        bool ld[kMaxQ];
+#pragma unroll
+        for (int q = 0; q < kMaxQ; ++q) {   // issue every load first (see stage_sh_rows)
+            const int e4 = threadIdx.x + q * kProjThreads, e = e4 << 2;
+            ld[q] = e4 < total4 && (vis[e / rest_f] || vis[(e + 3) / rest_f]);
+            if (ld[q]) v[q] = src4[e4];
+        }
+#pragma unroll
+        for (int q = 0; q < kMaxQ; ++q) {
+            if (ld[q]) {
+                const int e = (threadIdx.x + q * kProjThreads) << 2;
+                const float vv[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int g = (e + i) / rest_f, o = (e + i) - g * rest_f;
@@ -263,8 +285,28 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     RowSum s;
 #pragma unroll
     for (int i = 0; i < 12; ++i) s.v[i] = 0.f;
-    if (cnt <= kCoopRows)
-        for (int r = 0; r < cnt; ++r) row_add(s, a.rows, a.qmask, (int64_t)(base + r));
+    if (cnt <= kCoopRows) {
+        // one slot per iteration: its (up to four) quadrant rows are all requested before the first
+        // is consumed, and the next slot's mask byte is fetched one iteration ahead
+        int bits_next = cnt > 0 ? (int)a.qmask[base] : 0;
+        for (int r = 0; r < cnt; ++r) {
+            const int bits = bits_next;
+            if (r + 1 < cnt) bits_next = (int)a.qmask[base + r + 1];
+            const float4* rp = a.rows + 12 * (int64_t)(base + r);
+            float4 rv[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (bits & (1 << q)) { rv[q][0] = rp[3 * q]; rv[q][1] = rp[3 * q + 1]; rv[q][2] = rp[3 * q + 2]; }
+                else { rv[q][0] = rv[q][1] = rv[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // fixed order -> reproducible sums (x + 0 is exact)
+                s.v[0] += rv[q][0].x; s.v[1] += rv[q][0].y; s.v[2] += rv[q][0].z; s.v[3] += rv[q][0].w;
+                s.v[4] += rv[q][1].x; s.v[5] += rv[q][1].y; s.v[6] += rv[q][1].z; s.v[7] += rv[q][1].w;
+                s.v[8] += rv[q][2].x; s.v[9] += rv[q][2].y; s.v[10] += rv[q][2].z;
+            }
+        }
+    }
     unsigned long long big = __ballot(cnt > kCoopRows);
     while (big) {
         const int src = __ffsll((long long)big) - 1;
