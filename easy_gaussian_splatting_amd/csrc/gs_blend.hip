@@ -156,7 +156,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
             }
             if (lane < m) a.qmask[my_slot] = (uint8_t)mybits;
         }
-        __syncthreads();
+        // single-wave workgroup: LDS operations of one wave complete in issue order, so the staged
+        // records are visible without a workgroup barrier
+        __builtin_amdgcn_wave_barrier();
         for (unsigned long long rem = mq[0] | mq[1] | mq[2] | mq[3]; rem; rem &= rem - 1) {
             const int j = __builtin_ctzll(rem);
             const float4 q0 = srec[j * 3], q1 = srec[j * 3 + 1], q2 = srec[j * 3 + 2];
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) cnt[k] += __popcll(mq[k]);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     if (CKPT) {
         // publish sublist lengths and one work unit per 64-entry quadrant bucket
