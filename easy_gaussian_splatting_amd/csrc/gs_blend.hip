@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
             const float4* r = a.rec + 3 * (size_t)my_gid;
             const float4 q0 = r[0], q1 = r[1], q2 = r[2];
             srec[lane * 3] = q0; srec[lane * 3 + 1] = q1; srec[lane * 3 + 2] = q2;
-            const float ex = q2.y, ey = q2.z;   // negative when alpha can never reach 1/255
+            const float ex = q1.z, ey = q1.w;   // negative when alpha can never reach 1/255
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 hx[h] = ex >= 0.f && q0.x + ex >= qxlo[h] && q0.x - ex <= qxhi[h];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
             const float dxa = q0.x - fx0, dxb = q0.x - fx1, dya = q0.y - fy0, dyb = q0.y - fy1;
             const float sxa = q0.z * dxa * dxa, sxb = q0.z * dxb * dxb;   // hA dx^2
             const float bxa = q0.w * dxa, bxb = q0.w * dxb;               // B dx
-            const float op = q1.y, r = q1.z, g = q1.w, bl = q2.x;
+            const float op = q1.y, r = q2.x, g = q2.y, bl = q2.z;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if ((mq[k] >> j) & 1) {
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
             q0 = rp[0]; q1 = rp[1]; q2 = rp[2];
         }
         e[i].mx = q0.x; e[i].my = q0.y; e[i].hA = q0.z; e[i].Bc = q0.w; e[i].hC = q1.x; e[i].op = q1.y;
-        e[i].colr = q1.z; e[i].colg = q1.w; e[i].colb = q2.x;
+        e[i].colr = q2.x; e[i].colg = q2.y; e[i].colb = q2.z;
         // true conic entries for the mean gradient (the record stores them scaled by log2(e))
         e[i].At = 2.f * kLn2 * q0.z; e[i].Bt = kLn2 * q0.w; e[i].Ct = 2.f * kLn2 * q1.x;
         e[i].s_mx = e[i].s_my = e[i].s_ax = e[i].s_ay = e[i].s_A = e[i].s_B = e[i].s_C = e[i].s_vs = 0.f;

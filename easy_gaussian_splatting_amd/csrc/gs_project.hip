@@ -131,7 +131,12 @@ __device__ __forceinline__ void stage_sh_rows_split(const float* __restrict__ sh
     }
 }
 
-template <int DEG>
+// STAGE 0: geometry + colour in one launch.  STAGE 1: geometry only (radii, means2d, depths,
+// conics, footprint, record quads 0-1).  STAGE 2: colour only (SH evaluation -> colors_out and
+// record quad 2) for the Gaussians stage 1 found visible.  The split lets the host enqueue the
+// colour pass BEHIND the tile-count kernels: the one host read-back of the path (I, to size the
+// lists) then overlaps ~0.1 ms of SH streaming instead of leaving the GPU idle.
+template <int DEG, int STAGE>
 __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lds_cam = smem;
@@ -146,50 +151,62 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
     Camera cam;
     load_camera(a.viewmats, a.Ks, c, a.W, a.H, lds_cam, cam);
 
-    Splat2D s;
-    s.radius = 0; s.mx = s.my = s.depth = s.A = s.B = s.C = s.cxx = s.cyy = 0.f;
     float mean[3] = {0.f, 0.f, 0.f};
-    if (in_range) {
-        mean[0] = a.means[3 * n]; mean[1] = a.means[3 * n + 1]; mean[2] = a.means[3 * n + 2];
-        const float4 q4 = reinterpret_cast<const float4*>(a.quats)[n];
-        const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float scale[3] = {a.scales[3 * n], a.scales[3 * n + 1], a.scales[3 * n + 2]};
-        s = project_gaussian(mean, quat, scale, cam, a.W, a.H, a.eps2d, a.near_p, a.far_p, a.radius_clip);
-    }
-    const bool vis = s.radius > 0;
-    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-    float op = 0.f, ex = -1.f, ey = -1.f;
-    if (vis) {
-        tile_rect(s.mx, s.my, s.radius, GS_TILE, a.tw, a.th, x0, x1, y0, y1);
-        op = a.opacities[n];
-        alpha_extent(op, s.cxx, s.cyy, ex, ey);
-        // tight mode: keep only the tiles of the 3-sigma rectangle that hold a pixel centre where
-        // alpha can reach 1/255 (the blend skips every other pixel anyway: identical image)
-        if (a.tight) tile_rect_tight(s.mx, s.my, ex, ey, a.W, a.H, GS_TILE, x0, x1, y0, y1);
-    }
-    // tile footprint: rectangle + (for rectangles of <= 32 tiles) a row-major bit per tile
-    const int rw = x1 - x0, rect_tiles = rw * (y1 - y0);
-    uint32_t tmask = rect_tiles >= 32 ? 0xffffffffu : ((1u << rect_tiles) - 1u);
-    if (a.tight && rect_tiles > 0 && rect_tiles <= 32) {
-        // exact test per tile: some pixel centre of the tile must allow alpha >= 1/255
-        const float tau = __log2f(255.f * op) + 0.02f, lim = tau + 1e-4f * fabsf(tau);
-        const float qa = 0.5f * kLog2e * s.A, qb = kLog2e * s.B, qc = 0.5f * kLog2e * s.C;
-        tmask = 0u;
-        for (int i = 0; i < rect_tiles; ++i) {
-            const int ty = y0 + i / rw, tx = x0 + (i - (i / rw) * rw);
-            const float dx0 = (float)(tx * GS_TILE) + 0.5f - s.mx, dy0 = (float)(ty * GS_TILE) + 0.5f - s.my;
-            if (quad_min_on_rect(qa, qb, qc, dx0, dx0 + (float)(GS_TILE - 1), dy0, dy0 + (float)(GS_TILE - 1)) <= lim) tmask |= 1u << i;
+    if (in_range) { mean[0] = a.means[3 * n]; mean[1] = a.means[3 * n + 1]; mean[2] = a.means[3 * n + 2]; }
+    bool vis = false;
+    if (STAGE != 2) {
+        Splat2D s;
+        s.radius = 0; s.mx = s.my = s.depth = s.A = s.B = s.C = s.cxx = s.cyy = 0.f;
+        if (in_range) {
+            const float4 q4 = reinterpret_cast<const float4*>(a.quats)[n];
+            const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
+            const float scale[3] = {a.scales[3 * n], a.scales[3 * n + 1], a.scales[3 * n + 2]};
+            s = project_gaussian(mean, quat, scale, cam, a.W, a.H, a.eps2d, a.near_p, a.far_p, a.radius_clip);
         }
+        vis = s.radius > 0;
+        int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        float op = 0.f, ex = -1.f, ey = -1.f;
+        if (vis) {
+            tile_rect(s.mx, s.my, s.radius, GS_TILE, a.tw, a.th, x0, x1, y0, y1);
+            op = a.opacities[n];
+            alpha_extent(op, s.cxx, s.cyy, ex, ey);
+            // tight mode: keep only the tiles of the 3-sigma rectangle that hold a pixel centre where
+            // alpha can reach 1/255 (the blend skips every other pixel anyway: identical image)
+            if (a.tight) tile_rect_tight(s.mx, s.my, ex, ey, a.W, a.H, GS_TILE, x0, x1, y0, y1);
+        }
+        // tile footprint: rectangle + (for rectangles of <= 32 tiles) a row-major bit per tile
+        const int rw = x1 - x0, rect_tiles = rw * (y1 - y0);
+        uint32_t tmask = rect_tiles >= 32 ? 0xffffffffu : ((1u << rect_tiles) - 1u);
+        if (a.tight && rect_tiles > 0 && rect_tiles <= 32) {
+            // exact test per tile: some pixel centre of the tile must allow alpha >= 1/255
+            const float tau = __log2f(255.f * op) + 0.02f, lim = tau + 1e-4f * fabsf(tau);
+            const float qa = 0.5f * kLog2e * s.A, qb = kLog2e * s.B, qc = 0.5f * kLog2e * s.C;
+            tmask = 0u;
+            for (int i = 0; i < rect_tiles; ++i) {
+                const int ty = y0 + i / rw, tx = x0 + (i - (i / rw) * rw);
+                const float dx0 = (float)(tx * GS_TILE) + 0.5f - s.mx, dy0 = (float)(ty * GS_TILE) + 0.5f - s.my;
+                if (quad_min_on_rect(qa, qb, qc, dx0, dx0 + (float)(GS_TILE - 1), dy0, dy0 + (float)(GS_TILE - 1)) <= lim) tmask |= 1u << i;
+            }
+        }
+        const int cnt = rect_tiles <= 32 ? __popc(tmask) : rect_tiles;
+        if (in_range) {
+            a.radii[f] = s.radius;
+            reinterpret_cast<float2*>(a.means2d)[f] = make_float2(s.mx, s.my);
+            a.depths[f] = s.depth;
+            a.conics[3 * f] = s.A; a.conics[3 * f + 1] = s.B; a.conics[3 * f + 2] = s.C;
+            a.bbox[f] = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), tmask, (uint32_t)cnt);
+            a.tiles_per_gauss[f] = cnt;
+            if (vis) {
+                // blend record: conic pre-scaled so the kernels evaluate exp2(-(hA dx^2 + B dx dy + hC dy^2))
+                float4* r = a.rec + 3 * f;
+                r[0] = make_float4(s.mx, s.my, 0.5f * kLog2e * s.A, kLog2e * s.B);
+                r[1] = make_float4(0.5f * kLog2e * s.C, op, ex, ey);
+            }
+        }
+    } else {
+        vis = in_range && a.radii[f] > 0;
     }
-    const int cnt = rect_tiles <= 32 ? __popc(tmask) : rect_tiles;
-    if (in_range) {
-        a.radii[f] = s.radius;
-        reinterpret_cast<float2*>(a.means2d)[f] = make_float2(s.mx, s.my);
-        a.depths[f] = s.depth;
-        a.conics[3 * f] = s.A; a.conics[3 * f + 1] = s.B; a.conics[3 * f + 2] = s.C;
-        a.bbox[f] = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), tmask, (uint32_t)cnt);
-        a.tiles_per_gauss[f] = cnt;
-    }
+    if (STAGE == 1) return;
 
     float rgb[3] = {0.5f, 0.5f, 0.5f};
     if (DEG >= 0) {
@@ -218,13 +235,7 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
     }
     if (in_range) {
         a.colors_out[3 * f] = rgb[0]; a.colors_out[3 * f + 1] = rgb[1]; a.colors_out[3 * f + 2] = rgb[2];
-        if (vis) {
-            // blend record: conic pre-scaled so the kernels evaluate exp2(-(hA dx^2 + B dx dy + hC dy^2))
-            float4* r = a.rec + 3 * f;
-            r[0] = make_float4(s.mx, s.my, 0.5f * kLog2e * s.A, kLog2e * s.B);
-            r[1] = make_float4(0.5f * kLog2e * s.C, op, rgb[0], rgb[1]);
-            r[2] = make_float4(rgb[2], ex, ey, 0.f);
-        }
+        if (vis) a.rec[3 * f + 2] = make_float4(rgb[0], rgb[1], rgb[2], 0.f);
     }
 }
 
@@ -456,7 +467,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
                               const float* colors_in, const float* sh_rest, int colors_per_camera,
                               const float* viewmats, const float* Ks, int width, int height,
                               float eps2d, float near_plane, float far_plane, float radius_clip,
-                              int tile_culling, int32_t* radii,
+                              int tile_culling, int stage, int32_t* radii,
                               float* means2d, float* depths, float* conics, float* colors_out, float* rec,
                               uint32_t* bbox, int32_t* tiles_per_gauss) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
@@ -479,13 +490,19 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads), (unsigned)C);
     const size_t lds = proj_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;
-    switch (sh_degree) {
-        case 0: hipLaunchKernelGGL(project_fwd_kernel<0>, grid, dim3(kProjThreads), lds, st, a); break;
-        case 1: hipLaunchKernelGGL(project_fwd_kernel<1>, grid, dim3(kProjThreads), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(project_fwd_kernel<2>, grid, dim3(kProjThreads), lds, st, a); break;
-        case 3: hipLaunchKernelGGL(project_fwd_kernel<3>, grid, dim3(kProjThreads), lds, st, a); break;
-        default: hipLaunchKernelGGL(project_fwd_kernel<-1>, grid, dim3(kProjThreads), lds, st, a); break;
+    GS_REQUIRE(stage >= 0 && stage <= 2, "stage: 0 = geometry+colour, 1 = geometry, 2 = colour");
+#define GS_PF(D, S) hipLaunchKernelGGL((project_fwd_kernel<D, S>), grid, dim3(kProjThreads), (S) == 1 ? proj_lds_bytes(K, -1) : lds, st, a)
+#define GS_PF_DEG(S)                                                      \
+    switch (sh_degree) {                                                  \
+        case 0: GS_PF(0, S); break;                                       \
+        case 1: GS_PF(1, S); break;                                       \
+        case 2: GS_PF(2, S); break;                                       \
+        case 3: GS_PF(3, S); break;                                       \
+        default: GS_PF(-1, S); break;                                     \
     }
+    if (stage == 0) { GS_PF_DEG(0) } else if (stage == 1) { GS_PF_DEG(1) } else { GS_PF_DEG(2) }
+#undef GS_PF_DEG
+#undef GS_PF
     GS_LAUNCH_CHECK("project_fwd_kernel");
     return GS_OK;
 }

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as _ct
 import math
+import threading
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -60,6 +61,21 @@ def profile_stages(enable: bool) -> Optional[Dict]:
     return {k: [s.elapsed_time(e) for s, e in v] for k, v in out.items()}
 
 
+_tls = threading.local()
+
+
+def _pinned_info(device: torch.device) -> Tensor:
+    """Page-locked 4 x int64 landing buffer for the list sizes, one per (host thread, device)."""
+    cache = getattr(_tls, "pinned", None)
+    if cache is None:
+        cache = _tls.pinned = {}
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    buf = cache.get(key)
+    if buf is None:
+        buf = cache[key] = torch.empty((4,), dtype=torch.int64, pin_memory=True)
+    return buf
+
+
 class _Holder:
     """Carries non-tensor state between `rasterization()` and the autograd node without making
     the node own its own output (the weak reference lets backward attach `.absgrad` to the very
@@ -102,21 +118,32 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     rec = torch.empty((C * N, nat.GS_REC_FLOATS), **f32)
     bbox = torch.empty((C * N, 4), **i32)
     tiles_per_gauss = torch.empty((C, N), **i32)
-    _stage("gs_project_fwd", dev, lambda: nat.check(L.gs_project_fwd(st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
-                               _ptr(colors), _ptr(colors_rest), per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
-                               cfg["near_plane"], cfg["far_plane"], cfg["radius_clip"], cfg["tile_culling"], _ptr(radii),
-                               _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(colors_post), _ptr(rec),
-                               _ptr(bbox), _ptr(tiles_per_gauss)), "gs_project_fwd"))
+    def project(stage: int, tag: str):
+        _stage(tag, dev, lambda: nat.check(L.gs_project_fwd(
+            st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), _ptr(colors_rest),
+            per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"],
+            cfg["radius_clip"], cfg["tile_culling"], stage, _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics),
+            _ptr(colors_post), _ptr(rec), _ptr(bbox), _ptr(tiles_per_gauss)), "gs_project_fwd"))
 
+    # 1. geometry, 2. tile counts, 3. colours.  The list sizes {I, n_buckets, max_tile} must reach the
+    # host before the list buffers can be allocated -- the path's one host read-back.  The copy is
+    # queued right behind the count kernels and the SH colour pass behind the copy, so the host
+    # wakes on the copy's event while the GPU is still busy with SH: no idle gap.
+    project(1, "gs_project_fwd")
     ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
     workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     isect_offsets = torch.empty((C * tiles + 1,), **i32)
     bucket_offsets = torch.empty((C * tiles + 1,), **i32)
     info_dev = torch.empty((4,), dtype=torch.int64, device=dev)
-    info_host = (_ct.c_int64 * 4)()
     _stage("gs_bin_count", dev, lambda: nat.check(L.gs_bin_count(st, C, N, tw, th, _ptr(bbox), _ptr(workspace), ws_bytes, _ptr(isect_offsets),
-                             _ptr(bucket_offsets), _ptr(info_dev), info_host), "gs_bin_count"))
-    n_isects, n_buckets, max_tile = int(info_host[0]), int(info_host[1]), int(info_host[2])
+                             _ptr(bucket_offsets), _ptr(info_dev), None), "gs_bin_count"))
+    info_host = _pinned_info(dev)
+    info_host.copy_(info_dev, non_blocking=True)
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))
+    project(2, "gs_project_fwd_color")
+    ready.synchronize()
+    n_isects, n_buckets, max_tile = (int(v) for v in info_host[:3].tolist())
 
     cap = max(n_isects, 1)
     keys_tmp = torch.empty((cap,), dtype=torch.int64, device=dev)

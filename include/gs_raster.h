@@ -59,20 +59,24 @@ size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h);
  * sh_degree < 0: `colors_in` is already post-activation colour, [N,3] (colors_per_camera=0) or
  * [C,N,3] (=1); sh_rest is ignored.
  * Outputs: radii[C,N] i32 (0 = culled), means2d[C,N,2], depths[C,N], conics[C,N,3],
- * colors_out[C,N,3], rec[C*N*12] (mx, my, A*log2e/2, B*log2e | C*log2e/2, opacity, r, g |
- * b, ext_x, ext_y, 0: conic pre-scaled for exp2, opacity-aware half extents in pixels),
+ * colors_out[C,N,3], rec[C*N*12] (mx, my, A*log2e/2, B*log2e | C*log2e/2, opacity, ext_x, ext_y |
+ * r, g, b, 0: conic pre-scaled for exp2, opacity-aware half extents in pixels),
  * bbox[C*N*4] u32 (x0 | x1<<16, y0 | y1<<16: tile rectangle, min inclusive / max exclusive;
  * row-major tile bit mask for rectangles of <= 32 tiles; tile count),
  * tiles_per_gauss[C,N] i32.
  * tile_culling: 0 = gsplat's 3-sigma square (A.3; lists identical to the reference's), 1 = that
  * rectangle intersected with the opacity-aware extent and, for footprints of <= 32 tiles, an exact
  * ellipse-vs-tile test (tiles in which no pixel can reach alpha >= 1/255 are dropped; the rendered
- * image and all gradients are unchanged). */
+ * image and all gradients are unchanged).
+ * stage: 0 = everything; 1 = geometry only (all outputs except colors_out and the colour quad of
+ * rec); 2 = colour only, for the Gaussians a previous stage-1 call marked visible in radii.  Calling
+ * 1, then the gs_bin_count kernels, then 2 lets the colour pass overlap the host read-back of I. */
 int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* opacities,
                    const float* colors_in, const float* sh_rest, int colors_per_camera,
                    const float* viewmats, const float* Ks, int width, int height, float eps2d,
-                   float near_plane, float far_plane, float radius_clip, int tile_culling, int32_t* radii,
+                   float near_plane, float far_plane, float radius_clip, int tile_culling, int stage,
+                   int32_t* radii,
                    float* means2d, float* depths, float* conics, float* colors_out, float* rec, uint32_t* bbox,
                    int32_t* tiles_per_gauss);
 
