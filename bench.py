@@ -157,11 +157,14 @@ def main():
     for _ in range(args.warmup):
         train_step()
     barrier()
+    rendering.stats["sync_wait_ns"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = train_step()
+    t_enqueued = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
+    host_wait_ms = rendering.stats["sync_wait_ns"] * 1e-6 / args.steps
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -225,6 +228,10 @@ def main():
                        "n_visible": n_vis, "n_isects": n_isects, "n_isects_gsplat_lists": n_isects_ref,
                        "parallelism": f"view-dp{world}"},
             "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
+            # host diagnostics: ms/step the host spent blocked on the list-size read-back; if this is ~0
+            # the Python side, not the GPU, paces the loop on this box
+            "host": {"enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 4),
+                     "blocked_on_readback_ms_per_step": round(host_wait_ms, 4)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as _ct
 import math
 import threading
+import time
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -62,6 +63,9 @@ def profile_stages(enable: bool) -> Optional[Dict]:
 
 
 _tls = threading.local()
+# host-side diagnostics: time spent blocked on the list-size read-back (bench.py reports it; a wait
+# near zero means the host, not the GPU, paces the loop)
+stats = {"sync_wait_ns": 0, "calls": 0}
 
 
 def _pinned_info(device: torch.device) -> Tensor:
@@ -142,7 +146,10 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream(dev))
     project(2, "gs_project_fwd_color")
+    t_wait = time.perf_counter_ns()
     ready.synchronize()
+    stats["sync_wait_ns"] += time.perf_counter_ns() - t_wait
+    stats["calls"] += 1
     n_isects, n_buckets, max_tile = (int(v) for v in info_host[:3].tolist())
 
     cap = max(n_isects, 1)
