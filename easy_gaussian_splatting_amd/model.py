@@ -6,7 +6,10 @@ step drives); names and argument meaning follow /root/reference/model/gaussian.p
   GaussianModel.forward(data)                <- :351-374  (C=1 batching, clamp to [0,1])
   GaussianModel.update_statistics(...)       <- :188-197  (consumer of .absgrad and radii)
   build_optimizers(...)                      <- :389-412  (one Adam, six named groups)
-Densification, pruning, checkpoint IO, loaders and the viewer are out of scope.
+  GaussianModel.densify_and_prune / reset_opacities  <- :130-146, 259-349  ("next" row f-3: same
+      decisions, but one gather per tensor and three host reads instead of ~20 boolean-index
+      copies and 8 host syncs; works on torch.optim.Adam and on optim.FusedAdam state)
+Checkpoint IO, loaders and the viewer are out of scope.
 """
 from __future__ import annotations
 
@@ -23,8 +26,12 @@ from .rendering import rasterization
 class GaussianModel(nn.Module):
     def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, sh_0: Tensor, sh_rest: Tensor,
                  logit_opacities: Tensor, sh_degree: int, sh_degree_interval: int = 0,
-                 white_background: bool = False, fuse_sh_cat: bool = True):
+                 white_background: bool = False, fuse_sh_cat: bool = True,
+                 densify_grad_thresh: float = 0.0002, densify_scale_thresh: float = 0.01, num_splits: int = 2,
+                 prune_radii_ratio_thresh: float = 0.15, prune_scale_thresh: float = 0.1, min_opacity: float = 0.005):
         super().__init__()
+        self.DENSIFY_GRAD_THRESH, self.DENSIFY_SCALE_THRESH, self.NUM_SPLITS = densify_grad_thresh, densify_scale_thresh, num_splits
+        self.PRUNE_RADII_RATIO_THRESH, self.PRUNE_SCALE_THRESH, self.MIN_OPACITY = prune_radii_ratio_thresh, prune_scale_thresh, min_opacity
         self.means = nn.Parameter(means.float())  # [N, 3]
         self.log_scales = nn.Parameter(log_scales.float())  # [N, 3]
         self.quats = nn.Parameter(quats.float())  # [N, 4] wxyz
@@ -70,6 +77,114 @@ class GaussianModel(nn.Module):
 
     def up_sh_degree(self):
         self.active_sh_degree = min(self.active_sh_degree + 1, self.MAX_SH_DEGREE)
+
+    # ---------------------------------------------------------------- refinement (row f-3)
+    def _moments(self, name: str):
+        """(exp_avg, exp_avg_sq) of parameter `name` from either optimizer flavour (zeros if unset)."""
+        p = getattr(self, name)
+        opt = self.optimizer
+        if opt is None:
+            raise RuntimeError("optimizer has not been registered")
+        if hasattr(opt, "moments_of"):
+            return opt.moments_of(p)
+        st = opt.state.get(p, {})
+        if "exp_avg" in st:
+            return st["exp_avg"], st["exp_avg_sq"]
+        return torch.zeros_like(p), torch.zeros_like(p)
+
+    def _replace_parameters(self, new: Dict[str, Tensor], new_m: Dict[str, Tensor], new_v: Dict[str, Tensor]):
+        """Swaps in resized parameter tensors and their Adam moments (reference: the per-group
+        state surgery of model/gaussian.py:199-257)."""
+        opt = self.optimizer
+        old = {name: getattr(self, name) for name in self.param_names}
+        for name in self.param_names:
+            setattr(self, name, nn.Parameter(new[name].contiguous()))
+        if hasattr(opt, "replace_parameters"):
+            opt.replace_parameters([(getattr(self, n), new_m[n], new_v[n]) for n in self.param_names])
+            return
+        for group in opt.param_groups:
+            name = group["name"]
+            state = opt.state.pop(old[name], {})
+            group["params"][0] = getattr(self, name)
+            if "step" in state:   # a parameter Adam has never stepped keeps its (lazily created) empty state
+                state["exp_avg"], state["exp_avg_sq"] = new_m[name].contiguous(), new_v[name].contiguous()
+                opt.state[group["params"][0]] = state
+
+    @torch.no_grad()
+    def densify_and_prune(self, generator: Optional[torch.Generator] = None) -> Dict[str, Any]:
+        """Clone / split high-gradient Gaussians, prune transparent / huge ones, reset statistics
+        (/root/reference/model/gaussian.py:259-349).  Decisions are taken on the device; the host reads
+        three counts (split, clone, survivors) because tensor shapes need them."""
+        from .rendering import quat_to_rotmat_torch
+        n_old = self.nbr_gaussians
+        avg = self.grad_norm_accum / (self.collecting_counts + 1e-8)
+        avg = torch.where(torch.isnan(avg), torch.zeros_like(avg), avg)
+        high = avg >= self.DENSIFY_GRAD_THRESH
+        big = self.scales.amax(dim=-1) >= self.DENSIFY_SCALE_THRESH
+        split_mask, clone_mask = big & high, (~big) & high
+        split_idx = torch.nonzero(split_mask).squeeze(1)       # host read 1
+        clone_idx = torch.nonzero(clone_mask).squeeze(1)       # host read 2
+        ns, nc = split_idx.numel(), clone_idx.numel()
+        params = {name: getattr(self, name).detach() for name in self.param_names}
+        new_parts = {name: [] for name in self.param_names}
+        if ns:
+            rep = split_idx.repeat(self.NUM_SPLITS)            # [parents..., parents...] like .repeat(NUM_SPLITS, 1)
+            scales = torch.exp(params["log_scales"][rep])
+            noise = torch.randn((rep.numel(), 3), device=scales.device, generator=generator)
+            R = quat_to_rotmat_torch(params["quats"][rep])
+            offs = torch.bmm(R, (scales * noise).unsqueeze(-1)).squeeze(-1)
+            for name in self.param_names:
+                v = params[name][rep]
+                if name == "means":
+                    v = v + offs
+                elif name == "log_scales":
+                    v = torch.log(scales / (0.8 * self.NUM_SPLITS))
+                new_parts[name].append(v)
+        if nc:
+            for name in self.param_names:
+                new_parts[name].append(params[name][clone_idx])
+        n_new = ns * self.NUM_SPLITS + nc
+        # prune mask over [old | new]; new entries start with max_radii = 0 and are never "split parents"
+        cat = {name: (torch.cat([params[name]] + new_parts[name], dim=0) if n_new else params[name]) for name in self.param_names}
+        zeros_new = torch.zeros((n_new,), device=self.max_radii.device)
+        max_radii = torch.cat([self.max_radii, zeros_new])
+        was_split = torch.cat([split_mask, zeros_new.bool()])
+        low_op = torch.sigmoid(cat["logit_opacities"]) < self.MIN_OPACITY
+        big_r = max_radii > self.PRUNE_RADII_RATIO_THRESH
+        big_s = torch.exp(cat["log_scales"]).amax(dim=-1) > self.PRUNE_SCALE_THRESH
+        prune = low_op | big_r | big_s | was_split
+        keep_idx = torch.nonzero(~prune).squeeze(1)            # host read 3
+        counts = torch.stack([low_op.sum(), (low_op | big_r).sum(), (low_op | big_r | big_s).sum()])
+        new, new_m, new_v = {}, {}, {}
+        for name in self.param_names:
+            m, v = self._moments(name)
+            pad = [torch.zeros_like(p) for p in new_parts[name]]
+            new[name] = cat[name][keep_idx]
+            new_m[name] = (torch.cat([m] + pad, dim=0) if n_new else m)[keep_idx]
+            new_v[name] = (torch.cat([v] + pad, dim=0) if n_new else v)[keep_idx]
+        self._replace_parameters(new, new_m, new_v)
+        n = self.nbr_gaussians
+        dev = self.means.device
+        self.grad_norm_accum = torch.zeros((n,), device=dev)
+        self.collecting_counts = torch.zeros((n,), device=dev)
+        self.max_radii = torch.zeros((n,), device=dev)
+        c0, c1, c2 = (int(x) for x in counts.tolist())
+        return {"train/densify": {"split": ns, "clone": nc},
+                "train/prune": {"low_opacity": c0, "large_radii": c1 - c0, "large_scale": c2 - c1},
+                "train/nbr_gaussians": n, "n_before": n_old}
+
+    @torch.no_grad()
+    def reset_opacities(self):
+        """opacity <- min(opacity / 2, 2 * MIN_OPACITY); the group's Adam moments restart at zero
+        (/root/reference/model/gaussian.py:130-146)."""
+        target = torch.minimum(self.opacities * 0.5, torch.full_like(self.logit_opacities, self.MIN_OPACITY * 2.0))
+        new = {name: getattr(self, name).detach() for name in self.param_names}
+        new["logit_opacities"] = torch.logit(target)
+        new_m, new_v = {}, {}
+        for name in self.param_names:
+            m, v = self._moments(name)
+            new_m[name], new_v[name] = (torch.zeros_like(m), torch.zeros_like(v)) if name == "logit_opacities" else (m, v)
+        self._replace_parameters(new, new_m, new_v)
 
     def forward(self, data: Dict[str, Any]) -> Dict[str, Optional[Tensor]]:
         w2c = data["w2c"]

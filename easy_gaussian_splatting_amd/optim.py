@@ -20,6 +20,9 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params: List[Dict], betas=(0.9, 0.999), eps: float = 1e-8):
         defaults = dict(lr=1e-3, betas=betas, eps=eps)
         super().__init__(params, defaults)
+        self._build()
+
+    def _build(self, moments=None):
         self._plist = [(g, p) for g in self.param_groups for p in g["params"]]
         if not self._plist:
             raise ValueError("no parameters")
@@ -40,13 +43,37 @@ class FusedAdam(torch.optim.Optimizer):
         self.flat_param = torch.zeros(off, dtype=dt, device=dev)
         self.exp_avg = torch.zeros(off, dtype=dt, device=dev)
         self.exp_avg_sq = torch.zeros(off, dtype=dt, device=dev)
+        self._offs = offs
         with torch.no_grad():
-            for (_, p), o in zip(self._plist, offs):
+            for i, ((_, p), o) in enumerate(zip(self._plist, offs)):
                 n = p.numel()
                 self.flat_param[o:o + n].copy_(p.detach().reshape(-1))
+                if moments is not None:
+                    self.exp_avg[o:o + n].copy_(moments[i][0].reshape(-1))
+                    self.exp_avg_sq[o:o + n].copy_(moments[i][1].reshape(-1))
                 p.data = self.flat_param[o:o + n].view_as(p)   # parameters become views of the flat buffer
                 p.grad = None
-        self._step = 0
+        if not hasattr(self, "_step"):
+            self._step = 0
+
+    def moments_of(self, param):
+        """(exp_avg, exp_avg_sq) views shaped like `param`."""
+        for i, (_, p) in enumerate(self._plist):
+            if p is param:
+                o, n = self._offs[i], p.numel()
+                return self.exp_avg[o:o + n].view_as(p), self.exp_avg_sq[o:o + n].view_as(p)
+        raise KeyError("parameter not owned by this optimizer")
+
+    def replace_parameters(self, triples):
+        """Densify / prune / opacity reset: new parameter tensors (one per group, in group order) with
+        their moments; the flat buffers are rebuilt, the step count (bias correction) is kept, as
+        the reference keeps Adam's `step` when it swaps a group's tensor."""
+        assert len(triples) == len(self.param_groups)
+        moments = []
+        for group, (p, m, v) in zip(self.param_groups, triples):
+            group["params"] = [p]
+            moments.append((m.detach().clone(), v.detach().clone()))
+        self._build(moments)
 
     @torch.no_grad()
     def step(self, closure=None):

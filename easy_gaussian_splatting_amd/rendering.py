@@ -262,6 +262,17 @@ class _Rasterize(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+def quat_to_rotmat_torch(quats: Tensor) -> Tensor:
+    """wxyz quaternion (normalised here) -> rotation matrices [...,3,3]; the convention of
+    /root/reference/model/utils.py:31-55, used by the split sampling of densify_and_prune."""
+    q = torch.nn.functional.normalize(quats, dim=-1)
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1)
+    return R.reshape(quats.shape[:-1] + (3, 3))
+
+
 def rasterization(
     means: Tensor,  # [N, 3]
     quats: Tensor,  # [N, 4]  wxyz, need not be normalised

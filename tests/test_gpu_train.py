@@ -51,3 +51,39 @@ def test_training_fits_target_views(fused):
     assert np.isfinite(losses).all()
     assert last < 0.45 * first, (first, last)
     assert float(model.collecting_counts.max()) > 0 and float(model.grad_norm_accum.max()) > 0
+
+
+@pytest.mark.parametrize("fused", ["hip", True])
+def test_refinement_inside_the_train_loop(fused):
+    """densify_and_prune / reset_opacities change N between steps; the rasterizer, the statistics
+    and both optimizer flavours must follow."""
+    dev = torch.device("cuda:0")
+    sc = make_scene(3000, 160, 112, sh_degree=3, n_views=2, seed=6, scale_range=(0.02, 0.1), dist=4.0)
+    target_model = _model(sc, dev, 0.0, 0)
+    datas = [{"w2c": torch.from_numpy(sc["viewmats"][v]).to(dev), "K": torch.from_numpy(sc["Ks"][v]).to(dev), "width": 160, "height": 112}
+             for v in range(2)]
+    with torch.no_grad():
+        targets = [target_model(d)["render_img"] for d in datas]
+    model = _model(sc, dev, 1.0, 2)
+    model.DENSIFY_GRAD_THRESH = 1e-5
+    opt = build_optimizers(model, 1.6e-3, 5e-3, 1e-3, 2.5e-2, 1.25e-3, 5e-2, fused=fused)
+    lc = LossComputer(0.2)
+    sizes, losses = [model.nbr_gaussians], []
+    for it in range(130):
+        v = it % 2
+        out = model(datas[v])
+        loss = lc.get_loss_dict(out["render_img"], targets[v])["total"]
+        loss.backward()
+        model.update_statistics(datas[v], out)
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss.detach()))
+        if it in (30, 60):
+            info = model.densify_and_prune()
+            sizes.append(info["train/nbr_gaussians"])
+            assert model.means.shape[0] == model.sh_rest.shape[0] == model.grad_norm_accum.shape[0] == sizes[-1]
+        if it == 45:
+            model.reset_opacities()
+    assert sizes[1] != sizes[0]
+    # refinement and the opacity reset perturb the fit; it must recover and end below where it started
+    assert np.isfinite(losses).all() and np.mean(losses[-6:]) < 0.9 * np.mean(losses[:6])
