@@ -397,17 +397,22 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     a.isect_offsets = isect_offsets; a.keys = (unsigned long long*)keys_tmp; a.slot_gid = slot_gid;
     a.isect_ids = isect_ids; a.flatten_ids = flatten_ids; a.slots = slots;
     const unsigned grid = (unsigned)(C * tiles);
-    // size classes: <=2048 entries (16 KB LDS, 256 threads), <=16384 (128 KB LDS, 1024 threads),
-    // beyond that an in-place global-memory network (rare: pathological scenes only)
-    a.lo_excl = 0; a.hi_incl = kSortSmall;
-    hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(256), sizeof(uint64_t) * kSortSmall, st, a);
-    GS_LAUNCH_CHECK("tile_sort_kernel<small>");
-    if (max_tile_count > kSortSmall) {
-        a.lo_excl = kSortSmall; a.hi_incl = kSortLarge;
-        const size_t big_lds = sizeof(uint64_t) * kSortLarge;
-        if (int rc = ensure_lds((const void*)tile_sort_kernel<true>, big_lds)) return rc;
-        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(1024), big_lds, st, a);
-        GS_LAUNCH_CHECK("tile_sort_kernel<large>");
+    // size classes, each launched only if some tile needs it (the host knows max_tile_count): LDS and
+    // workgroup size grow with the class so that the common short lists keep many blocks per CU:
+    //   <= 2048: 256 threads, 16 KB | <= 4096: 512 thr, 32 KB | <= 8192: 1024 thr, 64 KB |
+    //   <= 16384: 1024 thr, 128 KB | beyond: in-place global network
+    const int cls_hi[4] = {kSortSmall, 4096, 8192, kSortLarge};
+    const int cls_threads[4] = {256, 512, 1024, 1024};
+    int lo_excl = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (max_tile_count > lo_excl) {
+            a.lo_excl = lo_excl; a.hi_incl = cls_hi[k];
+            const size_t lds_k = sizeof(uint64_t) * (size_t)cls_hi[k];
+            if (int rc = ensure_lds((const void*)tile_sort_kernel<true>, lds_k)) return rc;
+            hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(cls_threads[k]), lds_k, st, a);
+            GS_LAUNCH_CHECK("tile_sort_kernel<lds>");
+        }
+        lo_excl = cls_hi[k];
     }
     if (max_tile_count > kSortLarge) {
         a.lo_excl = kSortLarge; a.hi_incl = 0x7fffffff;
