@@ -97,3 +97,35 @@ extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* exp_a
     GS_LAUNCH_CHECK("adam_step_kernel");
     return GS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// update_statistics (/root/reference/model/gaussian.py:188-197) as ONE launch: the consumer of the
+// `.absgrad` / `radii` side channels.  For visible Gaussians (radius > 0):
+//   max_radii = max(max_radii, radius / max_hw);  grad_norm_accum += |absgrad|_2 * max_hw;  counts += 1
+// The reference spells this as ~10 boolean-index kernels.  Single camera (the reference's C = 1).
+namespace gs {
+__global__ __launch_bounds__(256) void update_statistics_kernel(int64_t n, float max_hw, const int32_t* __restrict__ radii,
+                                                                const float2* __restrict__ absgrad, float* __restrict__ max_radii,
+                                                                float* __restrict__ grad_norm_accum, float* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = radii[i];
+    if (r > 0) {
+        const float2 g = absgrad[i];
+        max_radii[i] = fmaxf(max_radii[i], (float)r / max_hw);
+        grad_norm_accum[i] += sqrtf(g.x * g.x + g.y * g.y) * max_hw;
+        counts[i] += 1.f;
+    }
+}
+}  // namespace gs
+
+extern "C" int gs_update_statistics(void* stream, int64_t n, float max_hw, const int32_t* radii, const float* absgrad,
+                                    float* max_radii, float* grad_norm_accum, float* counts) {
+    GS_REQUIRE(n >= 0 && max_hw > 0.f, "n >= 0 and positive image extent");
+    if (n == 0) return GS_OK;
+    GS_REQUIRE(radii && absgrad && max_radii && grad_norm_accum && counts, "null pointer");
+    hipLaunchKernelGGL(gs::update_statistics_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, max_hw,
+                       radii, reinterpret_cast<const float2*>(absgrad), max_radii, grad_norm_accum, counts);
+    GS_LAUNCH_CHECK("update_statistics_kernel");
+    return GS_OK;
+}

@@ -213,8 +213,19 @@ class GaussianModel(nn.Module):
     @torch.no_grad()
     def update_statistics(self, data: Dict[str, Any], model_output: Dict[str, Tensor]):
         max_hw = max(data["height"], data["width"])
-        radii = model_output["batch_radii"].detach()[0] / max_hw
-        xys_absgrad = model_output["batch_xys"].absgrad.detach()[0]
+        raw_radii, absgrad = model_output["batch_radii"].detach(), model_output["batch_xys"].absgrad.detach()
+        if raw_radii.is_cuda and not is_distributed() and raw_radii.shape[0] == 1 and self.max_radii.is_contiguous():
+            # single view, single process: one HIP launch instead of ~10 masked torch kernels
+            from . import _native as nat
+            st = torch.cuda.current_stream(raw_radii.device).cuda_stream
+            with torch.cuda.device(raw_radii.device):
+                nat.check(nat.lib().gs_update_statistics(
+                    st, raw_radii.shape[1], float(max_hw), raw_radii.contiguous().data_ptr(), absgrad.contiguous().data_ptr(),
+                    self.max_radii.data_ptr(), self.grad_norm_accum.data_ptr(), self.collecting_counts.data_ptr()),
+                    "gs_update_statistics")
+            return
+        radii = raw_radii[0] / max_hw
+        xys_absgrad = absgrad[0]
         visible = radii > 0.0
         # masked forms of the reference's three boolean-index updates (same values, no host sync)
         zero = torch.zeros_like(radii)

@@ -175,6 +175,13 @@ int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* 
                  const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
                  float beta2, float eps, int64_t step);
 
+/* Row a-3: the consumer of the side channels, `GaussianModel.update_statistics`
+ * (/root/reference/model/gaussian.py:188-197), as one launch for the reference's single camera:
+ * for radii[i] > 0: max_radii = max(max_radii, radii/max_hw); grad_norm_accum += |absgrad[i]|_2 * max_hw;
+ * counts += 1.  absgrad is [N,2]. */
+int gs_update_statistics(void* stream, int64_t n, float max_hw, const int32_t* radii, const float* absgrad,
+                         float* max_radii, float* grad_norm_accum, float* counts);
+
 #ifdef __cplusplus
 }
 #endif
