@@ -385,3 +385,40 @@ def test_concurrent_host_threads_on_separate_streams():
     [th.join() for th in threads]
     for i in range(4):
         assert torch.equal(ref[i], got[i])
+
+
+@pytest.mark.timeout(120)
+def test_degenerate_inputs_neither_hang_nor_poison():
+    """Zero / NaN quaternions, NaN and infinite means, zero and huge scales, opacities 0 / 1 / >1,
+    Gaussians on the near plane and behind the camera: the path must finish, keep every finite
+    Gaussian's contribution finite, and hand back finite gradients for the finite inputs."""
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    sc = make_scene(512, 96, 64, sh_degree=1, seed=77, k_store=4, scale_range=(0.02, 0.3), dist=4.0)
+    t = to_dev(sc)
+    means, quats, scales, opac, shs = (t[k].clone() for k in ("means", "quats", "scales", "opacities", "shs"))
+    quats[0] = 0.0
+    quats[1] = float("nan")
+    means[2] = float("nan")
+    means[3, 2] = float("inf")
+    scales[4] = 0.0
+    scales[5] = 1e6
+    scales[6] = torch.tensor([1e-12, 1e3, 1e-12], device=dev())
+    opac[7] = 0.0
+    opac[8] = 1.0
+    opac[9] = 5.0
+    means[10] = torch.tensor([0.0, 0.0, -4.0 + 0.01], device=dev())   # on the near plane of the z=+4 camera
+    means[11] = torch.tensor([0.0, 0.0, -10.0], device=dev())        # behind the camera
+    shs[12] = 1e6
+    ins = [x.requires_grad_(True) for x in (means, quats, scales, opac, shs)]
+    img, alpha, meta = rasterization(*ins, t["viewmats"], t["Ks"], 96, 64, sh_degree=1, packed=False,
+                                     backgrounds=t["backgrounds"], absgrad=True)
+    (img.sum() + alpha.sum()).backward()
+    torch.cuda.synchronize()
+    radii = meta["radii"][0]
+    assert int(radii[0]) == 0 and int(radii[1]) == 0 and int(radii[2]) == 0 and int(radii[11]) == 0
+    assert bool(torch.isfinite(alpha).all())
+    good = torch.ones(512, dtype=torch.bool, device=dev())
+    good[:13] = False
+    for p in ins:
+        assert bool(torch.isfinite(p.grad[good]).all())
+    assert bool(torch.isfinite(meta["means2d"].absgrad[0][good]).all())
