@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from easy_gaussian_splatting_amd import rendering  # noqa: E402
-from easy_gaussian_splatting_amd.distributed import GradBucket, all_reduce_param_grads  # noqa: E402
+from easy_gaussian_splatting_amd.distributed import GradBucket, ViewParallelStep, all_reduce_param_grads  # noqa: E402
 from easy_gaussian_splatting_amd.loss import LossComputer  # noqa: E402
 from easy_gaussian_splatting_amd.model import GaussianModel, build_optimizers  # noqa: E402
 from easy_gaussian_splatting_amd.synthetic import config_bench_1m  # noqa: E402
@@ -132,11 +132,18 @@ def main():
         optimizer = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused="hip")
         bucket = None
     loss_computer = LossComputer(lambda_ssim=0.2)
+    # N > 1: factorised exchange (all-gather of colour gradients + all-reduce of the geometry
+    # gradients, distributed.ViewParallelStep); GS_DP_EXCHANGE=allreduce selects the plain all-reduce
+    exchange = "none" if world == 1 else os.environ.get("GS_DP_EXCHANGE", "factorised")
+    vp = ViewParallelStep(model, optimizer) if (exchange == "factorised" and bucket is None) else None
 
     def train_step():
         out = model(data)
         loss = loss_computer.get_loss_dict(out["render_img"], gt_img, mask)["total"]
         loss.backward()
+        if vp is not None:
+            vp.step(data, out)
+            return out
         model.update_statistics(data, out)
         if bucket is not None:
             bucket.all_reduce_mean()
@@ -226,7 +233,8 @@ def main():
             "config": {"workload": f"{args.gaussians} Gaussians, {W}x{H}, SH degree {sc['sh_degree']}, "
                                    "1 view per GPU per step, full train step (fwd + L1/SSIM + bwd + stats + Adam)",
                        "n_visible": n_vis, "n_isects": n_isects, "n_isects_gsplat_lists": n_isects_ref,
-                       "parallelism": f"view-dp{world}"},
+                       "parallelism": f"view-dp{world}",
+                       "exchange": exchange if vp is not None or world == 1 else "allreduce"},
             "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
             # host diagnostics: ms/step the host spent blocked on the list-size read-back; if this is ~0
             # the Python side, not the GPU, paces the loop on this box

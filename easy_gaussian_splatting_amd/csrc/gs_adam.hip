@@ -6,7 +6,9 @@
 // pass, no zero-fill pass).  The whole step is a single HBM-streaming kernel: 16 B/lane loads of
 // p, g, m, v and stores of p, m, v -- 28 B per element.  Same arithmetic as torch's
 // `_single_tensor_adam`:  denom = sqrt(v)/sqrt(1-beta2^t) + eps;  p -= (lr/(1-beta1^t)) * m/denom.
-// A segment whose gradient pointer is NULL is skipped entirely (torch skips `p.grad is None`).
+// A segment whose gradient pointer is NULL is skipped entirely (torch skips `p.grad is None`);
+// the view-parallel step uses that to update the SH segments and the geometry segments in two
+// launches of the same step (distributed.py).  `grad_scale` folds the 1/world of a mean over ranks in.
 #include "gs_common.h"
 
 namespace gs {
@@ -22,6 +24,7 @@ struct AdamArgs {
     const float* g[kMaxSeg];      // gradient tensor of each segment (may be null)
     float step_size[kMaxSeg];     // lr / (1 - beta1^t)
     float beta1, beta2, eps, inv_sqrt_bc2;
+    float grad_scale;             // gradients are multiplied by this first (1/world for a mean over ranks)
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
@@ -48,6 +51,7 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
             g.x = e < len ? gp[e] : 0.f; g.y = e + 1 < len ? gp[e + 1] : 0.f;
             g.z = e + 2 < len ? gp[e + 2] : 0.f; g.w = 0.f;
         }
+        g.x *= a.grad_scale; g.y *= a.grad_scale; g.z *= a.grad_scale; g.w *= a.grad_scale;
         const float ss = a.step_size[s];
         float4 p = a.p[i], m = a.m[i], v = a.v[i];
         adam1(p.x, g.x, m.x, v.x, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
@@ -65,7 +69,7 @@ using namespace gs;
 extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
                             int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
                             const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
-                            float beta2, float eps, int64_t step) {
+                            float beta2, float eps, int64_t step, float grad_scale) {
     GS_REQUIRE(n >= 0 && (n & 3) == 0, "flat length must be a multiple of 4 (pad the buffers)");
     GS_REQUIRE(n_segments >= 1 && n_segments <= kMaxSeg, "1..8 segments");
     GS_REQUIRE(step >= 1, "step counts from 1");
@@ -91,6 +95,7 @@ extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* exp_a
         begin = seg_ends_host[k];
     }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.grad_scale = grad_scale;
     const int64_t want = (a.n4 + 255) / 256;
     const unsigned grid = (unsigned)(want < 256 * 16 ? want : 256 * 16);
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -249,7 +249,7 @@ struct ProjBwdArgs {
     const float4* rows;      // [I*4][3]: one row per (intersection slot, tile quadrant)
     const uint8_t* qmask;    // [I] by slot: which of the four quadrant rows exist
     float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_sh_rest, *v_means2d_abs, *v_means2d,
-        *v_conics, *v_colors_post;
+        *v_conics, *v_colors_post, *v_colors_pre;
 };
 
 struct RowSum {
@@ -269,6 +269,62 @@ __device__ __forceinline__ void row_add(RowSum& s, const float4* __restrict__ ro
             s.v[8] += c.x; s.v[9] += c.y; s.v[10] += c.z;
         }
     }
+}
+
+// Dense, coalesced write-out of one block's SH-gradient tile (LDS rows of 3K floats, row stride
+// 3K+1) to v_shs[n0 : n0+rows]: unsplit [N,K,3] or split v_sh_0[N,1,3] + v_sh_rest[N,K-1,3].
+__device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K, int64_t n0, float* v_colors,
+                                              float* v_sh_rest, bool accumulate) {
+    const int row_f = 3 * K, stride = row_f + 1;
+        if (v_sh_rest) {  // split layout: v_sh_0[N,1,3] and v_sh_rest[N,K-1,3]
+            const int rest_f = K == 16 ? 45 : row_f - 3, total = rows * rest_f;
+            float* d0 = v_colors + n0 * 3;
+            for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
+                const int g = e / 3;
+                float v = tile[g * stride + (e - 3 * g)];
+                if (accumulate) v += d0[e];
+                d0[e] = v;
+            }
+            float* dr = v_sh_rest + n0 * rest_f;
+            float4* dr4 = reinterpret_cast<float4*>(dr);
+            for (int e4 = threadIdx.x; e4 < (total >> 2); e4 += blockDim.x) {
+                float vv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int e = (e4 << 2) + i, g = e / rest_f;
+                    vv[i] = tile[g * stride + 3 + (e - g * rest_f)];
+                }
+                float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                if (accumulate) { const float4 o = dr4[e4]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                dr4[e4] = v;
+            }
+            for (int e = (total & ~3) + threadIdx.x; e < total; e += blockDim.x) {
+                const int g = e / rest_f;
+                float v = tile[g * stride + 3 + (e - g * rest_f)];
+                if (accumulate) v += dr[e];
+                dr[e] = v;
+            }
+        } else {
+        float* dst = v_colors + n0 * row_f;
+        if ((row_f & 3) == 0) {
+            const int per_row = row_f >> 2;
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            for (int e = threadIdx.x; e < rows * per_row; e += blockDim.x) {
+                const int g = e / per_row, q = e - g * per_row;
+                const float* sp = tile + g * stride + 4 * q;
+                float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                if (accumulate) { const float4 o = dst4[e]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                dst4[e] = v;
+            }
+        } else {
+            for (int e = threadIdx.x; e < rows * row_f; e += blockDim.x) {
+                const int g = e / row_f, o = e - g * row_f;
+                float v = tile[g * stride + o];
+                if (accumulate) v += dst[e];
+                dst[e] = v;
+            }
+        }
+        }
 }
 
 constexpr int kCoopRows = 48;  // Gaussians with more rows than this are summed by the whole wave
@@ -360,59 +416,17 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
             float rgb[3] = {a.colors_post[3 * f], a.colors_post[3 * f + 1], a.colors_post[3 * f + 2]};
             sh_vjp(DEG < 0 ? 0 : DEG, my, rgb, v_rgb, ux, uy, uz, dn, my, v_mean, false);
             for (int o = ka3; o < row_f; ++o) my[o] = 0.f;
+            if (a.v_colors_pre) {  // gradient w.r.t. the pre-clamp colour: what gs_sh_grad_views consumes
+                float* d = a.v_colors_pre + 3 * f;
+                d[0] = rgb[0] > 0.f ? v_rgb[0] : 0.f; d[1] = rgb[1] > 0.f ? v_rgb[1] : 0.f; d[2] = rgb[2] > 0.f ? v_rgb[2] : 0.f;
+            }
         } else if (in_range) {
             for (int o = 0; o < row_f; ++o) my[o] = 0.f;
+            if (a.v_colors_pre) { float* d = a.v_colors_pre + 3 * f; d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; }
         }
-        __syncthreads();
-        // dense write-out of v_shs[n0 : n0+rows, :, :]
-        if (a.v_sh_rest) {  // split layout: v_sh_0[N,1,3] and v_sh_rest[N,K-1,3]
-            const int rest_f = a.K == 16 ? 45 : row_f - 3, total = rows * rest_f;
-            float* d0 = a.v_colors + n0 * 3;
-            for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
-                const int g = e / 3;
-                float v = tile[g * stride + (e - 3 * g)];
-                if (a.accumulate) v += d0[e];
-                d0[e] = v;
-            }
-            float* dr = a.v_sh_rest + n0 * rest_f;
-            float4* dr4 = reinterpret_cast<float4*>(dr);
-            for (int e4 = threadIdx.x; e4 < (total >> 2); e4 += blockDim.x) {
-                float vv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = (e4 << 2) + i, g = e / rest_f;
-                    vv[i] = tile[g * stride + 3 + (e - g * rest_f)];
-                }
-                float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                if (a.accumulate) { const float4 o = dr4[e4]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                dr4[e4] = v;
-            }
-            for (int e = (total & ~3) + threadIdx.x; e < total; e += blockDim.x) {
-                const int g = e / rest_f;
-                float v = tile[g * stride + 3 + (e - g * rest_f)];
-                if (a.accumulate) v += dr[e];
-                dr[e] = v;
-            }
-        } else {
-        float* dst = a.v_colors + n0 * row_f;
-        if ((row_f & 3) == 0) {
-            const int per_row = row_f >> 2;
-            float4* dst4 = reinterpret_cast<float4*>(dst);
-            for (int e = threadIdx.x; e < rows * per_row; e += blockDim.x) {
-                const int g = e / per_row, q = e - g * per_row;
-                const float* sp = tile + g * stride + 4 * q;
-                float4 v = make_float4(sp[0], sp[1], sp[2], sp[3]);
-                if (a.accumulate) { const float4 o = dst4[e]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                dst4[e] = v;
-            }
-        } else {
-            for (int e = threadIdx.x; e < rows * row_f; e += blockDim.x) {
-                const int g = e / row_f, o = e - g * row_f;
-                float v = tile[g * stride + o];
-                if (a.accumulate) v += dst[e];
-                dst[e] = v;
-            }
-        }
+        if (a.v_colors) {  // NULL: the caller rebuilds the SH gradients from v_colors_pre (gs_sh_grad_views)
+            __syncthreads();
+            write_sh_tile(tile, rows, a.K, n0, a.v_colors, a.v_sh_rest, a.accumulate);
         }
     } else if (in_range) {
         if (a.colors_per_camera) {
@@ -458,9 +472,92 @@ static size_t proj_lds_bytes(int K, int degree) {
     return sizeof(float) * (32 + kProjThreads + (degree >= 0 ? (size_t)kProjThreads * (3 * K + 1) : 0));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// SH-parameter gradients of R views from the per-view pre-clamp colour gradients:
+//   v_sh[n][k][:] = sum_r Y_k(dir(mean_n, camera_r)) * v_colors_pre[r][n][:]      (views in order r = 0..R-1)
+// The view-parallel step exchanges v_colors_pre (3 floats per Gaussian and view) instead of the 48
+// SH gradients per Gaussian; every rank then rebuilds the identical dense SH gradient with this
+// kernel (distributed.py).  Same write-out as project_bwd_kernel.
+struct ShGradArgs {
+    int R, K;
+    int64_t N;
+    const float *means, *viewmats, *v_colors_pre;
+    float *v_colors, *v_sh_rest;
+};
+
+constexpr int kMaxViews = 64;
+
+template <int DEG>
+__global__ __launch_bounds__(kProjThreads) void sh_grad_views_kernel(const ShGradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* cam_pos = smem;                       // [kMaxViews * 3]
+    float* tile = smem + kMaxViews * 3;          // [kProjThreads * (3K + 1)]
+    const int64_t n0 = (int64_t)blockIdx.x * kProjThreads, n = n0 + threadIdx.x;
+    if ((int)threadIdx.x < a.R) {
+        Camera tmp;
+        const float kid[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+        make_camera(a.viewmats + 16 * threadIdx.x, kid, 1, 1, tmp);
+        cam_pos[3 * threadIdx.x] = tmp.pos[0]; cam_pos[3 * threadIdx.x + 1] = tmp.pos[1]; cam_pos[3 * threadIdx.x + 2] = tmp.pos[2];
+    }
+    __syncthreads();
+    constexpr int Ka = (DEG + 1) * (DEG + 1);
+    const int row_f = 3 * a.K, stride = row_f + 1;
+    float acc[3 * Ka];
+#pragma unroll
+    for (int i = 0; i < 3 * Ka; ++i) acc[i] = 0.f;
+    if (n < a.N) {
+        const float mean[3] = {a.means[3 * n], a.means[3 * n + 1], a.means[3 * n + 2]};
+        for (int r = 0; r < a.R; ++r) {
+            const float* v = a.v_colors_pre + 3 * ((int64_t)r * a.N + n);
+            const float vr = v[0], vg = v[1], vb = v[2];
+            if (vr == 0.f && vg == 0.f && vb == 0.f) continue;   // not visible in view r (x + 0 is exact)
+            Camera cam;
+            cam.pos[0] = cam_pos[3 * r]; cam.pos[1] = cam_pos[3 * r + 1]; cam.pos[2] = cam_pos[3 * r + 2];
+            float ux, uy, uz, Y[16];
+            view_dir(mean, cam, ux, uy, uz);
+            sh_basis(DEG, ux, uy, uz, Y);
+#pragma unroll
+            for (int k = 0; k < Ka; ++k) {
+                acc[3 * k] += Y[k] * vr; acc[3 * k + 1] += Y[k] * vg; acc[3 * k + 2] += Y[k] * vb;
+            }
+        }
+        float* my = tile + threadIdx.x * stride;
+#pragma unroll
+        for (int i = 0; i < 3 * Ka; ++i) my[i] = acc[i];
+        for (int o = 3 * Ka; o < row_f; ++o) my[o] = 0.f;
+    }
+    __syncthreads();
+    write_sh_tile(tile, (int)min((int64_t)kProjThreads, a.N - n0), a.K, n0, a.v_colors, a.v_sh_rest, false);
+}
+
 }  // namespace gs
 
 using namespace gs;
+
+extern "C" int gs_sh_grad_views(void* stream, int R, int64_t N, int K, int sh_degree, const float* means,
+                                const float* viewmats, const float* v_colors_pre, float* v_colors,
+                                float* v_sh_rest) {
+    GS_REQUIRE(R >= 1 && R <= kMaxViews, "1..64 views");
+    GS_REQUIRE(N >= 0 && sh_degree >= 0 && sh_degree <= 3, "N >= 0 and sh_degree in 0..3");
+    GS_REQUIRE(K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16, "K must hold (sh_degree+1)^2 coefficients and be <= 16");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(means && viewmats && v_colors_pre && v_colors, "null pointer");
+    ShGradArgs a;
+    a.R = R; a.K = K; a.N = N; a.means = means; a.viewmats = viewmats; a.v_colors_pre = v_colors_pre;
+    a.v_colors = v_colors; a.v_sh_rest = v_sh_rest;
+    dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
+    const size_t lds = sizeof(float) * (kMaxViews * 3 + (size_t)kProjThreads * (3 * K + 1));
+    hipStream_t st = (hipStream_t)stream;
+    switch (sh_degree) {
+        case 0: hipLaunchKernelGGL(sh_grad_views_kernel<0>, grid, dim3(kProjThreads), lds, st, a); break;
+        case 1: hipLaunchKernelGGL(sh_grad_views_kernel<1>, grid, dim3(kProjThreads), lds, st, a); break;
+        case 2: hipLaunchKernelGGL(sh_grad_views_kernel<2>, grid, dim3(kProjThreads), lds, st, a); break;
+        default: hipLaunchKernelGGL(sh_grad_views_kernel<3>, grid, dim3(kProjThreads), lds, st, a); break;
+    }
+    GS_LAUNCH_CHECK("sh_grad_views_kernel");
+    return GS_OK;
+}
 
 extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                               const float* quats, const float* scales, const float* opacities,
@@ -516,13 +613,14 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
                               const int32_t* tiles_per_gauss, const int32_t* cum_tiles,
                               const float* rows, const uint8_t* qmask, float* v_means, float* v_quats, float* v_scales,
                               float* v_opacities, float* v_colors, float* v_sh_rest, float* v_means2d_abs,
-                              float* v_means2d, float* v_conics, float* v_colors_post) {
+                              float* v_means2d, float* v_conics, float* v_colors_post, float* v_colors_pre) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
     GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
     GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
     if (N == 0) return GS_OK;
     GS_REQUIRE(means && quats && scales && colors_in && viewmats && Ks && radii && colors_post && tiles_per_gauss && cum_tiles && rows && qmask, "null input pointer");
-    GS_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_colors && v_means2d_abs, "null output pointer");
+    GS_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_means2d_abs, "null output pointer");
+    GS_REQUIRE(v_colors || (sh_degree >= 0 && v_colors_pre), "v_colors may be NULL only with SH colours and v_colors_pre given");
     ProjBwdArgs a;
     a.C = C; a.N = N; a.K = K; a.colors_per_camera = colors_per_camera; a.W = width; a.H = height;
     a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
@@ -532,7 +630,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.qmask = qmask;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_opacities = v_opacities;
     a.v_colors = v_colors; a.v_means2d_abs = v_means2d_abs; a.v_means2d = v_means2d;
-    a.v_conics = v_conics; a.v_colors_post = v_colors_post;
+    a.v_conics = v_conics; a.v_colors_post = v_colors_post; a.v_colors_pre = sh_degree >= 0 ? v_colors_pre : nullptr;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
     const size_t lds = proj_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;

@@ -6,9 +6,20 @@ exchange ONE thing per step -- the sum of parameter gradients (plus the densific
 so `update_statistics` sees every view).  `backend="nccl"` is RCCL over xGMI on ROCm; the same
 code runs on `gloo` for the CPU tests.
 
-Bucket layout: all six gradients are flattened into ONE fp32 buffer (59 floats per Gaussian at
-SH3) so a step issues a single large all-reduce instead of six small ones -- xGMI is
-point-to-point and per-link bound, large messages are what saturates it.
+Two exchange schemes:
+
+* `ViewParallelStep` (default of bench.py for N > 1) -- xGMI is point-to-point and per-link bound, so
+  the step is built around moving fewer bytes.  The SH coefficients are 48 of the 59 parameters
+  of a Gaussian, but their gradient is an outer product  v_sh[k] = Y_k(dir) * v_colour_pre  of a
+  basis every rank can evaluate itself (it has the means and, after a 64-byte exchange, every
+  camera) and 3 numbers per view.  So ranks all-gather `colors_pre_grad` (12 B per Gaussian and
+  view, plus the 64-byte camera matrix) and rebuild the dense SH gradient locally (`gs_sh_grad_views`, views summed in rank order
+  -> bitwise identical replicas); only the 11 geometry gradients + 2 statistics per Gaussian go
+  through an all-reduce.  Per rank and step at SH3, 1M Gaussians, 8 ranks: 12 MB into an
+  all-gather + 52 MB all-reduce (+ 4 MB MAX for the radii) instead of a 236 MB all-reduce, and
+  the SH half of the Adam step runs while the all-reduce is still in flight.
+* `GradBucket` / `all_reduce_param_grads` -- the plain scheme (all six gradients all-reduced),
+  kept for optimizers other than `optim.FusedAdam`.
 """
 from __future__ import annotations
 
@@ -74,6 +85,88 @@ def all_reduce_param_grads(params: Iterable[torch.nn.Parameter], group=None) -> 
         w.wait()
     for g in grads:
         g.div_(world)
+
+
+class ViewParallelStep:
+    """Exchange + parameter update of one training step with one view per rank.
+
+        vp = ViewParallelStep(model, optimizer)          # optimizer: optim.FusedAdam
+        out = model(data); loss.backward(); vp.step(data, out)
+
+    replaces `model.update_statistics(data, out); optimizer.step(); optimizer.zero_grad()` of the
+    reference loop (/root/reference/train.py:36-43, 57-58).  The update equals the single-process
+    step on the batch of all ranks' views with a mean-over-views loss.  With one rank it is exactly
+    the reference sequence."""
+
+    SH = ("sh_0", "sh_rest")
+    GEOMETRY = ("means", "log_scales", "quats", "logit_opacities")
+
+    def __init__(self, model, optimizer, group=None, sh_grad_fn=None):
+        self.model, self.opt, self.group = model, optimizer, group
+        self.world = dist.get_world_size(group) if is_distributed() else 1
+        if self.world > 1 and not hasattr(optimizer, "moments_of"):
+            raise TypeError("ViewParallelStep drives optim.FusedAdam (partial steps, folded 1/world scale)")
+        if sh_grad_fn is None:
+            from .rendering import sh_grad_views as sh_grad_fn
+        self.sh_grad_fn = sh_grad_fn
+        model.sh_grads = "colors_pre" if self.world > 1 else "dense"
+
+    def step(self, data, out) -> None:
+        m, opt = self.model, self.opt
+        if self.world == 1:
+            m.update_statistics(data, out)
+            opt.step()
+            opt.zero_grad()
+            return
+        world, group = self.world, self.group
+        N = m.means.shape[0]
+        xys = out["batch_xys"]
+        dt = m.means.dtype   # float32 in the product; the CPU tests drive this class in float64
+        f32 = dict(dtype=dt, device=m.means.device)
+        # (1) all-gather: every view's world->camera matrix (64 B) and pre-clamp colour gradient
+        #     (flat 1-D buffers: the layout every backend accepts for all_gather_into_tensor)
+        cams = torch.empty(world * 16, **f32)
+        w_cams = dist.all_gather_into_tensor(cams, data["w2c"].to(dt).reshape(-1).contiguous(), group=group, async_op=True)
+        pre_all = torch.empty(world * N * 3, **f32)
+        w_gather = dist.all_gather_into_tensor(pre_all, xys.colors_pre_grad[0].reshape(-1).contiguous(), group=group,
+                                               async_op=True)
+        # (2) all-reduce SUM: geometry gradients + the two additive statistics of this view
+        #     (/root/reference/model/gaussian.py:188-197), segments padded to 16 bytes
+        max_hw = float(max(data["height"], data["width"]))
+        radii = out["batch_radii"][0]
+        visible = radii > 0
+        geo = [getattr(m, name) for name in self.GEOMETRY]
+        pieces = [p.grad for p in geo]
+        pieces.append(torch.where(visible, torch.linalg.vector_norm(xys.absgrad[0], dim=-1) * max_hw, 0.0))
+        pieces.append(visible.to(dt))
+        offs, off = [], 0
+        for t in pieces:
+            offs.append(off)
+            off = (off + t.numel() + 3) // 4 * 4
+        flat = torch.zeros(off, **f32)
+        for t, o in zip(pieces, offs):
+            flat[o:o + t.numel()].copy_(t.reshape(-1))
+        w_sum = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        # (3) all-reduce MAX: normalised radii
+        rad = torch.where(visible, radii.to(dt) / max_hw, 0.0)
+        w_max = dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=group, async_op=True)
+        # SH half: rebuild the dense SH gradient of all views, update while (2) is in flight
+        w_cams.wait()
+        w_gather.wait()
+        v0, vr = self.sh_grad_fn(m.means, cams.view(world, 4, 4), pre_all.view(world, N, 3), m.active_sh_degree,
+                                 1 + m.sh_rest.shape[1])
+        m.sh_0.grad, m.sh_rest.grad = v0, vr
+        opt.step(only=self.SH, grad_scale=1.0 / world)
+        # geometry half
+        w_sum.wait()
+        for p, o in zip(geo, offs):
+            p.grad = flat[o:o + p.numel()].view_as(p)
+        opt.step(only=self.GEOMETRY, grad_scale=1.0 / world, advance=False)
+        m.grad_norm_accum.add_(flat[offs[4]:offs[4] + N])
+        m.collecting_counts.add_(flat[offs[5]:offs[5] + N].to(m.collecting_counts.dtype))
+        w_max.wait()
+        torch.maximum(m.max_radii, rad, out=m.max_radii)
+        opt.zero_grad()
 
 
 def all_reduce_statistics(grad_norm: Tensor, counts: Tensor, max_radii: Tensor, group=None) -> None:

@@ -202,6 +202,7 @@ class GaussianModel(nn.Module):
             backgrounds=self.BACKGROUND[None],
             absgrad=True,
             packed=False,
+            _sh_grads=getattr(self, "sh_grads", "dense"),
         )
         render_img = torch.clamp(batch_render_imgs[0], min=0.0, max=1.0)
         return {

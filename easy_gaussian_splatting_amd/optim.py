@@ -76,16 +76,23 @@ class FusedAdam(torch.optim.Optimizer):
         self._build(moments)
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, *, only=None, grad_scale: float = 1.0, advance: bool = True):
+        """One Adam step.  `only`: iterable of group names -- update just those groups (the others are
+        skipped like `grad is None`); with `advance=False` the step count is not incremented, so a
+        step can be issued in two launches (`step(only=A)`, then `step(only=B, advance=False)`).
+        `grad_scale` multiplies every gradient first (1/world: mean over ranks of summed gradients)."""
         if closure is not None:
             raise NotImplementedError("closures are not supported")
         from . import _native as nat
         L = nat.lib()
-        self._step += 1
+        if advance:
+            self._step += 1
         ns = len(self._plist)
         grads = []
-        for _, p in self._plist:
+        for grp, p in self._plist:
             g = p.grad
+            if only is not None and grp.get("name") not in only:
+                g = None
             if g is not None and (not g.is_contiguous() or g.dtype != torch.float32):
                 g = g.contiguous().float()
             grads.append(g)   # keep alive until the launch is queued
@@ -99,7 +106,7 @@ class FusedAdam(torch.optim.Optimizer):
         with torch.cuda.device(dev):
             nat.check(L.gs_adam_step(st, self.flat_param.numel(), self.flat_param.data_ptr(), self.exp_avg.data_ptr(),
                                      self.exp_avg_sq.data_ptr(), ns, ends, lens, gptr, lrs, float(b1), float(b2),
-                                     float(self.defaults["eps"]), self._step), "gs_adam_step")
+                                     float(self.defaults["eps"]), self._step, float(grad_scale)), "gs_adam_step")
 
     def zero_grad(self, set_to_none: bool = True):
         for _, p in self._plist:

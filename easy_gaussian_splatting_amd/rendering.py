@@ -235,8 +235,10 @@ class _Rasterize(torch.autograd.Function):
         v_quats = torch.empty((N, 4), **f32)
         v_scales = torch.empty((N, 3), **f32)
         v_opac = torch.empty((N,), **f32)
-        v_colors = torch.empty(colors.shape, **f32)
-        v_rest = torch.empty(colors_rest.shape, **f32) if ctx.split else None
+        factorised = cfg.get("sh_grads") == "colors_pre"
+        v_colors = None if factorised else torch.empty(colors.shape, **f32)
+        v_rest = torch.empty(colors_rest.shape, **f32) if (ctx.split and not factorised) else None
+        v_pre = torch.empty((C, N, 3), **f32) if factorised else None
         v_abs = torch.empty((C, N, 2), **f32)
         dbg = holder.debug
         v_m2 = v_cn = v_cp = None
@@ -249,17 +251,46 @@ class _Rasterize(torch.autograd.Function):
                                    cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
                                    _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
                                    _ptr(rows), _ptr(s["qmask"]), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
-                                   _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp)), "gs_project_bwd"))
+                                   _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), _ptr(v_pre)),
+                                   "gs_project_bwd"))
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp, rows=rows)
-        if holder.absgrad and holder.means2d_ref is not None:
+        if (holder.absgrad or factorised) and holder.means2d_ref is not None:
             m2 = holder.means2d_ref()
             if m2 is not None:
-                m2.absgrad = v_abs
+                if holder.absgrad:
+                    m2.absgrad = v_abs
+                if factorised:
+                    m2.colors_pre_grad = v_pre
         ni = ctx.needs_input_grad
         return (v_means if ni[0] else None, v_quats if ni[1] else None, v_scales if ni[2] else None,
-                v_opac if ni[3] else None, v_colors if ni[4] else None, v_rest if (ctx.split and ni[5]) else None,
+                v_opac if ni[3] else None, v_colors if (ni[4] and not factorised) else None,
+                v_rest if (ctx.split and ni[5] and not factorised) else None,
                 None, None, None, None, None)
+
+
+def sh_grad_views(means: Tensor, viewmats: Tensor, colors_pre_grad: Tensor, sh_degree: int, K: int,
+                  split: bool = True):
+    """SH-coefficient gradients of R views from their pre-clamp colour gradients (`gs_sh_grad_views`):
+    `v_sh[n,k,:] = sum_r Y_k(dir(means[n], camera r)) * colors_pre_grad[r,n,:]`.
+    means [N,3], viewmats [R,4,4], colors_pre_grad [R,N,3] -> (v_sh_0 [N,1,3], v_sh_rest [N,K-1,3])
+    if `split` else v_shs [N,K,3]."""
+    if not means.is_cuda:
+        raise RuntimeError("sh_grad_views() runs on the GPU only (there is no CPU fallback in this package)")
+    L = nat.lib()
+    R, N = colors_pre_grad.shape[0], means.shape[0]
+    assert colors_pre_grad.shape == (R, N, 3) and viewmats.shape == (R, 4, 4), (colors_pre_grad.shape, viewmats.shape)
+    f32 = dict(dtype=torch.float32, device=means.device)
+    means_c, vm_c, v_c = means.detach().contiguous(), viewmats.contiguous(), colors_pre_grad.contiguous()
+    if split:
+        v0 = torch.empty((N, 1, 3), **f32)
+        vr = torch.empty((N, K - 1, 3), **f32)
+    else:
+        v0, vr = torch.empty((N, K, 3), **f32), None
+    with torch.cuda.device(means.device):
+        nat.check(L.gs_sh_grad_views(_stream(means.device), R, N, K, sh_degree, _ptr(means_c), _ptr(vm_c), _ptr(v_c),
+                                     _ptr(v0), _ptr(vr if (vr is not None and K > 1) else None)), "gs_sh_grad_views")
+    return (v0, vr) if split else v0
 
 
 def quat_to_rotmat_torch(quats: Tensor) -> Tensor:
@@ -298,6 +329,7 @@ def rasterization(
     channel_chunk: int = 32,
     _debug: Optional[Dict] = None,
     _tile_culling: str = "tight",
+    _sh_grads: str = "dense",
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize 3D Gaussians to images; same tensor signature and return value as
     `gsplat.rendering.rasterization` (gsplat 1.0.0).
@@ -314,6 +346,11 @@ def rasterization(
     gradients are unaffected, only the internal lists (`tiles_per_gauss`, `isect_ids`,
     `flatten_ids`, `isect_offsets`) become a render-equivalent subset.  `"gsplat"` reproduces the
     reference's lists exactly.
+
+    `_sh_grads="colors_pre"` (SH colours only; used by `distributed.ViewParallelStep`) leaves the
+    gradients of the SH coefficients to `gs_sh_grad_views`: backward returns `None` for `colors`
+    and attaches `meta["means2d"].colors_pre_grad` ([C,N,3], gradient w.r.t. the pre-clamp
+    colour), which is all another rank needs to rebuild this view's SH-gradient term.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -374,7 +411,9 @@ def rasterization(
     bg_c = None if backgrounds is None else prep(backgrounds)
     cfg = dict(width=int(width), height=int(height), near_plane=float(near_plane),
                far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d),
-               sh_degree=sh_degree, tile_culling={"gsplat": 0, "tight": 1}[_tile_culling])
+               sh_degree=sh_degree, tile_culling={"gsplat": 0, "tight": 1}[_tile_culling], sh_grads=_sh_grads)
+    if _sh_grads not in ("dense", "colors_pre") or (_sh_grads == "colors_pre" and sh_degree is None):
+        raise ValueError("_sh_grads: 'dense', or 'colors_pre' together with sh_degree")
     holder = _Holder(absgrad)
     holder.debug = _debug
     with torch.cuda.device(means.device):

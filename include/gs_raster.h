@@ -138,7 +138,10 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
  * (sh_degree>=0; with the split layout v_colors is v_sh_0[N,1,3] and v_sh_rest[N,K-1,3]) or
  * v_colors[N,3]/[C,N,3]; v_means2d_abs[C,N,2] (the `.absgrad` side channel,
  * /root/reference/model/gaussian.py:191).
- * Optional (may be NULL): v_means2d[C,N,2], v_conics[C,N,3], v_colors_post[C,N,3]. */
+ * Optional (may be NULL): v_means2d[C,N,2], v_conics[C,N,3], v_colors_post[C,N,3] (gradient of the
+ * post-clamp colour), v_colors_pre[C,N,3] (SH colours only: gradient of the pre-clamp colour, zero
+ * for culled Gaussians).  With SH colours v_colors (and v_sh_rest) may be NULL when v_colors_pre is
+ * given: the SH-parameter gradients are then left to gs_sh_grad_views. */
 int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* colors_in,
                    const float* sh_rest, int colors_per_camera, const float* viewmats,
@@ -147,7 +150,17 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities,
                    float* v_colors, float* v_sh_rest, float* v_means2d_abs, float* v_means2d,
-                   float* v_conics, float* v_colors_post);
+                   float* v_conics, float* v_colors_post, float* v_colors_pre);
+
+/* Row e (view sharding): dense SH-parameter gradients of R views rebuilt from the per-view
+ * pre-clamp colour gradients,  v_sh[n][k][:] = sum_r Y_k(dir(means[n], camera r)) * v_colors_pre[r][n][:]
+ * (r ascending; the SH VJP of spherical_harmonics backward).  Ranks exchange
+ * v_colors_pre[N,3] per view (12 B per Gaussian) instead of the 48 SH gradients (192 B).
+ * viewmats[R,4,4]; output layout as gs_project_bwd: v_colors[N,K,3], or split v_colors = v_sh_0[N,1,3]
+ * and v_sh_rest[N,K-1,3].  R <= 64. */
+int gs_sh_grad_views(void* stream, int R, int64_t N, int K, int sh_degree, const float* means,
+                     const float* viewmats, const float* v_colors_pre, float* v_colors,
+                     float* v_sh_rest);
 
 /* ---- "next" row f-1: the loss that feeds v_render_colors ----
  * Fused L1 + (1 - SSIM) of /root/reference/model/gaussian.py:415-453 (torchmetrics SSIM:
@@ -169,11 +182,12 @@ int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const
  * tensors back to back, each padded to a multiple of 4 elements.  HOST arrays per segment:
  * seg_ends_host (exclusive padded end), seg_lens_host (true element count), seg_grads_host (device
  * pointer of that tensor's contiguous, 16-byte aligned gradient; NULL = skip the segment, as torch
- * skips `p.grad is None`), seg_lrs_host.  step counts from 1. */
+ * skips `p.grad is None`), seg_lrs_host.  step counts from 1.  Gradients are multiplied by
+ * grad_scale first (1.0 = torch semantics; 1/world turns a sum over ranks into the mean). */
 int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
                  int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
                  const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
-                 float beta2, float eps, int64_t step);
+                 float beta2, float eps, int64_t step, float grad_scale);
 
 /* Row a-3: the consumer of the side channels, `GaussianModel.update_statistics`
  * (/root/reference/model/gaussian.py:188-197), as one launch for the reference's single camera:

@@ -108,3 +108,138 @@ def test_single_process_helpers_are_noops():
     b.zero_()
     assert p[1].grad.abs().sum() == 0
     assert shard_views(8, rank=1, world=4) == [1, 5]
+
+
+# ------------------------------------------------------------------------------------------------
+# ViewParallelStep (factorised exchange): all-gather of the pre-clamp colour gradients + all-reduce of
+# the geometry gradients must give the same parameter update and statistics as one process that
+# back-propagates the mean loss over both views.  Stand-ins on CPU: the torch oracle renders, a
+# torch SH-basis einsum plays gs_sh_grad_views, plain SGD plays FusedAdam's partial steps.
+class _Model:
+    GEOM = ("means", "log_scales", "quats", "logit_opacities")
+
+    def __init__(self, sc):
+        dt = torch.float64
+        P = lambda a: torch.nn.Parameter(torch.tensor(a, dtype=dt))  # noqa: E731
+        self.means, self.quats = P(sc["means"]), P(sc["quats"])
+        self.log_scales = P(np.log(sc["scales"]))
+        o = np.clip(sc["opacities"], 1e-4, 1 - 1e-4)
+        self.logit_opacities = P(np.log(o / (1 - o)))
+        self.sh_0, self.sh_rest = P(sc["shs"][:, :1]), P(sc["shs"][:, 1:])
+        self.active_sh_degree = 1
+        n = sc["means"].shape[0]
+        self.grad_norm_accum, self.collecting_counts, self.max_radii = (torch.zeros(n, dtype=dt) for _ in range(3))
+
+    def named(self):
+        return {k: getattr(self, k) for k in ("means", "log_scales", "quats", "sh_0", "sh_rest", "logit_opacities")}
+
+    def inputs(self):
+        return self.means, self.quats, self.log_scales.exp(), torch.sigmoid(self.logit_opacities)
+
+
+class _SGD:
+    def __init__(self, model, lr=0.05):
+        self.model, self.lr, self.calls = model, lr, []
+
+    def moments_of(self, p):
+        raise KeyError
+
+    def step(self, only=None, grad_scale=1.0, advance=True):
+        self.calls.append((None if only is None else tuple(only), advance))
+        with torch.no_grad():
+            for name, p in self.model.named().items():
+                if (only is None or name in only) and p.grad is not None:
+                    p -= self.lr * grad_scale * p.grad
+
+    def zero_grad(self):
+        for p in self.model.named().values():
+            p.grad = None
+
+
+def _torch_sh_grad_views(means, cams, pre_all, deg, K):
+    from oracle import torch_oracle as TO
+    cam_pos = torch.linalg.inv(cams)[:, :3, 3]
+    d = means.detach()[None] - cam_pos[:, None, :]
+    d = d / d.norm(dim=-1, keepdim=True)
+    Y = TO.sh_basis(deg, d)                                    # [R,N,Ka]
+    v = torch.einsum("rnk,rnc->nkc", Y, pre_all)
+    v = torch.cat([v, torch.zeros((v.shape[0], K - v.shape[1], 3), dtype=v.dtype)], dim=1)
+    return v[:, :1].contiguous(), v[:, 1:].contiguous()
+
+
+def _vp_render(model, sc, view, target):
+    """One view through the oracle with the colours evaluated outside the rasterizer, so that the
+    gradient w.r.t. the pre-clamp colour (what gs_project_bwd emits as v_colors_pre) can be read."""
+    from oracle import torch_oracle as TO
+    dt = torch.float64
+    V = torch.tensor(sc["viewmats"][view:view + 1], dtype=dt); K = torch.tensor(sc["Ks"][view:view + 1], dtype=dt)
+    bg = torch.tensor(sc["backgrounds"][view:view + 1], dtype=dt)
+    means, quats, scales, opac = model.inputs()
+    with torch.no_grad():
+        radii = TO.project(means, quats, scales, V, K, sc["width"], sc["height"], 0.3, 0.01, 1e10, 0.0)[0]
+    cols = TO.spherical_harmonics(1, means, V, torch.cat([model.sh_0, model.sh_rest], dim=1), radii)
+    cols.retain_grad()
+    img, _, meta = TO.rasterization(means, quats, scales, opac, cols, V, K, sc["width"], sc["height"], sh_degree=None,
+                                    packed=False, backgrounds=bg, absgrad=True)
+    ((img - target[view:view + 1]) ** 2).mean().backward()
+    meta["means2d"].colors_pre_grad = (cols.grad * (cols > 0)).detach()
+    model.sh_0.grad = None; model.sh_rest.grad = None          # factorised mode: no local SH gradients
+    return {"batch_xys": meta["means2d"], "batch_radii": meta["radii"]}
+
+
+def _vp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from easy_gaussian_splatting_amd.distributed import ViewParallelStep
+    sc = _scene()
+    model = _Model(sc)
+    opt = _SGD(model)
+    vp = ViewParallelStep(model, opt, sh_grad_fn=_torch_sh_grad_views)
+    assert model.sh_grads == "colors_pre"
+    target = torch.rand((2, sc["height"], sc["width"], 3), generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    data = {"w2c": torch.tensor(sc["viewmats"][rank], dtype=torch.float64), "height": sc["height"], "width": sc["width"]}
+    for _ in range(2):
+        out = _vp_render(model, sc, rank, target)
+        vp.step(data, out)
+    assert opt.calls[:2] == [(("sh_0", "sh_rest"), True), (("means", "log_scales", "quats", "logit_opacities"), False)]
+    np.savez(os.path.join(out_dir, f"vp{rank}.npz"), gn=model.grad_norm_accum.numpy(), cnt=model.collecting_counts.numpy(),
+             rad=model.max_radii.numpy(), **{k: v.detach().numpy() for k, v in model.named().items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_parallel_step_equals_two_view_batch(tmp_path):
+    from oracle import torch_oracle as TO
+    port = _free_port()
+    mp.spawn(_vp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(os.path.join(tmp_path, f"vp{r}.npz")) for r in range(2))
+    for k in r0.files:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=f"replicas diverged in {k}")
+    # single-process reference: mean loss over both views through the ordinary SH path, plain SGD
+    sc = _scene()
+    model = _Model(sc)
+    dt = torch.float64
+    target = torch.rand((2, sc["height"], sc["width"], 3), generator=torch.Generator().manual_seed(5), dtype=dt)
+    V = torch.tensor(sc["viewmats"][:2], dtype=dt); K = torch.tensor(sc["Ks"][:2], dtype=dt)
+    bg = torch.tensor(sc["backgrounds"][:2], dtype=dt)
+    max_hw = max(sc["width"], sc["height"])
+    for _ in range(2):
+        means, quats, scales, opac = model.inputs()
+        img, _, meta = TO.rasterization(means, quats, scales, opac, torch.cat([model.sh_0, model.sh_rest], dim=1), V, K,
+                                        sc["width"], sc["height"], sh_degree=1, packed=False, backgrounds=bg, absgrad=True)
+        (((img - target) ** 2).mean(dim=(1, 2, 3)).sum() / 2).backward()
+        vis = meta["radii"] > 0
+        # each rank back-propagated its own un-divided view loss -> absgrad is twice the batch's
+        model.grad_norm_accum += (torch.where(vis, 2.0 * meta["means2d"].absgrad.norm(dim=-1) * max_hw, 0.0)).sum(0)
+        model.collecting_counts += vis.double().sum(0)
+        model.max_radii = torch.maximum(model.max_radii, torch.where(vis, meta["radii"].double() / max_hw, 0.0).max(0).values)
+        with torch.no_grad():
+            for p in model.named().values():
+                p -= 0.05 * p.grad
+                p.grad = None
+    for k, p in model.named().items():
+        np.testing.assert_allclose(r0[k], p.detach().numpy(), rtol=0, atol=1e-11 * max(1.0, float(p.detach().abs().max())), err_msg=k)
+    np.testing.assert_allclose(r0["gn"], model.grad_norm_accum.numpy(), atol=1e-10)
+    np.testing.assert_array_equal(r0["cnt"], model.collecting_counts.numpy())
+    np.testing.assert_array_equal(r0["rad"], model.max_radii.numpy())
