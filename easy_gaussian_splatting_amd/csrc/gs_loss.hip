@@ -5,8 +5,10 @@
 // never reaches -- every contributing window lies inside the image).
 //
 //   l1_ssim_fwd_kernel : one 32x32 tile per block.  Stages the tile + 5-pixel halo of both images
-//                        (mask-composited, all 3 channels, coalesced channel-last rows) in LDS,
-//                        runs the separable 11-tap window for the five moment maps, evaluates
+//                        (mask-composited, all 3 channels, coalesced channel-last rows; all global
+//                        loads issued before the first LDS store) in LDS, runs the separable
+//                        11-tap window for the five moment maps with register sliding windows
+//                        (row x 8 columns, then column x 4 rows per thread), evaluates
 //                        SSIM and its three partial derivatives (wrt mu_x, E[x^2], E[xy]) per
 //                        pixel, and writes per-block partial sums (deterministic reduction).
 //   l1_ssim_bwd_kernel : d loss / d render = window (*) derivative maps (+ L1 sign term), same
@@ -20,7 +22,9 @@ namespace gs {
 constexpr int kLT = 32;               // tile edge (outputs)
 constexpr int kHalo = 5;
 constexpr int kLR = kLT + 2 * kHalo;  // 42 staged rows / cols
-constexpr int kLRP = kLR + 1;         // padded row stride
+constexpr int kLRP = kLR + 1;         // padded row stride of the staged tiles
+constexpr int kHP = kLT + 1;          // row stride of the horizontal-pass buffers
+static_assert(kLT * (kLT / 4) == 256 && kLR * (kLT / 8) <= 256, "thread mapping of the separable passes");
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 __device__ __constant__ float kWin[11] = {1.0283800845e-03f, 7.5987581352e-03f, 3.6000772128e-02f,
@@ -32,7 +36,7 @@ struct LossArgs {
     int H, W;
     float lambda_ssim;
     const float *render, *gt, *mask;   // [H,W,3], [H,W,3], [H,W] or null
-    float* maps;                       // [3 (dmu, dxx, dxy)][3 ch][H][W]
+    float* maps;                       // [3 ch][H][W][3 (dmu, dxx, dxy)]: a tile row of one channel is one contiguous run
     float* partial;                    // [nblocks][2] (l1 sum, ssim sum)
     const float* gout;                 // device scalar: d loss_total
     float* v_render;                   // [H,W,3]
@@ -44,25 +48,45 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sx = lds;                         // [3][kLR][kLRP]
     float* sy = sx + 3 * kLR * kLRP;         // [3][kLR][kLRP]
-    float* hp = sy + 3 * kLR * kLRP;         // [5][kLR][kLT+1] horizontal pass of one channel
+    float* hp = sy + 3 * kLR * kLRP;         // [5][kLR][kHP] horizontal pass of one channel
     __shared__ float red[2][4];
     const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const int tid = threadIdx.x;
-    // ---- stage tile + halo (coordinates clamped; clamped values only feed discarded outputs)
+    // ---- stage tile + halo (coordinates clamped; clamped values only feed discarded outputs).
+    // All global loads of a thread are issued before its first LDS store: hipcc keeps a
+    // load -> LDS-store loop in program order (the store may alias the next load), which would
+    // cost one HBM round trip per element.
     float l1 = 0.f;
-    for (int e = tid; e < kLR * kLR * 3; e += 256) {
-        const int row = e / (kLR * 3), rem = e - row * (kLR * 3);
-        const int col = rem / 3, ch = rem - col * 3;
-        const int gy = y0 - kHalo + row, gx = x0 - kHalo + col;
-        const int cy = clampi(gy, 0, a.H - 1), cx = clampi(gx, 0, a.W - 1);
-        const size_t o = ((size_t)cy * a.W + cx) * 3 + ch;
-        const float g = a.gt[o];
-        float r = a.render[o];
-        if (a.mask) { const float m = a.mask[(size_t)cy * a.W + cx]; r = m * g + (1.f - m) * r; }
-        sx[(ch * kLR + row) * kLRP + col] = r;
-        sy[(ch * kLR + row) * kLRP + col] = g;
-        const bool own = row >= kHalo && row < kHalo + kLT && col >= kHalo && col < kHalo + kLT && gy < a.H && gx < a.W;
-        if (own) l1 += fabsf(r - g);
+    {
+        constexpr int kTot = kLR * kLR * 3, kPer = (kTot + 255) / 256;
+        float rv[kPer], gv[kPer], mv[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = tid + i * 256;
+            rv[i] = gv[i] = mv[i] = 0.f;
+            if (e < kTot) {
+                const int row = e / (kLR * 3), rem = e - row * (kLR * 3), col = rem / 3, ch = rem - col * 3;
+                const int cy = clampi(y0 - kHalo + row, 0, a.H - 1), cx = clampi(x0 - kHalo + col, 0, a.W - 1);
+                const size_t o = ((size_t)cy * a.W + cx) * 3 + ch;
+                gv[i] = a.gt[o]; rv[i] = a.render[o];
+                if (a.mask) mv[i] = a.mask[(size_t)cy * a.W + cx];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int e = tid + i * 256;
+            if (e < kTot) {
+                const int row = e / (kLR * 3), rem = e - row * (kLR * 3), col = rem / 3, ch = rem - col * 3;
+                const int gy = y0 - kHalo + row, gx = x0 - kHalo + col;
+                const float g = gv[i];
+                float r = rv[i];
+                if (a.mask) r = mv[i] * g + (1.f - mv[i]) * r;
+                sx[(ch * kLR + row) * kLRP + col] = r;
+                sy[(ch * kLR + row) * kLRP + col] = g;
+                const bool own = row >= kHalo && row < kHalo + kLT && col >= kHalo && col < kHalo + kLT && gy < a.H && gx < a.W;
+                if (own) l1 += fabsf(r - g);
+            }
+        }
     }
     __syncthreads();
     float ssim_sum = 0.f;
@@ -70,51 +94,71 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
     for (int ch = 0; ch < 3; ++ch) {
         const float* X = sx + ch * kLR * kLRP;
         const float* Y = sy + ch * kLR * kLRP;
-        // horizontal 11-tap pass: kLR rows x kLT cols x 5 maps
-        for (int e = tid; e < kLR * kLT; e += 256) {
-            const int row = e / kLT, col = e - row * kLT;
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+        // horizontal 11-tap pass with a register sliding window: one thread = one staged row x 8
+        // output columns (18 + 18 LDS reads feed 8 x 5 outputs); lanes run down the rows, so the
+        // odd row strides keep the reads and the writes conflict-free
+        if (tid < kLR * (kLT / 8)) {
+            const int g = tid / kLR, row = tid - g * kLR, c0 = 8 * g;
+            float xv[18], yv[18], xx[18], yy[18], xy[18];
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float xv = X[row * kLRP + col + k], yv = Y[row * kLRP + col + k], w = kWin[k];
-                m0 = fmaf(w, xv, m0); m1 = fmaf(w, yv, m1); m2 = fmaf(w * xv, xv, m2);
-                m3 = fmaf(w * yv, yv, m3); m4 = fmaf(w * xv, yv, m4);
+            for (int i = 0; i < 18; ++i) {
+                xv[i] = X[row * kLRP + c0 + i]; yv[i] = Y[row * kLRP + c0 + i];
+                xx[i] = xv[i] * xv[i]; yy[i] = yv[i] * yv[i]; xy[i] = xv[i] * yv[i];
             }
-            float* h = hp + row * (kLT + 1) + col;
-            h[0] = m0; h[kLR * (kLT + 1)] = m1; h[2 * kLR * (kLT + 1)] = m2; h[3 * kLR * (kLT + 1)] = m3; h[4 * kLR * (kLT + 1)] = m4;
+            float* h = hp + row * kHP + c0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const float w = kWin[k];
+                    m0 = fmaf(w, xv[j + k], m0); m1 = fmaf(w, yv[j + k], m1); m2 = fmaf(w, xx[j + k], m2);
+                    m3 = fmaf(w, yy[j + k], m3); m4 = fmaf(w, xy[j + k], m4);
+                }
+                h[j] = m0; h[kLR * kHP + j] = m1; h[2 * kLR * kHP + j] = m2; h[3 * kLR * kHP + j] = m3; h[4 * kLR * kHP + j] = m4;
+            }
         }
         __syncthreads();
-        // vertical pass + SSIM: 4 outputs per thread
-        for (int e = tid; e < kLT * kLT; e += 256) {
-            const int row = e / kLT, col = e - row * kLT;
-            const int gy = y0 + row, gx = x0 + col;
-            float mu_x = 0.f, mu_y = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+        // vertical pass + SSIM: one thread = one column x 4 output rows (14 LDS reads per map)
+        {
+            const int q = tid / kLT, col = tid - q * kLT, r0 = 4 * q;
+            float mom[5][4];
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float w = kWin[k];
-                const float* h = hp + (row + k) * (kLT + 1) + col;
-                mu_x = fmaf(w, h[0], mu_x); mu_y = fmaf(w, h[kLR * (kLT + 1)], mu_y);
-                exx = fmaf(w, h[2 * kLR * (kLT + 1)], exx); eyy = fmaf(w, h[3 * kLR * (kLT + 1)], eyy);
-                exy = fmaf(w, h[4 * kLR * (kLT + 1)], exy);
-            }
-            const bool interior = gy >= kHalo && gy < a.H - kHalo && gx >= kHalo && gx < a.W - kHalo;
-            if (gy < a.H && gx < a.W) {
-                float dmu = 0.f, dxx = 0.f, dxy = 0.f;
-                if (interior) {
-                    const float sxx = exx - mu_x * mu_x, syy = eyy - mu_y * mu_y, sxy = exy - mu_x * mu_y;
-                    const float n1 = 2.f * mu_x * mu_y + kC1, n2 = 2.f * sxy + kC2;
-                    const float d1 = mu_x * mu_x + mu_y * mu_y + kC1, d2 = sxx + syy + kC2;
-                    const float inv = 1.f / (d1 * d2);
-                    const float s = n1 * n2 * inv;
-                    ssim_sum += s;
-                    dxx = -s / d2;
-                    dxy = 2.f * n1 * inv;
-                    dmu = 2.f * mu_y * (n2 - n1) * inv - 2.f * mu_x * s / d1 + 2.f * mu_x * s / d2;
+            for (int mi = 0; mi < 5; ++mi) {
+                float hv[14];
+#pragma unroll
+                for (int i = 0; i < 14; ++i) hv[i] = hp[mi * kLR * kHP + (r0 + i) * kHP + col];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc = fmaf(kWin[k], hv[j + k], acc);
+                    mom[mi][j] = acc;
                 }
-                const size_t o = (size_t)gy * a.W + gx;
-                a.maps[(0 * 3 + ch) * plane + o] = dmu;
-                a.maps[(1 * 3 + ch) * plane + o] = dxx;
-                a.maps[(2 * 3 + ch) * plane + o] = dxy;
+            }
+            const int gx = x0 + col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gy = y0 + r0 + j;
+                const float mu_x = mom[0][j], mu_y = mom[1][j], exx = mom[2][j], eyy = mom[3][j], exy = mom[4][j];
+                const bool interior = gy >= kHalo && gy < a.H - kHalo && gx >= kHalo && gx < a.W - kHalo;
+                if (gy < a.H && gx < a.W) {
+                    float dmu = 0.f, dxx = 0.f, dxy = 0.f;
+                    if (interior) {
+                        const float sxx = exx - mu_x * mu_x, syy = eyy - mu_y * mu_y, sxy = exy - mu_x * mu_y;
+                        const float n1 = 2.f * mu_x * mu_y + kC1, n2 = 2.f * sxy + kC2;
+                        const float d1 = mu_x * mu_x + mu_y * mu_y + kC1, d2 = sxx + syy + kC2;
+                        const float inv = 1.f / (d1 * d2);
+                        const float s = n1 * n2 * inv;
+                        ssim_sum += s;
+                        dxx = -s / d2;
+                        dxy = 2.f * n1 * inv;
+                        dmu = 2.f * mu_y * (n2 - n1) * inv - 2.f * mu_x * s / d1 + 2.f * mu_x * s / d2;
+                    }
+                    const size_t o = (size_t)gy * a.W + gx;
+                    float* mp = a.maps + ((size_t)ch * plane + o) * 3;   // [ch][H][W][dmu, dxx, dxy]
+                    mp[0] = dmu; mp[1] = dxx; mp[2] = dxy;
+                }
             }
         }
         __syncthreads();
@@ -152,7 +196,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(int nblocks, const flo
 __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sm = lds;                       // [3 maps][kLR][kLRP] of one channel
-    float* hp = sm + 3 * kLR * kLRP;       // [3][kLR][kLT+1]
+    float* hp = sm + 3 * kLR * kLRP;       // [3][kLR][kHP]
     const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const int tid = threadIdx.x;
     const size_t plane = (size_t)a.H * a.W;
@@ -161,47 +205,75 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
     const float k_ssim = -g * a.lambda_ssim / cnt;                     // d(1 - mean ssim)
     const float k_l1 = g * (1.f - a.lambda_ssim) / ((float)a.H * (float)a.W * 3.f);
     for (int ch = 0; ch < 3; ++ch) {
-        for (int e = tid; e < 3 * kLR * kLR; e += 256) {
-            const int mi = e / (kLR * kLR), rem = e - mi * (kLR * kLR);
-            const int row = rem / kLR, col = rem - row * kLR;
-            const int gy = y0 - kHalo + row, gx = x0 - kHalo + col;
-            float v = 0.f;   // derivative maps are zero outside the image (and outside the interior)
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = a.maps[(mi * 3 + ch) * plane + (size_t)gy * a.W + gx];
-            sm[(mi * kLR + row) * kLRP + col] = v;
+        {   // loads first, LDS stores after (see the forward kernel)
+            constexpr int kTot = 3 * kLR * kLR, kPer = (kTot + 255) / 256;
+            float v[kPer];
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int e = tid + i * 256;
+                v[i] = 0.f;   // derivative maps are zero outside the image (and outside the interior)
+                if (e < kTot) {
+                    const int row = e / (kLR * 3), rem = e - row * (kLR * 3), col = rem / 3, mi = rem - col * 3;
+                    const int gy = y0 - kHalo + row, gx = x0 - kHalo + col;
+                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v[i] = a.maps[((size_t)ch * plane + (size_t)gy * a.W + gx) * 3 + mi];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) {
+                const int e = tid + i * 256;
+                if (e < kTot) {
+                    const int row = e / (kLR * 3), rem = e - row * (kLR * 3), col = rem / 3, mi = rem - col * 3;
+                    sm[(mi * kLR + row) * kLRP + col] = v[i];
+                }
+            }
         }
         __syncthreads();
-        for (int e = tid; e < kLR * kLT; e += 256) {
-            const int row = e / kLT, col = e - row * kLT;
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        if (tid < kLR * (kLT / 8)) {   // horizontal pass, sliding window: one row x 8 columns per thread
+            const int g = tid / kLR, row = tid - g * kLR, c0 = 8 * g;
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float w = kWin[k];
-                m0 = fmaf(w, sm[(0 * kLR + row) * kLRP + col + k], m0);
-                m1 = fmaf(w, sm[(1 * kLR + row) * kLRP + col + k], m1);
-                m2 = fmaf(w, sm[(2 * kLR + row) * kLRP + col + k], m2);
+            for (int mi = 0; mi < 3; ++mi) {
+                float v[18];
+#pragma unroll
+                for (int i = 0; i < 18; ++i) v[i] = sm[(mi * kLR + row) * kLRP + c0 + i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc = fmaf(kWin[k], v[j + k], acc);
+                    hp[mi * kLR * kHP + row * kHP + c0 + j] = acc;
+                }
             }
-            float* h = hp + row * (kLT + 1) + col;
-            h[0] = m0; h[kLR * (kLT + 1)] = m1; h[2 * kLR * (kLT + 1)] = m2;
         }
         __syncthreads();
-        for (int e = tid; e < kLT * kLT; e += 256) {
-            const int row = e / kLT, col = e - row * kLT;
-            const int gy = y0 + row, gx = x0 + col;
-            if (gy >= a.H || gx >= a.W) continue;
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        {   // vertical pass: one column x 4 rows per thread
+            const int q = tid / kLT, col = tid - q * kLT, r0 = 4 * q;
+            float c[3][4];
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float w = kWin[k];
-                const float* h = hp + (row + k) * (kLT + 1) + col;
-                c0 = fmaf(w, h[0], c0); c1 = fmaf(w, h[kLR * (kLT + 1)], c1); c2 = fmaf(w, h[2 * kLR * (kLT + 1)], c2);
+            for (int mi = 0; mi < 3; ++mi) {
+                float hv[14];
+#pragma unroll
+                for (int i = 0; i < 14; ++i) hv[i] = hp[mi * kLR * kHP + (r0 + i) * kHP + col];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) acc = fmaf(kWin[k], hv[j + k], acc);
+                    c[mi][j] = acc;
+                }
             }
-            const size_t o = ((size_t)gy * a.W + gx) * 3 + ch;
-            const float gtv = a.gt[o];
-            float r = a.render[o], keep = 1.f;
-            if (a.mask) { const float m = a.mask[(size_t)gy * a.W + gx]; r = m * gtv + (1.f - m) * r; keep = 1.f - m; }
-            const float d = r - gtv;
-            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            a.v_render[o] = keep * (k_ssim * (c0 + 2.f * r * c1 + gtv * c2) + k_l1 * sgn);
+            const int gx = x0 + col;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gy = y0 + r0 + j;
+                if (gy >= a.H || gx >= a.W) continue;
+                const size_t o = ((size_t)gy * a.W + gx) * 3 + ch;
+                const float gtv = a.gt[o];
+                float r = a.render[o], keep = 1.f;
+                if (a.mask) { const float m = a.mask[(size_t)gy * a.W + gx]; r = m * gtv + (1.f - m) * r; keep = 1.f - m; }
+                const float d = r - gtv;
+                const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                a.v_render[o] = keep * (k_ssim * (c[0][j] + 2.f * r * c[1][j] + gtv * c[2][j]) + k_l1 * sgn);
+            }
         }
         __syncthreads();
     }

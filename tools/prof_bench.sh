@@ -6,5 +6,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/$tag -o $tag -- pyt
 f=$(find /tmp/$tag -name "*kernel_stats.csv" | head -1)
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 cp "$f" $GRAFT_REPO_ROOT/gpurun_out/${tag}_kernel_stats.csv
-tail -1 /tmp/$tag.log > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_line.json
+grep "^{\"metric\"" /tmp/$tag.log | tail -1 > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_line.json
 cut -d, -f1-4 "$f" | head -16
