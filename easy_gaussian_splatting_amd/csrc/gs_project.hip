@@ -353,25 +353,33 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
 #pragma unroll
     for (int i = 0; i < 12; ++i) s.v[i] = 0.f;
     if (cnt <= kCoopRows) {
-        // one slot per iteration: its (up to four) quadrant rows are all requested before the first
-        // is consumed, and the next slot's mask byte is fetched one iteration ahead
-        int bits_next = cnt > 0 ? (int)a.qmask[base] : 0;
-        for (int r = 0; r < cnt; ++r) {
-            const int bits = bits_next;
-            if (r + 1 < cnt) bits_next = (int)a.qmask[base + r + 1];
+        // Software pipeline over the slots: the (up to four) quadrant rows of slot r+1 are requested
+        // before the rows of slot r are added, and the mask byte runs two slots ahead, so a Gaussian
+        // with k rows pays ~one HBM round trip instead of k.  Missing quadrants load nothing and add
+        // exact zeros (fixed order -> reproducible sums).
+        float4 cur[4][3], nxt[4][3];
+        auto fetch = [&](float4 (&dst)[4][3], int r, int bits) {
             const float4* rp = a.rows + 12 * (int64_t)(base + r);
-            float4 rv[4][3];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (bits & (1 << q)) { rv[q][0] = rp[3 * q]; rv[q][1] = rp[3 * q + 1]; rv[q][2] = rp[3 * q + 2]; }
-                else { rv[q][0] = rv[q][1] = rv[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
+                if (bits & (1 << q)) { dst[q][0] = rp[3 * q]; dst[q][1] = rp[3 * q + 1]; dst[q][2] = rp[3 * q + 2]; }
+                else { dst[q][0] = dst[q][1] = dst[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            }
+        };
+        int bits1 = cnt > 1 ? (int)a.qmask[base + 1] : 0;
+        if (cnt > 0) fetch(cur, 0, (int)a.qmask[base]);
+        for (int r = 0; r < cnt; ++r) {
+            const int bits2 = r + 2 < cnt ? (int)a.qmask[base + r + 2] : 0;
+            if (r + 1 < cnt) fetch(nxt, r + 1, bits1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s.v[0] += cur[q][0].x; s.v[1] += cur[q][0].y; s.v[2] += cur[q][0].z; s.v[3] += cur[q][0].w;
+                s.v[4] += cur[q][1].x; s.v[5] += cur[q][1].y; s.v[6] += cur[q][1].z; s.v[7] += cur[q][1].w;
+                s.v[8] += cur[q][2].x; s.v[9] += cur[q][2].y; s.v[10] += cur[q][2].z;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {   // fixed order -> reproducible sums (x + 0 is exact)
-                s.v[0] += rv[q][0].x; s.v[1] += rv[q][0].y; s.v[2] += rv[q][0].z; s.v[3] += rv[q][0].w;
-                s.v[4] += rv[q][1].x; s.v[5] += rv[q][1].y; s.v[6] += rv[q][1].z; s.v[7] += rv[q][1].w;
-                s.v[8] += rv[q][2].x; s.v[9] += rv[q][2].y; s.v[10] += rv[q][2].z;
-            }
+            for (int q = 0; q < 4; ++q) { cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1]; cur[q][2] = nxt[q][2]; }
+            bits1 = bits2;
         }
     }
     unsigned long long big = __ballot(cnt > kCoopRows);
