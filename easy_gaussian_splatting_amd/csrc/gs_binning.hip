@@ -199,23 +199,43 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
     const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
     const uint32_t* mine = hist_mat + ((size_t)c * G + grp) * tiles;
     const int32_t* toff = isect_offsets + (size_t)c * tiles;
-    for (int t = threadIdx.x; t < tiles; t += blockDim.x) cursor[t] = mine[t] + (uint32_t)toff[t];
+    // cursor init, loads batched ahead of the LDS stores (8 tiles per thread and round)
+    for (int t0 = 0; t0 < tiles; t0 += 8 * (int)blockDim.x) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * (int)blockDim.x + (int)threadIdx.x;
+            v[k] = t < tiles ? mine[t] + (uint32_t)toff[t] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * (int)blockDim.x + (int)threadIdx.x;
+            if (t < tiles) cursor[t] = v[k];
+        }
+    }
     __syncthreads();
     uint32_t running = grp_base[c * G + grp];
     const int64_t g0 = grp * per_group, g1 = min(N, g0 + per_group);
+    // the next round's footprint and depth are requested before this round's scatter
+    uint4 fp_next = make_uint4(0u, 0u, 0u, 0u);
+    float d_next = 0.f;
+    if (g0 + threadIdx.x < g1) { fp_next = bbox[(int64_t)c * N + g0 + threadIdx.x]; d_next = depths[(int64_t)c * N + g0 + threadIdx.x]; }
     for (int64_t base = g0; base < g1; base += blockDim.x) {
         const int64_t n = base + threadIdx.x;
         const int64_t f = (int64_t)c * N + n;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-        uint4 fp = make_uint4(0u, 0u, 0u, 0u);
-        if (n < g1) { fp = bbox[f]; unpack_bbox(fp, x0, x1, y0, y1); }
+        const uint4 fp = fp_next;
+        const float dcur = d_next;
+        if (n < g1) unpack_bbox(fp, x0, x1, y0, y1);
         const int w = x1 - x0, rect = w * (y1 - y0), cnt = (int)fp.w;
         uint32_t total;
         const uint32_t slot0 = running + block_excl_scan_add((uint32_t)cnt, scratch, &total);
         running += total;
+        // (after the scan: its barriers drain the vector-memory counter)
+        fp_next = make_uint4(0u, 0u, 0u, 0u);
+        if (n + blockDim.x < g1) { fp_next = bbox[f + blockDim.x]; d_next = depths[f + blockDim.x]; }
         if (n < g1) cum_tiles[f] = (int32_t)slot0;
-        uint32_t dbits = 0;
-        if (cnt > 0) dbits = __float_as_uint(depths[f]);
+        const uint32_t dbits = cnt > 0 ? __float_as_uint(dcur) : 0u;
         if (rect <= kCoopTiles) {
             uint32_t k = 0;
             for (uint32_t mb = fp.z; mb; mb &= mb - 1, ++k) {
