@@ -27,6 +27,17 @@ struct AdamArgs {
     float grad_scale;             // gradients are multiplied by this first (1/world for a mean over ranks)
 };
 
+// streaming (non-temporal) 16-byte accesses for data touched once per step
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4 x, float4* p) {
+    f4v v; v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
+    __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p));
+}
+
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
                                       float isbc2, float ss) {
     m = fmaf(b1, m, (1.f - b1) * g);
@@ -46,19 +57,20 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
         const int64_t len = a.seg_len[s];
         float4 g;
         if (e + 4 <= len) {
-            g = *reinterpret_cast<const float4*>(gp + e);
+            g = nt_load4(reinterpret_cast<const float4*>(gp + e));   // read once, then dead
         } else {  // the segment's padded tail
             g.x = e < len ? gp[e] : 0.f; g.y = e + 1 < len ? gp[e + 1] : 0.f;
             g.z = e + 2 < len ? gp[e + 2] : 0.f; g.w = 0.f;
         }
         g.x *= a.grad_scale; g.y *= a.grad_scale; g.z *= a.grad_scale; g.w *= a.grad_scale;
         const float ss = a.step_size[s];
-        float4 p = a.p[i], m = a.m[i], v = a.v[i];
+        float4 p = a.p[i], m = nt_load4(a.m + i), v = nt_load4(a.v + i);
         adam1(p.x, g.x, m.x, v.x, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
         adam1(p.y, g.y, m.y, v.y, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
         adam1(p.z, g.z, m.z, v.z, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
         adam1(p.w, g.w, m.w, v.w, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
-        a.p[i] = p; a.m[i] = m; a.v[i] = v;
+        a.p[i] = p;   // re-read by the next forward
+        nt_store4(m, a.m + i); nt_store4(v, a.v + i);   // streamed once per step
     }
 }
 
