@@ -27,17 +27,6 @@ struct AdamArgs {
     float grad_scale;             // gradients are multiplied by this first (1/world for a mean over ranks)
 };
 
-// streaming (non-temporal) 16-byte accesses for data touched once per step
-typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 nt_load4(const float4* p) {
-    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void nt_store4(float4 x, float4* p) {
-    f4v v; v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
-    __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p));
-}
-
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
                                       float isbc2, float ss) {
     m = fmaf(b1, m, (1.f - b1) * g);

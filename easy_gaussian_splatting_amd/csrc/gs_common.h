@@ -92,4 +92,18 @@ __device__ __forceinline__ T block_excl_scan_add(T v, T* scratch, T* total) {
     return res;
 }
 
+// streaming (non-temporal) 16-byte accesses for data that is touched once and then dead
+#ifdef __HIPCC__
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4 x, float4* p) {
+    f4v v; v.x = x.x; v.y = x.y; v.z = x.z; v.w = x.w;
+    __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p));
+}
+
+#endif
+
 }  // namespace gs

@@ -296,7 +296,7 @@ __device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K
                 }
                 float4 v = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 if (accumulate) { const float4 o = dr4[e4]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                dr4[e4] = v;
+                nt_store4(v, dr4 + e4);
             }
             for (int e = (total & ~3) + threadIdx.x; e < total; e += blockDim.x) {
                 const int g = e / rest_f;
