@@ -279,9 +279,45 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
     }
 }
 
+// torch.clamp(x, 0, 1) of /root/reference/model/gaussian.py:368 and its backward
+// (gradient passes where 0 <= x <= 1, the aten convention) as single passes over the image.
+__global__ __launch_bounds__(256) void clamp01_kernel(int64_t n4, int64_t n, const float* __restrict__ x,
+                                                      const float* __restrict__ v_out, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) {
+        const float4 a = reinterpret_cast<const float4*>(x)[i];
+        float4 r;
+        if (v_out) {
+            const float4 g = reinterpret_cast<const float4*>(v_out)[i];
+            r.x = (a.x >= 0.f && a.x <= 1.f) ? g.x : 0.f; r.y = (a.y >= 0.f && a.y <= 1.f) ? g.y : 0.f;
+            r.z = (a.z >= 0.f && a.z <= 1.f) ? g.z : 0.f; r.w = (a.w >= 0.f && a.w <= 1.f) ? g.w : 0.f;
+        } else {
+            r.x = fminf(fmaxf(a.x, 0.f), 1.f); r.y = fminf(fmaxf(a.y, 0.f), 1.f);
+            r.z = fminf(fmaxf(a.z, 0.f), 1.f); r.w = fminf(fmaxf(a.w, 0.f), 1.f);
+        }
+        reinterpret_cast<float4*>(out)[i] = r;
+    }
+    if (i == 0)
+        for (int64_t k = n4 * 4; k < n; ++k) {
+            const float a = x[k];
+            out[k] = v_out ? ((a >= 0.f && a <= 1.f) ? v_out[k] : 0.f) : fminf(fmaxf(a, 0.f), 1.f);
+        }
+}
+
 }  // namespace gs
 
 using namespace gs;
+
+extern "C" int gs_clamp01(void* stream, int64_t n, const float* x, const float* v_out, float* out) {
+    GS_REQUIRE(n >= 0, "n >= 0");
+    if (n == 0) return GS_OK;
+    GS_REQUIRE(x && out, "null pointer");
+    GS_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)v_out) & 15) == 0, "buffers must be 16-byte aligned");
+    const int64_t n4 = n >> 2, blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(clamp01_kernel, dim3((unsigned)(blocks > 0 ? blocks : 1)), dim3(256), 0, (hipStream_t)stream, n4, n, x, v_out, out);
+    GS_LAUNCH_CHECK("clamp01_kernel");
+    return GS_OK;
+}
 
 extern "C" size_t gs_loss_workspace_floats(int height, int width) {
     const size_t nb = (size_t)((width + kLT - 1) / kLT) * ((height + kLT - 1) / kLT);

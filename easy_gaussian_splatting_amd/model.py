@@ -23,6 +23,39 @@ from .distributed import all_reduce_statistics, is_distributed
 from .rendering import rasterization
 
 
+class _Clamp01(torch.autograd.Function):
+    """`torch.clamp(x, 0, 1)` (/root/reference/model/gaussian.py:368) with a one-pass backward
+    (aten's clamp backward is four elementwise kernels on a full-resolution image)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor) -> Tensor:
+        from . import _native as nat
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib().gs_clamp01(torch.cuda.current_stream(x.device).cuda_stream, x.numel(), x.data_ptr(), None,
+                                           out.data_ptr()), "gs_clamp01")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out: Tensor):
+        from . import _native as nat
+        (x,) = ctx.saved_tensors
+        v_out = v_out.contiguous()
+        v_in = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib().gs_clamp01(torch.cuda.current_stream(x.device).cuda_stream, x.numel(), x.data_ptr(),
+                                           v_out.data_ptr(), v_in.data_ptr()), "gs_clamp01")
+        return v_in
+
+
+def clamp01(x: Tensor) -> Tensor:
+    if x.is_cuda and x.dtype == torch.float32:
+        return _Clamp01.apply(x)
+    return torch.clamp(x, min=0.0, max=1.0)
+
+
 class GaussianModel(nn.Module):
     def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, sh_0: Tensor, sh_rest: Tensor,
                  logit_opacities: Tensor, sh_degree: int, sh_degree_interval: int = 0,
@@ -204,7 +237,7 @@ class GaussianModel(nn.Module):
             packed=False,
             _sh_grads=getattr(self, "sh_grads", "dense"),
         )
-        render_img = torch.clamp(batch_render_imgs[0], min=0.0, max=1.0)
+        render_img = clamp01(batch_render_imgs[0])
         return {
             "render_img": render_img,  # [H, W, 3]
             "batch_xys": meta["means2d"],  # [1, N, 2]

@@ -203,6 +203,7 @@ class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, holder):
         need_grad = any(ctx.needs_input_grad[:6])
+        ctx.set_materialize_grads(False)   # an unused render_alphas must not cost a zero-filled image
         render_colors, render_alphas, meta, state = _forward_stages(
             means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, need_grad)
         holder.meta = meta
@@ -224,7 +225,7 @@ class _Rasterize(torch.autograd.Function):
         C, N, K = s["C"], s["N"], s["K"]
         W, H = cfg["width"], cfg["height"]
         f32 = dict(dtype=torch.float32, device=dev)
-        v_rc = v_render_colors.contiguous()
+        v_rc = torch.zeros_like(render_colors) if v_render_colors is None else v_render_colors.contiguous()
         v_ra = None if v_render_alphas is None else v_render_alphas.contiguous()
         rows = torch.empty((max(s["n_isects"], 1) * 4, nat.GS_ROW_FLOATS), **f32)
         _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, _ptr(s["rec"]), _ptr(s["isect_offsets"]),

@@ -176,6 +176,11 @@ int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const
                    const float* gt, const float* mask, const float* workspace,
                    const float* v_total, float* v_render);
 
+/* Row a-2: `torch.clamp(render, 0, 1)` of /root/reference/model/gaussian.py:368 as one pass.
+ * v_out == NULL: out = clamp(x, 0, 1).  v_out != NULL: out = v_out where 0 <= x <= 1, else 0 (the
+ * backward of that clamp).  n floats, 16-byte aligned buffers. */
+int gs_clamp01(void* stream, int64_t n, const float* x, const float* v_out, float* out);
+
 /* ---- "next" row f-2: fused Adam over flat buffers (one torch.optim.Adam with six groups in the
  * reference, /root/reference/model/gaussian.py:389-412; defaults: no weight decay / amsgrad).
  * params, exp_avg, exp_avg_sq: flat fp32 device buffers of n elements holding n_segments parameter
