@@ -70,13 +70,17 @@ __device__ __forceinline__ void blend_pair(const float sigma, const float op, co
     done = done || stop;
 }
 
-template <bool CKPT>
-__global__ __launch_bounds__(64) void blend_fwd_kernel(const BlendFwdArgs a) {
-    __shared__ float4 srec[GS_BUCKET * 3];
-    const int t = blockIdx.x;
+// WAVES tiles per workgroup, one wave each; the waves share nothing (no workgroup barrier), the
+// grouping only lowers the number of workgroups the dispatcher has to launch.
+template <bool CKPT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArgs a) {
+    __shared__ float4 srec_all[WAVES][GS_BUCKET * 3];
+    float4* srec = srec_all[threadIdx.x >> 6];
+    const int t = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
+    if (t >= a.C * a.tiles) return;   // wave-uniform
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
     const int tyi = tt / a.tw, txi = tt - tyi * a.tw;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int x0 = txi * GS_TILE, y0 = tyi * GS_TILE;
     const int px0 = x0 + (lane & 7), py0 = y0 + (lane >> 3);   // quadrant 0 pixel; +8 for the others
     const float fx0 = (float)px0 + 0.5f, fy0 = (float)py0 + 0.5f, fx1 = fx0 + 8.f, fy1 = fy0 + 8.f;
@@ -393,14 +397,18 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     a.out_colors = render_colors; a.out_alphas = render_alphas;
     a.ckpt = reinterpret_cast<float4*>(ckpt); a.qlist = reinterpret_cast<int2*>(qlist); a.qcnt = qcnt; a.qmask = qmask;
     a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int2*>(unit_desc);
-    const unsigned grid = (unsigned)(C * a.tiles);
+    const unsigned n_tiles = (unsigned)(C * a.tiles);
     hipStream_t st = (hipStream_t)stream;
+    // 4 tiles (waves) per workgroup: same speed as single-wave workgroups on most boxes of the pool, but
+    // some boxes launch single-wave workgroups at half the rate (blend_fwd 0.63 instead of 0.33 ms)
+    constexpr int kFwdWaves = 4;
+    const dim3 grid((n_tiles + kFwdWaves - 1) / kFwdWaves), block(64 * kFwdWaves);
     if (train) {
         GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));
         if (n_isects > 0) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
-        hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(grid), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves>), grid, block, 0, st, a);
     } else {
-        hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(grid), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((blend_fwd_kernel<false, kFwdWaves>), grid, block, 0, st, a);
     }
     GS_LAUNCH_CHECK("blend_fwd_kernel");
     return GS_OK;

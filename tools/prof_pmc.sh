@@ -1,0 +1,11 @@
+#!/bin/bash
+# HBM traffic per launch of our kernels: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a
+# short bench run, summarised by tools/pmc_summary.py -> gpurun_out/<tag>_pmc_traffic.json  (run via gpurun)
+tag=${1:-pmc}
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/${tag}_$c -o $c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /tmp/${tag}_$c.log 2>&1
+done
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/${tag}_FETCH_SIZE /tmp/${tag}_WRITE_SIZE > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_traffic.json
+head -c 600 $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_traffic.json
