@@ -399,8 +399,9 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int2*>(unit_desc);
     const unsigned n_tiles = (unsigned)(C * a.tiles);
     hipStream_t st = (hipStream_t)stream;
-    // 4 tiles (waves) per workgroup: same speed as single-wave workgroups on most boxes of the pool, but
-    // some boxes launch single-wave workgroups at half the rate (blend_fwd 0.63 instead of 0.33 ms)
+    // 4 tiles (waves) per workgroup: measured equal to single-wave workgroups (0.33-0.36 ms at the bench
+    // size).  One box of the pool ran the single-wave form at 0.63 ms with every other kernel at its usual
+    // time; the cause was not established, a quarter of the workgroups is the conservative launch shape.
     constexpr int kFwdWaves = 4;
     const dim3 grid((n_tiles + kFwdWaves - 1) / kFwdWaves), block(64 * kFwdWaves);
     if (train) {

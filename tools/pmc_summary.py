@@ -21,7 +21,7 @@ def load(dirname, counter):
     for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if row.get("Counter_Name") == counter:
+                if row.get("Counter_Name") == counter and "gs::" in row["Kernel_Name"]:   # our kernels only
                     name = row["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0].strip()
                     out[name].append(float(row["Counter_Value"]))
     return out
