@@ -185,3 +185,30 @@ def test_two_ranks_equal_one_process_on_both_views(tmp_path):
     np.testing.assert_allclose(r0["gn"], ref["gn"], rtol=1e-4, atol=1e-6)
     np.testing.assert_array_equal(r0["cnt"], ref["cnt"])
     np.testing.assert_array_equal(r0["rad"], ref["rad"])
+
+
+def test_sh_grad_views_argument_checks_and_empty_input():
+    dev = torch.device("cuda:0")
+    means = torch.zeros((0, 3), device=dev)
+    vm = torch.eye(4, device=dev)[None]
+    v0, vr = sh_grad_views(means, vm, torch.zeros((1, 0, 3), device=dev), 3, 16)
+    assert v0.shape == (0, 1, 3) and vr.shape == (0, 15, 3)
+    means = torch.randn((5, 3), device=dev)
+    with pytest.raises(ValueError):   # more views than the kernel's camera table holds
+        sh_grad_views(means, torch.eye(4, device=dev).repeat(65, 1, 1), torch.zeros((65, 5, 3), device=dev), 3, 16)
+    with pytest.raises(ValueError):   # K too small for the degree
+        sh_grad_views(means, vm, torch.zeros((1, 5, 3), device=dev), 3, 9)
+    with pytest.raises(RuntimeError):  # no CPU fallback
+        sh_grad_views(means.cpu(), vm.cpu(), torch.zeros((1, 5, 3)), 3, 16)
+    # a view in which nothing is visible contributes exact zeros
+    out = sh_grad_views(means, vm, torch.zeros((1, 5, 3), device=dev), 2, 16, split=False)
+    assert out.shape == (5, 16, 3) and float(out.abs().max()) == 0.0
+
+
+def test_factorised_mode_needs_sh_colours():
+    dev = torch.device("cuda:0")
+    sc = make_scene(50, 64, 48, sh_degree=1, n_views=1, seed=3, dist=4.0)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
+    with pytest.raises(ValueError):
+        rasterization(t["means"], t["quats"], t["scales"], t["opacities"], torch.rand((50, 3), device=dev), t["viewmats"],
+                      t["Ks"], 64, 48, packed=False, _sh_grads="colors_pre")
