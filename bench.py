@@ -138,7 +138,11 @@ def main():
     vp = ViewParallelStep(model, optimizer) if (exchange == "factorised" and bucket is None) else None
 
     def train_step():
+        if vp is not None:
+            vp.begin_step(data)
         out = model(data)
+        if vp is not None:
+            vp.after_forward(data, out)
         loss = loss_computer.get_loss_dict(out["render_img"], gt_img, mask)["total"]
         loss.backward()
         if vp is not None:

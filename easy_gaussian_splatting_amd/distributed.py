@@ -91,7 +91,8 @@ class ViewParallelStep:
     """Exchange + parameter update of one training step with one view per rank.
 
         vp = ViewParallelStep(model, optimizer)          # optimizer: optim.FusedAdam
-        out = model(data); loss.backward(); vp.step(data, out)
+        vp.begin_step(data); out = model(data); vp.after_forward(data, out)     # (both hooks optional)
+        loss.backward(); vp.step(data, out)
 
     replaces `model.update_statistics(data, out); optimizer.step(); optimizer.zero_grad()` of the
     reference loop (/root/reference/train.py:36-43, 57-58).  The update equals the single-process
@@ -109,7 +110,31 @@ class ViewParallelStep:
         if sh_grad_fn is None:
             from .rendering import sh_grad_views as sh_grad_fn
         self.sh_grad_fn = sh_grad_fn
+        self._cams = self._rad = None
         model.sh_grads = "colors_pre" if self.world > 1 else "dense"
+
+    # Optional hooks that move the two small collectives off the end of the step (every rank must make
+    # the same calls in the same order; `step` issues whatever was not issued before).
+    def begin_step(self, data) -> None:
+        """Before the forward: exchange the cameras (64 B per rank)."""
+        if self.world == 1 or self._cams is not None:
+            return
+        dt, dev = self.model.means.dtype, self.model.means.device
+        cams = torch.empty(self.world * 16, dtype=dt, device=dev)
+        work = dist.all_gather_into_tensor(cams, data["w2c"].to(dt).reshape(-1).contiguous(), group=self.group, async_op=True)
+        self._cams = (cams, work)
+
+    def after_forward(self, data, out) -> None:
+        """After the forward: MAX all-reduce of the normalised radii, overlapped with loss + backward."""
+        if self.world == 1 or self._rad is not None:
+            return
+        dt = self.model.means.dtype
+        max_hw = float(max(data["height"], data["width"]))
+        radii = out["batch_radii"][0]
+        visible = radii > 0
+        rad = torch.where(visible, radii.to(dt) / max_hw, 0.0)
+        work = dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+        self._rad = (rad, visible, work)
 
     def step(self, data, out) -> None:
         m, opt = self.model, self.opt
@@ -123,18 +148,19 @@ class ViewParallelStep:
         xys = out["batch_xys"]
         dt = m.means.dtype   # float32 in the product; the CPU tests drive this class in float64
         f32 = dict(dtype=dt, device=m.means.device)
-        # (1) all-gather: every view's world->camera matrix (64 B) and pre-clamp colour gradient
-        #     (flat 1-D buffers: the layout every backend accepts for all_gather_into_tensor)
-        cams = torch.empty(world * 16, **f32)
-        w_cams = dist.all_gather_into_tensor(cams, data["w2c"].to(dt).reshape(-1).contiguous(), group=group, async_op=True)
+        max_hw = float(max(data["height"], data["width"]))
+        # (0) the small collectives, unless the hooks issued them already
+        self.begin_step(data)
+        self.after_forward(data, out)
+        (cams, w_cams), (rad, visible, w_max) = self._cams, self._rad
+        self._cams = self._rad = None
+        # (1) all-gather: every view's pre-clamp colour gradient (flat 1-D buffers: the layout every
+        #     backend accepts for all_gather_into_tensor)
         pre_all = torch.empty(world * N * 3, **f32)
         w_gather = dist.all_gather_into_tensor(pre_all, xys.colors_pre_grad[0].reshape(-1).contiguous(), group=group,
                                                async_op=True)
         # (2) all-reduce SUM: geometry gradients + the two additive statistics of this view
         #     (/root/reference/model/gaussian.py:188-197), segments padded to 16 bytes
-        max_hw = float(max(data["height"], data["width"]))
-        radii = out["batch_radii"][0]
-        visible = radii > 0
         geo = [getattr(m, name) for name in self.GEOMETRY]
         pieces = [p.grad for p in geo]
         pieces.append(torch.where(visible, torch.linalg.vector_norm(xys.absgrad[0], dim=-1) * max_hw, 0.0))
@@ -147,9 +173,6 @@ class ViewParallelStep:
         for t, o in zip(pieces, offs):
             flat[o:o + t.numel()].copy_(t.reshape(-1))
         w_sum = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        # (3) all-reduce MAX: normalised radii
-        rad = torch.where(visible, radii.to(dt) / max_hw, 0.0)
-        w_max = dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=group, async_op=True)
         # SH half: rebuild the dense SH gradient of all views, update while (2) is in flight
         w_cams.wait()
         w_gather.wait()

@@ -199,8 +199,12 @@ def _vp_worker(rank, world, port, out_dir):
     assert model.sh_grads == "colors_pre"
     target = torch.rand((2, sc["height"], sc["width"], 3), generator=torch.Generator().manual_seed(5), dtype=torch.float64)
     data = {"w2c": torch.tensor(sc["viewmats"][rank], dtype=torch.float64), "height": sc["height"], "width": sc["width"]}
-    for _ in range(2):
+    for it in range(2):   # first step with the two early-collective hooks, second without
+        if it == 0:
+            vp.begin_step(data)
         out = _vp_render(model, sc, rank, target)
+        if it == 0:
+            vp.after_forward(data, out)
         vp.step(data, out)
     assert opt.calls[:2] == [(("sh_0", "sh_rest"), True), (("means", "log_scales", "quats", "logit_opacities"), False)]
     np.savez(os.path.join(out_dir, f"vp{rank}.npz"), gn=model.grad_norm_accum.numpy(), cnt=model.collecting_counts.numpy(),

@@ -136,8 +136,12 @@ def _worker(rank, world, port, out_dir):
     model, opt, datas, targets = _make(dev)
     vp = ViewParallelStep(model, opt)
     lc = LossComputer(0.2)
-    for _ in range(3):
+    for it in range(3):
+        if it != 1:
+            vp.begin_step(datas[rank])
         out = model(datas[rank])
+        if it != 1:
+            vp.after_forward(datas[rank], out)
         lc.get_loss_dict(out["render_img"], targets[rank])["total"].backward()
         assert model.sh_0.grad is None and model.sh_rest.grad is None
         vp.step(datas[rank], out)
