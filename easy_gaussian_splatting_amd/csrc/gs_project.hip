@@ -539,9 +539,57 @@ __global__ __launch_bounds__(kProjThreads) void sh_grad_views_kernel(const ShGra
     write_sh_tile(tile, (int)min((int64_t)kProjThreads, a.N - n0), a.K, n0, a.v_colors, a.v_sh_rest, false);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Early colour gradient for the view-parallel exchange: v_colors_pre[f] = clamp-masked sum of the
+// colour lanes of Gaussian f's gradient rows (read from blend_bwd's compact rows_color copy) -- the only part of project_bwd's output other ranks
+// need.  Running it as its own light kernel right after blend_bwd lets the all-gather of
+// v_colors_pre overlap the (much longer) project_bwd.  Same row order as project_bwd -> same sums.
+__global__ __launch_bounds__(256) void colors_pre_grad_kernel(int64_t total, const int32_t* __restrict__ radii,
+                                                              const float* __restrict__ colors_post,
+                                                              const int32_t* __restrict__ tiles_per_gauss,
+                                                              const int32_t* __restrict__ cum_tiles,
+                                                              const float4* __restrict__ rows_color,
+                                                              const uint8_t* __restrict__ qmask,
+                                                              float* __restrict__ v_colors_pre) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= total) return;
+    float sr = 0.f, sg = 0.f, sb = 0.f;
+    if (radii[f] > 0) {
+        const int cnt = tiles_per_gauss[f], base = cum_tiles[f];
+        int bits = cnt > 0 ? (int)qmask[base] : 0;
+        for (int r = 0; r < cnt; ++r) {
+            const int bits_next = r + 1 < cnt ? (int)qmask[base + r + 1] : 0;
+            const float4* rp = rows_color + 4 * (int64_t)(base + r);
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (bits & (1 << q)) ? rp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sr += v[q].x; sg += v[q].y; sb += v[q].z; }
+            bits = bits_next;
+        }
+        sr = colors_post[3 * f] > 0.f ? sr : 0.f;
+        sg = colors_post[3 * f + 1] > 0.f ? sg : 0.f;
+        sb = colors_post[3 * f + 2] > 0.f ? sb : 0.f;
+    }
+    v_colors_pre[3 * f] = sr; v_colors_pre[3 * f + 1] = sg; v_colors_pre[3 * f + 2] = sb;
+}
+
 }  // namespace gs
 
 using namespace gs;
+
+extern "C" int gs_colors_pre_grad(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
+                                  const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows_color,
+                                  const uint8_t* qmask, float* v_colors_pre) {
+    GS_REQUIRE(C >= 1 && N >= 0, "C>=1, N>=0");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(radii && colors_post && tiles_per_gauss && cum_tiles && rows_color && qmask && v_colors_pre, "null pointer");
+    const int64_t total = (int64_t)C * N;
+    hipLaunchKernelGGL(colors_pre_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
+                       radii, colors_post, tiles_per_gauss, cum_tiles, reinterpret_cast<const float4*>(rows_color), qmask, v_colors_pre);
+    GS_LAUNCH_CHECK("colors_pre_grad_kernel");
+    return GS_OK;
+}
 
 extern "C" int gs_sh_grad_views(void* stream, int R, int64_t N, int K, int sh_degree, const float* means,
                                 const float* viewmats, const float* v_colors_pre, float* v_colors,
@@ -628,7 +676,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     if (N == 0) return GS_OK;
     GS_REQUIRE(means && quats && scales && colors_in && viewmats && Ks && radii && colors_post && tiles_per_gauss && cum_tiles && rows && qmask, "null input pointer");
     GS_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_means2d_abs, "null output pointer");
-    GS_REQUIRE(v_colors || (sh_degree >= 0 && v_colors_pre), "v_colors may be NULL only with SH colours and v_colors_pre given");
+    GS_REQUIRE(v_colors || sh_degree >= 0, "v_colors may be NULL only with SH colours (gradients rebuilt by gs_sh_grad_views)");
     ProjBwdArgs a;
     a.C = C; a.N = N; a.K = K; a.colors_per_camera = colors_per_camera; a.W = width; a.H = height;
     a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;

@@ -110,7 +110,9 @@ class ViewParallelStep:
         if sh_grad_fn is None:
             from .rendering import sh_grad_views as sh_grad_fn
         self.sh_grad_fn = sh_grad_fn
-        self._cams = self._rad = None
+        self._cams = self._rad = self._pre = None
+        if self.world > 1:   # started from inside backward(), as soon as the colour gradient exists
+            model.on_colors_pre = self._gather_colors_pre
         model.sh_grads = "colors_pre" if self.world > 1 else "dense"
 
     # Optional hooks that move the two small collectives off the end of the step (every rank must make
@@ -136,6 +138,17 @@ class ViewParallelStep:
         work = dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         self._rad = (rad, visible, work)
 
+    def _gather_colors_pre(self, colors_pre_grad: Tensor) -> None:
+        """All-gather of this view's pre-clamp colour gradient [1,N,3] (flat 1-D buffers: the layout
+        every backend accepts).  Called by the rasterizer's backward between the blend backward and
+        the projection backward, so the transfer overlaps the latter; `step` calls it otherwise."""
+        if self._pre is not None:
+            return
+        mine = colors_pre_grad[0].reshape(-1).contiguous()
+        pre_all = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        work = dist.all_gather_into_tensor(pre_all, mine, group=self.group, async_op=True)
+        self._pre = (pre_all, work)
+
     def step(self, data, out) -> None:
         m, opt = self.model, self.opt
         if self.world == 1:
@@ -154,11 +167,10 @@ class ViewParallelStep:
         self.after_forward(data, out)
         (cams, w_cams), (rad, visible, w_max) = self._cams, self._rad
         self._cams = self._rad = None
-        # (1) all-gather: every view's pre-clamp colour gradient (flat 1-D buffers: the layout every
-        #     backend accepts for all_gather_into_tensor)
-        pre_all = torch.empty(world * N * 3, **f32)
-        w_gather = dist.all_gather_into_tensor(pre_all, xys.colors_pre_grad[0].reshape(-1).contiguous(), group=group,
-                                               async_op=True)
+        # (1) all-gather of every view's pre-clamp colour gradient (normally already in flight)
+        self._gather_colors_pre(xys.colors_pre_grad)
+        pre_all, w_gather = self._pre
+        self._pre = None
         # (2) all-reduce SUM: geometry gradients + the two additive statistics of this view
         #     (/root/reference/model/gaussian.py:188-197), segments padded to 16 bytes
         geo = [getattr(m, name) for name in self.GEOMETRY]

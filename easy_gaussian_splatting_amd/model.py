@@ -236,6 +236,7 @@ class GaussianModel(nn.Module):
             absgrad=True,
             packed=False,
             _sh_grads=getattr(self, "sh_grads", "dense"),
+            _on_colors_pre=getattr(self, "on_colors_pre", None),
         )
         render_img = clamp01(batch_render_imgs[0])
         return {

@@ -85,13 +85,14 @@ class _Holder:
     the node own its own output (the weak reference lets backward attach `.absgrad` to the very
     tensor object that was handed out in `meta`)."""
 
-    __slots__ = ("meta", "means2d_ref", "absgrad", "debug")
+    __slots__ = ("meta", "means2d_ref", "absgrad", "debug", "on_colors_pre")
 
     def __init__(self, absgrad: bool):
         self.meta: Dict = {}
         self.means2d_ref = None
         self.absgrad = absgrad
         self.debug: Optional[Dict] = None
+        self.on_colors_pre = None
 
 
 def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, need_grad):
@@ -228,18 +229,30 @@ class _Rasterize(torch.autograd.Function):
         v_rc = torch.zeros_like(render_colors) if v_render_colors is None else v_render_colors.contiguous()
         v_ra = None if v_render_alphas is None else v_render_alphas.contiguous()
         rows = torch.empty((max(s["n_isects"], 1) * 4, nat.GS_ROW_FLOATS), **f32)
+        factorised = cfg.get("sh_grads") == "colors_pre"
+        rows_color = torch.empty((max(s["n_isects"], 1) * 4, 4), **f32) if factorised else None
         _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, _ptr(s["rec"]), _ptr(s["isect_offsets"]),
                                  _ptr(s["bucket_offsets"]), s["n_buckets"], _ptr(s["qlist"]), _ptr(s["qcnt"]), _ptr(s["unit_counter"]),
                                  _ptr(s["unit_desc"]), _ptr(s["ckpt"]), _ptr(render_colors), _ptr(render_alphas),
-                                 _ptr(v_rc), _ptr(v_ra), _ptr(rows)), "gs_blend_bwd"))
+                                 _ptr(v_rc), _ptr(v_ra), _ptr(rows), _ptr(rows_color)), "gs_blend_bwd"))
         v_means = torch.empty((N, 3), **f32)
         v_quats = torch.empty((N, 4), **f32)
         v_scales = torch.empty((N, 3), **f32)
         v_opac = torch.empty((N,), **f32)
-        factorised = cfg.get("sh_grads") == "colors_pre"
         v_colors = None if factorised else torch.empty(colors.shape, **f32)
         v_rest = torch.empty(colors_rest.shape, **f32) if (ctx.split and not factorised) else None
-        v_pre = torch.empty((C, N, 3), **f32) if factorised else None
+        v_pre = None
+        if factorised:
+            # the colour gradient other ranks need, before the long projection backward: its exchange
+            # (holder.on_colors_pre, e.g. an all-gather) overlaps gs_project_bwd
+            v_pre = torch.empty((C, N, 3), **f32)
+            _stage("gs_colors_pre_grad", dev, lambda: nat.check(L.gs_colors_pre_grad(
+                st, C, N, _ptr(s["radii"]), _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
+                _ptr(rows_color), _ptr(s["qmask"]), _ptr(v_pre)), "gs_colors_pre_grad"))
+            if holder.means2d_ref is not None and holder.means2d_ref() is not None:
+                holder.means2d_ref().colors_pre_grad = v_pre
+            if holder.on_colors_pre is not None:
+                holder.on_colors_pre(v_pre)
         v_abs = torch.empty((C, N, 2), **f32)
         dbg = holder.debug
         v_m2 = v_cn = v_cp = None
@@ -252,17 +265,14 @@ class _Rasterize(torch.autograd.Function):
                                    cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
                                    _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
                                    _ptr(rows), _ptr(s["qmask"]), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
-                                   _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), _ptr(v_pre)),
+                                   _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), None),
                                    "gs_project_bwd"))
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp, rows=rows)
-        if (holder.absgrad or factorised) and holder.means2d_ref is not None:
+        if holder.absgrad and holder.means2d_ref is not None:
             m2 = holder.means2d_ref()
             if m2 is not None:
-                if holder.absgrad:
-                    m2.absgrad = v_abs
-                if factorised:
-                    m2.colors_pre_grad = v_pre
+                m2.absgrad = v_abs
         ni = ctx.needs_input_grad
         return (v_means if ni[0] else None, v_quats if ni[1] else None, v_scales if ni[2] else None,
                 v_opac if ni[3] else None, v_colors if (ni[4] and not factorised) else None,
@@ -331,6 +341,7 @@ def rasterization(
     _debug: Optional[Dict] = None,
     _tile_culling: str = "tight",
     _sh_grads: str = "dense",
+    _on_colors_pre=None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize 3D Gaussians to images; same tensor signature and return value as
     `gsplat.rendering.rasterization` (gsplat 1.0.0).
@@ -351,7 +362,9 @@ def rasterization(
     `_sh_grads="colors_pre"` (SH colours only; used by `distributed.ViewParallelStep`) leaves the
     gradients of the SH coefficients to `gs_sh_grad_views`: backward returns `None` for `colors`
     and attaches `meta["means2d"].colors_pre_grad` ([C,N,3], gradient w.r.t. the pre-clamp
-    colour), which is all another rank needs to rebuild this view's SH-gradient term.
+    colour), which is all another rank needs to rebuild this view's SH-gradient term.  It is computed
+    right after the blend backward; `_on_colors_pre(tensor)` is called at that point, before the
+    projection backward is queued, so that an exchange started there overlaps it.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -417,6 +430,7 @@ def rasterization(
         raise ValueError("_sh_grads: 'dense', or 'colors_pre' together with sh_degree")
     holder = _Holder(absgrad)
     holder.debug = _debug
+    holder.on_colors_pre = _on_colors_pre
     with torch.cuda.device(means.device):
         render_colors, render_alphas = _Rasterize.apply(means_c, quats_c, scales_c, opac_c, colors_c, rest_c,
                                                         viewmats_c, Ks_c, bg_c, cfg, holder)

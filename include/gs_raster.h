@@ -128,7 +128,7 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
                  const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_counter,
                  const int32_t* unit_desc, const float* ckpt, const float* render_colors,
                  const float* render_alphas, const float* v_render_colors,
-                 const float* v_render_alphas, float* rows);
+                 const float* v_render_alphas, float* rows, float* rows_color);
 
 /* Row reduction + SH-bwd + P-bwd fused (replaces the atomics of the blend backward,
  * spherical_harmonics backward and fully_fused_projection backward).  Sums each Gaussian's rows
@@ -140,8 +140,9 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
  * /root/reference/model/gaussian.py:191).
  * Optional (may be NULL): v_means2d[C,N,2], v_conics[C,N,3], v_colors_post[C,N,3] (gradient of the
  * post-clamp colour), v_colors_pre[C,N,3] (SH colours only: gradient of the pre-clamp colour, zero
- * for culled Gaussians).  With SH colours v_colors (and v_sh_rest) may be NULL when v_colors_pre is
- * given: the SH-parameter gradients are then left to gs_sh_grad_views. */
+ * for culled Gaussians).  With SH colours v_colors (and v_sh_rest) may be NULL: the SH-parameter
+ * gradients are then left to gs_sh_grad_views (fed by v_colors_pre from here or from
+ * gs_colors_pre_grad). */
 int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* colors_in,
                    const float* sh_rest, int colors_per_camera, const float* viewmats,
@@ -151,6 +152,14 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities,
                    float* v_colors, float* v_sh_rest, float* v_means2d_abs, float* v_means2d,
                    float* v_conics, float* v_colors_post, float* v_colors_pre);
+
+/* Row e (view sharding): v_colors_pre[C,N,3] alone, from gs_blend_bwd's optional compact output
+ * rows_color[I*4][4] (the colour lanes of the gradient rows; NULL there = not written) -- identical to the
+ * optional output of gs_project_bwd, but available before that (long) kernel runs, so that its
+ * exchange between ranks overlaps the rest of the backward.  colors_post[C,N,3] from gs_project_fwd. */
+int gs_colors_pre_grad(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
+                       const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows_color,
+                       const uint8_t* qmask, float* v_colors_pre);
 
 /* Row e (view sharding): dense SH-parameter gradients of R views rebuilt from the per-view
  * pre-clamp colour gradients,  v_sh[n][k][:] = sum_r Y_k(dir(means[n], camera r)) * v_colors_pre[r][n][:]

@@ -167,7 +167,7 @@ def _torch_sh_grad_views(means, cams, pre_all, deg, K):
     return v[:, :1].contiguous(), v[:, 1:].contiguous()
 
 
-def _vp_render(model, sc, view, target):
+def _vp_render(model, sc, view, target, early_gather=False):
     """One view through the oracle with the colours evaluated outside the rasterizer, so that the
     gradient w.r.t. the pre-clamp colour (what gs_project_bwd emits as v_colors_pre) can be read."""
     from oracle import torch_oracle as TO
@@ -183,6 +183,8 @@ def _vp_render(model, sc, view, target):
                                     packed=False, backgrounds=bg, absgrad=True)
     ((img - target[view:view + 1]) ** 2).mean().backward()
     meta["means2d"].colors_pre_grad = (cols.grad * (cols > 0)).detach()
+    if early_gather and getattr(model, "on_colors_pre", None) is not None:   # what the rasterizer's backward does
+        model.on_colors_pre(meta["means2d"].colors_pre_grad)
     model.sh_0.grad = None; model.sh_rest.grad = None          # factorised mode: no local SH gradients
     return {"batch_xys": meta["means2d"], "batch_radii": meta["radii"]}
 
@@ -202,7 +204,7 @@ def _vp_worker(rank, world, port, out_dir):
     for it in range(2):   # first step with the two early-collective hooks, second without
         if it == 0:
             vp.begin_step(data)
-        out = _vp_render(model, sc, rank, target)
+        out = _vp_render(model, sc, rank, target, early_gather=(it == 0))
         if it == 0:
             vp.after_forward(data, out)
         vp.step(data, out)

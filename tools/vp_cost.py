@@ -45,3 +45,23 @@ def pack():
         flat[o:o + t.numel()].copy_(t.reshape(-1)); o += t.numel()
     return flat
 print("pack 13N floats        %.3f ms" % timeit(pack))
+
+# the early colour-gradient kernel and the projection backward without its SH write-out, at the bench workload
+from easy_gaussian_splatting_amd import rendering
+from easy_gaussian_splatting_amd.rendering import rasterization
+from easy_gaussian_splatting_amd.synthetic import config_bench_1m
+import numpy as np
+sc = config_bench_1m()
+t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
+ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
+sh0 = t["shs"][:, :1].contiguous().requires_grad_(True); shr = t["shs"][:, 1:].contiguous().requires_grad_(True)
+for mode in ("dense", "colors_pre"):
+    def it():
+        img, _, meta = rasterization(*ins, (sh0, shr), t["viewmats"][:1], t["Ks"][:1], sc["width"], sc["height"], sh_degree=3,
+                                     packed=False, backgrounds=t["backgrounds"][:1], absgrad=True, _sh_grads=mode)
+        img.sum().backward()
+    for _ in range(3): it()
+    rendering.profile_stages(True)
+    for _ in range(5): it()
+    st = rendering.profile_stages(False)
+    print(mode, ", ".join(f"{k[3:]}={np.mean(v):.3f}" for k, v in sorted(st.items()) if "bwd" in k or "pre" in k))
