@@ -25,6 +25,7 @@ constexpr int kLR = kLT + 2 * kHalo;  // 42 staged rows / cols
 constexpr int kLRP = kLR + 1;         // padded row stride of the staged tiles
 constexpr int kHP = kLT + 1;          // row stride of the horizontal-pass buffers
 static_assert(kLT * (kLT / 4) == 256 && kLR * (kLT / 8) <= 256, "thread mapping of the separable passes");
+static_assert(kLR % 2 == 0 && kLR * 3 <= 128, "staging: two 128-thread halves, one staged row each");
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 __device__ __constant__ float kWin[11] = {1.0283800845e-03f, 7.5987581352e-03f, 3.6000772128e-02f,
@@ -58,33 +59,38 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
     // cost one HBM round trip per element.
     float l1 = 0.f;
     {
-        constexpr int kTot = kLR * kLR * 3, kPer = (kTot + 255) / 256;
-        float rv[kPer], gv[kPer], mv[kPer];
+        // Row-wise mapping: a staged row is one contiguous run of 42 x 3 floats in the channel-last
+        // images; thread j < 126 of each 128-thread half owns element j (column j/3, channel j%3,
+        // computed once) of every second row -- no per-element index arithmetic.
+        constexpr int kRowsPer = kLR / 2;   // 21 rows per half
+        const int half = tid >> 7, j = tid & 127;
+        const bool lane_on = j < kLR * 3;
+        const int col = j / 3, ch = j - col * 3;
+        const int gx = x0 - kHalo + col, cx = clampi(gx, 0, a.W - 1);
+        const bool col_own = col >= kHalo && col < kHalo + kLT && gx < a.W;
+        float rv[kRowsPer], gv[kRowsPer], mv[kRowsPer];
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            const int e = tid + i * 256;
+        for (int i = 0; i < kRowsPer; ++i) {
             rv[i] = gv[i] = mv[i] = 0.f;
-            if (e < kTot) {
-                const int row = e / (kLR * 3), rem = e - row * (kLR * 3), col = rem / 3, ch = rem - col * 3;
-                const int cy = clampi(y0 - kHalo + row, 0, a.H - 1), cx = clampi(x0 - kHalo + col, 0, a.W - 1);
+            if (lane_on) {
+                const int cy = clampi(y0 - kHalo + half + 2 * i, 0, a.H - 1);
                 const size_t o = ((size_t)cy * a.W + cx) * 3 + ch;
                 gv[i] = a.gt[o]; rv[i] = a.render[o];
                 if (a.mask) mv[i] = a.mask[(size_t)cy * a.W + cx];
             }
         }
+        float* dx = sx + (ch * kLR + half) * kLRP + col;
+        float* dy = sy + (ch * kLR + half) * kLRP + col;
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            const int e = tid + i * 256;
-            if (e < kTot) {
-                const int row = e / (kLR * 3), rem = e - row * (kLR * 3), col = rem / 3, ch = rem - col * 3;
-                const int gy = y0 - kHalo + row, gx = x0 - kHalo + col;
+        for (int i = 0; i < kRowsPer; ++i) {
+            if (lane_on) {
+                const int row = half + 2 * i, gy = y0 - kHalo + row;
                 const float g = gv[i];
                 float r = rv[i];
                 if (a.mask) r = mv[i] * g + (1.f - mv[i]) * r;
-                sx[(ch * kLR + row) * kLRP + col] = r;
-                sy[(ch * kLR + row) * kLRP + col] = g;
-                const bool own = row >= kHalo && row < kHalo + kLT && col >= kHalo && col < kHalo + kLT && gy < a.H && gx < a.W;
-                if (own) l1 += fabsf(r - g);
+                dx[2 * i * kLRP] = r;
+                dy[2 * i * kLRP] = g;
+                if (col_own && row >= kHalo && row < kHalo + kLT && gy < a.H) l1 += fabsf(r - g);
             }
         }
     }
@@ -205,26 +211,24 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
     const float k_ssim = -g * a.lambda_ssim / cnt;                     // d(1 - mean ssim)
     const float k_l1 = g * (1.f - a.lambda_ssim) / ((float)a.H * (float)a.W * 3.f);
     for (int ch = 0; ch < 3; ++ch) {
-        {   // loads first, LDS stores after (see the forward kernel)
-            constexpr int kTot = 3 * kLR * kLR, kPer = (kTot + 255) / 256;
-            float v[kPer];
+        {   // loads first, LDS stores after; row-wise mapping as in the forward kernel: a tile row of one
+            // channel's derivative maps is one contiguous run of 42 x 3 floats
+            constexpr int kRowsPer = kLR / 2;
+            const int half = tid >> 7, j = tid & 127;
+            const int col = j / 3, mi = j - col * 3;
+            const int gx = x0 - kHalo + col;
+            const bool lane_on = j < kLR * 3 && gx >= 0 && gx < a.W;
+            float v[kRowsPer];
 #pragma unroll
-            for (int i = 0; i < kPer; ++i) {
-                const int e = tid + i * 256;
+            for (int i = 0; i < kRowsPer; ++i) {
+                const int gy = y0 - kHalo + half + 2 * i;
                 v[i] = 0.f;   // derivative maps are zero outside the image (and outside the interior)
-                if (e < kTot) {
-                    const int row = e / (kLR * 3), rem = e - row * (kLR * 3), col = rem / 3, mi = rem - col * 3;
-                    const int gy = y0 - kHalo + row, gx = x0 - kHalo + col;
-                    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v[i] = a.maps[((size_t)ch * plane + (size_t)gy * a.W + gx) * 3 + mi];
-                }
+                if (lane_on && gy >= 0 && gy < a.H) v[i] = a.maps[((size_t)ch * plane + (size_t)gy * a.W + gx) * 3 + mi];
             }
+            if (j < kLR * 3) {
+                float* d = sm + (mi * kLR + half) * kLRP + col;
 #pragma unroll
-            for (int i = 0; i < kPer; ++i) {
-                const int e = tid + i * 256;
-                if (e < kTot) {
-                    const int row = e / (kLR * 3), rem = e - row * (kLR * 3), col = rem / 3, mi = rem - col * 3;
-                    sm[(mi * kLR + row) * kLRP + col] = v[i];
-                }
+                for (int i = 0; i < kRowsPer; ++i) d[2 * i * kLRP] = v[i];
             }
         }
         __syncthreads();
