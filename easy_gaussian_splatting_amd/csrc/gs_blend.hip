@@ -252,23 +252,24 @@ struct EntryState {
     bool has;
 };
 
-__device__ __forceinline__ void bwd_pair(EntryState& e, const bool act, const float4 d0, const float2 d1,
-                                         float& T, float& P) {
+// (pixels outside the pipeline window arrive with T < 0; slots past the end of the sublist have
+// opacity 0, hence alpha 0: neither needs a flag of its own)
+__device__ __forceinline__ void bwd_pair(EntryState& e, const float4 d0, const float2 d1, float& T, float& P) {
     const float dx = e.mx - d1.x, dy = e.my - d1.y;
     const float sigma = fmaf(dy, fmaf(e.hC, dy, e.Bc * dx), e.hA * dx * dx);   // same op sequence as the forward
     const float vis = fast_exp2(-sigma);
     const float ov = e.op * vis;
     const float alpha = fminf(kAlphaMax, ov);
-    const bool ok = act && e.has && T > 0.f && sigma >= 0.f && alpha >= kAlphaMin;
+    const bool ok = T > 0.f && sigma >= 0.f && alpha >= kAlphaMin;
     const float w = alpha * T;
     const float Tn = fmaf(-alpha, T, T);   // identical to the forward's update
     const bool stop = ok && Tn <= kTMin;
     const bool contrib = ok && !stop;
     const float cv = e.colr * d0.x + e.colg * d0.y + e.colb * d0.z;
-    const float Pn = fmaf(w, cv, P);
+    const float wm = contrib ? w : 0.f;
+    const float Pn = fmaf(wm, cv, P);   // == P exactly when the entry does not contribute: no select for P below
     const float ra = fast_rcp(1.f - alpha);
     const float v_alpha = fmaf(T, cv, ra * (d0.w + Pn));
-    const float wm = contrib ? w : 0.f;
     e.s_r = fmaf(wm, d0.x, e.s_r); e.s_g = fmaf(wm, d0.y, e.s_g); e.s_b = fmaf(wm, d0.z, e.s_b);
     const float vs = (contrib && ov <= kAlphaMax) ? -ov * v_alpha : 0.f;   // d loss / d sigma
     const float hx = vs * dx, hy = vs * dy;
@@ -277,7 +278,7 @@ __device__ __forceinline__ void bwd_pair(EntryState& e, const bool act, const fl
     e.s_mx += gx; e.s_my += gy; e.s_ax += fabsf(gx); e.s_ay += fabsf(gy);
     e.s_vs += vs;
     T = contrib ? Tn : (stop ? -1.f : T);
-    P = contrib ? Pn : P;
+    P = Pn;
 }
 
 __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBwdArgs a) {
@@ -357,8 +358,9 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         const float4 d0 = spix[pc].d0, ck = spix[pc].ck;
         const float2 d1 = sctr[pc];
         if (r == 0) { T = ck.x; P = ck.y * d0.x + ck.z * d0.y + ck.w * d0.z; }
+        T = act ? T : -1.f;   // pipeline fill / drain: nothing contributes
 #pragma unroll
-        for (int i = 0; i < kPerLane; ++i) bwd_pair(e[i], act, d0, d1, T, P);
+        for (int i = 0; i < kPerLane; ++i) bwd_pair(e[i], d0, d1, T, P);
         T_out = T; P_out = P;
     }
 
