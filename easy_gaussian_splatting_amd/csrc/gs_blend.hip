@@ -54,24 +54,29 @@ struct BlendFwdArgs {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// One (pixel, Gaussian) pair of the forward; straight-line, predicated.
+// One (pixel, Gaussian) pair of the forward; straight-line, predicated.  The entry's alpha is
+// masked once (v_cndmask costs more than an fp32 multiply on gfx950, tools/micro/): a masked alpha
+// of 0 leaves T and the colour sums bit-for-bit unchanged (fma(-0, T, T) == T, fma(r, 0, c) == c).
+// The stop rule (T would fall to 1e-4: the entry is NOT blended, the pixel is finished) fires a
+// handful of times per pixel at most, so it lives behind a wave-uniform branch.
 __device__ __forceinline__ void blend_pair(const float sigma, const float op, const float r,
                                            const float g, const float b, float& T, float& cr,
                                            float& cg, float& cb, bool& done) {
     const float alpha = fminf(kAlphaMax, op * fast_exp2(-sigma));
     const bool ok = !done && sigma >= 0.f && alpha >= kAlphaMin;
-    const float w = alpha * T;
-    const float Tn = fmaf(-alpha, T, T);   // explicit: fwd and bwd must round identically
+    const float am = ok ? alpha : 0.f;
+    float w = am * T;
+    float Tn = fmaf(-am, T, T);   // explicit: fwd and bwd must round identically
     const bool stop = ok && Tn <= kTMin;
-    const bool contrib = ok && !stop;
-    const float wm = contrib ? w : 0.f;
-    cr = fmaf(r, wm, cr); cg = fmaf(g, wm, cg); cb = fmaf(b, wm, cb);
-    T = contrib ? Tn : T;
-    done = done || stop;
+    if (__builtin_expect(__any(stop), 0)) {
+        w = stop ? 0.f : w;
+        Tn = stop ? T : Tn;
+        done = done || stop;
+    }
+    cr = fmaf(r, w, cr); cg = fmaf(g, w, cg); cb = fmaf(b, w, cb);
+    T = Tn;
 }
 
-// WAVES tiles per workgroup, one wave each; the waves share nothing (no workgroup barrier), the
-// grouping only lowers the number of workgroups the dispatcher has to launch.
 template <bool CKPT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArgs a) {
     __shared__ float4 srec_all[WAVES][GS_BUCKET * 3];
