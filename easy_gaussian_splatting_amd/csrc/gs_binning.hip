@@ -11,9 +11,13 @@
 //                       group bases, {I, n_buckets, max_tile}
 //   bin_emit_kernel     same blocks as hist: per-tile write cursor in LDS (returning ds_add),
 //                       emits (depth bits << 32 | row slot) into its tile's segment
-//   tile_sort_kernel    one block per tile: bitonic sort of the 64-bit keys in LDS -> depth order,
-//                       ties by flatten index (slot order == flatten order), as the stable global
-//                       sort of the reference yields.
+//   tile_radix_sort_kernel  one block per tile (lists up to 8192 entries): four stable 8-bit LDS
+//                       counting passes on the depth word -> depth order; ties by flatten index
+//                       (slot order == flatten order), as the stable global sort of the reference
+//                       yields, restored by the bitonic network in the rare tile that has
+//                       out-of-order equal depths.
+//   tile_sort_kernel    bitonic network on the 64-bit keys, in LDS (<= 16384 entries) or in place
+//                       in global memory beyond that.
 // The "slot" carried in the key's low word is the index of this intersection's gradient row
 // (cum_tiles[f] + k): rows of one Gaussian are contiguous, which lets the backward reduce them
 // with plain coalesced loads instead of float atomics.
@@ -330,7 +334,130 @@ __global__ void tile_sort_kernel(const SortArgs a) {
     }
 }
 
-constexpr int kSortSmall = 2048, kSortLarge = 16384;
+// ------------------------------------------------------------------------------------------------
+// LDS radix sort of one tile's keys (depth bits << 32 | slot): four stable 8-bit counting passes
+// on the depth word, ping-ponging between two LDS buffers.  The bitonic network above moves every
+// key through LDS ~log^2(n)/2 times and sits on the LDS store rate (ds_write_b64 is a third of the
+// read rate on gfx950); this moves each key 4 times.
+//   per pass:  counts[wave][digit] by LDS atomics -> exclusive scan (digit-major, wave-minor) ->
+//              every wave re-walks ITS contiguous slice in order, 64 keys at a time, ranks each key
+//              among the equal digits of the 64 (eight ballots) and scatters.
+// A pass whose digit is the same for all keys is skipped (the exponent byte of the depths, mostly).
+// Equal depths must come out in slot order (the stable-sort contract of the reference, A.3) but
+// arrive in arbitrary order: a tile in which an equal-depth pair is out of order -- practically
+// never -- is re-sorted on the full 64-bit key by the bitonic network.
+template <int T>
+__global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+    constexpr int W = T / 64;
+    const int tile = blockIdx.x;
+    const int lo = a.isect_offsets[tile], n = a.isect_offsets[tile + 1] - lo;
+    if (n <= a.lo_excl || n > a.hi_incl) return;
+    const int cap = a.hi_incl;
+    unsigned long long* src = skeys;
+    unsigned long long* dst = skeys + cap;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(skeys + 2 * cap);   // [W][256]: counts, then offsets, of this pass
+    uint32_t* nxt = cnt + W * 256;                                  // [W][256]: counts of the next pass
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long* gk = a.keys + lo;
+    // every wave owns a contiguous slice of positions (stable passes need position order)
+    const int per_wave = ((n + W * 64 - 1) / (W * 64)) * 64;
+    const int w_lo = min(n, wave * per_wave), w_hi = min(n, w_lo + per_wave);
+    // slice of a position without an integer division: positions and slice length in units of 64 are
+    // small integers, (a + 0.5) / b truncates exactly in fp32
+    const float inv_pw64 = 1.0f / (float)(per_wave >> 6);
+    auto owner = [inv_pw64](int pos) { return (int)(((float)(pos >> 6) + 0.5f) * inv_pw64); };
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int i = tid; i < 2 * W * 256; i += T) cnt[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < n; i += T) {   // load + digit counts of pass 0 for the slice the key sits in
+        const unsigned long long k = gk[i];
+        src[i] = k;
+        atomicAdd(&cnt[owner(i) * 256 + (int)((k >> 32) & 255ull)], 1u);
+    }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 32 + 8 * pass;
+        __syncthreads();   // counts of this pass complete, keys in place
+        if (wave == 0) {
+            // digit-major, wave-minor exclusive scan by one wave: lane l owns digits 4l .. 4l+3
+            uint32_t c[4][W], tot[4], mine = 0;
+            bool all_in_one = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                tot[q] = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) { c[q][w] = cnt[w * 256 + 4 * lane + q]; tot[q] += c[q][w]; }
+                all_in_one |= (int)tot[q] == n;
+                mine += tot[q];
+            }
+            uint32_t run = wave_incl_scan_add(mine) - mine;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int w = 0; w < W; ++w) { cnt[w * 256 + 4 * lane + q] = run; run += c[q][w]; }
+            const bool skip = __any(all_in_one);   // one digit holds every key: nothing to move in this pass
+            if (lane == 0) s_flag = skip ? 1 : 0;
+        } else {
+            for (int i = tid - 64; i < W * 256; i += T - 64) nxt[i] = 0u;
+        }
+        __syncthreads();
+        const bool skip = s_flag != 0;
+        const int nshift = shift + 8;
+        if (skip) {
+            if (pass < 3)   // keys stay where they are: count the next digit in place
+                for (int i = w_lo + lane; i < w_hi; i += 64) atomicAdd(&nxt[wave * 256 + (int)((src[i] >> nshift) & 255ull)], 1u);
+        } else {
+            for (int base = w_lo; base < w_hi; base += 64) {
+                const int i = base + lane;
+                const bool valid = i < w_hi;
+                const unsigned long long k = valid ? src[i] : 0ull;
+                const int d = (int)((k >> shift) & 255ull);
+                unsigned long long peers = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool bit = (d >> b) & 1;
+                    const unsigned long long bm = __ballot(bit);
+                    peers &= bit ? bm : ~bm;
+                }
+                if (valid) {
+                    const int rank = __popcll(peers & lt_mask);
+                    const uint32_t off = cnt[wave * 256 + d];
+                    const uint32_t pos = off + (uint32_t)rank;
+                    dst[pos] = k;
+                    if (rank == 0) cnt[wave * 256 + d] = off + (uint32_t)__popcll(peers);   // after every peer's read (in-order LDS)
+                    if (pass < 3) atomicAdd(&nxt[owner((int)pos) * 256 + (int)((k >> nshift) & 255ull)], 1u);
+                }
+            }
+            unsigned long long* t = src; src = dst; dst = t;
+        }
+        uint32_t* tc = cnt; cnt = nxt; nxt = tc;
+    }
+    // equal depths out of slot order?  (keys are unique, so "not ascending" can only mean that)
+    __syncthreads();
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int i = tid + 1; i < n; i += T) bad |= src[i] < src[i - 1];
+    if (bad) s_flag = 1;
+    __syncthreads();
+    if (s_flag) {
+        int P = 1;
+        while (P < n) P <<= 1;
+        bitonic_sort_keys(src, n, P);
+    }
+    const int cam = tile / a.tiles, tix = tile - cam * a.tiles;
+    const long long hi_bits = ((long long)cam << (32 + a.tile_bits)) | ((long long)tix << 32);
+    for (int i = tid; i < n; i += T) {
+        const unsigned long long k = src[i];
+        const uint32_t slot = (uint32_t)k;
+        a.slots[lo + i] = (int32_t)slot;
+        a.flatten_ids[lo + i] = a.slot_gid[slot];
+        a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
+    }
+}
+
+constexpr int kSortLarge = 16384;
 
 }  // namespace gs
 
@@ -417,22 +544,31 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     a.isect_offsets = isect_offsets; a.keys = (unsigned long long*)keys_tmp; a.slot_gid = slot_gid;
     a.isect_ids = isect_ids; a.flatten_ids = flatten_ids; a.slots = slots;
     const unsigned grid = (unsigned)(C * tiles);
-    // size classes, each launched only if some tile needs it (the host knows max_tile_count): LDS and
-    // workgroup size grow with the class so that the common short lists keep many blocks per CU:
-    //   <= 2048: 256 threads, 16 KB | <= 4096: 512 thr, 32 KB | <= 8192: 1024 thr, 64 KB |
-    //   <= 16384: 1024 thr, 128 KB | beyond: in-place global network
-    const int cls_hi[4] = {kSortSmall, 4096, 8192, kSortLarge};
-    const int cls_threads[4] = {256, 512, 1024, 1024};
+    // size classes, each launched only if some tile needs it (the host knows max_tile_count):
+    //   radix (two key buffers + 2 x 1 KB of counters per wave):
+    //     <= 1024: 256 threads, 24 KB | <= 4096: 256 thr, 72 KB | <= 8192: 512 thr, 144 KB
+    //   bitonic: <= 16384: 1024 thr, 128 KB | beyond: in-place global network
     int lo_excl = 0;
-    for (int k = 0; k < 4; ++k) {
+    auto radix = [&](auto kernel, int threads, int hi) -> int {
         if (max_tile_count > lo_excl) {
-            a.lo_excl = lo_excl; a.hi_incl = cls_hi[k];
-            const size_t lds_k = sizeof(uint64_t) * (size_t)cls_hi[k];
-            if (int rc = ensure_lds((const void*)tile_sort_kernel<true>, lds_k)) return rc;
-            hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(cls_threads[k]), lds_k, st, a);
-            GS_LAUNCH_CHECK("tile_sort_kernel<lds>");
+            a.lo_excl = lo_excl; a.hi_incl = hi;
+            const size_t lds_k = 2 * sizeof(uint64_t) * (size_t)hi + 2 * sizeof(uint32_t) * 256 * (size_t)(threads / 64);
+            if (int rc = ensure_lds((const void*)kernel, lds_k)) return rc;
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_k, st, a);
+            GS_LAUNCH_CHECK("tile_radix_sort_kernel");
         }
-        lo_excl = cls_hi[k];
+        lo_excl = hi;
+        return GS_OK;
+    };
+    if (int rc = radix(tile_radix_sort_kernel<256>, 256, 1024)) return rc;
+    if (int rc = radix(tile_radix_sort_kernel<256>, 256, 4096)) return rc;
+    if (int rc = radix(tile_radix_sort_kernel<512>, 512, 8192)) return rc;
+    if (max_tile_count > lo_excl) {
+        a.lo_excl = lo_excl; a.hi_incl = kSortLarge;
+        const size_t lds_k = sizeof(uint64_t) * (size_t)kSortLarge;
+        if (int rc = ensure_lds((const void*)tile_sort_kernel<true>, lds_k)) return rc;
+        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(1024), lds_k, st, a);
+        GS_LAUNCH_CHECK("tile_sort_kernel<lds>");
     }
     if (max_tile_count > kSortLarge) {
         a.lo_excl = kSortLarge; a.hi_incl = 0x7fffffff;
