@@ -477,3 +477,26 @@ def test_randomised_configurations(case):
     check_forward(hip, fw, max_razor_frac=5e-2, lists=culling == "gsplat")
     if fw["n_isects"] > 0:
         check_backward(hip, fw)
+
+
+@pytest.mark.parametrize("n,lo,hi", [(250, 64, 1024), (1500, 1024, 4096), (5000, 4096, 8192), (10000, 8192, 16384)])
+def test_every_sort_size_class_orders_like_a_stable_global_sort(n, lo, hi):
+    """One scene per size class of the per-tile sort (radix <= 1024 / 4096 / 8192, bitonic <= 16384):
+    inside every tile the ids must be ordered by (depth bits, flatten id), every id exactly once."""
+    rng = np.random.default_rng(n)
+    sc = make_scene(n, 64, 48, sh_degree=0, seed=100 + n, scale_range=(0.2, 0.6), dist=4.0, extent=(0.3, 0.3, 0.5))
+    sc["opacities"] = (rng.random(n) * 0.02 + 0.004).astype(np.float32)
+    hip = run_hip(sc, bwd=False)
+    meta = hip["meta"]
+    off = meta["isect_offsets"].reshape(-1).cpu().numpy().astype(np.int64)
+    fid = meta["flatten_ids"].cpu().numpy().astype(np.int64)
+    ids = meta["isect_ids"].cpu().numpy()
+    counts = np.diff(np.append(off, fid.size))
+    assert lo < counts.max() <= hi, counts.max()
+    depth_bits = meta["depths"].reshape(-1).cpu().numpy().view(np.int32).astype(np.int64)
+    assert fid.size == int(meta["tiles_per_gauss"].sum())
+    for t in range(off.size):
+        seg = fid[off[t]: off[t] + counts[t]]
+        key = depth_bits[seg] * (1 << 32) + seg
+        assert np.all(np.diff(key) > 0), f"tile {t} not in (depth, id) order"
+        assert np.array_equal(ids[off[t]: off[t] + counts[t]] & 0xFFFFFFFF, depth_bits[seg])
