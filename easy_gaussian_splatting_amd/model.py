@@ -238,7 +238,7 @@ class GaussianModel(nn.Module):
             _sh_grads=getattr(self, "sh_grads", "dense"),
             _on_colors_pre=getattr(self, "on_colors_pre", None),
         )
-        render_img = clamp01(batch_render_imgs[0])
+        render_img = clamp01(batch_render_imgs.squeeze(0))   # (a view both ways: `[0]` would cost a zero-fill + copy in backward)
         return {
             "render_img": render_img,  # [H, W, 3]
             "batch_xys": meta["means2d"],  # [1, N, 2]
