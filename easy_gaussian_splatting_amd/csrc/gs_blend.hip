@@ -111,7 +111,13 @@ __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArg
         bool qa[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) qa[k] = !__all(done[k]);
-        if (!(qa[0] || qa[1] || qa[2] || qa[3])) break;
+        if (!(qa[0] || qa[1] || qa[2] || qa[3])) {
+            // every pixel of the tile is finished: the rest of the list contributes nothing, but its
+            // quadrant masks must still read "no rows" (this replaces a memset of the whole array)
+            if (CKPT)
+                for (int i = lo + b * GS_BUCKET + lane; i < hi; i += 64) a.qmask[a.slots[i]] = 0;
+            break;
+        }
         const int first = lo + b * GS_BUCKET;
         const int m = min(GS_BUCKET, hi - first);
         bool hx[2] = {false, false}, hy[2] = {false, false};
@@ -414,7 +420,6 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     const dim3 grid((n_tiles + kFwdWaves - 1) / kFwdWaves), block(64 * kFwdWaves);
     if (train) {
         GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));
-        if (n_isects > 0) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
         hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves>), grid, block, 0, st, a);
     } else {
         hipLaunchKernelGGL((blend_fwd_kernel<false, kFwdWaves>), grid, block, 0, st, a);

@@ -55,6 +55,7 @@ class _FusedL1SSIM(torch.autograd.Function):
         L = nat.lib()
         H, W = render_img.shape[:2]
         dev = render_img.device
+        ctx.set_materialize_grads(False)   # no zero-filled gradients for the two value-only outputs
         r, g = render_img.contiguous(), gt_img.contiguous()
         m = None if mask is None else mask.contiguous()
         ws = torch.empty((int(L.gs_loss_workspace_floats(H, W)),), dtype=torch.float32, device=dev)
@@ -73,6 +74,8 @@ class _FusedL1SSIM(torch.autograd.Function):
         from . import _native as nat
         L = nat.lib()
         saved = ctx.saved_tensors
+        if v_total is None:
+            return None, None, None, None
         r, g, ws = saved[:3]
         m = saved[3] if len(saved) > 3 else None
         H, W = r.shape[:2]

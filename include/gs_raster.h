@@ -109,7 +109,8 @@ int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, con
  *   qcnt[C*tiles*4]     sublist lengths
  *   ckpt[4*n_buckets*64*4] f32  per 64-entry quadrant bucket: the quadrant's 64 pixel states
  *                       (T -- negative once saturated / outside the image -- and accumulated rgb)
- *   qmask[I] u8         by gradient-row slot: which quadrant rows of an intersection exist
+ *   qmask[I] u8         by gradient-row slot: which quadrant rows of an intersection exist (fully
+ *                       written: entries behind a tile's saturation point read 0)
  *   unit_counter[1], unit_desc[4*n_buckets*2] i32   work units (tile*4+quadrant, bucket) */
 int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                  const float* backgrounds, const int32_t* isect_offsets,

@@ -500,3 +500,22 @@ def test_every_sort_size_class_orders_like_a_stable_global_sort(n, lo, hi):
         key = depth_bits[seg] * (1 << 32) + seg
         assert np.all(np.diff(key) > 0), f"tile {t} not in (depth, id) order"
         assert np.array_equal(ids[off[t]: off[t] + counts[t]] & 0xFFFFFFFF, depth_bits[seg])
+
+
+def test_saturated_tiles_stop_early_and_leave_clean_masks():
+    """Opaque, stacked splats: every pixel of most tiles reaches T <= 1e-4 long before the end of its list,
+    so the forward abandons the rest of the list (whose quadrant masks must still read 'no rows') and the
+    backward must not pick up anything from the abandoned part.  Run twice over dirty allocator memory."""
+    n = 6000
+    sc = make_scene(n, 96, 80, sh_degree=1, seed=41, scale_range=(0.25, 0.6), dist=4.0, extent=(0.4, 0.4, 0.6))
+    sc["opacities"] = np.full(n, 0.97, dtype=np.float32)
+    fw = run_oracle(sc)
+    assert float((fw["render_alphas"] > 1 - 2e-4).mean()) > 0.5, "scene must saturate"
+    counts = np.diff(np.append(fw["isect_offsets"].reshape(-1), fw["n_isects"]))
+    assert counts.max() > 1024
+    for _ in range(2):
+        junk = torch.full((64 << 20,), 0x7f, dtype=torch.uint8, device="cuda:0")   # poison the caching allocator's pool
+        del junk
+        hip = run_hip(sc)
+        assert check_forward(hip, fw, max_razor_frac=0.5)
+        check_backward(hip, fw)
