@@ -49,15 +49,6 @@ class GradBucket:
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
 
-    @classmethod
-    def from_flat(cls, flat: Tensor, params: Iterable[torch.nn.Parameter]) -> "GradBucket":
-        """Wraps a gradient buffer that already backs the parameters' `.grad` views
-        (optim.FusedAdam owns it)."""
-        self = cls.__new__(cls)
-        self.params = list(params)
-        self.flat = flat
-        return self
-
     def zero_(self):
         self.flat.zero_()
 
