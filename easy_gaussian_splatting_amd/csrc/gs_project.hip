@@ -12,7 +12,7 @@ namespace gs {
 constexpr int kProjThreads = 256;
 
 struct ProjFwdArgs {
-    int C, K, colors_per_camera, W, H, tw, th, tight;
+    int C, K, colors_per_camera, W, H, tw, th, tight, activations;
     int64_t N;
     float eps2d, near_p, far_p, radius_clip;
     const float *means, *quats, *scales, *opacities, *colors_in, *sh_rest, *viewmats, *Ks;
@@ -22,6 +22,12 @@ struct ProjFwdArgs {
     uint4* bbox;
     int32_t* tiles_per_gauss;
 };
+
+// activations != 0: `scales` / `opacities` hold the reference model's parameters (log-scales, logit
+// opacities, /root/reference/model/gaussian.py:98-103) and exp / sigmoid are applied here, so that the
+// model's four activation kernels (two forward, two backward) disappear.
+__device__ __forceinline__ float act_scale(float v, int activations) { return activations ? expf(v) : v; }
+__device__ __forceinline__ float act_opacity(float v, int activations) { return activations ? 1.0f / (1.0f + expf(-v)) : v; }
 
 // dynamic LDS carve (dwords): [0,32) camera | [32, 32+256) visibility | SH tile 256*(3K+1)
 __device__ __forceinline__ void load_camera(const float* viewmats, const float* Ks, int c, int W,
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
         if (in_range) {
             const float4 q4 = reinterpret_cast<const float4*>(a.quats)[n];
             const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-            const float scale[3] = {a.scales[3 * n], a.scales[3 * n + 1], a.scales[3 * n + 2]};
+            const float scale[3] = {act_scale(a.scales[3 * n], a.activations), act_scale(a.scales[3 * n + 1], a.activations),
+                                    act_scale(a.scales[3 * n + 2], a.activations)};
             s = project_gaussian(mean, quat, scale, cam, a.W, a.H, a.eps2d, a.near_p, a.far_p, a.radius_clip);
         }
         vis = s.radius > 0;
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
         float op = 0.f, ex = -1.f, ey = -1.f;
         if (vis) {
             tile_rect(s.mx, s.my, s.radius, GS_TILE, a.tw, a.th, x0, x1, y0, y1);
-            op = a.opacities[n];
+            op = act_opacity(a.opacities[n], a.activations);
             alpha_extent(op, s.cxx, s.cyy, ex, ey);
             // tight mode: keep only the tiles of the 3-sigma rectangle that hold a pixel centre where
             // alpha can reach 1/255 (the blend skips every other pixel anyway: identical image)
@@ -250,6 +257,8 @@ struct ProjBwdArgs {
     const uint8_t* qmask;    // [I] by slot: which of the four quadrant rows exist
     float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_sh_rest, *v_means2d_abs, *v_means2d,
         *v_conics, *v_colors_post, *v_colors_pre;
+    const float* opacities;   // raw (logit) opacities, read only when activations != 0
+    int activations;
 };
 
 struct RowSum {
@@ -448,26 +457,32 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     }
 
     // ---- 3. projection VJP
+    float sc_fac[3] = {1.f, 1.f, 1.f}, op_fac = 1.f;   // d activated / d raw (identity without activations)
     if (vis) {
         const float4 q4 = reinterpret_cast<const float4*>(a.quats)[n];
         const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float scale[3] = {a.scales[3 * n], a.scales[3 * n + 1], a.scales[3 * n + 2]};
+        const float scale[3] = {act_scale(a.scales[3 * n], a.activations), act_scale(a.scales[3 * n + 1], a.activations),
+                                act_scale(a.scales[3 * n + 2], a.activations)};
+        if (a.activations) { sc_fac[0] = scale[0]; sc_fac[1] = scale[1]; sc_fac[2] = scale[2]; }
         ProjChain p;
         if (project_chain(mean, quat, scale, cam, a.eps2d, a.near_p, a.far_p, p))
             project_vjp(scale, cam, p, s.v[0], s.v[1], s.v[4], s.v[5], s.v[6], 0.f, v_mean, v_quat, v_scale);
     }
     if (in_range) {
+        if (a.activations && vis) { const float o = act_opacity(a.opacities[n], 1); op_fac = o * (1.f - o); }
+        v_scale[0] *= sc_fac[0]; v_scale[1] *= sc_fac[1]; v_scale[2] *= sc_fac[2];
+        const float v_op = s.v[7] * op_fac;
         float* vm = a.v_means + 3 * n; float* vq = a.v_quats + 4 * n; float* vs = a.v_scales + 3 * n;
         if (a.accumulate) {
             vm[0] += v_mean[0]; vm[1] += v_mean[1]; vm[2] += v_mean[2];
             vq[0] += v_quat[0]; vq[1] += v_quat[1]; vq[2] += v_quat[2]; vq[3] += v_quat[3];
             vs[0] += v_scale[0]; vs[1] += v_scale[1]; vs[2] += v_scale[2];
-            a.v_opacities[n] += s.v[7];
+            a.v_opacities[n] += v_op;
         } else {
             vm[0] = v_mean[0]; vm[1] = v_mean[1]; vm[2] = v_mean[2];
             vq[0] = v_quat[0]; vq[1] = v_quat[1]; vq[2] = v_quat[2]; vq[3] = v_quat[3];
             vs[0] = v_scale[0]; vs[1] = v_scale[1]; vs[2] = v_scale[2];
-            a.v_opacities[n] = s.v[7];
+            a.v_opacities[n] = v_op;
         }
         reinterpret_cast<float2*>(a.v_means2d_abs)[f] = make_float2(s.v[2], s.v[3]);
         if (a.v_means2d) reinterpret_cast<float2*>(a.v_means2d)[f] = make_float2(s.v[0], s.v[1]);
@@ -620,7 +635,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
                               const float* colors_in, const float* sh_rest, int colors_per_camera,
                               const float* viewmats, const float* Ks, int width, int height,
                               float eps2d, float near_plane, float far_plane, float radius_clip,
-                              int tile_culling, int stage, int32_t* radii,
+                              int tile_culling, int stage, int activations, int32_t* radii,
                               float* means2d, float* depths, float* conics, float* colors_out, float* rec,
                               uint32_t* bbox, int32_t* tiles_per_gauss) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
@@ -634,7 +649,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.C = C; a.N = N; a.K = K; a.colors_per_camera = colors_per_camera; a.W = width; a.H = height;
     a.tw = (width + GS_TILE - 1) / GS_TILE; a.th = (height + GS_TILE - 1) / GS_TILE;
     a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane; a.radius_clip = radius_clip;
-    a.tight = tile_culling != 0;
+    a.tight = tile_culling != 0; a.activations = activations != 0;
     a.means = means; a.quats = quats; a.scales = scales; a.opacities = opacities; a.colors_in = colors_in;
     a.sh_rest = sh_degree >= 0 ? sh_rest : nullptr;
     a.viewmats = viewmats; a.Ks = Ks; a.radii = radii; a.means2d = means2d; a.depths = depths;
@@ -669,7 +684,8 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
                               const int32_t* tiles_per_gauss, const int32_t* cum_tiles,
                               const float* rows, const uint8_t* qmask, float* v_means, float* v_quats, float* v_scales,
                               float* v_opacities, float* v_colors, float* v_sh_rest, float* v_means2d_abs,
-                              float* v_means2d, float* v_conics, float* v_colors_post, float* v_colors_pre) {
+                              float* v_means2d, float* v_conics, float* v_colors_post, float* v_colors_pre,
+                              const float* opacities, int activations) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
     GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
     GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
@@ -687,6 +703,8 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_opacities = v_opacities;
     a.v_colors = v_colors; a.v_means2d_abs = v_means2d_abs; a.v_means2d = v_means2d;
     a.v_conics = v_conics; a.v_colors_post = v_colors_post; a.v_colors_pre = sh_degree >= 0 ? v_colors_pre : nullptr;
+    GS_REQUIRE(!activations || opacities, "activations need the raw opacities");
+    a.opacities = opacities; a.activations = activations != 0;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
     const size_t lds = proj_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;

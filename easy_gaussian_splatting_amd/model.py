@@ -221,11 +221,13 @@ class GaussianModel(nn.Module):
 
     def forward(self, data: Dict[str, Any]) -> Dict[str, Optional[Tensor]]:
         w2c = data["w2c"]
+        # on the GPU the raw parameters go in and exp / sigmoid happen inside the projection kernels
+        raw = self.means.is_cuda and getattr(self, "fuse_activations", True)
         batch_render_imgs, _, meta = rasterization(
             means=self.means,
             quats=self.quats,
-            scales=self.scales,
-            opacities=self.opacities,
+            scales=self.log_scales if raw else self.scales,
+            opacities=self.logit_opacities if raw else self.opacities,
             colors=(self.sh_0, self.sh_rest) if self.fuse_sh_cat else self.shs,
             sh_degree=self.active_sh_degree,
             viewmats=w2c[None],
@@ -236,6 +238,7 @@ class GaussianModel(nn.Module):
             absgrad=True,
             packed=False,
             _sh_grads=getattr(self, "sh_grads", "dense"),
+            _activations="exp_sigmoid" if raw else "none",
             _on_colors_pre=getattr(self, "on_colors_pre", None),
         )
         render_img = clamp01(batch_render_imgs.squeeze(0))   # (a view both ways: `[0]` would cost a zero-fill + copy in backward)

@@ -127,7 +127,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         _stage(tag, dev, lambda: nat.check(L.gs_project_fwd(
             st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), _ptr(colors_rest),
             per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"],
-            cfg["radius_clip"], cfg["tile_culling"], stage, _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics),
+            cfg["radius_clip"], cfg["tile_culling"], stage, cfg.get("activations", 0), _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics),
             _ptr(colors_post), _ptr(rec), _ptr(bbox), _ptr(tiles_per_gauss)), "gs_project_fwd"))
 
     # 1. geometry, 2. tile counts, 3. colours.  The list sizes {I, n_buckets, max_tile} must reach the
@@ -212,14 +212,14 @@ class _Rasterize(torch.autograd.Function):
         ctx.split = colors_rest is not None
         if need_grad:
             extra = (colors_rest,) if ctx.split else ()
-            ctx.save_for_backward(means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas, *extra)
+            ctx.save_for_backward(means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas, opacities, *extra)
         return render_colors, render_alphas
 
     @staticmethod
     def backward(ctx, v_render_colors, v_render_alphas):
         L = nat.lib()
-        means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas = ctx.saved_tensors[:8]
-        colors_rest = ctx.saved_tensors[8] if ctx.split else None
+        means, quats, scales, colors, viewmats, Ks, render_colors, render_alphas, opacities = ctx.saved_tensors[:9]
+        colors_rest = ctx.saved_tensors[9] if ctx.split else None
         s, cfg, holder = ctx.state, ctx.cfg, ctx.holder
         dev = means.device
         st = _stream(dev)
@@ -265,8 +265,8 @@ class _Rasterize(torch.autograd.Function):
                                    cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
                                    _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
                                    _ptr(rows), _ptr(s["qmask"]), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
-                                   _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), None),
-                                   "gs_project_bwd"))
+                                   _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), None,
+                                   _ptr(opacities), cfg.get("activations", 0)), "gs_project_bwd"))
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp, rows=rows)
         if holder.absgrad and holder.means2d_ref is not None:
@@ -342,6 +342,7 @@ def rasterization(
     _tile_culling: str = "tight",
     _sh_grads: str = "dense",
     _on_colors_pre=None,
+    _activations: str = "none",
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize 3D Gaussians to images; same tensor signature and return value as
     `gsplat.rendering.rasterization` (gsplat 1.0.0).
@@ -365,6 +366,11 @@ def rasterization(
     colour), which is all another rank needs to rebuild this view's SH-gradient term.  It is computed
     right after the blend backward; `_on_colors_pre(tensor)` is called at that point, before the
     projection backward is queued, so that an exchange started there overlaps it.
+
+    `_activations="exp_sigmoid"`: `scales` and `opacities` are the reference model's raw parameters
+    (log-scales, logit opacities, /root/reference/model/gaussian.py:98-103); exp and sigmoid are applied
+    inside the projection kernels and the returned gradients are w.r.t. the raw parameters, which
+    removes the model's four activation kernels per step.  `meta["opacities"]` then holds the logits.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -425,7 +431,8 @@ def rasterization(
     bg_c = None if backgrounds is None else prep(backgrounds)
     cfg = dict(width=int(width), height=int(height), near_plane=float(near_plane),
                far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d),
-               sh_degree=sh_degree, tile_culling={"gsplat": 0, "tight": 1}[_tile_culling], sh_grads=_sh_grads)
+               sh_degree=sh_degree, tile_culling={"gsplat": 0, "tight": 1}[_tile_culling], sh_grads=_sh_grads,
+               activations={"none": 0, "exp_sigmoid": 1}[_activations])
     if _sh_grads not in ("dense", "colors_pre") or (_sh_grads == "colors_pre" and sh_degree is None):
         raise ValueError("_sh_grads: 'dense', or 'colors_pre' together with sh_degree")
     holder = _Holder(absgrad)

@@ -75,7 +75,7 @@ int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    const float* quats, const float* scales, const float* opacities,
                    const float* colors_in, const float* sh_rest, int colors_per_camera,
                    const float* viewmats, const float* Ks, int width, int height, float eps2d,
-                   float near_plane, float far_plane, float radius_clip, int tile_culling, int stage,
+                   float near_plane, float far_plane, float radius_clip, int tile_culling, int stage, int activations,
                    int32_t* radii,
                    float* means2d, float* depths, float* conics, float* colors_out, float* rec, uint32_t* bbox,
                    int32_t* tiles_per_gauss);
@@ -143,7 +143,10 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
  * post-clamp colour), v_colors_pre[C,N,3] (SH colours only: gradient of the pre-clamp colour, zero
  * for culled Gaussians).  With SH colours v_colors (and v_sh_rest) may be NULL: the SH-parameter
  * gradients are then left to gs_sh_grad_views (fed by v_colors_pre from here or from
- * gs_colors_pre_grad). */
+ * gs_colors_pre_grad).
+ * activations != 0 (both directions): `scales` / `opacities` are the reference model's log-scales and
+ * logit opacities (/root/reference/model/gaussian.py:98-103); exp / sigmoid are applied inside and
+ * v_scales / v_opacities are gradients w.r.t. those raw parameters.  0 = gsplat's contract. */
 int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* colors_in,
                    const float* sh_rest, int colors_per_camera, const float* viewmats,
@@ -152,7 +155,8 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities,
                    float* v_colors, float* v_sh_rest, float* v_means2d_abs, float* v_means2d,
-                   float* v_conics, float* v_colors_post, float* v_colors_pre);
+                   float* v_conics, float* v_colors_post, float* v_colors_pre,
+                   const float* opacities, int activations);
 
 /* Row e (view sharding): v_colors_pre[C,N,3] alone, from gs_blend_bwd's optional compact output
  * rows_color[I*4][4] (the colour lanes of the gradient rows; NULL there = not written) -- identical to the

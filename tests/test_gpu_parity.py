@@ -519,3 +519,33 @@ def test_saturated_tiles_stop_early_and_leave_clean_masks():
         hip = run_hip(sc)
         assert check_forward(hip, fw, max_razor_frac=0.5)
         check_backward(hip, fw)
+
+
+def test_in_kernel_activations_equal_torch_activations():
+    """_activations='exp_sigmoid': log-scales / logit opacities in, exp / sigmoid inside the projection kernels,
+    gradients w.r.t. the raw parameters out -- must equal torch.exp / torch.sigmoid in front of the plain call."""
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    sc = make_scene(4000, 208, 144, sh_degree=2, n_views=2, seed=55, scale_range=(0.02, 0.2), dist=4.0)
+    t = to_dev(sc)
+    op = t["opacities"].clamp(1e-3, 1 - 1e-3)
+    raw_s, raw_o = torch.log(t["scales"]), torch.log(op / (1 - op))
+    vc = torch.randn((2, 144, 208, 3), generator=torch.Generator().manual_seed(2)).to(raw_s.device)
+
+    def run(fused):
+        ls, lo = raw_s.clone().requires_grad_(True), raw_o.clone().requires_grad_(True)
+        others = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "shs")]
+        s_in, o_in = (ls, lo) if fused else (torch.exp(ls), torch.sigmoid(lo))
+        img, alpha, meta = rasterization(others[0], others[1], s_in, o_in, others[2], t["viewmats"], t["Ks"], 208, 144,
+                                         sh_degree=2, packed=False, backgrounds=t["backgrounds"], absgrad=True,
+                                         _activations="exp_sigmoid" if fused else "none")
+        (img * vc).sum().backward()
+        return img.detach(), meta, [ls.grad, lo.grad] + [p.grad for p in others]
+
+    img_a, meta_a, g_a = run(True)
+    img_b, meta_b, g_b = run(False)
+    assert torch.equal(meta_a["radii"], meta_b["radii"])
+    assert float((img_a - img_b).abs().max()) < 2e-6
+    for name, a, b in zip(("log_scales", "logit_opacities", "means", "quats", "shs"), g_a, g_b):
+        rel = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        assert rel < 2e-5, (name, rel)
+    assert float((meta_a["means2d"].absgrad - meta_b["means2d"].absgrad).abs().max()) <= 2e-5 * float(meta_b["means2d"].absgrad.abs().max())
