@@ -137,6 +137,8 @@ def main():
     exchange = "none" if world == 1 else os.environ.get("GS_DP_EXCHANGE", "factorised")
     vp = ViewParallelStep(model, optimizer) if (exchange == "factorised" and bucket is None) else None
 
+    one = torch.ones((), device=device)   # root gradient, allocated once (backward() would fill a new one per step)
+
     def train_step():
         if vp is not None:
             vp.begin_step(data)
@@ -144,7 +146,7 @@ def main():
         if vp is not None:
             vp.after_forward(data, out)
         loss = loss_computer.get_loss_dict(out["render_img"], gt_img, mask)["total"]
-        loss.backward()
+        loss.backward(gradient=one)
         if vp is not None:
             vp.step(data, out)
             return out
