@@ -131,7 +131,7 @@ def main():
     else:  # one HIP kernel per step over flat params/moments; gradients are autograd's own tensors
         optimizer = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused="hip")
         bucket = None
-    loss_computer = LossComputer(lambda_ssim=0.2)
+    loss_computer = LossComputer(lambda_ssim=0.2, clamp_input=True)   # the model's clamp(0,1) is applied inside the loss kernels
     # N > 1: factorised exchange (all-gather of colour gradients + all-reduce of the geometry
     # gradients, distributed.ViewParallelStep); GS_DP_EXCHANGE=allreduce selects the plain all-reduce
     exchange = "none" if world == 1 else os.environ.get("GS_DP_EXCHANGE", "factorised")
@@ -142,7 +142,7 @@ def main():
     def train_step():
         if vp is not None:
             vp.begin_step(data)
-        out = model(data)
+        out = model(data, clamp=False)
         if vp is not None:
             vp.after_forward(data, out)
         loss = loss_computer.get_loss_dict(out["render_img"], gt_img, mask)["total"]

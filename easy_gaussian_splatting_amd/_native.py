@@ -48,8 +48,8 @@ SIGNATURES = {
     "gs_colors_pre_grad": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P]),
     "gs_sh_grad_views": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P]),
     "gs_loss_workspace_floats": (_Z, [_I, _I]),
-    "gs_l1_ssim_fwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _P, _P]),
-    "gs_l1_ssim_bwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
+    "gs_l1_ssim_fwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _I, _P, _P]),
+    "gs_l1_ssim_bwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P]),
     "gs_clamp01": (_I, [_P, _L, _P, _P, _P]),
     "gs_update_statistics": (_I, [_P, _L, _F, _P, _P, _P, _P, _P]),
     "gs_adam_step": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F]),

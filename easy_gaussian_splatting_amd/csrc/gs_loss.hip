@@ -35,6 +35,7 @@ __device__ __constant__ float kWin[11] = {1.0283800845e-03f, 7.5987581352e-03f, 
 
 struct LossArgs {
     int H, W;
+    int clamp_input;                   // render is the un-clamped image: clamp to [0,1] on load, mask the gradient
     float lambda_ssim;
     const float *render, *gt, *mask;   // [H,W,3], [H,W,3], [H,W] or null
     float* maps;                       // [3 ch][H][W][3 (dmu, dxx, dxy)]: a tile row of one channel is one contiguous run
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
                 const int row = half + 2 * i, gy = y0 - kHalo + row;
                 const float g = gv[i];
                 float r = rv[i];
+                if (a.clamp_input) r = fminf(fmaxf(r, 0.f), 1.f);   // torch.clamp(render, 0, 1) of the model, folded in
                 if (a.mask) r = mv[i] * g + (1.f - mv[i]) * r;
                 dx[2 * i * kLRP] = r;
                 dy[2 * i * kLRP] = g;
@@ -273,7 +275,8 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
                 const size_t o = ((size_t)gy * a.W + gx) * 3 + ch;
                 const float gtv = a.gt[o];
                 float r = a.render[o], keep = 1.f;
-                if (a.mask) { const float m = a.mask[(size_t)gy * a.W + gx]; r = m * gtv + (1.f - m) * r; keep = 1.f - m; }
+                if (a.clamp_input) { keep = (r >= 0.f && r <= 1.f) ? 1.f : 0.f; r = fminf(fmaxf(r, 0.f), 1.f); }   // clamp's backward
+                if (a.mask) { const float m = a.mask[(size_t)gy * a.W + gx]; r = m * gtv + (1.f - m) * r; keep *= 1.f - m; }
                 const float d = r - gtv;
                 const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
                 a.v_render[o] = keep * (k_ssim * (c[0][j] + 2.f * r * c[1][j] + gtv * c[2][j]) + k_l1 * sgn);
@@ -329,11 +332,12 @@ extern "C" size_t gs_loss_workspace_floats(int height, int width) {
 }
 
 extern "C" int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_ssim, const float* render,
-                              const float* gt, const float* mask, float* workspace, float* out3) {
+                              const float* gt, const float* mask, int clamp_input, float* workspace, float* out3) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
     GS_REQUIRE(render && gt && workspace && out3, "null pointer");
     LossArgs a;
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;
+    a.clamp_input = clamp_input != 0;
     a.maps = workspace; a.partial = workspace + 9 * (size_t)height * width; a.gout = nullptr; a.v_render = nullptr;
     dim3 grid((width + kLT - 1) / kLT, (height + kLT - 1) / kLT);
     const size_t lds = sizeof(float) * (6 * kLR * kLRP + 5 * kLR * (kLT + 1));
@@ -349,12 +353,13 @@ extern "C" int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_
 }
 
 extern "C" int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const float* render,
-                              const float* gt, const float* mask, const float* workspace, const float* v_total,
-                              float* v_render) {
+                              const float* gt, const float* mask, int clamp_input, const float* workspace,
+                              const float* v_total, float* v_render) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
     GS_REQUIRE(render && gt && workspace && v_total && v_render, "null pointer");
     LossArgs a;
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;
+    a.clamp_input = clamp_input != 0;
     a.maps = const_cast<float*>(workspace); a.partial = nullptr; a.gout = v_total; a.v_render = v_render;
     dim3 grid((width + kLT - 1) / kLT, (height + kLT - 1) / kLT);
     const size_t lds = sizeof(float) * (3 * kLR * kLRP + 3 * kLR * (kLT + 1));

@@ -50,7 +50,7 @@ class _FusedL1SSIM(torch.autograd.Function):
     """HIP path (csrc/gs_loss.hip): two stencil kernels forward, one backward, no atomics."""
 
     @staticmethod
-    def forward(ctx, render_img: Tensor, gt_img: Tensor, mask, lambda_ssim: float):
+    def forward(ctx, render_img: Tensor, gt_img: Tensor, mask, lambda_ssim: float, clamp_input: bool = False):
         from . import _native as nat
         L = nat.lib()
         H, W = render_img.shape[:2]
@@ -62,7 +62,9 @@ class _FusedL1SSIM(torch.autograd.Function):
         out = torch.empty((3,), dtype=torch.float32, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
         nat.check(L.gs_l1_ssim_fwd(st, H, W, float(lambda_ssim), r.data_ptr(), g.data_ptr(),
-                                   None if m is None else m.data_ptr(), ws.data_ptr(), out.data_ptr()), "gs_l1_ssim_fwd")
+                                   None if m is None else m.data_ptr(), int(clamp_input), ws.data_ptr(), out.data_ptr()),
+                  "gs_l1_ssim_fwd")
+        ctx.clamp_input = bool(clamp_input)
         ctx.save_for_backward(r, g, ws) if m is None else ctx.save_for_backward(r, g, ws, m)
         ctx.lam = float(lambda_ssim)
         total, l1, ssim_loss = out[2], out[0], out[1]
@@ -75,7 +77,7 @@ class _FusedL1SSIM(torch.autograd.Function):
         L = nat.lib()
         saved = ctx.saved_tensors
         if v_total is None:
-            return None, None, None, None
+            return None, None, None, None, None
         r, g, ws = saved[:3]
         m = saved[3] if len(saved) > 3 else None
         H, W = r.shape[:2]
@@ -83,19 +85,26 @@ class _FusedL1SSIM(torch.autograd.Function):
         vt = v_total.contiguous().float()
         st = torch.cuda.current_stream(r.device).cuda_stream
         nat.check(L.gs_l1_ssim_bwd(st, H, W, ctx.lam, r.data_ptr(), g.data_ptr(), None if m is None else m.data_ptr(),
-                                   ws.data_ptr(), vt.data_ptr(), v_render.data_ptr()), "gs_l1_ssim_bwd")
-        return v_render, None, None, None
+                                   int(ctx.clamp_input), ws.data_ptr(), vt.data_ptr(), v_render.data_ptr()), "gs_l1_ssim_bwd")
+        return v_render, None, None, None, None
 
 
 class LossComputer:
-    def __init__(self, lambda_ssim: float = 0.2, fused: bool = True):
+    """`clamp_input=True`: `render_img` is the model's UN-clamped image (`GaussianModel.forward(data, clamp=False)`)
+    and `torch.clamp(., 0, 1)` of /root/reference/model/gaussian.py:368 happens inside the loss (both directions);
+    the result equals clamp-then-loss, two full-resolution kernels fewer per step."""
+
+    def __init__(self, lambda_ssim: float = 0.2, fused: bool = True, clamp_input: bool = False):
         self.lambda_ssim = lambda_ssim
         self.fused = fused
+        self.clamp_input = clamp_input
 
     def get_loss_dict(self, render_img: Tensor, gt_img: Tensor, mask: Tensor = None) -> Dict[str, Tensor]:
         if self.fused and render_img.is_cuda and render_img.dtype == torch.float32:
-            total, l1, ssim_loss = _FusedL1SSIM.apply(render_img, gt_img, mask, self.lambda_ssim)
+            total, l1, ssim_loss = _FusedL1SSIM.apply(render_img, gt_img, mask, self.lambda_ssim, self.clamp_input)
             return {"l1": l1, "ssim": ssim_loss, "total": total}
+        if self.clamp_input:
+            render_img = torch.clamp(render_img, min=0.0, max=1.0)
         if mask is not None:
             m = mask.unsqueeze(2)
             render_img = m * gt_img + (1.0 - m) * render_img

@@ -219,7 +219,9 @@ class GaussianModel(nn.Module):
             new_m[name], new_v[name] = (torch.zeros_like(m), torch.zeros_like(v)) if name == "logit_opacities" else (m, v)
         self._replace_parameters(new, new_m, new_v)
 
-    def forward(self, data: Dict[str, Any]) -> Dict[str, Optional[Tensor]]:
+    def forward(self, data: Dict[str, Any], clamp: bool = True) -> Dict[str, Optional[Tensor]]:
+        """`clamp=False` returns the un-clamped image for `LossComputer(clamp_input=True)` (the clamp of
+        /root/reference/model/gaussian.py:368 then happens inside the loss kernels)."""
         w2c = data["w2c"]
         # on the GPU the raw parameters go in and exp / sigmoid happen inside the projection kernels
         raw = self.means.is_cuda and getattr(self, "fuse_activations", True)
@@ -241,7 +243,9 @@ class GaussianModel(nn.Module):
             _activations="exp_sigmoid" if raw else "none",
             _on_colors_pre=getattr(self, "on_colors_pre", None),
         )
-        render_img = clamp01(batch_render_imgs.squeeze(0))   # (a view both ways: `[0]` would cost a zero-fill + copy in backward)
+        render_img = batch_render_imgs.squeeze(0)   # (a view both ways: `[0]` would cost a zero-fill + copy in backward)
+        if clamp:
+            render_img = clamp01(render_img)
         return {
             "render_img": render_img,  # [H, W, 3]
             "batch_xys": meta["means2d"],  # [1, N, 2]

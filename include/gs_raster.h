@@ -182,12 +182,14 @@ int gs_sh_grad_views(void* stream, int R, int64_t N, int K, int sh_degree, const
  * render / gt are [H,W,3]; mask [H,W] may be NULL (render := mask*gt + (1-mask)*render).
  * workspace holds gs_loss_workspace_floats(H,W) floats and carries the SSIM derivative maps from
  * the forward to the backward.  out3 = {l1, 1-ssim, (1-lambda)*l1 + lambda*(1-ssim)}.
- * v_total: device scalar d(loss)/d(out3[2]);  v_render[H,W,3] is fully written. */
+ * v_total: device scalar d(loss)/d(out3[2]);  v_render[H,W,3] is fully written.
+ * clamp_input != 0: `render` is the rasterizer's un-clamped image; torch.clamp(render, 0, 1) of
+ * GaussianModel.forward (/root/reference/model/gaussian.py:368) and its backward are applied inside. */
 size_t gs_loss_workspace_floats(int height, int width);
 int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_ssim, const float* render,
-                   const float* gt, const float* mask, float* workspace, float* out3);
+                   const float* gt, const float* mask, int clamp_input, float* workspace, float* out3);
 int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const float* render,
-                   const float* gt, const float* mask, const float* workspace,
+                   const float* gt, const float* mask, int clamp_input, const float* workspace,
                    const float* v_total, float* v_render);
 
 /* Row a-2: `torch.clamp(render, 0, 1)` of /root/reference/model/gaussian.py:368 as one pass.

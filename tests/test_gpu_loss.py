@@ -47,3 +47,26 @@ def test_clamp01_matches_torch_clamp(shape):
     assert torch.equal(ya, yb)
     ya.backward(v.to(dev)); yb.backward(v.to(dev))
     assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_loss_with_folded_clamp_equals_clamp_then_loss(use_mask):
+    """LossComputer(clamp_input=True) on the un-clamped image == torch.clamp(., 0, 1) followed by the loss,
+    values and gradient (aten's clamp passes the gradient at exactly 0 and 1)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    H, W = 70, 93
+    gt = torch.rand(H, W, 3, generator=g)
+    x = gt + 0.5 * torch.randn(H, W, 3, generator=g)          # a good part lies outside [0, 1]
+    x.view(-1)[::13] = 0.0; x.view(-1)[5::17] = 1.0
+    mask = (torch.rand(H, W, generator=g) > 0.7).float().to(dev) if use_mask else None
+    a = x.clone().to(dev).requires_grad_(True)
+    b = x.clone().to(dev).requires_grad_(True)
+    la = LossComputer(0.2, clamp_input=True).get_loss_dict(a, gt.to(dev), mask)
+    lb = LossComputer(0.2).get_loss_dict(torch.clamp(b, min=0.0, max=1.0), gt.to(dev), mask)
+    for k in ("l1", "ssim", "total"):
+        assert abs(la[k].item() - lb[k].item()) <= 1e-6 * max(1.0, abs(lb[k].item())), k
+    (la["total"] * 1.3).backward(); (lb["total"] * 1.3).backward()
+    assert float((a.grad - b.grad).abs().max()) <= 1e-6 * float(b.grad.abs().max())
+    outside = (x < 0) | (x > 1)
+    assert float(a.grad.cpu()[outside].abs().max()) == 0.0
