@@ -109,8 +109,8 @@ __device__ __forceinline__ void stage_sh_rows_split(const float* __restrict__ sh
         bool ld[kMaxQ];
 #pragma unroll
         for (int q = 0; q < kMaxQ; ++q) {   // issue every load first (see stage_sh_rows)
-            const int e4 = threadIdx.x + q * kProjThreads, e = e4 << 2;
-            ld[q] = e4 < total4 && (vis[e / rest_f] || vis[(e + 3) / rest_f]);
+            const int e4 = threadIdx.x + q * kProjThreads;
+            ld[q] = e4 < total4;   // culled rows are loaded too: 12 % more bytes, but a dense stream (-8 % on the kernel)
             if (ld[q]) v[q] = nt_load4(src4 + e4);
         }
 #pragma unroll
