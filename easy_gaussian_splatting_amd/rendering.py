@@ -63,6 +63,7 @@ def profile_stages(enable: bool) -> Optional[Dict]:
 
 
 _tls = threading.local()
+_cap_hint: Dict[int, int] = {}   # per device: list capacity to pre-allocate (last intersection count + 25 %)
 # host-side diagnostics: time spent blocked on the list-size read-back (bench.py reports it; a wait
 # near zero means the host, not the GPU, paces the loop)
 stats = {"sync_wait_ns": 0, "calls": 0}
@@ -147,19 +148,28 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream(dev))
     project(2, "gs_project_fwd_color")
+    # The list buffers are allocated BEFORE the host blocks, from the size the previous call on this
+    # device needed (+25 %): the window between the host waking up and the emit kernel being queued is
+    # what the colour pass has to cover, and six allocator calls do not belong in it.
+    hint_key = dev.index if dev.index is not None else torch.cuda.current_device()
+    cap = _cap_hint.get(hint_key, 0)
+
+    def alloc_lists(c):
+        return (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32),
+                torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32), torch.empty((c,), **i32))
+
+    cum_tiles = torch.empty((C * N,), **i32)
+    lists = alloc_lists(cap) if cap > 0 else None
     t_wait = time.perf_counter_ns()
     ready.synchronize()
     stats["sync_wait_ns"] += time.perf_counter_ns() - t_wait
     stats["calls"] += 1
     n_isects, n_buckets, max_tile = (int(v) for v in info_host[:3].tolist())
-
-    cap = max(n_isects, 1)
-    keys_tmp = torch.empty((cap,), dtype=torch.int64, device=dev)
-    slot_gid = torch.empty((cap,), **i32)
-    cum_tiles = torch.empty((C * N,), **i32)
-    isect_ids = torch.empty((cap,), dtype=torch.int64, device=dev)
-    flatten_ids = torch.empty((cap,), **i32)
-    slots = torch.empty((cap,), **i32)
+    if lists is None or n_isects > cap:
+        cap = max(n_isects, 1)
+        lists = alloc_lists(cap)
+    _cap_hint[hint_key] = n_isects + (n_isects >> 2) + 1024
+    keys_tmp, slot_gid, isect_ids, flatten_ids, slots = lists
     _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, _ptr(bbox), _ptr(depths), _ptr(workspace), ws_bytes,
                                  _ptr(isect_offsets), n_isects, max_tile, _ptr(keys_tmp), _ptr(slot_gid),
                                  _ptr(cum_tiles), _ptr(isect_ids), _ptr(flatten_ids), _ptr(slots)), "gs_bin_emit_sort"))
