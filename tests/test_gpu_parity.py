@@ -57,7 +57,7 @@ def run_oracle(sc, use_bg=True, dtype=np.float64):
                      backgrounds=sc["backgrounds"] if use_bg else None, dtype=dtype)
 
 
-def check_forward(hip, fw, max_razor_frac=1e-2, lists=True):
+def check_forward(hip, fw, max_razor_frac=1e-2, lists=True, outlier_frac=0.0):
     meta = hip["meta"]
     radii = meta["radii"].cpu().numpy()
     mism = radii != fw["radii"]
@@ -79,8 +79,10 @@ def check_forward(hip, fw, max_razor_frac=1e-2, lists=True):
         strict &= err < 10 * FWD_ATOL
         assert (err >= 10 * FWD_ATOL).mean() < 1e-3
     assert razor.mean() <= max_razor_frac
-    assert err[strict].max(initial=0) <= FWD_ATOL, f"forward RGB err {err[strict].max()}"
-    assert aerr[strict].max(initial=0) <= FWD_ATOL, f"forward alpha err {aerr[strict].max()}"
+    # outlier_frac > 0 only where the reference itself is the wrong precision for a pixel-exact claim
+    # (fp64 oracle at hundreds of contributors per pixel; the fp32 oracle is then checked strictly)
+    assert (err[strict] > FWD_ATOL).mean() <= outlier_frac, f"forward RGB err {err[strict].max()}, {(err[strict] > FWD_ATOL).sum()} pixels"
+    assert (aerr[strict] > FWD_ATOL).mean() <= outlier_frac, f"forward alpha err {aerr[strict].max()}"
     cmax = max(1.0, float(fw["colors"].max()))
     assert err.max(initial=0) <= 4.0 / 255.0 * cmax, "even a flipped contributor is bounded by ~its weight"
     return exact_lists
@@ -549,3 +551,24 @@ def test_in_kernel_activations_equal_torch_activations():
         rel = float((a - b).abs().max() / (b.abs().max() + 1e-30))
         assert rel < 2e-5, (name, rel)
     assert float((meta_a["means2d"].absgrad - meta_b["means2d"].absgrad).abs().max()) <= 2e-5 * float(meta_b["means2d"].absgrad.abs().max())
+
+
+@pytest.mark.skipif((os.cpu_count() or 1) < 32, reason="the C oracle needs many host cores to finish the 1M / 1080p workload in seconds")
+def test_full_size_matches_oracle():
+    """BASELINE.json metric workload (1 M Gaussians, 1920x1080, SH3) against the oracle itself.  With 400-700
+    contributors per pixel fp32 and fp64 arithmetic take different threshold decisions in a few hundred pixels
+    (fp32 oracle vs fp64 oracle: ~200 pixels above 1e-4), so: against the fp64 oracle at most 1e-5 of the
+    non-razor pixels may exceed 1e-4 (observed: 3 of 2.06 M, mean error 1.3e-6); against the fp32 build of the
+    same oracle every non-razor pixel must be within 1e-4 (observed max 8e-7); lists bit-exact; all gradients
+    within 1e-3 rel (fp32 oracle arbitrating flips, as in every backward check)."""
+    sc = config_bench_1m()
+    fw = run_oracle(sc)
+    fw32 = run_oracle(sc, dtype=np.float32)
+    hip = run_hip(sc)
+    check_forward(hip, fw, max_razor_frac=1e-2, outlier_frac=1e-5)
+    check_forward(hip, fw32, max_razor_frac=1e-2)   # (lists are compared bit for bit whenever every radius agrees)
+    check_backward(hip, fw)
+    hip_t = run_hip(sc, culling="tight")      # the default list mode: same image and gradients, shorter lists
+    assert hip_t["meta"]["flatten_ids"].numel() < hip["meta"]["flatten_ids"].numel()
+    check_forward(hip_t, fw32, max_razor_frac=1e-2, lists=False)
+    check_backward(hip_t, fw)
