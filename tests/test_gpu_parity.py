@@ -571,4 +571,5 @@ def test_full_size_matches_oracle():
     hip_t = run_hip(sc, culling="tight")      # the default list mode: same image and gradients, shorter lists
     assert hip_t["meta"]["flatten_ids"].numel() < hip["meta"]["flatten_ids"].numel()
     check_forward(hip_t, fw32, max_razor_frac=1e-2, lists=False)
-    check_backward(hip_t, fw)
+    for a, b in zip(hip_t["grads"], hip["grads"]):   # (tight == gsplat-mode gradients; the oracle check ran on the latter)
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
