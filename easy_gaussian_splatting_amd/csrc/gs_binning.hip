@@ -132,14 +132,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
     int n_tiles_total, int n_groups_total, const uint32_t* __restrict__ tile_cnt,
     const uint32_t* __restrict__ grp_tot, int32_t* __restrict__ isect_offsets,
     int32_t* __restrict__ bucket_offsets, uint32_t* __restrict__ grp_base,
-    int64_t* __restrict__ info) {
+    int64_t* __restrict__ info, int32_t* __restrict__ tile_order) {
     __shared__ unsigned long long scratch[17];
     unsigned long long carry_i = 0, carry_b = 0;
     uint32_t max_cnt = 0;
     const int chunk = kBinThreads * kScanItems;
+    uint32_t v[kScanItems];   // (the last chunk's counts stay in registers for the launch order below)
     for (int base = 0; base < n_tiles_total; base += chunk) {
         const int first = base + threadIdx.x * kScanItems;
-        uint32_t v[kScanItems];
         unsigned long long si = 0, sb = 0;
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) {
@@ -179,6 +179,42 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
         info[0] = (int64_t)carry_i; info[1] = (int64_t)carry_b; info[2] = (int64_t)mm; info[3] = 0;
     }
     __syncthreads();
+    // Launch order for the blend forward (one wave per tile): longest lists first, so that the short
+    // ones fill the gaps at the end instead of the long ones sticking out (-10 % on its run time).
+    // Counting sort into 64 quarter-octave length classes with LDS atomics -- the order inside a class
+    // is arbitrary, which only permutes independent work.  One register-resident chunk only.
+    if (tile_order) {
+        if (n_tiles_total > chunk) {
+            for (int i = threadIdx.x; i < n_tiles_total; i += kBinThreads) tile_order[i] = i;
+        } else {
+            __shared__ uint32_t cls_cnt[64], cls_base[64];
+            auto cls_of = [](uint32_t x) -> int {   // 4 * floor(log2 x) + the next two bits, 0 for x < 2
+                if (x < 2u) return 0;
+                const int lg = 31 - __clz((int)x);
+                return min(63, (lg << 2) | (int)((x << (31 - lg)) >> 29 & 3u));
+            };
+            if (threadIdx.x < 64) cls_cnt[threadIdx.x] = 0u;
+            __syncthreads();
+            const int first = threadIdx.x * kScanItems;
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k)
+                if (first + k < n_tiles_total) atomicAdd(&cls_cnt[cls_of(v[k])], 1u);
+            __syncthreads();
+            if (threadIdx.x < 64) {   // descending classes: lane l owns class 63 - l
+                const int c = 63 - (int)threadIdx.x;
+                const uint32_t n = cls_cnt[c];
+                cls_base[c] = wave_incl_scan_add(n) - n;
+                cls_cnt[c] = 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kScanItems; ++k)
+                if (first + k < n_tiles_total) {
+                    const int c = cls_of(v[k]);
+                    tile_order[cls_base[c] + atomicAdd(&cls_cnt[c], 1u)] = first + k;
+                }
+        }
+    }
     // group bases (few thousand values at most): serial chunks of kBinThreads
     unsigned long long gcarry = 0;
     for (int base = 0; base < n_groups_total; base += kBinThreads) {
@@ -478,7 +514,7 @@ static int ensure_lds(const void* fn, size_t bytes) {
 
 extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile_h, const uint32_t* bbox,
                             void* workspace, size_t workspace_bytes, int32_t* isect_offsets,
-                            int32_t* bucket_offsets, int64_t* info_dev, int64_t* info_host) {
+                            int32_t* bucket_offsets, int32_t* tile_order, int64_t* info_dev, int64_t* info_host) {
     GS_REQUIRE(C >= 1 && N >= 0 && tile_w > 0 && tile_h > 0, "C>=1, N>=0, positive tile grid");
     const int tiles = tile_w * tile_h;
     GS_REQUIRE((size_t)tiles * 4 + 128 <= 160 * 1024, "tile grid too large for the LDS histogram (max 40928 tiles per camera)");
@@ -503,7 +539,7 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
                        tiles, hist, tile_cnt);
     GS_LAUNCH_CHECK("bin_colscan_kernel");
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(kBinThreads), 0, st, (int)ct, C * L.groups, tile_cnt,
-                       grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev);
+                       grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev, tile_order);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
     if (info_host) {
         GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));

@@ -37,6 +37,7 @@
 namespace gs {
 
 struct BlendFwdArgs {
+    const int32_t* tile_order;   // optional (gs_bin_count)
     int C, W, H, tw, tiles;
     const float4* rec;
     const float* bg;
@@ -81,8 +82,9 @@ template <bool CKPT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArgs a) {
     __shared__ float4 srec_all[WAVES][GS_BUCKET * 3];
     float4* srec = srec_all[threadIdx.x >> 6];
-    const int t = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
-    if (t >= a.C * a.tiles) return;   // wave-uniform
+    const int ti = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
+    if (ti >= a.C * a.tiles) return;   // wave-uniform
+    const int t = a.tile_order ? a.tile_order[ti] : ti;   // launch slot -> tile (longest lists first)
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
     const int tyi = tt / a.tw, txi = tt - tyi * a.tw;
     const int lane = threadIdx.x & 63;
@@ -394,7 +396,7 @@ using namespace gs;
 
 extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                             const float* backgrounds, const int32_t* isect_offsets,
-                            const int32_t* bucket_offsets, const int32_t* flatten_ids,
+                            const int32_t* bucket_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
                             const int32_t* slots, int64_t n_isects, float* render_colors,
                             float* render_alphas, float* ckpt, int32_t* qlist, int32_t* qcnt,
                             uint8_t* qmask, int32_t* unit_counter, int32_t* unit_desc) {
@@ -411,6 +413,7 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     a.out_colors = render_colors; a.out_alphas = render_alphas;
     a.ckpt = reinterpret_cast<float4*>(ckpt); a.qlist = reinterpret_cast<int2*>(qlist); a.qcnt = qcnt; a.qmask = qmask;
     a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int2*>(unit_desc);
+    a.tile_order = tile_order;
     const unsigned n_tiles = (unsigned)(C * a.tiles);
     hipStream_t st = (hipStream_t)stream;
     // 4 tiles (waves) per workgroup: measured equal to single-wave workgroups (0.33-0.36 ms at the bench

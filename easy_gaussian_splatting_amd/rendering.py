@@ -141,8 +141,9 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     isect_offsets = torch.empty((C * tiles + 1,), **i32)
     bucket_offsets = torch.empty((C * tiles + 1,), **i32)
     info_dev = torch.empty((4,), dtype=torch.int64, device=dev)
+    tile_order = torch.empty((C * tiles,), **i32)   # launch order of the blend forward: longest lists first
     _stage("gs_bin_count", dev, lambda: nat.check(L.gs_bin_count(st, C, N, tw, th, _ptr(bbox), _ptr(workspace), ws_bytes, _ptr(isect_offsets),
-                             _ptr(bucket_offsets), _ptr(info_dev), None), "gs_bin_count"))
+                             _ptr(bucket_offsets), _ptr(tile_order), _ptr(info_dev), None), "gs_bin_count"))
     info_host = _pinned_info(dev)
     info_host.copy_(info_dev, non_blocking=True)
     ready = torch.cuda.Event()
@@ -186,7 +187,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         unit_counter = torch.empty((1,), **i32)
         unit_desc = torch.empty((4 * nbk, 2), **i32)
     _stage("gs_blend_fwd", dev, lambda: nat.check(L.gs_blend_fwd(st, C, W, H, _ptr(rec), _ptr(backgrounds), _ptr(isect_offsets),
-                             _ptr(bucket_offsets), _ptr(flatten_ids), _ptr(slots), n_isects, _ptr(render_colors),
+                             _ptr(bucket_offsets), _ptr(tile_order), _ptr(flatten_ids), _ptr(slots), n_isects, _ptr(render_colors),
                              _ptr(render_alphas), _ptr(ckpt), _ptr(qlist), _ptr(qcnt), _ptr(qmask),
                              _ptr(unit_counter), _ptr(unit_desc)), "gs_blend_fwd"))
 

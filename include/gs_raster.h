@@ -84,10 +84,12 @@ int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
  * isect_offset_encode).  Writes isect_offsets[C*tiles+1] (exclusive; last = I),
  * bucket_offsets[C*tiles+1] (exclusive scan of ceil(count/64)), info_dev[4] =
  * {I, n_buckets, max entries in one tile, 0}.  If info_host != NULL the four values are copied
- * there and the stream is synchronised (the one host sync of the exact mode). */
+ * there and the stream is synchronised (the one host sync of the exact mode).
+ * tile_order[C*tiles] (optional, may be NULL): a launch order for gs_blend_fwd, tiles with the longest
+ * lists first (a permutation of 0 .. C*tiles-1; the order among lists of similar length is arbitrary). */
 int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile_h, const uint32_t* bbox,
                  void* workspace, size_t workspace_bytes, int32_t* isect_offsets,
-                 int32_t* bucket_offsets, int64_t* info_dev, int64_t* info_host);
+                 int32_t* bucket_offsets, int32_t* tile_order, int64_t* info_dev, int64_t* info_host);
 
 /* I-emit + per-tile depth sort (replaces the emitting half of isect_tiles and the global
  * cub::DeviceRadixSort).  Needs the workspace as left by gs_bin_count.  keys_tmp[I] u64 and
@@ -114,7 +116,7 @@ int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, con
  *   unit_counter[1], unit_desc[4*n_buckets*2] i32   work units (tile*4+quadrant, bucket) */
 int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                  const float* backgrounds, const int32_t* isect_offsets,
-                 const int32_t* bucket_offsets, const int32_t* flatten_ids, const int32_t* slots,
+                 const int32_t* bucket_offsets, const int32_t* tile_order, const int32_t* flatten_ids, const int32_t* slots,
                  int64_t n_isects, float* render_colors, float* render_alphas, float* ckpt,
                  int32_t* qlist, int32_t* qcnt, uint8_t* qmask, int32_t* unit_counter,
                  int32_t* unit_desc);

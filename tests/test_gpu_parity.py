@@ -573,3 +573,46 @@ def test_full_size_matches_oracle():
     check_forward(hip_t, fw32, max_razor_frac=1e-2, lists=False)
     for a, b in zip(hip_t["grads"], hip["grads"]):   # (tight == gsplat-mode gradients; the oracle check ran on the latter)
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+
+
+def test_tile_launch_order_is_a_longest_first_permutation():
+    """gs_bin_count's tile_order: a permutation of the tiles in which quarter-octave length classes never
+    increase (longest lists first); the order inside a class is arbitrary."""
+    import ctypes as ct
+    from easy_gaussian_splatting_amd import _native as nat
+    d = dev()
+    sc = make_scene(20000, 640, 368, sh_degree=0, seed=77, scale_range=(0.01, 0.3), dist=4.0)
+    t = to_dev(sc)
+    L = nat.lib()
+    C, N = 1, 20000
+    tw, th = (sc["width"] + 15) // 16, (sc["height"] + 15) // 16
+    tiles = tw * th
+    i32 = dict(dtype=torch.int32, device=d); f32 = dict(dtype=torch.float32, device=d)
+    radii = torch.empty((C, N), **i32); m2 = torch.empty((C, N, 2), **f32); dep = torch.empty((C, N), **f32)
+    con = torch.empty((C, N, 3), **f32); col = torch.empty((C, N, 3), **f32); rec = torch.empty((C * N, 12), **f32)
+    bbox = torch.empty((C * N, 4), **i32); tpg = torch.empty((C, N), **i32)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda x: x.data_ptr()
+    nat.check(L.gs_project_fwd(st, C, N, 1, 0, P(t["means"]), P(t["quats"]), P(t["scales"]), P(t["opacities"]), P(t["shs"]), None, 0,
+                               P(t["viewmats"]), P(t["Ks"]), sc["width"], sc["height"], 0.3, 0.01, 1e10, 0.0, 1, 0, 0, P(radii), P(m2), P(dep),
+                               P(con), P(col), P(rec), P(bbox), P(tpg)), "gs_project_fwd")
+    ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=d)
+    off = torch.empty((tiles + 1,), **i32); boff = torch.empty((tiles + 1,), **i32); order = torch.full((tiles,), -1, **i32)
+    info = torch.empty((4,), dtype=torch.int64, device=d)
+    host = (ct.c_int64 * 4)()
+    nat.check(L.gs_bin_count(st, C, N, tw, th, P(bbox), P(ws), ws_bytes, P(off), P(boff), P(order), P(info), host), "gs_bin_count")
+    off, order = off.cpu().numpy().astype(np.int64), order.cpu().numpy()
+    lens = np.diff(off)
+    assert sorted(order.tolist()) == list(range(tiles))
+
+    def cls(x):
+        x = int(x)
+        if x < 2:
+            return 0
+        lg = x.bit_length() - 1
+        return min(63, (lg << 2) | ((x << (31 - lg)) >> 29 & 3))
+
+    seq = np.array([cls(lens[i]) for i in order])
+    assert np.all(np.diff(seq) <= 0), "length classes must not increase along the launch order"
+    assert seq[0] == max(cls(v) for v in lens) and host[2] == lens.max() and host[0] == lens.sum()
