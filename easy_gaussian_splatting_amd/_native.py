@@ -51,6 +51,7 @@ SIGNATURES = {
     "gs_l1_ssim_fwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _I, _P, _P]),
     "gs_l1_ssim_bwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P]),
     "gs_clamp01": (_I, [_P, _L, _P, _P, _P]),
+    "gs_pack_view_step": (_I, [_P, _L, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_update_statistics": (_I, [_P, _L, _F, _P, _P, _P, _P, _P]),
     "gs_adam_step": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F]),
 }

@@ -135,3 +135,45 @@ extern "C" int gs_update_statistics(void* stream, int64_t n, float max_hw, const
     GS_LAUNCH_CHECK("update_statistics_kernel");
     return GS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// View-parallel step (distributed.ViewParallelStep): everything one rank contributes to the SUM
+// all-reduce in ONE pass -- the four geometry gradients and this view's two additive statistics of
+// /root/reference/model/gaussian.py:188-197 (|absgrad|_2 * max_hw and the visibility count), packed
+// into a flat buffer whose six segments start at multiples of 4 floats: [means 3N | log_scales 3N |
+// quats 4N | logit_opacities N | grad_norm N | count N].  Replaces ~12 elementwise launches.
+namespace gs {
+__global__ __launch_bounds__(256) void pack_view_step_kernel(int64_t n, float max_hw, const float* __restrict__ v_means,
+                                                             const float* __restrict__ v_scales, const float* __restrict__ v_quats,
+                                                             const float* __restrict__ v_opac, const int32_t* __restrict__ radii,
+                                                             const float2* __restrict__ absgrad, float* __restrict__ flat,
+                                                             int64_t o_scales, int64_t o_quats, int64_t o_opac, int64_t o_gn, int64_t o_cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flat[3 * i] = v_means[3 * i]; flat[3 * i + 1] = v_means[3 * i + 1]; flat[3 * i + 2] = v_means[3 * i + 2];
+    flat[o_scales + 3 * i] = v_scales[3 * i]; flat[o_scales + 3 * i + 1] = v_scales[3 * i + 1]; flat[o_scales + 3 * i + 2] = v_scales[3 * i + 2];
+    reinterpret_cast<float4*>(flat + o_quats)[i] = reinterpret_cast<const float4*>(v_quats)[i];
+    flat[o_opac + i] = v_opac[i];
+    const bool vis = radii[i] > 0;
+    const float2 g = absgrad[i];
+    flat[o_gn + i] = vis ? sqrtf(g.x * g.x + g.y * g.y) * max_hw : 0.f;
+    flat[o_cnt + i] = vis ? 1.f : 0.f;
+}
+}  // namespace gs
+
+extern "C" int gs_pack_view_step(void* stream, int64_t n, float max_hw, const float* v_means, const float* v_scales,
+                                 const float* v_quats, const float* v_opacities, const int32_t* radii, const float* absgrad,
+                                 float* flat) {
+    GS_REQUIRE(n >= 0 && max_hw > 0.f, "n >= 0 and positive image extent");
+    if (n == 0) return GS_OK;
+    GS_REQUIRE(v_means && v_scales && v_quats && v_opacities && radii && absgrad && flat, "null pointer");
+    GS_REQUIRE((((uintptr_t)v_quats | (uintptr_t)flat) & 15) == 0, "v_quats and flat must be 16-byte aligned");
+    auto pad4 = [](int64_t x) { return (x + 3) / 4 * 4; };
+    const int64_t o_scales = pad4(3 * n), o_quats = o_scales + pad4(3 * n), o_opac = o_quats + 4 * n, o_gn = o_opac + pad4(n),
+                  o_cnt = o_gn + pad4(n);
+    hipLaunchKernelGGL(gs::pack_view_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, max_hw,
+                       v_means, v_scales, v_quats, v_opacities, radii, reinterpret_cast<const float2*>(absgrad), flat, o_scales, o_quats,
+                       o_opac, o_gn, o_cnt);
+    GS_LAUNCH_CHECK("pack_view_step_kernel");
+    return GS_OK;
+}

@@ -165,16 +165,28 @@ class ViewParallelStep:
         # (2) all-reduce SUM: geometry gradients + the two additive statistics of this view
         #     (/root/reference/model/gaussian.py:188-197), segments padded to 16 bytes
         geo = [getattr(m, name) for name in self.GEOMETRY]
-        pieces = [p.grad for p in geo]
-        pieces.append(torch.where(visible, torch.linalg.vector_norm(xys.absgrad[0], dim=-1) * max_hw, 0.0))
-        pieces.append(visible.to(dt))
+        sizes = [p.numel() for p in geo] + [N, N]
         offs, off = [], 0
-        for t in pieces:
+        for n_el in sizes:
             offs.append(off)
-            off = (off + t.numel() + 3) // 4 * 4
-        flat = torch.zeros(off, **f32)
-        for t, o in zip(pieces, offs):
-            flat[o:o + t.numel()].copy_(t.reshape(-1))
+            off = (off + n_el + 3) // 4 * 4
+        if dt == torch.float32 and m.means.is_cuda:
+            # one HIP pass packs the four gradients and derives the two statistics (gs_pack_view_step)
+            from . import _native as nat
+            flat = torch.empty(off, **f32)
+            g = [p.grad.contiguous() for p in geo]
+            with torch.cuda.device(m.means.device):
+                nat.check(nat.lib().gs_pack_view_step(
+                    torch.cuda.current_stream(m.means.device).cuda_stream, N, max_hw, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
+                    g[3].data_ptr(), out["batch_radii"][0].contiguous().data_ptr(), xys.absgrad[0].contiguous().data_ptr(),
+                    flat.data_ptr()), "gs_pack_view_step")
+        else:   # the CPU tests drive this class with float64 tensors
+            pieces = [p.grad for p in geo]
+            pieces.append(torch.where(visible, torch.linalg.vector_norm(xys.absgrad[0], dim=-1) * max_hw, 0.0))
+            pieces.append(visible.to(dt))
+            flat = torch.zeros(off, **f32)
+            for t, o in zip(pieces, offs):
+                flat[o:o + t.numel()].copy_(t.reshape(-1))
         w_sum = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         # SH half: rebuild the dense SH gradient of all views, update while (2) is in flight
         w_cams.wait()

@@ -212,6 +212,14 @@ int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* 
                  const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
                  float beta2, float eps, int64_t step, float grad_scale);
 
+/* Row e: this rank's contribution to the SUM all-reduce of the view-parallel step in one pass: the four
+ * geometry gradients and this view's two additive statistics (|absgrad|_2 * max_hw, visibility count)
+ * packed into flat = [means 3N | log_scales 3N | quats 4N | logit_opacities N | grad_norm N | count N],
+ * every segment padded to a multiple of 4 floats (flat holds 4*ceil(3N/4)*2 + 4N + 3*4*ceil(N/4) floats). */
+int gs_pack_view_step(void* stream, int64_t n, float max_hw, const float* v_means, const float* v_scales,
+                      const float* v_quats, const float* v_opacities, const int32_t* radii, const float* absgrad,
+                      float* flat);
+
 /* Row a-3: the consumer of the side channels, `GaussianModel.update_statistics`
  * (/root/reference/model/gaussian.py:188-197), as one launch for the reference's single camera:
  * for radii[i] > 0: max_radii = max(max_radii, radii/max_hw); grad_norm_accum += |absgrad[i]|_2 * max_hw;
