@@ -55,16 +55,15 @@ struct BlendFwdArgs {
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// One (pixel, Gaussian) pair of the forward; straight-line, predicated.  The entry's alpha is
+// One (pixel, Gaussian) pair of the forward (alpha and the take-it test come from the caller, which
+// skips entries no pixel takes); straight-line, predicated.  The entry's alpha is
 // masked once (v_cndmask costs more than an fp32 multiply on gfx950, tools/micro/): a masked alpha
 // of 0 leaves T and the colour sums bit-for-bit unchanged (fma(-0, T, T) == T, fma(r, 0, c) == c).
 // The stop rule (T would fall to 1e-4: the entry is NOT blended, the pixel is finished) fires a
 // handful of times per pixel at most, so it lives behind a wave-uniform branch.
-__device__ __forceinline__ void blend_pair(const float sigma, const float op, const float r,
+__device__ __forceinline__ void blend_pair(const float alpha, const bool ok, const float r,
                                            const float g, const float b, float& T, float& cr,
                                            float& cg, float& cb, bool& done) {
-    const float alpha = fminf(kAlphaMax, op * fast_exp2(-sigma));
-    const bool ok = !done && sigma >= 0.f && alpha >= kAlphaMin;
     const float am = ok ? alpha : 0.f;
     float w = am * T;
     float Tn = fmaf(-am, T, T);   // explicit: fwd and bwd must round identically
@@ -153,28 +152,16 @@ __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArg
                 }
             }
         }
-        unsigned long long mq[4];
-        int jstar[4] = {-1, -1, -1, -1}, kbstar[4] = {0, 0, 0, 0};
+        // mq[k]: entries whose footprint can reach quadrant k (they are evaluated);  cq[k]: the subset for
+        // which at least one pixel of the quadrant takes the entry (alpha >= 1/255, pixel not finished).
+        // Only those enter the backward's sublist -- 13 % of the evaluated (entry, quadrant) pairs on the
+        // bench workload turn out to contribute to no pixel centre, and skipping them costs the backward
+        // nothing in accuracy: they have no gradient.
+        unsigned long long mq[4], cq[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
         for (int k = 0; k < 4; ++k) mq[k] = __ballot(bit[k]);
-        if (CKPT) {
-            int mybits = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int rank = __popcll(mq[k] & lt_mask);
-                if (bit[k]) {
-                    a.qlist[(size_t)4 * lo + (size_t)k * len + cnt[k] + rank] = make_int2(my_gid, my_slot);
-                    mybits |= 1 << k;
-                }
-                // the sublist entry that opens a new 64-entry quadrant bucket (at most one per bucket)
-                const int need = (GS_BUCKET - (cnt[k] & (GS_BUCKET - 1))) & (GS_BUCKET - 1);
-                const unsigned long long bs = __ballot(bit[k] && rank == need);
-                if (bs) { jstar[k] = __builtin_ctzll(bs); kbstar[k] = (cnt[k] + need) / GS_BUCKET; }
-            }
-            if (lane < m) a.qmask[my_slot] = (uint8_t)mybits;
-        }
-        // single-wave workgroup: LDS operations of one wave complete in issue order, so the staged
-        // records are visible without a workgroup barrier
+        // single-wave tile: LDS operations of one wave complete in issue order, so the staged records
+        // are visible without a workgroup barrier
         __builtin_amdgcn_wave_barrier();
         for (unsigned long long rem = mq[0] | mq[1] | mq[2] | mq[3]; rem; rem &= rem - 1) {
             const int j = __builtin_ctzll(rem);
@@ -183,19 +170,37 @@ __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArg
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if ((mq[k] >> j) & 1) {
-                    if (CKPT && j == jstar[k])
-                        a.ckpt[((size_t)4 * bucket0 + (size_t)k * nb + kbstar[k]) * 64 + lane] =
-                            make_float4(done[k] ? -1.f : T[k], cr[k], cg[k], cb[k]);
                     // the offsets are formed per quadrant (an entry touches 1.7 of the 4 on average);
                     // same operation sequence as the backward: (hA dx) dx, B dx, two fma
                     const float dx = q0.x - ((k & 1) ? fx1 : fx0), dy = q0.y - ((k >> 1) ? fy1 : fy0);
                     const float sigma = fmaf(dy, fmaf(q1.x, dy, q0.w * dx), q0.z * dx * dx);
-                    blend_pair(sigma, op, r, g, bl, T[k], cr[k], cg[k], cb[k], done[k]);
+                    const float alpha = fminf(kAlphaMax, op * fast_exp2(-sigma));
+                    const bool ok = !done[k] && sigma >= 0.f && alpha >= kAlphaMin;
+                    if (CKPT) {
+                        if (!__any(ok)) continue;   // no pixel of the quadrant takes it: nothing to blend, nothing to list
+                        // the sublist entry that opens a new 64-entry quadrant bucket saves the pixel states before it
+                        const int pos = cnt[k] + (int)__popcll(cq[k]);
+                        if ((pos & (GS_BUCKET - 1)) == 0)
+                            a.ckpt[((size_t)4 * bucket0 + (size_t)k * nb + pos / GS_BUCKET) * 64 + lane] =
+                                make_float4(done[k] ? -1.f : T[k], cr[k], cg[k], cb[k]);
+                        cq[k] |= 1ull << j;
+                    }
+                    blend_pair(alpha, ok, r, g, bl, T[k], cr[k], cg[k], cb[k], done[k]);
                 }
             }
         }
+        if (CKPT) {   // compacted quadrant sublists of (flatten id, slot) pairs, in list order
+            int mybits = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cnt[k] += __popcll(mq[k]);
+            for (int k = 0; k < 4; ++k) {
+                if ((cq[k] >> lane) & 1) {
+                    a.qlist[(size_t)4 * lo + (size_t)k * len + cnt[k] + __popcll(cq[k] & lt_mask)] = make_int2(my_gid, my_slot);
+                    mybits |= 1 << k;
+                }
+                cnt[k] += __popcll(cq[k]);
+            }
+            if (lane < m) a.qmask[my_slot] = (uint8_t)mybits;
+        }
         __builtin_amdgcn_wave_barrier();
     }
     if (CKPT) {

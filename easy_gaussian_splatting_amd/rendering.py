@@ -214,7 +214,9 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, holder):
-        need_grad = any(ctx.needs_input_grad[:6])
+        # (needs_input_grad reflects requires_grad of the inputs even under torch.no_grad(); the grad mode
+        #  is captured by the caller, forward() itself always runs with grad disabled)
+        need_grad = bool(cfg.get("grad_enabled", True)) and any(ctx.needs_input_grad[:6])
         ctx.set_materialize_grads(False)   # an unused render_alphas must not cost a zero-filled image
         render_colors, render_alphas, meta, state = _forward_stages(
             means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, need_grad)
@@ -443,7 +445,7 @@ def rasterization(
     cfg = dict(width=int(width), height=int(height), near_plane=float(near_plane),
                far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d),
                sh_degree=sh_degree, tile_culling={"gsplat": 0, "tight": 1}[_tile_culling], sh_grads=_sh_grads,
-               activations={"none": 0, "exp_sigmoid": 1}[_activations])
+               activations={"none": 0, "exp_sigmoid": 1}[_activations], grad_enabled=torch.is_grad_enabled())
     if _sh_grads not in ("dense", "colors_pre") or (_sh_grads == "colors_pre" and sh_degree is None):
         raise ValueError("_sh_grads: 'dense', or 'colors_pre' together with sh_degree")
     holder = _Holder(absgrad)

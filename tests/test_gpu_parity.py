@@ -616,3 +616,25 @@ def test_tile_launch_order_is_a_longest_first_permutation():
     seq = np.array([cls(lens[i]) for i in order])
     assert np.all(np.diff(seq) <= 0), "length classes must not increase along the launch order"
     assert seq[0] == max(cls(v) for v in lens) and host[2] == lens.max() and host[0] == lens.sum()
+
+
+def test_no_grad_takes_the_inference_path():
+    """Under torch.no_grad() parameters that require grad must not make the forward build the backward's
+    lists and checkpoints (same image, no training buffers kept)."""
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    sc = make_scene(3000, 160, 112, sh_degree=2, seed=9, scale_range=(0.02, 0.2), dist=4.0)
+    t = to_dev(sc)
+    ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+    img_g, _, _ = rasterization(*ins, t["viewmats"], t["Ks"], 160, 112, sh_degree=2, packed=False, backgrounds=t["backgrounds"])
+    assert img_g.requires_grad
+    with torch.no_grad():
+        img_n, _, _ = rasterization(*ins, t["viewmats"], t["Ks"], 160, 112, sh_degree=2, packed=False, backgrounds=t["backgrounds"])
+    assert not img_n.requires_grad and torch.equal(img_n, img_g.detach())
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        out = rasterization(*ins, t["viewmats"], t["Ks"], 160, 112, sh_degree=2, packed=False, backgrounds=t["backgrounds"])
+    held_inference = torch.cuda.memory_allocated() - base
+    del out
+    out = rasterization(*ins, t["viewmats"], t["Ks"], 160, 112, sh_degree=2, packed=False, backgrounds=t["backgrounds"])
+    held_training = torch.cuda.memory_allocated() - base
+    assert held_inference < held_training, (held_inference, held_training)
