@@ -227,3 +227,18 @@ def shard_views(n_views: int, rank: Optional[int] = None, world: Optional[int] =
     if world is None:
         world = dist.get_world_size() if is_distributed() else 1
     return list(range(rank, n_views, world))
+
+
+def assert_replicas_identical(t: Tensor, what: str = "tensor", group=None) -> None:
+    """Cheap replica-consistency check (one 3-number all-reduce): every rank must hold the same shape and
+    the same checksum of `t`; raises on all ranks otherwise.  Used after densify_and_prune, where a
+    rank-dependent RNG draw would silently make the replicas diverge."""
+    if not is_distributed():
+        return
+    x = t.detach().double()
+    mine = torch.stack([torch.tensor(float(t.numel()), dtype=torch.float64, device=t.device), x.sum(), (x * x).sum()])
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"replicas diverged: {what} differs between ranks (numel/sum/sumsq min {lo.tolist()} max {hi.tolist()})")

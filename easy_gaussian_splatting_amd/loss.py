@@ -1,11 +1,12 @@
 """L1 + (1 - SSIM) as the reference's train step uses it
-(/root/reference/model/gaussian.py:415-453, lambda_ssim = 0.2 in configs/*.yaml:46).
+(/root/reference/model/gaussian.py:415-453, lambda_ssim = 0.2 in configs/*.yaml:46), plus the optional
+scale-ratio regulariser (/root/reference/model/gaussian.py:376-386, 437-440).
 
-The reference takes SSIM from torchmetrics (`StructuralSimilarityIndexMeasure(data_range=1.0)`),
-which is not installed here; `ssim()` restates that metric in plain torch: 11x11 Gaussian window
-(sigma 1.5), reflect padding, K1=0.01, K2=0.03, mean over the un-padded interior.  Plain torch on
-purpose: the loss produces `v_render_colors` for the hot path, it is not part of it
-(SURVEY.md section 8f-1 lists a fused HIP version as "next").
+On the GPU (default) the loss is the fused HIP path of csrc/gs_loss.hip (`_FusedL1SSIM`: two stencil
+kernels forward, one backward -- SURVEY.md section 8f-1).  The reference takes SSIM from torchmetrics
+(`StructuralSimilarityIndexMeasure(data_range=1.0)`), which is not installed here; `ssim()` restates that
+metric in plain torch (11x11 Gaussian window, sigma 1.5, reflect padding, K1=0.01, K2=0.03, mean over the
+un-padded interior) and is what the CPU tests and `LossComputer(fused=False)` use.
 """
 from __future__ import annotations
 
@@ -61,9 +62,10 @@ class _FusedL1SSIM(torch.autograd.Function):
         ws = torch.empty((int(L.gs_loss_workspace_floats(H, W)),), dtype=torch.float32, device=dev)
         out = torch.empty((3,), dtype=torch.float32, device=dev)
         st = torch.cuda.current_stream(dev).cuda_stream
-        nat.check(L.gs_l1_ssim_fwd(st, H, W, float(lambda_ssim), r.data_ptr(), g.data_ptr(),
-                                   None if m is None else m.data_ptr(), int(clamp_input), ws.data_ptr(), out.data_ptr()),
-                  "gs_l1_ssim_fwd")
+        with torch.cuda.device(dev):
+            nat.check(L.gs_l1_ssim_fwd(st, H, W, float(lambda_ssim), r.data_ptr(), g.data_ptr(),
+                                       None if m is None else m.data_ptr(), int(clamp_input), ws.data_ptr(), out.data_ptr()),
+                      "gs_l1_ssim_fwd")
         ctx.clamp_input = bool(clamp_input)
         ctx.save_for_backward(r, g, ws) if m is None else ctx.save_for_backward(r, g, ws, m)
         ctx.lam = float(lambda_ssim)
@@ -84,8 +86,9 @@ class _FusedL1SSIM(torch.autograd.Function):
         v_render = torch.empty_like(r)
         vt = v_total.contiguous().float()
         st = torch.cuda.current_stream(r.device).cuda_stream
-        nat.check(L.gs_l1_ssim_bwd(st, H, W, ctx.lam, r.data_ptr(), g.data_ptr(), None if m is None else m.data_ptr(),
-                                   int(ctx.clamp_input), ws.data_ptr(), vt.data_ptr(), v_render.data_ptr()), "gs_l1_ssim_bwd")
+        with torch.cuda.device(r.device):
+            nat.check(L.gs_l1_ssim_bwd(st, H, W, ctx.lam, r.data_ptr(), g.data_ptr(), None if m is None else m.data_ptr(),
+                                       int(ctx.clamp_input), ws.data_ptr(), vt.data_ptr(), v_render.data_ptr()), "gs_l1_ssim_bwd")
         return v_render, None, None, None, None
 
 
@@ -94,15 +97,29 @@ class LossComputer:
     and `torch.clamp(., 0, 1)` of /root/reference/model/gaussian.py:368 happens inside the loss (both directions);
     the result equals clamp-then-loss, two full-resolution kernels fewer per step."""
 
-    def __init__(self, lambda_ssim: float = 0.2, fused: bool = True, clamp_input: bool = False):
+    def __init__(self, lambda_ssim: float = 0.2, fused: bool = True, clamp_input: bool = False,
+                 model=None, lambda_scale: float = 0.0):
+        """`model` + `lambda_scale`: the reference's `LossComputer(model, lambda_ssim, lambda_scale)`
+        (/root/reference/model/gaussian.py:415-419) -- when the model's `USE_SCALE_REGULARIZATION` is set,
+        `lambda_scale * model.get_regularization_dict()["scale_reg"]` is added to the total (:437-440)."""
         self.lambda_ssim = lambda_ssim
         self.fused = fused
         self.clamp_input = clamp_input
+        self.model = model
+        self.lambda_scale = lambda_scale
+
+    def _add_regularization(self, d: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        if self.model is not None:
+            reg = self.model.get_regularization_dict()
+            if "scale_reg" in reg:
+                d["scale_reg"] = reg["scale_reg"]
+                d["total"] = d["total"] + self.lambda_scale * reg["scale_reg"]
+        return d
 
     def get_loss_dict(self, render_img: Tensor, gt_img: Tensor, mask: Tensor = None) -> Dict[str, Tensor]:
         if self.fused and render_img.is_cuda and render_img.dtype == torch.float32:
             total, l1, ssim_loss = _FusedL1SSIM.apply(render_img, gt_img, mask, self.lambda_ssim, self.clamp_input)
-            return {"l1": l1, "ssim": ssim_loss, "total": total}
+            return self._add_regularization({"l1": l1, "ssim": ssim_loss, "total": total})
         if self.clamp_input:
             render_img = torch.clamp(render_img, min=0.0, max=1.0)
         if mask is not None:
@@ -113,4 +130,4 @@ class LossComputer:
         g = gt_img.permute(2, 0, 1)[None]
         ssim_loss = 1.0 - ssim(g, r)
         total = (1.0 - self.lambda_ssim) * l1 + self.lambda_ssim * ssim_loss
-        return {"l1": l1, "ssim": ssim_loss, "total": total}
+        return self._add_regularization({"l1": l1, "ssim": ssim_loss, "total": total})

@@ -13,6 +13,7 @@ Checkpoint IO, loaders and the viewer are out of scope.
 """
 from __future__ import annotations
 
+import math
 from typing import Any, Dict, Optional
 
 import torch
@@ -56,13 +57,30 @@ def clamp01(x: Tensor) -> Tensor:
     return torch.clamp(x, min=0.0, max=1.0)
 
 
+class LR_Scheduler:
+    """Log-linear interpolation lr_init -> lr_final over max_steps, constant afterwards
+    (/root/reference/model/utils.py:19-28; pinned by tests/golden/ref_model_utils.npz `lrs`)."""
+
+    def __init__(self, lr_init: float, lr_final: float, max_steps: int) -> None:
+        self.lr_init, self.lr_final, self.max_steps = lr_init, lr_final, max_steps
+
+    def __call__(self, cur_step: int) -> float:
+        t = min(1.0, cur_step / self.max_steps)
+        return float(math.exp(math.log(self.lr_init) * (1.0 - t) + math.log(self.lr_final) * t))
+
+
 class GaussianModel(nn.Module):
     def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, sh_0: Tensor, sh_rest: Tensor,
                  logit_opacities: Tensor, sh_degree: int, sh_degree_interval: int = 0,
                  white_background: bool = False, fuse_sh_cat: bool = True,
                  densify_grad_thresh: float = 0.0002, densify_scale_thresh: float = 0.01, num_splits: int = 2,
-                 prune_radii_ratio_thresh: float = 0.15, prune_scale_thresh: float = 0.1, min_opacity: float = 0.005):
+                 prune_radii_ratio_thresh: float = 0.15, prune_scale_thresh: float = 0.1, min_opacity: float = 0.005,
+                 means_lr_init: float = 1.6e-4, means_lr_final: float = 1.6e-6, means_lr_schedule_max_steps: int = 30000,
+                 use_scale_regularization: bool = False, max_scale_ratio: float = 10.0):
         super().__init__()
+        # (defaults: /root/reference/configs/tandt_db.yaml:17-44)
+        self.means_lr_scheduler = LR_Scheduler(means_lr_init, means_lr_final, means_lr_schedule_max_steps)
+        self.USE_SCALE_REGULARIZATION, self.MAX_SCALE_RATIO = use_scale_regularization, float(max_scale_ratio)
         self.DENSIFY_GRAD_THRESH, self.DENSIFY_SCALE_THRESH, self.NUM_SPLITS = densify_grad_thresh, densify_scale_thresh, num_splits
         self.PRUNE_RADII_RATIO_THRESH, self.PRUNE_SCALE_THRESH, self.MIN_OPACITY = prune_radii_ratio_thresh, prune_scale_thresh, min_opacity
         self.means = nn.Parameter(means.float())  # [N, 3]
@@ -110,6 +128,26 @@ class GaussianModel(nn.Module):
 
     def up_sh_degree(self):
         self.active_sh_degree = min(self.active_sh_degree + 1, self.MAX_SH_DEGREE)
+
+    def update_learning_rate(self, step: int):
+        """Only the `means` group follows a schedule (/root/reference/model/gaussian.py:121-128)."""
+        if self.optimizer is None:
+            raise RuntimeError("optimizer has not been registered")
+        for param_group in self.optimizer.param_groups:
+            if param_group["name"] == "means":
+                param_group["lr"] = self.means_lr_scheduler(step)
+                return
+        raise RuntimeError("the param_group 'means' isn't in the optimizer")
+
+    def get_regularization_dict(self) -> Dict[str, Tensor]:
+        """mean(max(max_k s_k / min_k s_k, MAX_SCALE_RATIO) - MAX_SCALE_RATIO) when enabled
+        (/root/reference/model/gaussian.py:376-386; off in both shipped configs)."""
+        reg: Dict[str, Tensor] = {}
+        if self.USE_SCALE_REGULARIZATION:
+            scales = self.scales
+            ratio = scales.amax(dim=1) / scales.amin(dim=1)
+            reg["scale_reg"] = torch.mean(torch.clamp(ratio, min=self.MAX_SCALE_RATIO) - self.MAX_SCALE_RATIO)
+        return reg
 
     # ---------------------------------------------------------------- refinement (row f-3)
     def _moments(self, name: str):
@@ -164,6 +202,10 @@ class GaussianModel(nn.Module):
             rep = split_idx.repeat(self.NUM_SPLITS)            # [parents..., parents...] like .repeat(NUM_SPLITS, 1)
             scales = torch.exp(params["log_scales"][rep])
             noise = torch.randn((rep.numel(), 3), device=scales.device, generator=generator)
+            if is_distributed():
+                # replicas must stay bitwise identical (distributed.ViewParallelStep): every rank splits with
+                # rank 0's noise, whatever state its own generator is in
+                torch.distributed.broadcast(noise, src=0)
             R = quat_to_rotmat_torch(params["quats"][rep])
             offs = torch.bmm(R, (scales * noise).unsqueeze(-1)).squeeze(-1)
             for name in self.param_names:
@@ -202,6 +244,9 @@ class GaussianModel(nn.Module):
         self.collecting_counts = torch.zeros((n,), device=dev)
         self.max_radii = torch.zeros((n,), device=dev)
         c0, c1, c2 = (int(x) for x in counts.tolist())
+        if is_distributed():
+            from .distributed import assert_replicas_identical
+            assert_replicas_identical(self.means, "means after densify_and_prune")
         return {"train/densify": {"split": ns, "clone": nc},
                 "train/prune": {"low_opacity": c0, "large_radii": c1 - c0, "large_scale": c2 - c1},
                 "train/nbr_gaussians": n, "n_before": n_old}
@@ -239,6 +284,10 @@ class GaussianModel(nn.Module):
             backgrounds=self.BACKGROUND[None],
             absgrad=True,
             packed=False,
+            # the model consumes only radii / means2d / the image (:188-197, 371-372), which are identical in
+            # both list modes: take the shorter, render-equivalent lists (set `tile_culling = "gsplat"` for
+            # bit-exact gsplat list arrays in `meta`)
+            _tile_culling=getattr(self, "tile_culling", "tight"),
             _sh_grads=getattr(self, "sh_grads", "dense"),
             _activations="exp_sigmoid" if raw else "none",
             _on_colors_pre=getattr(self, "on_colors_pre", None),

@@ -20,6 +20,9 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params: List[Dict], betas=(0.9, 0.999), eps: float = 1e-8):
         defaults = dict(lr=1e-3, betas=betas, eps=eps)
         super().__init__(params, defaults)
+        for g in self.param_groups:   # one launch, one set of hyper-parameters (the reference uses Adam's defaults in every group)
+            if tuple(g["betas"]) != tuple(betas) or g["eps"] != eps:
+                raise NotImplementedError("FusedAdam: per-group betas / eps are not supported (only per-group lr)")
         self._build()
 
     def _build(self, moments=None):
@@ -75,6 +78,44 @@ class FusedAdam(torch.optim.Optimizer):
             moments.append((m.detach().clone(), v.detach().clone()))
         self._build(moments)
 
+    # ---- checkpointing: torch.optim.Adam's layout (state[p] = {step, exp_avg, exp_avg_sq}), so a checkpoint
+    # written by the reference's `optimizer.state_dict()` (/root/reference/utils.py:48-87) loads here and back
+    def state_dict(self):
+        for i, (_, p) in enumerate(self._plist):
+            m, v = self.moments_of(p)
+            self.state[p] = {"step": torch.tensor(float(self._step)), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        try:
+            return super().state_dict()
+        finally:
+            self.state.clear()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)   # validates the group structure, restores lr etc., fills self.state
+        steps = set()
+        with torch.no_grad():
+            for _, p in self._plist:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                m, v = self.moments_of(p)
+                m.copy_(st["exp_avg"].reshape(m.shape))
+                v.copy_(st["exp_avg_sq"].reshape(v.shape))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FusedAdam keeps one step count; the checkpoint holds {sorted(steps)}")
+        if steps:
+            self._step = steps.pop()
+        self.state.clear()
+
+    def _check_views(self):
+        """Parameters must still be the views of `flat_param` that `_build` made them (a later
+        `model.to(...)` / `p.data = ...` silently detaches them from what `step` updates)."""
+        base = self.flat_param.data_ptr()
+        for (_, p), o in zip(self._plist, self._offs):
+            if p.data_ptr() != base + 4 * o:
+                raise RuntimeError("FusedAdam: a parameter no longer aliases the flat buffer (moved or re-assigned "
+                                   "after the optimizer was built); rebuild the optimizer")
+
     @torch.no_grad()
     def step(self, closure=None, *, only=None, grad_scale: float = 1.0, advance: bool = True):
         """One Adam step.  `only`: iterable of group names -- update just those groups (the others are
@@ -85,6 +126,7 @@ class FusedAdam(torch.optim.Optimizer):
             raise NotImplementedError("closures are not supported")
         from . import _native as nat
         L = nat.lib()
+        self._check_views()
         if advance:
             self._step += 1
         ns = len(self._plist)

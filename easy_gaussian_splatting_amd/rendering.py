@@ -352,7 +352,7 @@ def rasterization(
     rasterize_mode: str = "classic",
     channel_chunk: int = 32,
     _debug: Optional[Dict] = None,
-    _tile_culling: str = "tight",
+    _tile_culling: str = "gsplat",
     _sh_grads: str = "dense",
     _on_colors_pre=None,
     _activations: str = "none",
@@ -367,11 +367,12 @@ def rasterization(
     Only the configuration the reference exercises is implemented natively; anything else raises
     `NotImplementedError` instead of silently computing something different.
 
-    `_tile_culling="tight"` (default) drops, from gsplat's 3-sigma tile rectangle of each Gaussian,
-    the tiles in which no pixel can reach alpha >= 1/255; the image, alphas, radii, means2d and all
-    gradients are unaffected, only the internal lists (`tiles_per_gauss`, `isect_ids`,
-    `flatten_ids`, `isect_offsets`) become a render-equivalent subset.  `"gsplat"` reproduces the
-    reference's lists exactly.
+    `_tile_culling="gsplat"` (default) reproduces the reference's lists exactly: `meta["tiles_per_gauss"]`,
+    `["isect_ids"]`, `["flatten_ids"]`, `["isect_offsets"]` are bit-for-bit gsplat's.  `"tight"` (opt-in; what
+    `model.GaussianModel` passes, since the reference model reads only `radii` and `means2d`,
+    /root/reference/model/gaussian.py:188-197, 371-372) drops, from gsplat's 3-sigma tile rectangle of each
+    Gaussian, the tiles in which no pixel can reach alpha >= 1/255; the image, alphas, radii, means2d and
+    all gradients are unaffected, only those four list arrays become a render-equivalent subset.
 
     `_sh_grads="colors_pre"` (SH colours only; used by `distributed.ViewParallelStep`) leaves the
     gradients of the SH coefficients to `gs_sh_grad_views`: backward returns `None` for `colors`
@@ -426,6 +427,10 @@ def rasterization(
         raise NotImplementedError(f"only tile_size={_TILE} is implemented")
     if sparse_grad:
         raise NotImplementedError("sparse_grad requires packed=True")
+    if viewmats.requires_grad or Ks.requires_grad:
+        # gsplat returns camera gradients; the reference never asks for them and this path
+        # does not compute them -- refuse instead of handing back None silently
+        raise NotImplementedError("gradients w.r.t. viewmats / Ks are not implemented (the reference's cameras are constants)")
     if not means.is_cuda:
         raise RuntimeError("rasterization() runs on the GPU only: tensors must live on a HIP device "
                            "(there is no CPU fallback in this package)")

@@ -47,6 +47,25 @@ def make_scene(n: int, width: int, height: int, sh_degree: int = 3, n_views: int
                 width=width, height=height, sh_degree=sh_degree)
 
 
+def dense_scene(n: int, seed: int, width: int = 64, height: int = 48, normal: float = 0.08, flat: float = 0.03):
+    """Long per-tile lists (every Gaussian lands in the central tiles) that stay OFF the blend's thresholds:
+    most Gaussians can never reach alpha = 1/255 (listed, evaluated, never taken, never near the threshold),
+    `normal` of them are ordinary faint splats and `flat` are flat, image-covering ones that contribute to
+    every pixel without crossing 1/255 -- the lists are walked to the end (total alpha stays below saturation)
+    while only a few per cent of the pixels sit within 1e-4 of a discontinuity."""
+    rng = np.random.default_rng(seed)
+    sc = make_scene(n, width, height, sh_degree=0, seed=seed, scale_range=(0.2, 0.6), dist=4.0, extent=(0.3, 0.3, 0.5))
+    u = rng.random(n)
+    op = rng.uniform(0.0005, 0.0035, n)
+    k1 = u < normal
+    op[k1] = rng.uniform(0.004, 0.024, int(k1.sum()))
+    k2 = (u >= normal) & (u < normal + flat)
+    op[k2] = rng.uniform(0.006, 0.008, int(k2.sum()))
+    sc["scales"][k2] = rng.uniform(12, 20, (int(k2.sum()), 3)).astype(np.float32)
+    sc["opacities"] = op.astype(np.float32)
+    return sc
+
+
 # BASELINE.json configs (synthetic stand-ins at the stated N / HxW; see SURVEY.md section 8d)
 def config_s1(seed=42):
     return make_scene(10_000, 256, 256, sh_degree=0, seed=seed, extent=(2, 2, 2), scale_range=(0.01, 0.1), dist=5.0)

@@ -369,7 +369,8 @@ int gso_blend_fwd(int C, int N, int W, int H, int tile, const real* means2d, con
 }
 
 /* Per-pixel distance to the blend's discontinuities (alpha >= 1/255 test, T <= 1e-4 early-out,
- * sigma >= 0 test): min over the pairs the forward visits of the RELATIVE gap to the threshold.
+ * sigma >= 0 test): min over the pairs the forward visits of the RELATIVE gap to the threshold
+ * (for sigma: relative to the magnitude of the quadratic form's terms).
  * Pixels with a tiny margin can legitimately flip a contributor under 1-ulp arithmetic
  * differences; parity tests use this to separate them from real errors. */
 int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, const real* conics,
@@ -394,7 +395,13 @@ int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, 
                 if (alpha > ALPHA_MAX) alpha = ALPHA_MAX;
                 real ma = RABS(alpha - ALPHA_MIN) / ALPHA_MIN;
                 if (ma < m) m = ma;
-                if (RABS(sigma) < m && opac[g] >= ALPHA_MIN) m = RABS(sigma);
+                /* sigma >= 0: the form is positive (semi-)definite, so only rounding inside its own evaluation can
+                 * make it negative -- the gap is measured relative to the magnitude of its three terms */
+                if (opac[g] >= ALPHA_MIN) {
+                    real mag = (real)0.5 * (RABS(conics[3 * g] * dx * dx) + RABS(conics[3 * g + 2] * dy * dy)) + RABS(conics[3 * g + 1] * dx * dy);
+                    real ms = mag > 0 ? RABS(sigma) / mag : 1;
+                    if (ms < m) m = ms;
+                }
                 if (sigma < 0 || alpha < ALPHA_MIN) continue;
                 real Tn = T * (1 - alpha);
                 real mt = RABS(Tn - T_MIN) / T_MIN;

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from oracle import c_oracle as CO
-from scenes import config_bench_1m, config_s1, make_scene
+from scenes import config_bench_1m, config_s1, dense_scene, make_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -57,10 +57,35 @@ def run_oracle(sc, use_bg=True, dtype=np.float64):
                      backgrounds=sc["backgrounds"] if use_bg else None, dtype=dtype)
 
 
+MAX_RAZOR_FRAC = 0.05   # scenes are built to stay off the blend thresholds (synthetic.dense_scene)
+
+
+def _mismatch_pixels(meta, fw, mism):
+    """[C,H,W] mask of the pixels whose tile list can differ because a radius differs by the ceil() of a
+    rounding error: the tiles either rectangle (HIP's or the oracle's) of such a Gaussian touches."""
+    C, N = fw["radii"].shape
+    inp = fw["_inputs"]
+    W, H, tile = inp["width"], inp["height"], inp["tile_size"]
+    tw, th = fw["tile_width"], fw["tile_height"]
+    tmask = np.zeros((C, th, tw), bool)
+    rad_h = meta["radii"].cpu().numpy()
+    for c, n in zip(*np.nonzero(mism)):
+        r = max(int(rad_h[c, n]), int(fw["radii"][c, n]))
+        mx, my = fw["means2d"][c, n]
+        x0, x1 = int(np.clip(np.floor((mx - r) / tile), 0, tw)), int(np.clip(np.ceil((mx + r) / tile), 0, tw))
+        y0, y1 = int(np.clip(np.floor((my - r) / tile), 0, th)), int(np.clip(np.ceil((my + r) / tile), 0, th))
+        tmask[c, y0:y1, x0:x1] = True
+    return np.repeat(np.repeat(tmask, tile, axis=1), tile, axis=2)[:, :H, :W]
+
+
 def check_forward(hip, fw, max_razor_frac=1e-2, lists=True, outlier_frac=0.0):
+    assert max_razor_frac <= MAX_RAZOR_FRAC
     meta = hip["meta"]
     radii = meta["radii"].cpu().numpy()
     mism = radii != fw["radii"]
+    if mism.any():   # fp32 vs fp64 ceil(3 sigma): must be a +-1 flip of a visible Gaussian, and rare
+        print(f"[parity] {int(mism.sum())} of {mism.size} radii differ from the oracle's")
+        assert np.abs(radii.astype(np.int64) - fw["radii"])[mism].max() <= 1, "a radius differs by more than the ceil() flip"
     assert mism.mean() <= 1e-4, f"radii mismatch fraction {mism.mean()}"
     same = ~mism
     assert np.abs(meta["means2d"].cpu().numpy() - fw["means2d"])[same].max(initial=0) < 2e-3
@@ -68,17 +93,17 @@ def check_forward(hip, fw, max_razor_frac=1e-2, lists=True, outlier_frac=0.0):
     con = meta["conics"].cpu().numpy()
     assert (np.abs(con - fw["conics"]) / (np.abs(fw["conics"]) + 1e-2))[same].max(initial=0) < 2e-3
     exact_lists = (not mism.any()) and (not lists or np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), fw["tiles_per_gauss"]))
-    if exact_lists and lists:  # integer / index work must then be bit-exact
+    if lists and not mism.any():  # integer / index work must then be bit-exact
+        assert np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), fw["tiles_per_gauss"])
         assert np.array_equal(meta["isect_offsets"].cpu().numpy(), fw["isect_offsets"])
         assert np.array_equal(meta["flatten_ids"].cpu().numpy(), fw["flatten_ids"])
     err = np.abs(hip["img"].detach().cpu().numpy() - fw["render_colors"]).max(-1)
     aerr = np.abs(hip["alpha"].detach().cpu().numpy() - fw["render_alphas"])[..., 0]
     razor = CO.blend_margin(fw) < 1e-4
     strict = ~razor
-    if not exact_lists:  # a flipped radius / tile rectangle changes a few lists; those pixels are razor-edge too
-        strict &= err < 10 * FWD_ATOL
-        assert (err >= 10 * FWD_ATOL).mean() < 1e-3
-    assert razor.mean() <= max_razor_frac
+    if mism.any():  # only the tiles a flipped radius touches may hold a different list
+        strict &= ~_mismatch_pixels(meta, fw, mism)
+    assert razor.mean() <= max_razor_frac, f"razor-edge pixel fraction {razor.mean()}"
     # outlier_frac > 0 only where the reference itself is the wrong precision for a pixel-exact claim
     # (fp64 oracle at hundreds of contributors per pixel; the fp32 oracle is then checked strictly)
     assert (err[strict] > FWD_ATOL).mean() <= outlier_frac, f"forward RGB err {err[strict].max()}, {(err[strict] > FWD_ATOL).sum()} pixels"
@@ -92,7 +117,8 @@ def check_backward(hip, fw, rtol=GRAD_RTOL):
     """Gradients within `rtol` of the tensor's largest reference magnitude.  The reference is the fp64
     oracle; when a pixel sits on a blend discontinuity, fp32 arithmetic (the path's dtype) may flip
     that one contributor and move a single Gaussian's gradient by more than the tolerance -- in
-    that case the fp32 build of the same oracle, which takes the same decision, is the arbiter."""
+    that case the fp32 build of the same oracle, which takes the same decision, is the arbiter, and
+    then for EVERY tensor of the call (one arbiter per call, never a per-tensor pick)."""
     bw = CO.backward(fw, hip["vc"], hip["va"])
     names = ["v_means", "v_quats", "v_scales", "v_opacities", "v_colors"]
 
@@ -111,8 +137,8 @@ def check_backward(hip, fw, rtol=GRAD_RTOL):
         fw32 = CO.render(inp["means"], inp["quats"], inp["scales"], fw["opacities"][0], inp["shs"] if inp["shs"] is not None else fw["colors"],
                          inp["viewmats"], inp["Ks"], inp["width"], inp["height"], sh_degree=inp["sh_degree"], backgrounds=inp["bg"],
                          dtype=np.float32)
-        err32 = errors(CO.backward(fw32, hip["vc"].astype(np.float32), hip["va"].astype(np.float32)))
-        err = {k: min(err[k], err32[k]) for k in err}
+        print(f"[parity] fp64 arbiter failed ({ {k: float('%.2e' % v) for k, v in err.items()} }); fp32 oracle arbitrates all tensors")
+        err = errors(CO.backward(fw32, hip["vc"].astype(np.float32), hip["va"].astype(np.float32)))
     for name, e in err.items():
         assert e <= rtol, f"{name}: rel err {e}"
     return bw
@@ -244,20 +270,18 @@ def test_empty_and_invisible_inputs():
 def test_large_tile_lists_hit_every_sort_class():
     """Tiles with > 2048 (LDS large class) and > 16384 (global-memory class) entries, and Gaussians
     that cover every tile (wave-cooperative binning and row-reduction paths)."""
-    rng = np.random.default_rng(0)
-    n = 20000
-    sc = make_scene(n, 64, 48, sh_degree=0, seed=12, scale_range=(0.2, 0.6), dist=4.0, extent=(0.3, 0.3, 0.5))
-    sc["opacities"] = (rng.random(n) * 0.02 + 0.004).astype(np.float32)  # faint: lists are walked to the end
+    sc = dense_scene(20000, 12)   # faint / never-taken / flat mixture: lists are walked to the end
     hip, fw = run_hip(sc), run_oracle(sc)
     counts = np.diff(np.append(fw["isect_offsets"].reshape(-1), fw["n_isects"]))
     assert counts.max() > 16384 and fw["tiles_per_gauss"].max() == 12
-    assert check_forward(hip, fw, max_razor_frac=0.5)  # lists must match exactly (bit-exact sort)
+    assert float(fw["render_alphas"].max()) < 1 - 2e-4, "no pixel may saturate: every list is walked to its end"
+    assert check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC)  # lists must match exactly (bit-exact sort)
     check_backward(hip, fw)
-    sc2 = make_scene(3000, 64, 48, sh_degree=0, seed=13, scale_range=(0.2, 0.6), dist=4.0, extent=(0.3, 0.3, 0.5))
+    sc2 = dense_scene(3000, 13)
     hip2, fw2 = run_hip(sc2), run_oracle(sc2)
     c2 = np.diff(np.append(fw2["isect_offsets"].reshape(-1), fw2["n_isects"]))
     assert 2048 < c2.max() <= 16384
-    assert check_forward(hip2, fw2, max_razor_frac=0.5)
+    assert check_forward(hip2, fw2, max_razor_frac=MAX_RAZOR_FRAC)
     check_backward(hip2, fw2)
 
 
@@ -476,7 +500,7 @@ def test_randomised_configurations(case):
         grads = list(grads[:4]) + [torch.cat([grads[4], grads[5]], dim=1)]
     hip = dict(img=img, alpha=alpha, meta=meta, grads=grads, vc=vc.numpy().astype(np.float64), va=va.numpy().astype(np.float64))
     fw = run_oracle(sc, use_bg=use_bg)
-    check_forward(hip, fw, max_razor_frac=5e-2, lists=culling == "gsplat")
+    check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC, lists=culling == "gsplat")
     if fw["n_isects"] > 0:
         check_backward(hip, fw)
 
@@ -485,9 +509,7 @@ def test_randomised_configurations(case):
 def test_every_sort_size_class_orders_like_a_stable_global_sort(n, lo, hi):
     """One scene per size class of the per-tile sort (radix <= 1024 / 4096 / 8192, bitonic <= 16384):
     inside every tile the ids must be ordered by (depth bits, flatten id), every id exactly once."""
-    rng = np.random.default_rng(n)
-    sc = make_scene(n, 64, 48, sh_degree=0, seed=100 + n, scale_range=(0.2, 0.6), dist=4.0, extent=(0.3, 0.3, 0.5))
-    sc["opacities"] = (rng.random(n) * 0.02 + 0.004).astype(np.float32)
+    sc = dense_scene(n, 100 + n)
     hip = run_hip(sc, bwd=False)
     meta = hip["meta"]
     off = meta["isect_offsets"].reshape(-1).cpu().numpy().astype(np.int64)
@@ -519,7 +541,7 @@ def test_saturated_tiles_stop_early_and_leave_clean_masks():
         junk = torch.full((64 << 20,), 0x7f, dtype=torch.uint8, device="cuda:0")   # poison the caching allocator's pool
         del junk
         hip = run_hip(sc)
-        assert check_forward(hip, fw, max_razor_frac=0.5)
+        assert check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC)
         check_backward(hip, fw)
 
 

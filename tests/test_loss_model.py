@@ -52,3 +52,60 @@ def test_model_activations_and_optimizer_groups():
     opt = build_optimizers(m, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2)
     assert [g["name"] for g in opt.param_groups] == m.param_names
     assert [g["lr"] for g in opt.param_groups] == [1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2]
+
+
+def test_means_lr_schedule_matches_reference_fixture():
+    """`update_learning_rate` / `LR_Scheduler` against values captured from the reference's own
+    model/utils.py:19-28 (tests/golden/make_golden.py: `lrs`)."""
+    import os
+    from easy_gaussian_splatting_amd.model import LR_Scheduler
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_model_utils.npz"))
+    sched = LR_Scheduler(float(z["lr_init"]), float(z["lr_final"]), int(z["lr_max_steps"]))
+    got = np.array([sched(int(s)) for s in z["lr_steps"]])
+    assert np.allclose(got, z["lrs"], rtol=1e-12, atol=0)
+    N = 6
+    m = GaussianModel(means=torch.zeros(N, 3), log_scales=torch.zeros(N, 3), quats=torch.ones(N, 4), sh_0=torch.zeros(N, 1, 3),
+                      sh_rest=torch.zeros(N, 15, 3), logit_opacities=torch.zeros(N), sh_degree=3,
+                      means_lr_init=float(z["lr_init"]), means_lr_final=float(z["lr_final"]), means_lr_schedule_max_steps=int(z["lr_max_steps"]))
+    try:
+        m.update_learning_rate(10)
+        raise AssertionError("must refuse without an optimizer")
+    except RuntimeError:
+        pass
+    opt = build_optimizers(m, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2)
+    for s, lr in zip(z["lr_steps"], z["lrs"]):
+        m.update_learning_rate(int(s))
+        lrs = {g["name"]: g["lr"] for g in opt.param_groups}
+        assert abs(lrs["means"] - lr) <= 1e-12 * lr
+        assert lrs["log_scales"] == 5e-3 and lrs["logit_opacities"] == 5e-2   # only the means group is scheduled
+
+
+def test_scale_ratio_regulariser_and_total():
+    """mean(max(s_max / s_min, R) - R), added as lambda_scale * reg to the total; gradient reaches log_scales
+    (/root/reference/model/gaussian.py:376-386, 437-440)."""
+    g = torch.Generator().manual_seed(3)
+    N = 50
+    ls = torch.randn(N, 3, generator=g) * 1.5
+    m = GaussianModel(means=torch.zeros(N, 3), log_scales=ls, quats=torch.ones(N, 4), sh_0=torch.zeros(N, 1, 3),
+                      sh_rest=torch.zeros(N, 0, 3), logit_opacities=torch.zeros(N), sh_degree=0,
+                      use_scale_regularization=True, max_scale_ratio=4.0)
+    reg = m.get_regularization_dict()["scale_reg"]
+    s = np.exp(ls.double().numpy())
+    ratio = s.max(1) / s.min(1)
+    ref = np.mean(np.maximum(ratio, 4.0) - 4.0)
+    assert ref > 0 and abs(reg.item() - ref) < 1e-5 * ref
+    r, t = torch.rand(32, 48, 3, generator=g), torch.rand(32, 48, 3, generator=g)
+    plain = LossComputer(lambda_ssim=0.2).get_loss_dict(r, t, torch.zeros(32, 48))
+    d = LossComputer(lambda_ssim=0.2, model=m, lambda_scale=0.5).get_loss_dict(r, t, torch.zeros(32, 48))
+    assert abs(d["total"].item() - (plain["total"].item() + 0.5 * reg.item())) < 1e-6 and "scale_reg" in d
+    d["total"].backward()
+    assert m.log_scales.grad is not None and float(m.log_scales.grad.abs().max()) > 0
+    # d reg / d log_s = ratio/N * (+1 at argmax, -1 at argmin) where ratio > R
+    exp_g = np.zeros((N, 3))
+    for i in range(N):
+        if ratio[i] > 4.0:
+            exp_g[i, s[i].argmax()] += 0.5 * ratio[i] / N
+            exp_g[i, s[i].argmin()] -= 0.5 * ratio[i] / N
+    assert np.abs(m.log_scales.grad.numpy() - exp_g).max() < 1e-5 * np.abs(exp_g).max()
+    m.USE_SCALE_REGULARIZATION = False
+    assert m.get_regularization_dict() == {}
