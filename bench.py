@@ -6,40 +6,208 @@
 A "step" is one training iteration of the reference's loop around the seam
 (/root/reference/train.py:93-157 without DataLoader / TensorBoard): activations ->
 rasterization forward -> clamp -> L1 + (1-SSIM) -> backward -> update_statistics ->
-[RCCL all-reduce of the flat gradient bucket when N>1] -> Adam step -> zero grads,
+[gradient exchange over RCCL when N>1] -> Adam step -> zero grads,
 on the workload BASELINE.json quotes its metric on: 1 M Gaussians, 1920x1080, SH degree 3
 (synthetic generator of SURVEY.md section 8d; there is no dataset in this environment).
 One rank per GPU, one view per rank per step (weak scaling); `value` = view-iterations/s of the
 whole job.  Forward-only render fps of the same workload is reported next to it.
 
-Extra objects: `roofline` for the dominant blend kernel (algorithmic bytes of SURVEY.md 8d over
-its HIP-event duration on the launch stream) and `cpu_baseline` (the C/OpenMP oracle timed on
-the host cores on a bounded sample; rank 0, N=1 only).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process stays GPU-free, starts N
+fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), waits for them and exits with
+the first non-zero status.  Under `torch.distributed.run` (WORLD_SIZE set) it is one of the ranks.
+
+Extra objects: `roofline` for the dominant blend kernel (algorithmic bytes of SURVEY.md 8d for the
+intersections the launch actually processed, over its HIP-event duration on the launch stream),
+`roofline_compute` (the same kernel against the VALU issue rate, the limiter it actually has) and
+`cpu_baseline` (the C/OpenMP oracle timed on the host cores on a bounded sample; rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from easy_gaussian_splatting_amd import rendering  # noqa: E402
-from easy_gaussian_splatting_amd.distributed import GradBucket, ViewParallelStep, all_reduce_param_grads  # noqa: E402
-from easy_gaussian_splatting_amd.loss import LossComputer  # noqa: E402
-from easy_gaussian_splatting_amd.model import GaussianModel, build_optimizers  # noqa: E402
-from easy_gaussian_splatting_amd.synthetic import config_bench_1m  # noqa: E402
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_SIMD = 1024            # 256 CUs x 4 SIMD-32
+VALU_CYCLES_PER_WAVE_INST = 2.0   # wave64 on a SIMD-32 (same guide, cycle-constants table)
+CLOCK_HZ = 2.4e9
+PROFILE_TAGS = ("r02", "r01")     # committed rocprofv3 summaries under profiles/, newest first
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary timings (gsplat-list mode, long lists)")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP Adam")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured hipGraph")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Parent of an N-rank run: never touches the GPU (no torch.cuda / HIP call happens in this process),
+    starts N fresh interpreters on this file, one per GPU, and returns the first non-zero exit status."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            r = p.poll()
+            if r is None:
+                continue
+            procs.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                deadline = time.time() + 30.0   # a failed rank leaves the others stuck in a collective
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ helpers
+def _percentiles(ms):
+    import numpy as np
+    a = np.asarray(ms, dtype=np.float64)
+    return {"median": round(float(np.median(a)), 4), "p10": round(float(np.percentile(a, 10)), 4),
+            "p90": round(float(np.percentile(a, 90)), 4), "mean": round(float(a.mean()), 4), "n": int(a.size)}
+
+
+def _profile_json(name: str):
+    for tag in PROFILE_TAGS:
+        path = os.path.join(ROOT, "profiles", f"{tag}_{name}")
+        try:
+            with open(path) as f:
+                return json.load(f), f"profiles/{tag}_{name}"
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def pmc_traffic(kernel_prefix: str):
+    """HBM bytes per launch of the kernel whose name starts with `kernel_prefix`, from the committed rocprofv3
+    --pmc passes of this same command (profiles/rNN_pmc_traffic.json, produced by tools/pmc_summary.py with the
+    gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); None when no such profile is committed."""
+    data, src = _profile_json("pmc_traffic.json")
+    if not data:
+        return None, None
+    for k, v in data.items():
+        if k.startswith(kernel_prefix) and v.get("traffic_bytes_per_launch") is not None:
+            return v["traffic_bytes_per_launch"], src
+    return None, src
+
+
+def sq_counters(kernel_prefix: str):
+    data, src = _profile_json("sq_counters.json")
+    if not data:
+        return None, None
+    for k, v in data.items():
+        if k.startswith(kernel_prefix):
+            return v, src
+    return None, src
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sc, sample_n: int, reps: int):
+    """Oracle (C + OpenMP, all host cores) on the first `sample_n` Gaussians of the same workload: rasterization
+    forward + backward, one warm-up (spins the OpenMP pool up, pages the arrays in) + `reps` timed repetitions.
+    Plus the S1 leg of BASELINE.md section 3: the pure-PyTorch restatement on configs[0] (10 k Gaussians, 256x256,
+    SH0), forward and forward+backward.  Reported baselines only."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle as CO
+    CO.build()
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    n = min(sample_n, sc["means"].shape[0])
+    W, H = sc["width"], sc["height"]
+    vc = None
+    times, n_isects = [], 0
+    for rep in range(reps + 1):
+        t0 = time.perf_counter()
+        fw = CO.render(sc["means"][:n], sc["quats"][:n], sc["scales"][:n], sc["opacities"][:n], sc["shs"][:n],
+                       sc["viewmats"][:1], sc["Ks"][:1], W, H, sh_degree=sc["sh_degree"],
+                       backgrounds=sc["backgrounds"][:1], dtype=np.float32)
+        if vc is None:
+            vc = (np.random.default_rng(0).standard_normal(fw["render_colors"].shape) / (W * H)).astype(np.float32)
+        CO.backward(fw, vc)
+        if rep > 0:
+            times.append(time.perf_counter() - t0)
+        n_isects = fw["n_isects"]
+    med = float(np.median(times))
+    out = {"value": round(1.0 / med, 4), "unit": "iters/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+           "reps_s": [round(t, 3) for t in times],
+           "sample": f"oracle/c (C+OpenMP) rasterization fwd+bwd, first {n} of the workload's Gaussians at {W}x{H} "
+                     f"SH{sc['sh_degree']}, I={n_isects} (gsplat lists), median of {reps} repetitions after 1 warm-up"}
+    # S1 leg: pure-PyTorch restatement (oracle/torch_oracle.py), all cores
+    try:
+        from easy_gaussian_splatting_amd.synthetic import config_s1
+        from oracle import torch_oracle as TO
+        torch.set_num_threads(cores)
+        s1 = config_s1()
+        T = lambda k: torch.from_numpy(s1[k]).double()
+        ins = [T(k).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+
+        def s1_run(bwd):
+            t0 = time.perf_counter()
+            img, alpha, _ = TO.rasterization(*ins, T("viewmats"), T("Ks"), 256, 256, sh_degree=0, packed=False, backgrounds=T("backgrounds"))
+            if bwd:
+                torch.autograd.grad(img.sum(), ins)
+            return time.perf_counter() - t0
+
+        s1_run(False)
+        f = min(s1_run(False) for _ in range(2))
+        fb = min(s1_run(True) for _ in range(2))
+        out["s1_torch"] = {"workload": "configs[0]: 10k Gaussians, 256x256, SH0, oracle/torch_oracle.py (fp64, autograd), "
+                                       f"{cores} threads", "fwd_ms": round(1e3 * f, 1), "fwd_bwd_ms": round(1e3 * fb, 1)}
+    except Exception as e:   # the S1 leg must never cost the bench line
+        out["s1_torch"] = {"error": repr(e)[:200]}
+    return out
 
 
 def build_workload(n_gauss: int, n_views: int, device):
+    import numpy as np
+    import torch
+    from easy_gaussian_splatting_amd.model import GaussianModel
+    from easy_gaussian_splatting_amd.synthetic import config_bench_1m
     sc = config_bench_1m(seed=42, n=n_gauss, n_views=max(n_views, 1))
     t = lambda a: torch.from_numpy(a).to(device)
     shs = t(sc["shs"])
@@ -51,68 +219,52 @@ def build_workload(n_gauss: int, n_views: int, device):
     return sc, model
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
-    command (profiles/r01_pmc_traffic.json, produced by tools/pmc_summary.py with the gfx950
-    FETCH_SIZE x2 correction of MI355X_MICROARCH.md); None when no such profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel, {}).get("traffic_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
-
-
-def cpu_baseline(sc, sample_n: int):
-    """Oracle (C + OpenMP, all host cores) on the first `sample_n` Gaussians of the same workload:
-    one rasterization forward + backward.  Reported baseline only."""
-    from oracle import c_oracle as CO
-    CO.build()
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    n = min(sample_n, sc["means"].shape[0])
-    W, H = sc["width"], sc["height"]
-    t0 = time.time()
-    fw = CO.render(sc["means"][:n], sc["quats"][:n], sc["scales"][:n], sc["opacities"][:n], sc["shs"][:n],
-                   sc["viewmats"][:1], sc["Ks"][:1], W, H, sh_degree=sc["sh_degree"],
-                   backgrounds=sc["backgrounds"][:1], dtype=np.float32)
-    vc = (np.random.default_rng(0).standard_normal(fw["render_colors"].shape) / (W * H)).astype(np.float32)
-    CO.backward(fw, vc)
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "iters/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/c (C+OpenMP) rasterization fwd+bwd, first {n} of the workload's Gaussians "
-                      f"at {W}x{H} SH{sc['sh_degree']}, I={fw['n_isects']}, 1 repetition, {dt:.2f} s"}
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of the HIP Adam")
-    args = ap.parse_args()
-
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args) -> int:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --gpus equal to the number of ranks")
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+    import torch
+    import torch.distributed as dist
+
+    if os.environ.get("GS_BENCH_DRYRUN") == "1":
+        # launcher self-test (tests/test_bench_launcher.py): rendezvous only, no GPU, no product code
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": dist.get_world_size(), "rank_sum": float(t.item())}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return 0
+
+    import numpy as np
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
-    dev_index = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and n_dev < world:
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, this node shows {n_dev} "
+                         "(RCCL refuses two ranks on one device; GS_BENCH_BACKEND=gloo exercises the code path only)")
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm.  GS_BENCH_BACKEND=gloo only exists to exercise this code path with
-        # several ranks on a 1-GPU box (RCCL refuses two ranks on one device); never used for numbers.
-        backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+        # GS_BENCH_BACKEND=gloo only exists to exercise this code path with several ranks on a 1-GPU box; never used for numbers
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+
+    from easy_gaussian_splatting_amd import rendering
+    from easy_gaussian_splatting_amd.distributed import GradBucket, ViewParallelStep, all_reduce_param_grads
+    from easy_gaussian_splatting_amd.loss import LossComputer
+    from easy_gaussian_splatting_amd.model import build_optimizers
 
     n_views = max(8, world)
     sc, model = build_workload(args.gaussians, n_views, device)
@@ -125,17 +277,20 @@ def main():
     gt_img = torch.nn.functional.interpolate(gt_img.permute(2, 0, 1)[None], size=(H, W), mode="bilinear",
                                              align_corners=False)[0].permute(1, 2, 0).contiguous()
     mask = torch.zeros((H, W), device=device)
+    lrs = (1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2)   # /root/reference/configs/tandt_db.yaml
     if args.torch_adam:
-        optimizer = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused=True)
+        optimizer = build_optimizers(model, *lrs, fused=True)
         bucket = GradBucket(model.parameters())
     else:  # one HIP kernel per step over flat params/moments; gradients are autograd's own tensors
-        optimizer = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused="hip")
+        optimizer = build_optimizers(model, *lrs, fused="hip")
         bucket = None
     loss_computer = LossComputer(lambda_ssim=0.2, clamp_input=True)   # the model's clamp(0,1) is applied inside the loss kernels
     # N > 1: factorised exchange (all-gather of colour gradients + all-reduce of the geometry
     # gradients, distributed.ViewParallelStep); GS_DP_EXCHANGE=allreduce selects the plain all-reduce
     exchange = "none" if world == 1 else os.environ.get("GS_DP_EXCHANGE", "factorised")
     vp = ViewParallelStep(model, optimizer) if (exchange == "factorised" and bucket is None) else None
+    if world > 1 and vp is None:
+        exchange = "allreduce"
 
     one = torch.ones((), device=device)   # root gradient, allocated once (backward() would fill a new one per step)
 
@@ -161,72 +316,129 @@ def main():
             optimizer.zero_grad()
         return out
 
+    # Single GPU, HIP Adam: the whole step is captured once into a hipGraph and replayed (train_graph.TrainStepGraph:
+    # capacity-sized list buffers, no host read-back; a step whose lists outgrow the capacity is a device-side no-op
+    # that the runner detects, re-captures with larger buffers and replays)
+    graph_step = None
+    if world == 1 and not args.no_graph and not args.torch_adam:
+        try:
+            from easy_gaussian_splatting_amd.train_graph import TrainStepGraph
+            graph_step = TrainStepGraph(model, optimizer, loss_computer, data, gt_img, mask)
+        except ImportError:
+            graph_step = None
+    step_fn = graph_step.step if graph_step is not None else train_step
+
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_loop(fn, steps, warmup):
+        """EXACTLY `steps` calls of fn between barrier+synchronize brackets (wall clock, the contract's number),
+        with one HIP event per step boundary on the launch stream for the per-step distribution."""
+        for _ in range(warmup):
+            fn()
+        barrier()
+        rendering.stats["sync_wait_ns"] = 0
+        stream = torch.cuda.current_stream(device)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        evs[0].record(stream)
+        for i in range(steps):
+            fn()
+            evs[i + 1].record(stream)
+        t_enq = time.perf_counter() - t0
+        barrier()
+        elapsed = time.perf_counter() - t0
+        per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+        return elapsed, t_enq, per_step, rendering.stats["sync_wait_ns"] * 1e-6 / max(steps, 1)
+
     # ---- train iterations (the timed region)
-    for _ in range(args.warmup):
-        train_step()
-    barrier()
-    rendering.stats["sync_wait_ns"] = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = train_step()
-    t_enqueued = time.perf_counter() - t0
-    barrier()
-    elapsed = time.perf_counter() - t0
-    host_wait_ms = rendering.stats["sync_wait_ns"] * 1e-6 / args.steps
+    elapsed, t_enqueued, step_ms, host_wait_ms = timed_loop(step_fn, args.steps, args.warmup)
+    if graph_step is not None:
+        graph_step.finish()   # deferred overflow check of the last replay
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     # ---- forward-only render fps (eval path: /root/reference/eval.py:38-43, but synchronised)
-    with torch.no_grad():
-        for _ in range(max(3, args.warmup // 2)):
+    def fwd_only():
+        with torch.no_grad():
             model(data)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            model(data)
-        torch.cuda.synchronize()
-        fwd_elapsed = time.perf_counter() - t1
+
+    fwd_elapsed, _, fwd_ms, _ = timed_loop(fwd_only, args.steps, max(3, args.warmup // 2))
+
+    extras = {}
+    if world == 1 and not args.no_extras:
+        # the same two numbers with the reference's own (3-sigma) tile lists, i.e. meta's list arrays bit-exact
+        model.tile_culling = "gsplat"
+        e2, _, s2, _ = timed_loop(train_step, min(args.steps, 50), 10)
+        f2, _, fm2, _ = timed_loop(fwd_only, min(args.steps, 50), 5)
+        model.tile_culling = "tight"
+        extras["gsplat_list_mode"] = {"train_iters_per_s": round(min(args.steps, 50) / e2, 2), "train_ms": _percentiles(s2),
+                                      "forward_fps": round(min(args.steps, 50) / f2, 2), "forward_ms": _percentiles(fm2),
+                                      "note": "eager (not graph-replayed) steps with _tile_culling='gsplat'"}
 
     # ---- per-stage device times (HIP events on the launch stream), outside the timed region
     rendering.profile_stages(True)
     for _ in range(min(args.steps, 20)):
-        out = train_step()
+        train_step()
     stages = rendering.profile_stages(False) or {}
     stage_ms = {k: float(np.mean(v)) for k, v in stages.items()}
 
+    rc = 0
     if rank == 0:
+        dbg = {}
+        ins = [p.detach().clone().requires_grad_(True) for p in (model.means, model.quats, model.log_scales, model.logit_opacities)]
+        _, _, meta = rendering.rasterization(ins[0], ins[1], ins[2], ins[3], (model.sh_0, model.sh_rest),
+                                             data["w2c"][None], data["K"][None], W, H,
+                                             sh_degree=model.active_sh_degree, packed=False,
+                                             backgrounds=model.BACKGROUND[None], absgrad=True, _tile_culling="tight",
+                                             _activations="exp_sigmoid", _debug=dbg)
         with torch.no_grad():
-            _, _, meta = rendering.rasterization(model.means, model.quats, model.scales, model.opacities, model.shs,
-                                                 data["w2c"][None], data["K"][None], W, H,
-                                                 sh_degree=model.active_sh_degree, packed=False,
-                                                 backgrounds=model.BACKGROUND[None], absgrad=True)
             _, _, meta_ref = rendering.rasterization(model.means, model.quats, model.scales, model.opacities, model.shs,
                                                      data["w2c"][None], data["K"][None], W, H,
                                                      sh_degree=model.active_sh_degree, packed=False,
                                                      backgrounds=model.BACKGROUND[None], _tile_culling="gsplat")
-        n_isects = int(meta["flatten_ids"].shape[0])
-        # I of the reference's own lists (gsplat's 3-sigma rectangles): the unit SURVEY.md 8d's
-        # byte model counts; the default tight culling walks a render-equivalent subset of it
-        n_isects_ref = int(meta_ref["flatten_ids"].shape[0])
+        n_isects = int(meta["flatten_ids"].shape[0])          # what the timed launches walk (tight lists)
+        n_isects_ref = int(meta_ref["flatten_ids"].shape[0])  # the reference's own lists (gsplat's 3-sigma rectangles)
         n_vis = int((meta["radii"] > 0).sum().item())
-        # algorithmic bytes per launch: SURVEY.md section 8d
-        alg = {"gs_blend_fwd": 40 * n_isects_ref + 20 * H * W,
-               "gs_blend_bwd": 40 * n_isects_ref + 24 * H * W + 88 * n_isects_ref}
+        # algorithmic bytes per launch: SURVEY.md section 8d, for the intersections the launch processed
+        alg = {"gs_blend_fwd": 40 * n_isects + 20 * H * W,
+               "gs_blend_bwd": 40 * n_isects + 24 * H * W + 88 * n_isects}
+        kname = {"gs_blend_fwd": "blend_fwd_kernel", "gs_blend_bwd": "blend_bwd_kernel"}
         dom = max(alg, key=lambda k: stage_ms.get(k, 0.0))
         t_ms = stage_ms.get(dom, float("nan"))
         achieved = alg[dom] / (t_ms * 1e-3) / 1e9 if t_ms == t_ms and t_ms > 0 else None
-        roofline = {"bound": "hbm", "kernel": {"gs_blend_fwd": "blend_fwd_kernel", "gs_blend_bwd": "blend_bwd_kernel"}[dom],
+        traffic, traffic_src = pmc_traffic(kname[dom])
+        roofline = {"bound": "hbm", "kernel": kname[dom],
                     "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": pmc_traffic(roof_kernel := {"gs_blend_fwd": "blend_fwd_kernel", "gs_blend_bwd": "blend_bwd_kernel"}[dom]),
-                    "algorithmic_bytes": alg[dom], "avg_launch_ms": None if t_ms != t_ms else round(t_ms, 4)}
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes": alg[dom], "n_isects_processed": n_isects,
+                    "algorithmic_bytes_gsplat_lists": (40 + (88 if dom == "gs_blend_bwd" else 0)) * n_isects_ref + (24 if dom == "gs_blend_bwd" else 20) * H * W,
+                    "avg_launch_ms": None if t_ms != t_ms else round(t_ms, 4),
+                    # priced against HBM as the contract asks; the kernel's actual limiter is VALU issue (roofline_compute)
+                    "limiter": "valu-issue"}
+        # compute view of the same kernel: (pixel, Gaussian) pairs and VALU wave-instructions against the issue rate
+        rc_obj = {"bound": "valu-issue", "kernel": kname[dom]}
+        if dom == "gs_blend_bwd" and dbg.get("unit_counter") is not None:
+            n_units = int(dbg["unit_counter"].item())
+            listed = int(dbg["qcnt"].sum().item())
+            ue = int(dbg.get("unit_entries", 64))
+            rc_obj.update(work_units=n_units, entries_per_unit=ue, quadrant_entries_listed=listed,
+                          pairs_evaluated=n_units * ue * 64, pairs_listed=listed * 64,
+                          pairs_evaluated_per_s=None if not t_ms or t_ms != t_ms else round(n_units * ue * 64 / (t_ms * 1e-3), 0))
+        sq, sq_src = sq_counters(kname[dom])
+        peak_rate = N_SIMD * CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST
+        rc_obj.update(peak=round(peak_rate / 1e9, 1), unit="G wave-instr/s",
+                      peak_note="1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (nominal clock; sustained clocks are lower)")
+        if sq and sq.get("SQ_INSTS_VALU") and t_ms == t_ms and t_ms > 0:
+            rate = sq["SQ_INSTS_VALU"] / (t_ms * 1e-3)
+            rc_obj.update(valu_wave_insts_per_launch=sq["SQ_INSTS_VALU"], achieved=round(rate / 1e9, 1),
+                          frac=round(rate / peak_rate, 4), counters_source=sq_src,
+                          counters={k: sq[k] for k in sorted(sq) if k.startswith("SQ_")})
         result = {
             "metric": "train iters/sec + forward render fps, 1M Gaussians @ 1080p",
             "value": round(world * args.steps / elapsed, 3), "unit": "iters/s",
@@ -234,26 +446,45 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "step_ms": _percentiles(step_ms),
             "forward_fps": round(args.steps / fwd_elapsed, 2),
             "forward_ms": round(1e3 * fwd_elapsed / args.steps, 4),
+            "forward_step_ms": _percentiles(fwd_ms),
             "config": {"workload": f"{args.gaussians} Gaussians, {W}x{H}, SH degree {sc['sh_degree']}, "
                                    "1 view per GPU per step, full train step (fwd + L1/SSIM + bwd + stats + Adam)",
                        "n_visible": n_vis, "n_isects": n_isects, "n_isects_gsplat_lists": n_isects_ref,
-                       "parallelism": f"view-dp{world}",
-                       "exchange": exchange if vp is not None or world == 1 else "allreduce"},
+                       "list_mode": "tight (model default; image, radii, means2d and gradients identical to the gsplat-list mode)",
+                       "parallelism": f"view-dp{world}", "exchange": exchange,
+                       "step_launch": "hipGraph replay" if graph_step is not None else "eager",
+                       "exchange_bytes_per_rank": None if world == 1 else (
+                           {"all_gather_colors_pre": 12 * args.gaussians, "all_reduce_geometry_stats": 4 * 13 * args.gaussians,
+                            "all_reduce_max_radii": 4 * args.gaussians} if vp is not None else
+                           {"all_reduce_grads": 4 * 59 * args.gaussians, "all_reduce_stats": 12 * args.gaussians})},
             "stage_ms": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
-            # host diagnostics: ms/step the host spent blocked on the list-size read-back; if this is ~0
-            # the Python side, not the GPU, paces the loop on this box
+            # host diagnostics: ms/step the host spent enqueueing, and blocked on the list-size read-back (0 when
+            # the captured step is replayed: no read-back exists on that path)
             "host": {"enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 4),
                      "blocked_on_readback_ms_per_step": round(host_wait_ms, 4)},
             "roofline": roofline,
+            "roofline_compute": rc_obj,
         }
+        if graph_step is not None:
+            result["host"]["graph"] = graph_step.report()
+        result.update(extras)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(sc, args.cpu_sample)
+            result["cpu_baseline"] = cpu_baseline(sc, args.cpu_sample, args.cpu_reps)
         print(json.dumps(result), flush=True)
     if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -221,6 +221,8 @@ class _Rasterize(torch.autograd.Function):
         render_colors, render_alphas, meta, state = _forward_stages(
             means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, need_grad)
         holder.meta = meta
+        if holder.debug is not None:   # work-unit counters of the backward (bench.py's compute roofline)
+            holder.debug.update(unit_counter=state["unit_counter"], qcnt=state["qcnt"], unit_entries=nat.GS_BUCKET)
         ctx.cfg, ctx.holder, ctx.state = cfg, holder, state
         ctx.split = colors_rest is not None
         if need_grad:

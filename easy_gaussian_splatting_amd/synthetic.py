@@ -74,3 +74,23 @@ def config_s1(seed=42):
 def config_bench_1m(seed=42, n=1_000_000, n_views=1):
     return make_scene(n, 1920, 1080, sh_degree=3, n_views=n_views, seed=seed, extent=(4, 2.25, 4),
                       scale_range=(0.003, 0.03), dist=8.0, white_bg=False)
+
+
+def config_s2(seed=42, n=300_000):
+    """configs[1]: "Lego" stand-in -- ~300 k Gaussians, 800x800, SH3, white background
+    (/root/reference/configs/nerf_synthetic.yaml:2)."""
+    return make_scene(n, 800, 800, sh_degree=3, seed=seed, extent=(3.0, 3.0, 3.0), scale_range=(0.003, 0.03), dist=8.0,
+                      white_bg=True)
+
+
+def config_s3(seed=42, n=2_000_000, n_views=1):
+    """configs[2] / [3]: "Truck" stand-in -- ~2 M Gaussians, 1920x1080, SH3, black background
+    (/root/reference/configs/tandt_db.yaml:2); n_views > 1 gives the views of the sharded batch."""
+    return make_scene(n, 1920, 1080, sh_degree=3, n_views=n_views, seed=seed, extent=(4, 2.25, 4), scale_range=(0.003, 0.03),
+                      dist=8.0, white_bg=False)
+
+
+def config_s5(seed=42, n=5_000_000):
+    """configs[4]: 5 M Gaussians, 3840x2160, SH3 (the HBM stress)."""
+    return make_scene(n, 3840, 2160, sh_degree=3, seed=seed, extent=(4, 2.25, 4), scale_range=(0.002, 0.02), dist=8.0,
+                      white_bg=False)

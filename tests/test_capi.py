@@ -70,3 +70,16 @@ def test_product_package_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_camera_gradients_are_refused_not_dropped():
+    """gsplat returns gradients for viewmats; this path does not compute them and the reference never asks
+    (SURVEY.md 8b): asking must raise, not hand back None silently."""
+    import pytest
+    import torch
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    z = torch.zeros
+    V = torch.eye(4)[None].clone().requires_grad_(True)
+    K = torch.eye(3)[None]
+    with pytest.raises(NotImplementedError):
+        rasterization(z(2, 3), z(2, 4), z(2, 3), z(2), z(2, 3), V, K, 16, 16, packed=False)

@@ -40,3 +40,57 @@ def test_fused_adam_matches_torch_adam(n):
     for name in a.param_names:
         pa, pb = getattr(a, name).detach().cpu().numpy(), getattr(b, name).detach().cpu().numpy()
         assert np.abs(pa - pb).max() <= 2e-6 * max(1.0, np.abs(pa).max()), name
+
+
+def test_fused_adam_state_dict_round_trip_and_torch_layout():
+    """state_dict() exports torch.optim.Adam's layout (step / exp_avg / exp_avg_sq per parameter); loading it into a
+    fresh FusedAdam -- or into torch.optim.Adam -- continues the same trajectory (/root/reference/utils.py:48-87
+    checkpoints `optimizer.state_dict()`)."""
+    dev = torch.device("cuda:0")
+    lrs = (1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2)
+    g = torch.Generator().manual_seed(4)
+
+    def grads(m):
+        return {name: torch.randn(getattr(m, name).shape, generator=g).to(dev) for name in m.param_names}
+
+    a = _model(777, dev, 5)
+    oa = build_optimizers(a, *lrs, fused="hip")
+    for _ in range(3):
+        for name, gr in grads(a).items():
+            getattr(a, name).grad = gr
+        oa.step(); oa.zero_grad()
+    sd = oa.state_dict()
+    assert len(sd["state"]) == 6 and all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in sd["state"].values())
+    assert all(float(v["step"]) == 3.0 for v in sd["state"].values())
+    assert len(oa.state) == 0   # nothing lingers in the base-class state
+    # resume twice: a fresh FusedAdam and a plain torch Adam, same parameters, same next gradient
+    b, c = _model(777, dev, 5), _model(777, dev, 5)
+    ob, oc = build_optimizers(b, *lrs, fused="hip"), build_optimizers(c, *lrs)
+    with torch.no_grad():
+        for name in a.param_names:
+            getattr(b, name).copy_(getattr(a, name)); getattr(c, name).copy_(getattr(a, name))
+    ob.load_state_dict(sd); oc.load_state_dict(sd)
+    assert ob._step == 3
+    nxt = grads(a)
+    for m, o in ((a, oa), (b, ob), (c, oc)):
+        for name in m.param_names:
+            getattr(m, name).grad = nxt[name].clone()
+        o.step(); o.zero_grad()
+    for name in a.param_names:
+        pa, pb, pc = (getattr(m, name).detach() for m in (a, b, c))
+        assert torch.equal(pa, pb), name
+        assert float((pa - pc).abs().max()) <= 2e-6 * max(1.0, float(pc.abs().max())), name
+
+
+def test_fused_adam_detects_detached_parameters_and_rejects_group_betas():
+    dev = torch.device("cuda:0")
+    m = _model(64, dev, 1)
+    opt = build_optimizers(m, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, fused="hip")
+    m.means.data = m.means.data.clone()   # what a later model.to(...) does: the parameter no longer aliases the flat buffer
+    m.means.grad = torch.zeros_like(m.means)
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        opt.step()
+    from easy_gaussian_splatting_amd.optim import FusedAdam
+    p = torch.nn.Parameter(torch.zeros(8, device=dev))
+    with pytest.raises(NotImplementedError):
+        FusedAdam([{"params": [p], "lr": 1e-3, "betas": (0.5, 0.9), "name": "x"}])

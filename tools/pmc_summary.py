@@ -1,42 +1,66 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSV passes into HBM bytes per launch for our kernels.
+"""Summarise rocprofv3 --pmc CSV passes per kernel (template arguments kept, so the training and inference
+instantiations of blend_fwd_kernel and the two stages of project_fwd_kernel stay separate).
 
-    python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_pmc_traffic.json
+    python tools/pmc_summary.py traffic <dir FETCH_SIZE> <dir WRITE_SIZE>   > profiles/rNN_pmc_traffic.json
+    python tools/pmc_summary.py counters <dir> [<dir> ...]                   > profiles/rNN_sq_counters.json
 
-FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B?  No: rocprofv3 reports them in
-kilobytes (1 unit = 1024 B).  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): on gfx950
-FETCH_SIZE reads exactly half of the bytes of a wide coalesced stream -> doubled here; WRITE_SIZE
-is exact.  Collected in separate passes (TCC slots: FETCH_SIZE 3 + WRITE_SIZE 2 > 4).
+traffic: HBM bytes per launch.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 B; per
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE reads exactly half of the bytes of a wide
+coalesced stream on gfx950 -> doubled here; WRITE_SIZE is exact.  Collected in separate passes
+(TCC slots: FETCH_SIZE 3 + WRITE_SIZE 2 > 4).
+counters: plain per-launch averages of every counter found (SQ_* passes of tools/prof_sq.sh).
 """
 import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
 
-def load(dirname, counter):
-    out = defaultdict(list)
+def kernel_key(full: str) -> str:
+    """'void gs::blend_fwd_kernel<true, 4>(gs::BlendFwdArgs)' -> 'blend_fwd_kernel<true, 4>'."""
+    name = re.sub(r"\(.*$", "", full).strip()
+    name = re.sub(r"^void\s+", "", name)
+    return name.replace("gs::", "").strip()
+
+
+def load(dirname):
+    out = defaultdict(lambda: defaultdict(list))
     for path in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if row.get("Counter_Name") == counter and "gs::" in row["Kernel_Name"]:   # our kernels only
-                    name = row["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0].strip()
-                    out[name].append(float(row["Counter_Value"]))
+                if "gs::" in row["Kernel_Name"]:   # our kernels only
+                    out[kernel_key(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return out
 
 
+def avg(v):
+    return sum(v) / max(len(v), 1)
+
+
 def main():
-    fetch = load(sys.argv[1], "FETCH_SIZE")
-    write = load(sys.argv[2], "WRITE_SIZE")
-    res = {}
-    for k in sorted(set(fetch) | set(write)):
-        fb = 2.0 * 1024.0 * (sum(fetch[k]) / max(len(fetch[k]), 1)) if k in fetch else None
-        wb = 1024.0 * (sum(write[k]) / max(len(write[k]), 1)) if k in write else None
-        res[k] = {"launches_fetch": len(fetch.get(k, [])), "launches_write": len(write.get(k, [])),
-                  "fetch_bytes_per_launch_x2_corrected": fb, "write_bytes_per_launch": wb,
-                  "traffic_bytes_per_launch": None if fb is None or wb is None else fb + wb}
+    mode = sys.argv[1]
+    if mode == "traffic":
+        fetch, write = load(sys.argv[2]), load(sys.argv[3])
+        res = {}
+        for k in sorted(set(fetch) | set(write)):
+            f, w = fetch.get(k, {}).get("FETCH_SIZE"), write.get(k, {}).get("WRITE_SIZE")
+            fb = 2.0 * 1024.0 * avg(f) if f else None
+            wb = 1024.0 * avg(w) if w else None
+            res[k] = {"launches_fetch": len(f or []), "launches_write": len(w or []),
+                      "fetch_bytes_per_launch_x2_corrected": fb, "write_bytes_per_launch": wb,
+                      "traffic_bytes_per_launch": None if fb is None or wb is None else fb + wb}
+    else:
+        res = defaultdict(dict)
+        for d in sys.argv[2:]:
+            for k, counters in load(d).items():
+                for c, v in counters.items():
+                    res[k][c] = avg(v)
+                    res[k]["launches"] = len(v)
+        res = {k: res[k] for k in sorted(res)}
     json.dump(res, sys.stdout, indent=1)
 
 

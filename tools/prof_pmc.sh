@@ -4,8 +4,8 @@
 tag=${1:-pmc}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/${tag}_$c -o $c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 > /tmp/${tag}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/${tag}_$c -o $c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --no-graph --steps 4 --warmup 2 > /tmp/${tag}_$c.log 2>&1
 done
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/${tag}_FETCH_SIZE /tmp/${tag}_WRITE_SIZE > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_traffic.json
-head -c 600 $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_traffic.json
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py traffic /tmp/${tag}_FETCH_SIZE /tmp/${tag}_WRITE_SIZE > $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_traffic.json
+head -c 400 $GRAFT_REPO_ROOT/gpurun_out/${tag}_pmc_traffic.json
