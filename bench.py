@@ -152,7 +152,6 @@ def cpu_baseline(sc, sample_n: int, reps: int):
     Plus the S1 leg of BASELINE.md section 3: the pure-PyTorch restatement on configs[0] (10 k Gaussians, 256x256,
     SH0), forward and forward+backward.  Reported baselines only."""
     import numpy as np
-    import torch
     from oracle import c_oracle as CO
     CO.build()
     cores = os.cpu_count() or 1
@@ -177,27 +176,31 @@ def cpu_baseline(sc, sample_n: int, reps: int):
            "reps_s": [round(t, 3) for t in times],
            "sample": f"oracle/c (C+OpenMP) rasterization fwd+bwd, first {n} of the workload's Gaussians at {W}x{H} "
                      f"SH{sc['sh_degree']}, I={n_isects} (gsplat lists), median of {reps} repetitions after 1 warm-up"}
-    # S1 leg: pure-PyTorch restatement (oracle/torch_oracle.py), all cores
+    # S1 leg: pure-PyTorch restatement (oracle/torch_oracle.py) in its own process, bounded by a hard timeout.  (In
+    # this process the C oracle's OpenMP pool is still spinning; torch's own pool at the box's full core count on
+    # top of it crawls.)  Small tensors: more than 16 threads only add synchronisation.
+    threads = min(cores, 16)
+    code = (
+        "import sys, time, json, torch; sys.path.insert(0, %r)\n"
+        "from easy_gaussian_splatting_amd.synthetic import config_s1\n"
+        "from oracle import torch_oracle as TO\n"
+        "torch.set_num_threads(%d)\n"
+        "s1 = config_s1(); T = lambda k: torch.from_numpy(s1[k]).double()\n"
+        "ins = [T(k).requires_grad_(True) for k in ('means', 'quats', 'scales', 'opacities', 'shs')]\n"
+        "def run(bwd):\n"
+        "    t0 = time.perf_counter()\n"
+        "    img, alpha, _ = TO.rasterization(*ins, T('viewmats'), T('Ks'), 256, 256, sh_degree=0, packed=False, backgrounds=T('backgrounds'))\n"
+        "    if bwd: torch.autograd.grad(img.sum(), ins)\n"
+        "    return time.perf_counter() - t0\n"
+        "run(False); f = min(run(False) for _ in range(2)); fb = min(run(True) for _ in range(2))\n"
+        "print(json.dumps({'fwd_ms': round(1e3 * f, 1), 'fwd_bwd_ms': round(1e3 * fb, 1)}))\n" % (ROOT, threads))
     try:
-        from easy_gaussian_splatting_amd.synthetic import config_s1
-        from oracle import torch_oracle as TO
-        torch.set_num_threads(cores)
-        s1 = config_s1()
-        T = lambda k: torch.from_numpy(s1[k]).double()
-        ins = [T(k).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
-
-        def s1_run(bwd):
-            t0 = time.perf_counter()
-            img, alpha, _ = TO.rasterization(*ins, T("viewmats"), T("Ks"), 256, 256, sh_degree=0, packed=False, backgrounds=T("backgrounds"))
-            if bwd:
-                torch.autograd.grad(img.sum(), ins)
-            return time.perf_counter() - t0
-
-        s1_run(False)
-        f = min(s1_run(False) for _ in range(2))
-        fb = min(s1_run(True) for _ in range(2))
-        out["s1_torch"] = {"workload": "configs[0]: 10k Gaussians, 256x256, SH0, oracle/torch_oracle.py (fp64, autograd), "
-                                       f"{cores} threads", "fwd_ms": round(1e3 * f, 1), "fwd_bwd_ms": round(1e3 * fb, 1)}
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="passive")
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=90)
+        s1 = json.loads(p.stdout.strip().splitlines()[-1])
+        s1["workload"] = ("configs[0]: 10k Gaussians, 256x256, SH0, oracle/torch_oracle.py (fp64, autograd), "
+                          f"{threads} threads, best of 2")
+        out["s1_torch"] = s1
     except Exception as e:   # the S1 leg must never cost the bench line
         out["s1_torch"] = {"error": repr(e)[:200]}
     return out
@@ -482,6 +485,9 @@ def run_rank(args) -> int:
 
 def main():
     args = parse_args()
+    if os.environ.get("GS_BENCH_FAULT_AFTER"):   # debugging aid: dump every thread's stack after N seconds (and go on)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["GS_BENCH_FAULT_AFTER"]), repeat=False, file=sys.stderr)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     sys.exit(run_rank(args))

@@ -18,11 +18,16 @@ import torch
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params: List[Dict], betas=(0.9, 0.999), eps: float = 1e-8):
-        defaults = dict(lr=1e-3, betas=betas, eps=eps)
+        # torch.optim.Adam's hyper-parameter keys at their defaults, so a state_dict() from here loads into
+        # torch.optim.Adam and vice versa (none of them is implemented: they must stay at these values)
+        defaults = dict(lr=1e-3, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                        capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False)
         super().__init__(params, defaults)
         for g in self.param_groups:   # one launch, one set of hyper-parameters (the reference uses Adam's defaults in every group)
             if tuple(g["betas"]) != tuple(betas) or g["eps"] != eps:
                 raise NotImplementedError("FusedAdam: per-group betas / eps are not supported (only per-group lr)")
+            if g["weight_decay"] or g["amsgrad"] or g["maximize"]:
+                raise NotImplementedError("FusedAdam: weight_decay / amsgrad / maximize are not implemented")
         self._build()
 
     def _build(self, moments=None):

@@ -47,12 +47,15 @@ def make_scene(n: int, width: int, height: int, sh_degree: int = 3, n_views: int
                 width=width, height=height, sh_degree=sh_degree)
 
 
-def dense_scene(n: int, seed: int, width: int = 64, height: int = 48, normal: float = 0.08, flat: float = 0.03):
+def dense_scene(n: int, seed: int, width: int = 64, height: int = 48, normal: float = None, flat: float = None):
     """Long per-tile lists (every Gaussian lands in the central tiles) that stay OFF the blend's thresholds:
     most Gaussians can never reach alpha = 1/255 (listed, evaluated, never taken, never near the threshold),
     `normal` of them are ordinary faint splats and `flat` are flat, image-covering ones that contribute to
     every pixel without crossing 1/255 -- the lists are walked to the end (total alpha stays below saturation)
     while only a few per cent of the pixels sit within 1e-4 of a discontinuity."""
+    # population sizes capped so that the optical depth of the densest pixel stays well below ln(1e4)
+    normal = min(0.08, 250.0 / n) if normal is None else normal
+    flat = min(0.03, 350.0 / n) if flat is None else flat
     rng = np.random.default_rng(seed)
     sc = make_scene(n, width, height, sh_degree=0, seed=seed, scale_range=(0.2, 0.6), dist=4.0, extent=(0.3, 0.3, 0.5))
     u = rng.random(n)

@@ -369,14 +369,22 @@ int gso_blend_fwd(int C, int N, int W, int H, int tile, const real* means2d, con
 }
 
 /* Per-pixel distance to the blend's discontinuities (alpha >= 1/255 test, T <= 1e-4 early-out,
- * sigma >= 0 test): min over the pairs the forward visits of the RELATIVE gap to the threshold
- * (for sigma: relative to the magnitude of the quadratic form's terms).
- * Pixels with a tiny margin can legitimately flip a contributor under 1-ulp arithmetic
- * differences; parity tests use this to separate them from real errors. */
+ * sigma >= 0 test): min over the pairs the forward visits of the gap to the threshold, RELATIVE to the
+ * threshold and NORMALISED by how far fp32 inputs can move the tested quantity, so that "margin < 1e-4"
+ * reads "an fp32 evaluation of this pixel may legitimately take the other branch":
+ *   - the path under test (like gsplat itself) holds means2d in fp32: a few ulps of a ~1000 px coordinate
+ *     (view transform + perspective divide, each rounded) are dmu ~ 3e-4 px, which moves
+ *     ln(alpha) = ln(op) - sigma by |d sigma / d mu| * dmu -- 1e-3 and more for sharp splats;
+ *   - the conic's own rounding moves sigma by ~1e-5 of the magnitude of its terms;
+ *   - T inherits the accumulated relative error of every alpha blended before.
+ * margin = gap * 1e-4 / (1e-4 + reachable relative perturbation).  Parity tests exempt pixels with
+ * margin < 1e-4 from the strict bound (they must stay rare and are still bounded by one contributor's weight). */
+#define GSO_EPS32 ((real)1.1920929e-7)
 int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, const real* conics,
                      const real* opac, const int32_t* isect_offsets, const int32_t* flatten_ids,
                      int64_t I, real* margin) {
     int tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile;
+    const real base = (real)1e-4;
     (void)N;
 #pragma omp parallel for schedule(dynamic, 64) collapse(2)
     for (int c = 0; c < C; c++)
@@ -386,25 +394,31 @@ int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, 
             int64_t lo = isect_offsets[t];
             int64_t hi = (t + 1 < (long)C * tw * th) ? isect_offsets[t + 1] : I;
             real px = j + (real)0.5, py = i + (real)0.5;
-            real T = 1, m = 1;
+            real T = 1, m = 1, eT = 0;
             for (int64_t k = lo; k < hi; k++) {
                 int32_t g = flatten_ids[k];
-                real dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
-                real sigma = (real)0.5 * (conics[3 * g] * dx * dx + conics[3 * g + 2] * dy * dy) + conics[3 * g + 1] * dx * dy;
+                real mux = means2d[2 * g], muy = means2d[2 * g + 1];
+                real A = conics[3 * g], B = conics[3 * g + 1], Cc = conics[3 * g + 2];
+                real dx = mux - px, dy = muy - py;
+                real sigma = (real)0.5 * (A * dx * dx + Cc * dy * dy) + B * dx * dy;
                 real alpha = opac[g] * REXP(-sigma);
                 if (alpha > ALPHA_MAX) alpha = ALPHA_MAX;
-                real ma = RABS(alpha - ALPHA_MIN) / ALPHA_MIN;
+                real mag = (real)0.5 * (RABS(A * dx * dx) + RABS(Cc * dy * dy)) + RABS(B * dx * dy);
+                real amax = RABS(mux) > RABS(muy) ? RABS(mux) : RABS(muy);
+                real dmu = 4 * GSO_EPS32 * (amax > 64 ? amax : 64);
+                real es = (RABS(A * dx + B * dy) + RABS(B * dx + Cc * dy)) * dmu + (real)1e-5 * mag;   /* reachable |d sigma| */
+                real ma = RABS(alpha - ALPHA_MIN) / ALPHA_MIN * base / (base + es);
                 if (ma < m) m = ma;
                 /* sigma >= 0: the form is positive (semi-)definite, so only rounding inside its own evaluation can
                  * make it negative -- the gap is measured relative to the magnitude of its three terms */
                 if (opac[g] >= ALPHA_MIN) {
-                    real mag = (real)0.5 * (RABS(conics[3 * g] * dx * dx) + RABS(conics[3 * g + 2] * dy * dy)) + RABS(conics[3 * g + 1] * dx * dy);
                     real ms = mag > 0 ? RABS(sigma) / mag : 1;
                     if (ms < m) m = ms;
                 }
                 if (sigma < 0 || alpha < ALPHA_MIN) continue;
                 real Tn = T * (1 - alpha);
-                real mt = RABS(Tn - T_MIN) / T_MIN;
+                eT += alpha / (1 - alpha) * es;
+                real mt = RABS(Tn - T_MIN) / T_MIN * base / (base + eT);
                 if (mt < m) m = mt;
                 if (Tn <= T_MIN) break;
                 T = Tn;

@@ -60,27 +60,43 @@ def run_oracle(sc, use_bg=True, dtype=np.float64):
 MAX_RAZOR_FRAC = 0.05   # scenes are built to stay off the blend thresholds (synthetic.dense_scene)
 
 
-def _mismatch_pixels(meta, fw, mism):
-    """[C,H,W] mask of the pixels whose tile list can differ because a radius differs by the ceil() of a
-    rounding error: the tiles either rectangle (HIP's or the oracle's) of such a Gaussian touches."""
+def _affected_tiles(meta, fw, sel):
+    """[C,th,tw] mask of the tiles whose list may legitimately differ from the oracle's: every tile that the
+    rectangle of a Gaussian in `sel` touches, in either version, grown by one pixel."""
     C, N = fw["radii"].shape
-    inp = fw["_inputs"]
-    W, H, tile = inp["width"], inp["height"], inp["tile_size"]
+    tile = fw["_inputs"]["tile_size"]
     tw, th = fw["tile_width"], fw["tile_height"]
     tmask = np.zeros((C, th, tw), bool)
     rad_h = meta["radii"].cpu().numpy()
-    for c, n in zip(*np.nonzero(mism)):
-        r = max(int(rad_h[c, n]), int(fw["radii"][c, n]))
+    for c, n in zip(*np.nonzero(sel)):
+        r = max(int(rad_h[c, n]), int(fw["radii"][c, n])) + 1
         mx, my = fw["means2d"][c, n]
         x0, x1 = int(np.clip(np.floor((mx - r) / tile), 0, tw)), int(np.clip(np.ceil((mx + r) / tile), 0, tw))
         y0, y1 = int(np.clip(np.floor((my - r) / tile), 0, th)), int(np.clip(np.ceil((my + r) / tile), 0, th))
         tmask[c, y0:y1, x0:x1] = True
-    return np.repeat(np.repeat(tmask, tile, axis=1), tile, axis=2)[:, :H, :W]
+    return tmask
+
+
+def _lists_equal_outside(meta, fw, tmask):
+    """Bit-exact comparison of every tile's sorted run, except the tiles in `tmask`."""
+    ok = ~tmask.reshape(-1)
+    off_h = meta["isect_offsets"].reshape(-1).cpu().numpy().astype(np.int64)
+    fid_h = meta["flatten_ids"].cpu().numpy()
+    cnt_h = np.diff(np.append(off_h, fid_h.size))
+    off_o = fw["isect_offsets"].reshape(-1).astype(np.int64)
+    cnt_o = np.diff(np.append(off_o, fw["n_isects"]))
+    assert np.array_equal(cnt_h[ok], cnt_o[ok]), "tile list lengths differ in tiles no rounding flip touches"
+    assert np.array_equal(fid_h[np.repeat(ok, cnt_h)], fw["flatten_ids"][np.repeat(ok, cnt_o)]), "sorted ids differ"
 
 
 def check_forward(hip, fw, max_razor_frac=1e-2, lists=True, outlier_frac=0.0):
+    """Forward parity.  Integer outputs are bit-exact except where an fp32-vs-fp64 rounding difference crosses an
+    integer decision: radius = ceil(3 sigma) (+-1), or an edge mu +- r of the tile rectangle landing within 2e-3 px of
+    a tile boundary.  Such Gaussians are counted and printed, must be rare, and only the tiles they touch are
+    exempt from the bit-exact list comparison and the strict pixel bound."""
     assert max_razor_frac <= MAX_RAZOR_FRAC
     meta = hip["meta"]
+    tile = fw["_inputs"]["tile_size"]
     radii = meta["radii"].cpu().numpy()
     mism = radii != fw["radii"]
     if mism.any():   # fp32 vs fp64 ceil(3 sigma): must be a +-1 flip of a visible Gaussian, and rare
@@ -92,17 +108,33 @@ def check_forward(hip, fw, max_razor_frac=1e-2, lists=True, outlier_frac=0.0):
     assert np.abs(meta["depths"].cpu().numpy() - fw["depths"])[same].max(initial=0) < 1e-4
     con = meta["conics"].cpu().numpy()
     assert (np.abs(con - fw["conics"]) / (np.abs(fw["conics"]) + 1e-2))[same].max(initial=0) < 2e-3
-    exact_lists = (not mism.any()) and (not lists or np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), fw["tiles_per_gauss"]))
-    if lists and not mism.any():  # integer / index work must then be bit-exact
-        assert np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), fw["tiles_per_gauss"])
-        assert np.array_equal(meta["isect_offsets"].cpu().numpy(), fw["isect_offsets"])
-        assert np.array_equal(meta["flatten_ids"].cpu().numpy(), fw["flatten_ids"])
+    differ = mism.copy()
+    if lists:
+        edge = (meta["tiles_per_gauss"].cpu().numpy() != fw["tiles_per_gauss"]) & same
+        if edge.any():   # same radius, different rectangle: an edge of mu +- r must sit on a tile boundary
+            print(f"[parity] {int(edge.sum())} of {edge.size} tile rectangles differ from the oracle's (edge on a tile boundary)")
+            mu, r = fw["means2d"][edge], fw["radii"][edge][:, None].astype(np.float64)
+            edges = np.concatenate([mu - r, mu + r], axis=1) / tile
+            assert np.abs(edges - np.round(edges)).min(axis=1).max() <= 2e-3 / tile, "a tile rectangle differs away from any tile boundary"
+            assert edge.mean() <= 2e-4
+        differ |= edge
+    exact_lists = not differ.any()
+    tmask = _affected_tiles(meta, fw, differ) if differ.any() else np.zeros((radii.shape[0], fw["tile_height"], fw["tile_width"]), bool)
+    if lists:  # integer / index work is bit-exact wherever no rounding flip reaches
+        if exact_lists:
+            assert np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), fw["tiles_per_gauss"])
+            assert np.array_equal(meta["isect_offsets"].cpu().numpy(), fw["isect_offsets"])
+            assert np.array_equal(meta["flatten_ids"].cpu().numpy(), fw["flatten_ids"])
+        else:
+            assert tmask.mean() <= 0.02, f"{tmask.mean()} of the tiles touched by rounding flips"
+            _lists_equal_outside(meta, fw, tmask)
     err = np.abs(hip["img"].detach().cpu().numpy() - fw["render_colors"]).max(-1)
     aerr = np.abs(hip["alpha"].detach().cpu().numpy() - fw["render_alphas"])[..., 0]
     razor = CO.blend_margin(fw) < 1e-4
     strict = ~razor
-    if mism.any():  # only the tiles a flipped radius touches may hold a different list
-        strict &= ~_mismatch_pixels(meta, fw, mism)
+    if differ.any():  # only the tiles a flipped radius / rectangle touches may hold a different list
+        H, W = err.shape[1:]
+        strict &= ~np.repeat(np.repeat(tmask, tile, axis=1), tile, axis=2)[:, :H, :W]
     assert razor.mean() <= max_razor_frac, f"razor-edge pixel fraction {razor.mean()}"
     # outlier_frac > 0 only where the reference itself is the wrong precision for a pixel-exact claim
     # (fp64 oracle at hundreds of contributors per pixel; the fp32 oracle is then checked strictly)
