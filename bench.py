@@ -356,8 +356,15 @@ def run_rank(args) -> int:
         per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
         return elapsed, t_enq, per_step, rendering.stats["sync_wait_ns"] * 1e-6 / max(steps, 1)
 
+    def trace(msg):
+        if os.environ.get("GS_BENCH_TRACE") == "1":
+            torch.cuda.synchronize()
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    trace("setup done")
     # ---- train iterations (the timed region)
     elapsed, t_enqueued, step_ms, host_wait_ms = timed_loop(step_fn, args.steps, args.warmup)
+    trace("timed loop done")
     if graph_step is not None:
         graph_step.finish()   # deferred overflow check of the last replay
     if world > 1:
@@ -370,7 +377,9 @@ def run_rank(args) -> int:
         with torch.no_grad():
             model(data)
 
+    trace("graph finished")
     fwd_elapsed, _, fwd_ms, _ = timed_loop(fwd_only, args.steps, max(3, args.warmup // 2))
+    trace("forward loop done")
 
     extras = {}
     if world == 1 and not args.no_extras:
@@ -389,6 +398,7 @@ def run_rank(args) -> int:
         train_step()
     stages = rendering.profile_stages(False) or {}
     stage_ms = {k: float(np.mean(v)) for k, v in stages.items()}
+    trace("stage profile done")
 
     rc = 0
     if rank == 0:

@@ -53,6 +53,10 @@ SIGNATURES = {
     "gs_clamp01": (_I, [_P, _L, _P, _P, _P]),
     "gs_pack_view_step": (_I, [_P, _L, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_update_statistics": (_I, [_P, _L, _F, _P, _P, _P, _P, _P]),
+    "gs_guard_set": (_I, [_P, _L, _L]),
+    "gs_step_status": (_I, [_P, _P, _P, _P]),
+    "gs_adam_hyper": (_I, [_P, _I, _P, _F, _F, _L, _P]),
+    "gs_adam_step_dev": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P, _P]),
     "gs_adam_step": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F]),
 }
 

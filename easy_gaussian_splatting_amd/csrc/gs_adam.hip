@@ -25,6 +25,10 @@ struct AdamArgs {
     float step_size[kMaxSeg];     // lr / (1 - beta1^t)
     float beta1, beta2, eps, inv_sqrt_bc2;
     float grad_scale;             // gradients are multiplied by this first (1/world for a mean over ranks)
+    const float* hyper;           // optional device array {1/sqrt(1-beta2^t), step_size[0..nseg-1]} (gs_adam_hyper): replaces
+                                  // inv_sqrt_bc2 / step_size above, so a captured launch can be replayed with a new step count
+    const int64_t* guard;         // step guard (gs_guard_set) or nullptr
+    int64_t* applied;             // optional device counter of steps that were really applied (not skipped by the guard)
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
@@ -36,6 +40,9 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 }
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
+    if (guard_tripped(a.guard)) return;
+    if (a.applied != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.applied[0] += 1;
+    const float isbc2 = a.hyper ? a.hyper[0] : a.inv_sqrt_bc2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += (int64_t)gridDim.x * blockDim.x) {
         int s = 0;
 #pragma unroll
@@ -52,12 +59,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
             g.z = e + 2 < len ? gp[e + 2] : 0.f; g.w = 0.f;
         }
         g.x *= a.grad_scale; g.y *= a.grad_scale; g.z *= a.grad_scale; g.w *= a.grad_scale;
-        const float ss = a.step_size[s];
+        const float ss = a.hyper ? a.hyper[1 + s] : a.step_size[s];
         float4 p = a.p[i], m = nt_load4(a.m + i), v = nt_load4(a.v + i);
-        adam1(p.x, g.x, m.x, v.x, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
-        adam1(p.y, g.y, m.y, v.y, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
-        adam1(p.z, g.z, m.z, v.z, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
-        adam1(p.w, g.w, m.w, v.w, a.beta1, a.beta2, a.eps, a.inv_sqrt_bc2, ss);
+        adam1(p.x, g.x, m.x, v.x, a.beta1, a.beta2, a.eps, isbc2, ss);
+        adam1(p.y, g.y, m.y, v.y, a.beta1, a.beta2, a.eps, isbc2, ss);
+        adam1(p.z, g.z, m.z, v.z, a.beta1, a.beta2, a.eps, isbc2, ss);
+        adam1(p.w, g.w, m.w, v.w, a.beta1, a.beta2, a.eps, isbc2, ss);
         a.p[i] = p;   // re-read by the next forward
         nt_store4(m, a.m + i); nt_store4(v, a.v + i);   // streamed once per step
     }
@@ -67,16 +74,17 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
 
 using namespace gs;
 
-extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
-                            int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
-                            const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
-                            float beta2, float eps, int64_t step, float grad_scale) {
+static int adam_launch(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
+                       int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
+                       const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
+                       float beta2, float eps, int64_t step, float grad_scale, const float* hyper_dev, int64_t* applied_dev) {
     GS_REQUIRE(n >= 0 && (n & 3) == 0, "flat length must be a multiple of 4 (pad the buffers)");
     GS_REQUIRE(n_segments >= 1 && n_segments <= kMaxSeg, "1..8 segments");
     GS_REQUIRE(step >= 1, "step counts from 1");
     if (n == 0) return GS_OK;
     GS_REQUIRE(params && exp_avg && exp_avg_sq && seg_ends_host && seg_lens_host && seg_grads_host && seg_lrs_host, "null pointer");
     AdamArgs a;
+    a.hyper = hyper_dev; a.applied = applied_dev; a.guard = current_guard().info;
     a.n4 = n >> 2;
     a.p = reinterpret_cast<float4*>(params);
     a.m = reinterpret_cast<float4*>(exp_avg); a.v = reinterpret_cast<float4*>(exp_avg_sq);
@@ -104,6 +112,46 @@ extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* exp_a
     return GS_OK;
 }
 
+extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
+                            int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
+                            const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
+                            float beta2, float eps, int64_t step, float grad_scale) {
+    return adam_launch(stream, n, params, exp_avg, exp_avg_sq, n_segments, seg_ends_host, seg_lens_host, seg_grads_host,
+                       seg_lrs_host, beta1, beta2, eps, step, grad_scale, nullptr, nullptr);
+}
+
+extern "C" int gs_adam_step_dev(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
+                                int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
+                                const float* const* seg_grads_host, float beta1, float beta2, float eps, float grad_scale,
+                                const float* hyper_dev, int64_t* applied_dev) {
+    GS_REQUIRE(hyper_dev != nullptr, "hyper_dev (gs_adam_hyper) is required");
+    const float zero_lrs[kMaxSeg] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return adam_launch(stream, n, params, exp_avg, exp_avg_sq, n_segments, seg_ends_host, seg_lens_host, seg_grads_host,
+                       zero_lrs, beta1, beta2, eps, 1, grad_scale, hyper_dev, applied_dev);
+}
+
+namespace gs {
+struct HyperArgs { float v[1 + kMaxSeg]; int n; };
+__global__ void adam_hyper_kernel(const HyperArgs h, float* __restrict__ out) {
+    if (threadIdx.x < (unsigned)h.n) out[threadIdx.x] = h.v[threadIdx.x];
+}
+}  // namespace gs
+
+extern "C" int gs_adam_hyper(void* stream, int n_segments, const float* seg_lrs_host, float beta1, float beta2,
+                             int64_t step, float* hyper_dev) {
+    GS_REQUIRE(n_segments >= 1 && n_segments <= kMaxSeg && seg_lrs_host && hyper_dev, "1..8 segments, non-null pointers");
+    GS_REQUIRE(step >= 1, "step counts from 1");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    HyperArgs h;
+    h.n = 1 + n_segments;
+    h.v[0] = (float)(1.0 / sqrt(bc2));
+    for (int k = 0; k < kMaxSeg; ++k) h.v[1 + k] = k < n_segments ? (float)((double)seg_lrs_host[k] / bc1) : 0.f;
+    // values travel as kernel arguments (copied at launch): no host buffer that a later call could overwrite
+    hipLaunchKernelGGL(gs::adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h, hyper_dev);
+    GS_LAUNCH_CHECK("adam_hyper_kernel");
+    return GS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // update_statistics (/root/reference/model/gaussian.py:188-197) as ONE launch: the consumer of the
 // `.absgrad` / `radii` side channels.  For visible Gaussians (radius > 0):
@@ -112,9 +160,10 @@ extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* exp_a
 namespace gs {
 __global__ __launch_bounds__(256) void update_statistics_kernel(int64_t n, float max_hw, const int32_t* __restrict__ radii,
                                                                 const float2* __restrict__ absgrad, float* __restrict__ max_radii,
-                                                                float* __restrict__ grad_norm_accum, float* __restrict__ counts) {
+                                                                float* __restrict__ grad_norm_accum, float* __restrict__ counts,
+                                                                const int64_t* __restrict__ guard) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || guard_tripped(guard)) return;
     const int r = radii[i];
     if (r > 0) {
         const float2 g = absgrad[i];
@@ -131,7 +180,7 @@ extern "C" int gs_update_statistics(void* stream, int64_t n, float max_hw, const
     if (n == 0) return GS_OK;
     GS_REQUIRE(radii && absgrad && max_radii && grad_norm_accum && counts, "null pointer");
     hipLaunchKernelGGL(gs::update_statistics_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, max_hw,
-                       radii, reinterpret_cast<const float2*>(absgrad), max_radii, grad_norm_accum, counts);
+                       radii, reinterpret_cast<const float2*>(absgrad), max_radii, grad_norm_accum, counts, gs::current_guard().info);
     GS_LAUNCH_CHECK("update_statistics_kernel");
     return GS_OK;
 }

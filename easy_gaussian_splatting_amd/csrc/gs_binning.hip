@@ -21,6 +21,10 @@
 // The "slot" carried in the key's low word is the index of this intersection's gradient row
 // (cum_tiles[f] + k): rows of one Gaussian are contiguous, which lets the backward reduce them
 // with plain coalesced loads instead of float atomics.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "gs_common.h"
 
 namespace gs {
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
     int n_tiles_total, int n_groups_total, const uint32_t* __restrict__ tile_cnt,
     const uint32_t* __restrict__ grp_tot, int32_t* __restrict__ isect_offsets,
     int32_t* __restrict__ bucket_offsets, uint32_t* __restrict__ grp_base,
-    int64_t* __restrict__ info, int32_t* __restrict__ tile_order) {
+    int64_t* __restrict__ info, int32_t* __restrict__ tile_order, int64_t cap_isects, int64_t cap_tile) {
     __shared__ unsigned long long scratch[17];
     unsigned long long carry_i = 0, carry_b = 0;
     uint32_t max_cnt = 0;
@@ -176,7 +180,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
         for (int i = 0; i < kBinThreads / 64; ++i) mm = max(mm, smax[i]);
         isect_offsets[n_tiles_total] = (int32_t)carry_i;
         bucket_offsets[n_tiles_total] = (int32_t)carry_b;
-        info[0] = (int64_t)carry_i; info[1] = (int64_t)carry_b; info[2] = (int64_t)mm; info[3] = 0;
+        info[0] = (int64_t)carry_i; info[1] = (int64_t)carry_b; info[2] = (int64_t)mm;
+        if (cap_isects > 0) {
+            // guarded step (gs_guard_set): flags are sticky -- once a step does not fit, this and every later
+            // step is a no-op until the host has re-sized the buffers and cleared the word
+            const int64_t f = ((int64_t)carry_i > cap_isects ? 1 : 0) | ((int64_t)mm > cap_tile ? 2 : 0);
+            if (f) info[3] |= f;
+        } else {
+            info[3] = 0;
+        }
     }
     __syncthreads();
     // Launch order for the blend forward (one wave per tile): longest lists first, so that the short
@@ -232,8 +244,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
     const float* __restrict__ depths, const uint32_t* __restrict__ hist_mat,
     const int32_t* __restrict__ isect_offsets, const uint32_t* __restrict__ grp_base,
     unsigned long long* __restrict__ keys, int32_t* __restrict__ slot_gid,
-    int32_t* __restrict__ cum_tiles) {
+    int32_t* __restrict__ cum_tiles, const int64_t* __restrict__ guard) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (guard_tripped(guard)) return;
     uint32_t* cursor = lds;                                    // [tiles]
     uint32_t* scratch = lds + tiles;                           // [32]
     const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
@@ -340,12 +353,14 @@ struct SortArgs {
     int64_t* isect_ids;
     int32_t* flatten_ids;
     int32_t* slots;
+    const int64_t* guard;
 };
 
 template <bool IN_LDS>
 __global__ void tile_sort_kernel(const SortArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     const int t = blockIdx.x;
+    if (guard_tripped(a.guard)) return;
     const int lo = a.isect_offsets[t], hi = a.isect_offsets[t + 1];
     const int n = hi - lo;
     if (n <= a.lo_excl || n > a.hi_incl) return;
@@ -387,6 +402,7 @@ __global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     constexpr int W = T / 64;
     const int tile = blockIdx.x;
+    if (guard_tripped(a.guard)) return;
     const int lo = a.isect_offsets[tile], n = a.isect_offsets[tile + 1] - lo;
     if (n <= a.lo_excl || n > a.hi_incl) return;
     const int cap = a.hi_incl;
@@ -505,9 +521,20 @@ extern "C" size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_
     return bin_layout(C, N, tile_w * tile_h).total;
 }
 
+// (the attribute is raised once per kernel and size: nothing but launches reaches the stream afterwards, which
+//  keeps a warmed-up pipeline capturable into a hipGraph)
 static int ensure_lds(const void* fn, size_t bytes) {
     if (bytes > 64 * 1024) {
-        GS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        static std::mutex mu;
+        static std::map<std::pair<int, const void*>, size_t> done;
+        int dev = 0;
+        GS_HIP_CHECK(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu);
+        size_t& have = done[{dev, fn}];
+        if (have < bytes) {
+            GS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            have = bytes;
+        }
     }
     return GS_OK;
 }
@@ -538,8 +565,10 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)((ct + 255) / 256)), dim3(256), 0, st, C, L.groups,
                        tiles, hist, tile_cnt);
     GS_LAUNCH_CHECK("bin_colscan_kernel");
+    const Guard gd = current_guard();
+    GS_REQUIRE(gd.info == nullptr || gd.info == info_dev, "the guard set by gs_guard_set must be this call's info_dev");
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(kBinThreads), 0, st, (int)ct, C * L.groups, tile_cnt,
-                       grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev, tile_order);
+                       grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev, tile_order, gd.cap_isects, gd.cap_tile);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
     if (info_host) {
         GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -569,7 +598,7 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     if (int rc = ensure_lds((const void*)bin_emit_kernel, lds)) return rc;
     hipLaunchKernelGGL(bin_emit_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, tile_w, tiles,
                        L.per_group, (const uint4*)bbox, depths, hist, isect_offsets, grp_base,
-                       (unsigned long long*)keys_tmp, slot_gid, cum_tiles);
+                       (unsigned long long*)keys_tmp, slot_gid, cum_tiles, current_guard().info);
     GS_LAUNCH_CHECK("bin_emit_kernel");
     if (n_isects == 0) return GS_OK;
     SortArgs a;
@@ -579,6 +608,7 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     a.tile_bits = tb;
     a.isect_offsets = isect_offsets; a.keys = (unsigned long long*)keys_tmp; a.slot_gid = slot_gid;
     a.isect_ids = isect_ids; a.flatten_ids = flatten_ids; a.slots = slots;
+    a.guard = current_guard().info;
     const unsigned grid = (unsigned)(C * tiles);
     // size classes, each launched only if some tile needs it (the host knows max_tile_count):
     //   radix (two key buffers + 2 x 1 KB of counters per wave):

@@ -50,6 +50,7 @@ struct BlendFwdArgs {
     uint8_t* qmask;        // [I] by slot        which quadrant rows of an intersection exist
     int32_t* unit_counter; // [1]
     int2* unit_desc;       // [4*n_buckets]      (tile*4+quadrant, bucket index within the sublist)
+    const int64_t* guard;  // step guard (gs_guard_set) or nullptr
 };
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArg
     float4* srec = srec_all[threadIdx.x >> 6];
     const int ti = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
     if (ti >= a.C * a.tiles) return;   // wave-uniform
+    if (guard_tripped(a.guard)) return;
     const int t = a.tile_order ? a.tile_order[ti] : ti;   // launch slot -> tile (longest lists first)
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
     const int tyi = tt / a.tw, txi = tt - tyi * a.tw;
@@ -246,6 +248,7 @@ struct BlendBwdArgs {
     const float *out_colors, *out_alphas, *v_colors, *v_alphas;
     float4* rows;   // [I*4][3]
     float4* rows_color;   // optional [I*4]: a compact copy of the rows' colour lanes (view-parallel exchange)
+    const int64_t* guard;
 };
 
 constexpr int kBwdWaves = 4;
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
     __shared__ float2 sctr_all[kBwdWaves][4][64];   // 2 KB per wave: pixel centres
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane >> 4, r = lane & (kRowLanes - 1);
+    if (guard_tripped(a.guard)) return;
     const int n_units = a.unit_counter[0];
     const int unit = ((int)blockIdx.x * kBwdWaves + wave) * 4 + row;
     if (((int)blockIdx.x * kBwdWaves + wave) * 4 >= n_units) return;   // wave-uniform
@@ -419,6 +423,7 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     a.ckpt = reinterpret_cast<float4*>(ckpt); a.qlist = reinterpret_cast<int2*>(qlist); a.qcnt = qcnt; a.qmask = qmask;
     a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int2*>(unit_desc);
     a.tile_order = tile_order;
+    a.guard = current_guard().info;
     const unsigned n_tiles = (unsigned)(C * a.tiles);
     hipStream_t st = (hipStream_t)stream;
     // 4 tiles (waves) per workgroup: measured equal to single-wave workgroups (0.33-0.36 ms at the bench
@@ -458,6 +463,7 @@ extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const fl
     a.ckpt = reinterpret_cast<const float4*>(ckpt); a.out_colors = render_colors;
     a.out_alphas = render_alphas; a.v_colors = v_render_colors; a.v_alphas = v_render_alphas;
     a.rows = reinterpret_cast<float4*>(rows); a.rows_color = reinterpret_cast<float4*>(rows_color);
+    a.guard = current_guard().info;
     // upper bound on work units: 4 quadrant sublists per tile, each at most as long as the tile list
     const int64_t max_units = 4 * n_buckets;
     const unsigned grid = (unsigned)((max_units + 4 * kBwdWaves - 1) / (4 * kBwdWaves));

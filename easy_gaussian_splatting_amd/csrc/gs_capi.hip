@@ -12,8 +12,40 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static thread_local Guard g_guard = {nullptr, 0, 0};
+Guard current_guard() { return g_guard; }
 }  // namespace gs
 
-extern "C" int gs_version(void) { return 100; }
+extern "C" int gs_guard_set(const int64_t* info_dev, int64_t cap_isects, int64_t cap_tile) {
+    if (info_dev != nullptr && (cap_isects <= 0 || cap_tile <= 0)) {
+        gs::set_error("invalid argument: a guard needs positive capacities");
+        return GS_ERR_ARG;
+    }
+    gs::g_guard.info = info_dev;
+    gs::g_guard.cap_isects = info_dev ? cap_isects : 0;
+    gs::g_guard.cap_tile = info_dev ? cap_tile : 0;
+    return GS_OK;
+}
+
+namespace gs {
+__global__ void step_status_kernel(const int64_t* __restrict__ info, const int64_t* __restrict__ applied,
+                                   volatile int64_t* __restrict__ status) {
+    if (threadIdx.x < 4) status[threadIdx.x] = info[threadIdx.x];
+    if (threadIdx.x == 4) status[4] = applied ? applied[0] : 0;
+    __threadfence_system();
+}
+}  // namespace gs
+
+extern "C" int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied_dev, int64_t* status) {
+    if (!info_dev || !status) {
+        gs::set_error("invalid argument: null pointer");
+        return GS_ERR_ARG;
+    }
+    hipLaunchKernelGGL(gs::step_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info_dev, applied_dev, status);
+    GS_LAUNCH_CHECK("step_status_kernel");
+    return GS_OK;
+}
+
+extern "C" int gs_version(void) { return 200; }
 extern "C" const char* gs_last_error(void) { return gs::g_err; }
 extern "C" const char* gs_arch(void) { return "gfx950"; }

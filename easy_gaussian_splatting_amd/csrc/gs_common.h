@@ -40,6 +40,18 @@ void set_error(const char* fmt, ...);
 
 constexpr int kWave = 64;
 
+// Step guard (gs_guard_set, include/gs_raster.h): a device int64[4] info block {I, n_buckets, max tile, flags} plus
+// the capacities the caller sized its list buffers for.  While set (per host thread), gs_bin_count raises
+// flags when a capacity is exceeded and every kernel that walks or fills the lists -- and the kernels that
+// apply the step (statistics, Adam) -- returns at once when flags != 0.
+struct Guard {
+    const int64_t* info;   // device pointer, nullptr = unguarded
+    int64_t cap_isects;    // capacity of the intersection-indexed buffers
+    int64_t cap_tile;      // longest tile list the sort classes launched can take
+};
+Guard current_guard();
+__device__ __forceinline__ bool guard_tripped(const int64_t* info) { return info != nullptr && info[3] != 0; }
+
 // Workspace layout of the binning stage (all offsets in bytes, 256-B aligned).
 struct BinLayout {
     int groups;          // Gaussian groups per camera

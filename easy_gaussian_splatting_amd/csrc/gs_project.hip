@@ -259,6 +259,7 @@ struct ProjBwdArgs {
         *v_conics, *v_colors_post, *v_colors_pre;
     const float* opacities;   // raw (logit) opacities, read only when activations != 0
     int activations;
+    const int64_t* guard;     // step guard (gs_guard_set) or nullptr
 };
 
 struct RowSum {
@@ -341,6 +342,7 @@ constexpr int kCoopRows = 48;  // Gaussians with more rows than this are summed 
 template <int DEG>
 __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (guard_tripped(a.guard)) return;
     float* lds_cam = smem;
     int* vis_s = reinterpret_cast<int*>(smem + 32);
     float* tile = smem + 32 + kProjThreads;
@@ -705,6 +707,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.v_conics = v_conics; a.v_colors_post = v_colors_post; a.v_colors_pre = sh_degree >= 0 ? v_colors_pre : nullptr;
     GS_REQUIRE(!activations || opacities, "activations need the raw opacities");
     a.opacities = opacities; a.activations = activations != 0;
+    a.guard = current_guard().info;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
     const size_t lds = proj_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;

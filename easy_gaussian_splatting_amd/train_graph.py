@@ -1,0 +1,400 @@
+"""The reference's train step as ONE replayable hipGraph (SURVEY.md section 8b "Sync").
+
+`TrainStepGraph.step(data, gt_img)` runs, for the reference's single camera per iteration
+(/root/reference/train.py:36-58, 93-157):
+
+    activations + projection + SH colour -> tile lists -> per-tile sort -> blend forward ->
+    clamp + L1 + (1 - SSIM) forward / backward -> blend backward -> projection / SH backward ->
+    update_statistics -> Adam step (-> gradients dropped)
+
+through the C ABI of include/gs_raster.h directly -- the same kernels, in the same order, on the same
+inputs as `model(data)` / `LossComputer` / `loss.backward()` / `update_statistics` / `FusedAdam.step` issue
+them, so the two paths agree bit for bit (tests/test_gpu_train_graph.py) -- but
+
+* every buffer lives in a persistent workspace sized by CAPACITY (high-water mark of the intersection count
+  + margin), nothing is allocated per step and the host never reads a size back: the list kernels, the
+  statistics and Adam run under the library's step guard (`gs_guard_set`) -- a step whose lists outgrow the
+  capacity is a device-side no-op, and so is every step queued behind it;
+* the whole sequence is captured once into a hipGraph and replayed: per step the host enqueues the input
+  copies, one tiny launch that carries Adam's bias corrections / learning rates as kernel arguments, and the
+  graph;
+* overflow is detected lazily and without any runtime call: the last launch of every step writes {I, max tile
+  list, flags, applied-step count} into page-locked host memory the device can address, which the host polls as
+  plain memory; the runner then grows the workspace, re-captures and replays the steps that were skipped, in
+  order, with the inputs it kept for them -- the trajectory is exactly the one an unlimited workspace would
+  have taken.  (Copy + event based polling between replays of the same graph faulted on this ROCm build.)
+
+A change of N (densify_and_prune), of the parameter storage (reset_opacities), of the active SH degree or of
+the image size re-builds the workspace and re-captures.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import math
+from collections import deque
+from typing import Any, Dict, Optional
+
+import torch
+from torch import Tensor
+
+from . import _native as nat
+from .optim import FusedAdam
+
+_TILE = nat.GS_TILE
+_SORT_CLASSES = (1024, 4096, 8192, 16384)
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class TrainStepGraph:
+    def __init__(self, model, optimizer: FusedAdam, loss_computer, data: Dict[str, Any], gt_img: Tensor,
+                 mask: Optional[Tensor] = None, margin: float = 1.3, use_graph: bool = True, check_every: int = 16):
+        if not isinstance(optimizer, FusedAdam):
+            raise TypeError("TrainStepGraph drives optim.FusedAdam (flat parameter / moment buffers)")
+        if not getattr(loss_computer, "clamp_input", False) or not getattr(loss_computer, "fused", True):
+            raise ValueError("TrainStepGraph needs LossComputer(fused=True, clamp_input=True)")
+        if getattr(loss_computer, "model", None) is not None and getattr(model, "USE_SCALE_REGULARIZATION", False):
+            raise NotImplementedError("the scale regulariser is not part of the captured step")
+        self.model, self.opt, self.lc = model, optimizer, loss_computer
+        self.margin, self.use_graph, self.check_every = float(margin), bool(use_graph), int(check_every)
+        self.dev = model.means.device
+        self.W, self.H = int(data["width"]), int(data["height"])
+        self.has_mask = mask is not None
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        # The step runs on a stream of its own, fenced against the caller's current stream on both sides.  (Replays on
+        # the legacy NULL stream -- torch's default -- interleaved with other work on that stream end in GPU memory
+        # faults on this ROCm build; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 also avoids them.  A dedicated stream does not
+        # need the runtime knob.)
+        self.stream = torch.cuda.Stream(self.dev)
+        self.cap = 0
+        self.cap_tile = _SORT_CLASSES[0]
+        self.pending: deque = deque()     # steps issued but not yet confirmed applied: (t, lrs, w2c, K, gt, mask)
+        # {I, n_buckets, max tile, flags, applied} of the latest finished step, written by the device (gs_step_status)
+        self.status = torch.zeros((8,), dtype=torch.int64, pin_memory=True)
+        self.confirmed = 0                # steps known to be applied
+        self.issued = 0
+        self.stats = {"captures": 0, "overflows": 0, "replayed_steps": 0, "rebuilds": 0}
+        self._key = None
+        self.confirmed_at_build = 0
+        self._last_inputs = (data["w2c"], data["K"], gt_img, mask)
+        self._build(data, gt_img, mask)
+
+    # ------------------------------------------------------------------------------------------ workspace
+    def _state_key(self):
+        m = self.model
+        return (m.means.shape[0], self.opt.flat_param.data_ptr(), m.max_radii.data_ptr(), m.grad_norm_accum.data_ptr(),
+                m.collecting_counts.data_ptr(), m.active_sh_degree, getattr(m, "tile_culling", "tight"), self.W, self.H)
+
+    def _build(self, data, gt_img, mask, min_cap: int = 0, min_cap_tile: int = 0):
+        """(Re-)allocates the workspace for the model as it is now, learns the capacities from one blocking probe
+        of the list sizes if needed, warms every kernel up eagerly and captures the step."""
+        m, dev = self.model, self.dev
+        L = nat.lib()
+        self.N = N = m.means.shape[0]
+        self.K = 1 + m.sh_rest.shape[1]
+        W, H = self.W, self.H
+        self.tw, self.th = math.ceil(W / _TILE), math.ceil(H / _TILE)
+        tiles = self.tw * self.th
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        b = self.buf = {}
+        b["viewmats"] = torch.empty((1, 4, 4), **f32)
+        b["Ks"] = torch.empty((1, 3, 3), **f32)
+        b["gt"] = torch.empty((H, W, 3), **f32)
+        b["mask"] = torch.empty((H, W), **f32) if self.has_mask else None
+        b["bg"] = m.BACKGROUND.detach().reshape(1, 3).to(dev, torch.float32).contiguous().clone()
+        b["radii"] = torch.empty((1, N), **i32)
+        b["means2d"] = torch.empty((1, N, 2), **f32)
+        b["depths"] = torch.empty((1, N), **f32)
+        b["conics"] = torch.empty((1, N, 3), **f32)
+        b["colors_post"] = torch.empty((1, N, 3), **f32)
+        b["rec"] = torch.empty((N, nat.GS_REC_FLOATS), **f32)
+        b["bbox"] = torch.empty((N, 4), **i32)
+        b["tiles_per_gauss"] = torch.empty((1, N), **i32)
+        b["cum_tiles"] = torch.empty((N,), **i32)
+        self.ws_bytes = int(L.gs_bin_workspace_bytes(1, N, self.tw, self.th))
+        b["ws"] = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+        b["isect_offsets"] = torch.empty((tiles + 1,), **i32)
+        b["bucket_offsets"] = torch.empty((tiles + 1,), **i32)
+        b["tile_order"] = torch.empty((tiles,), **i32)
+        b["info"] = torch.zeros((4,), dtype=torch.int64, device=dev)
+        b["applied"] = torch.zeros((1,), dtype=torch.int64, device=dev)
+        b["render_colors"] = torch.empty((1, H, W, 3), **f32)
+        b["render_alphas"] = torch.empty((1, H, W, 1), **f32)
+        b["loss_ws"] = torch.empty((int(L.gs_loss_workspace_floats(H, W)),), **f32)
+        b["loss3"] = torch.zeros((3,), **f32)
+        b["one"] = torch.ones((), **f32)
+        b["v_render"] = torch.empty((H, W, 3), **f32)
+        b["qcnt"] = torch.empty((tiles * 4,), **i32)
+        b["unit_counter"] = torch.zeros((1,), **i32)
+        b["v_abs"] = torch.empty((1, N, 2), **f32)
+        self.grads = {"means": torch.empty((N, 3), **f32), "log_scales": torch.empty((N, 3), **f32),
+                      "quats": torch.empty((N, 4), **f32), "sh_0": torch.empty((N, 1, 3), **f32),
+                      "sh_rest": torch.empty((N, self.K - 1, 3), **f32) if self.K > 1 else None,
+                      "logit_opacities": torch.empty((N,), **f32)}
+        b["hyper"] = torch.zeros((16,), **f32)
+        self._set_inputs(data["w2c"], data["K"], gt_img, mask)
+        if self.cap == 0 or min_cap or min_cap_tile:
+            n_isects, max_tile = self._probe()
+            self.cap = max(int(max(n_isects, min_cap) * self.margin) + 4096, self.cap)
+            need_tile = max(int(max(max_tile, min_cap_tile) * 1.5), self.cap_tile)
+            self.cap_tile = next((c for c in _SORT_CLASSES if c >= need_tile), 1 << 30)
+        self._alloc_lists()
+        self._key = self._state_key()
+        # eager warm-up of the guarded pipeline (raises every kernel attribute; also a functional check before capture)
+        self._capture()
+        self.stats["rebuilds"] += 1
+
+    def _alloc_lists(self):
+        b, dev, cap = self.buf, self.dev, self.cap
+        tiles = self.tw * self.th
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.cap_buckets = cap // nat.GS_BUCKET + tiles + 1
+        b["keys_tmp"] = torch.empty((cap,), dtype=torch.int64, device=dev)
+        b["slot_gid"] = torch.empty((cap,), **i32)
+        b["isect_ids"] = torch.empty((cap,), dtype=torch.int64, device=dev)
+        b["flatten_ids"] = torch.empty((cap,), **i32)
+        b["slots"] = torch.empty((cap,), **i32)
+        b["ckpt"] = torch.empty((4 * self.cap_buckets, 64, 4), **f32)
+        b["qlist"] = torch.empty((4 * cap, 2), **i32)
+        b["qmask"] = torch.empty((cap,), dtype=torch.uint8, device=dev)
+        b["unit_desc"] = torch.empty((4 * self.cap_buckets, 2), **i32)
+        b["rows"] = torch.empty((4 * cap, nat.GS_ROW_FLOATS), **f32)
+
+    def _set_inputs(self, w2c: Tensor, K: Tensor, gt: Tensor, mask: Optional[Tensor]):
+        b = self.buf
+        if w2c.data_ptr() != b["viewmats"].data_ptr():   # (the static buffer itself = "same as last step")
+            b["viewmats"][0].copy_(w2c, non_blocking=True)
+        if K.data_ptr() != b["Ks"].data_ptr():
+            b["Ks"][0].copy_(K, non_blocking=True)
+        if gt.data_ptr() != b["gt"].data_ptr():
+            b["gt"].copy_(gt, non_blocking=True)
+        if self.has_mask:
+            if mask is None:
+                raise ValueError("this runner was built with a mask; pass one every step")
+            if mask.data_ptr() != b["mask"].data_ptr():
+                b["mask"].copy_(mask, non_blocking=True)
+
+    def _st(self) -> int:
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    class _OnStepStream:
+        """`with runner._on_stream():` -- everything inside is enqueued on the runner's stream, ordered after the
+        caller's current stream on entry and before it on exit."""
+
+        def __init__(self, runner):
+            self.r = runner
+
+        def __enter__(self):
+            r = self.r
+            self.outer = torch.cuda.current_stream(r.dev)
+            r.stream.wait_stream(self.outer)
+            self.ctx = torch.cuda.stream(r.stream)
+            self.ctx.__enter__()
+
+        def __exit__(self, *exc):
+            self.ctx.__exit__(*exc)
+            self.outer.wait_stream(self.r.stream)
+            return False
+
+    def _on_stream(self):
+        return TrainStepGraph._OnStepStream(self)
+
+    stop_after = int(__import__('os').environ.get('GS_TG_STOP_AFTER', '0'))
+    debug_sync = False   # set True to synchronise after every stage (locates a faulting kernel; never under capture)
+
+    class _Stop(Exception):
+        pass
+
+    def _ck(self, rc: int, what: str) -> None:
+        nat.check(rc, what)
+        self._stage_no = getattr(self, "_stage_no", 0) + 1
+        if self.stop_after and self._stage_no >= self.stop_after:   # debugging aid: truncate the pipeline
+            raise TrainStepGraph._Stop()
+        if self.debug_sync and not torch.cuda.is_current_stream_capturing():
+            self.stream.synchronize()
+
+    def _project_and_count(self):
+        L, b, m = nat.lib(), self.buf, self.model
+        st = self._st()
+        culling = {"gsplat": 0, "tight": 1}[getattr(m, "tile_culling", "tight")]
+        self._ck(L.gs_project_fwd(st, 1, self.N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
+                                   _p(m.logit_opacities), _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0,
+                                   _p(b["viewmats"]), _p(b["Ks"]), self.W, self.H, 0.3, 0.01, 1e10, 0.0, culling, 0, 1,
+                                   _p(b["radii"]), _p(b["means2d"]), _p(b["depths"]), _p(b["conics"]), _p(b["colors_post"]),
+                                   _p(b["rec"]), _p(b["bbox"]), _p(b["tiles_per_gauss"])), "gs_project_fwd")
+        self._ck(L.gs_bin_count(st, 1, self.N, self.tw, self.th, _p(b["bbox"]), _p(b["ws"]), self.ws_bytes, _p(b["isect_offsets"]),
+                                 _p(b["bucket_offsets"]), _p(b["tile_order"]), _p(b["info"]), None), "gs_bin_count")
+
+    def _probe(self):
+        """One blocking read of {I, max tile list} for the current inputs (build time only)."""
+        with torch.cuda.device(self.dev), self._on_stream():
+            self._project_and_count()
+        info = self.buf["info"].tolist()
+        self.buf["info"].zero_()
+        return int(info[0]), int(info[2])
+
+    def _enqueue_step(self):
+        """The whole step on the current stream, guarded; nothing here allocates or synchronises."""
+        L, b, m, opt = nat.lib(), self.buf, self.model, self.opt
+        st = self._st()
+        N, W, H = self.N, self.W, self.H
+        nat.check(L.gs_guard_set(_p(b["info"]), self.cap, self.cap_tile), "gs_guard_set")
+        self._stage_no = 0
+        try:
+            self._project_and_count()
+            self._ck(L.gs_bin_emit_sort(st, 1, N, self.tw, self.th, _p(b["bbox"]), _p(b["depths"]), _p(b["ws"]), self.ws_bytes,
+                                         _p(b["isect_offsets"]), self.cap, self.cap_tile, _p(b["keys_tmp"]), _p(b["slot_gid"]),
+                                         _p(b["cum_tiles"]), _p(b["isect_ids"]), _p(b["flatten_ids"]), _p(b["slots"])), "gs_bin_emit_sort")
+            self._ck(L.gs_blend_fwd(st, 1, W, H, _p(b["rec"]), _p(b["bg"]), _p(b["isect_offsets"]), _p(b["bucket_offsets"]),
+                                     _p(b["tile_order"]), _p(b["flatten_ids"]), _p(b["slots"]), self.cap, _p(b["render_colors"]),
+                                     _p(b["render_alphas"]), _p(b["ckpt"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["qmask"]),
+                                     _p(b["unit_counter"]), _p(b["unit_desc"])), "gs_blend_fwd")
+            lam = float(self.lc.lambda_ssim)
+            self._ck(L.gs_l1_ssim_fwd(st, H, W, lam, _p(b["render_colors"]), _p(b["gt"]), _p(b["mask"]), 1, _p(b["loss_ws"]),
+                                       _p(b["loss3"])), "gs_l1_ssim_fwd")
+            self._ck(L.gs_l1_ssim_bwd(st, H, W, lam, _p(b["render_colors"]), _p(b["gt"]), _p(b["mask"]), 1, _p(b["loss_ws"]),
+                                       _p(b["one"]), _p(b["v_render"])), "gs_l1_ssim_bwd")
+            self._ck(L.gs_blend_bwd(st, 1, W, H, _p(b["rec"]), _p(b["isect_offsets"]), _p(b["bucket_offsets"]), self.cap_buckets,
+                                     _p(b["qlist"]), _p(b["qcnt"]), _p(b["unit_counter"]), _p(b["unit_desc"]), _p(b["ckpt"]),
+                                     _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"]), None),
+                      "gs_blend_bwd")
+            g = self.grads
+            self._ck(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
+                                       _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0, _p(b["viewmats"]), _p(b["Ks"]), W, H,
+                                       0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]),
+                                       _p(b["cum_tiles"]), _p(b["rows"]), _p(b["qmask"]), _p(g["means"]), _p(g["quats"]),
+                                       _p(g["log_scales"]), _p(g["logit_opacities"]), _p(g["sh_0"]), _p(g["sh_rest"]), _p(b["v_abs"]),
+                                       None, None, None, None, _p(m.logit_opacities), 1), "gs_project_bwd")
+            self._ck(L.gs_update_statistics(st, N, float(max(H, W)), _p(b["radii"]), _p(b["v_abs"]), _p(m.max_radii),
+                                             _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_update_statistics")
+            ns = len(opt._plist)
+            ends = (ct.c_int64 * ns)(*opt._ends)
+            lens = (ct.c_int64 * ns)(*opt._lens)
+            gptr = (ct.c_void_p * ns)(*[_p(g[grp["name"]]) for grp, _ in opt._plist])
+            b1, b2 = opt.defaults["betas"]
+            self._ck(L.gs_adam_step_dev(st, opt.flat_param.numel(), _p(opt.flat_param), _p(opt.exp_avg), _p(opt.exp_avg_sq), ns,
+                                         ends, lens, gptr, float(b1), float(b2), float(opt.defaults["eps"]), 1.0, _p(b["hyper"]),
+                                         _p(b["applied"])), "gs_adam_step_dev")
+            self._ck(L.gs_step_status(st, _p(b["info"]), _p(b["applied"]), self.status.data_ptr()), "gs_step_status")
+        except TrainStepGraph._Stop:
+            pass
+        finally:
+            L.gs_guard_set(None, 0, 0)
+
+    def _hyper(self, t: int, lrs):
+        L, opt = nat.lib(), self.opt
+        ns = len(opt._plist)
+        b1, b2 = opt.defaults["betas"]
+        nat.check(L.gs_adam_hyper(self._st(), ns, (ct.c_float * ns)(*lrs), float(b1), float(b2), int(t), _p(self.buf["hyper"])),
+                  "gs_adam_hyper")
+
+    def _capture(self):
+        """Warm-up outside capture is NOT possible without applying a step, so the first launch of every kernel
+        happens on a throw-away copy of the optimizer state: parameters, moments and statistics are saved, one eager
+        guarded step runs (raising kernel attributes, validating capacities), and the state is restored."""
+        opt, m = self.opt, self.model
+        names = ("max_radii", "grad_norm_accum", "collecting_counts")
+        with torch.cuda.device(self.dev), self._on_stream():
+            saved = [opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()] + [getattr(m, n).clone() for n in names]
+            self._hyper(max(opt._step, 0) + 1, [float(grp["lr"]) for grp, _ in opt._plist])
+            self._enqueue_step()
+            self.stream.synchronize()
+            info = self.buf["info"].tolist()
+            with torch.no_grad():
+                opt.flat_param.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
+                for n, s in zip(names, saved[3:]):
+                    getattr(m, n).copy_(s)
+            self.buf["applied"].zero_()
+            if info[3] != 0:   # the capacities learnt from the probe do not hold (cannot happen unless inputs changed in between)
+                self.buf["info"].zero_()
+                raise RuntimeError(f"TrainStepGraph: warm-up step overflowed its own capacities {info}")
+            self.graph = None
+            if self.use_graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream):
+                    self._enqueue_step()
+                self.graph = g
+                self.stats["captures"] += 1
+            self.stream.synchronize()
+        self.status.zero_()   # (nothing is in flight: the warm-up step's status words are stale)
+        self.confirmed_at_build = self.confirmed
+
+    # ------------------------------------------------------------------------------------------ stepping
+    def _issue(self, entry):
+        t, lrs, w2c, K, gt, mask = entry
+        with torch.cuda.device(self.dev), self._on_stream():
+            self._set_inputs(w2c, K, gt, mask)
+            self._hyper(t, lrs)
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._enqueue_step()
+        self.pending.append(entry)
+        self.issued += 1
+
+    def step(self, data: Optional[Dict[str, Any]] = None, gt_img: Optional[Tensor] = None, mask: Optional[Tensor] = None):
+        """One training iteration.  `data` / `gt_img` / `mask` default to the previous step's (static buffers are
+        re-used as they are).  Returns the runner's static output tensors (valid until the next step)."""
+        if self._state_key() != self._key:
+            self.finish()
+            cur = self._last_inputs if data is None else (data["w2c"], data["K"], gt_img if gt_img is not None else self.buf["gt"], mask)
+            if data is not None:
+                self.W, self.H = int(data["width"]), int(data["height"])
+            self.cap = 0
+            self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None)
+        b = self.buf
+        w2c = b["viewmats"][0] if data is None else data["w2c"]
+        K = b["Ks"][0] if data is None else data["K"]
+        gt = b["gt"] if gt_img is None else gt_img
+        mk = (b["mask"] if mask is None else mask) if self.has_mask else None
+        self._last_inputs = (w2c, K, gt, mk)
+        opt = self.opt
+        opt._step += 1
+        self._issue((opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk))
+        if self.issued % self.check_every == 0:
+            self._poll(block=False)
+        return {"render_img": b["render_colors"][0], "loss3": b["loss3"], "batch_radii": b["radii"], "absgrad": b["v_abs"]}
+
+    def _poll(self, block: bool):
+        """Reads the device-written status words (plain host memory) and retires the steps known to be applied."""
+        if block:
+            self.stream.synchronize()
+        n_isects, _, max_tile, flags, applied = (int(v) for v in self.status[:5].tolist())
+        done = min(self.confirmed_at_build + applied - self.confirmed, len(self.pending))
+        for _ in range(max(done, 0)):
+            self.pending.popleft()
+        self.confirmed += max(done, 0)
+        if flags != 0:
+            self._recover(n_isects, max_tile)
+
+    def _recover(self, n_isects: int, max_tile: int):
+        """A step did not fit: everything issued after the last applied step was skipped on the device.  Grow, re-capture,
+        replay the skipped steps in order."""
+        self.stream.synchronize()
+        applied = int(self.buf["applied"].item())
+        done = self.confirmed_at_build + applied - self.confirmed
+        for _ in range(done):
+            self.pending.popleft()
+        self.confirmed += done
+        redo = list(self.pending)
+        self.pending.clear()
+        self.issued -= len(redo)
+        self.stats["overflows"] += 1
+        self.stats["replayed_steps"] += len(redo)
+        first = redo[0]
+        self._build({"w2c": first[2], "K": first[3]}, first[4], first[5], min_cap=n_isects, min_cap_tile=max_tile)
+        for e in redo:
+            self._issue(e)
+
+    def finish(self):
+        """Blocks until every issued step is known to be applied (replaying overflowed ones)."""
+        while self.pending:
+            self._poll(block=True)
+
+    def report(self) -> Dict[str, Any]:
+        return dict(self.stats, capacity_isects=self.cap, capacity_tile_list=self.cap_tile, steps=self.confirmed,
+                    graph=self.graph is not None)

@@ -46,6 +46,24 @@ int gs_version(void);
 const char* gs_last_error(void);
 const char* gs_arch(void); /* "gfx950" */
 
+/* Step guard: lets a whole step (forward, backward, statistics, Adam) be enqueued -- and captured into a
+ * hipGraph -- without the host ever reading the list sizes back (SURVEY.md section 8b "Sync").  The caller
+ * sizes every intersection-indexed buffer for cap_isects entries (bucket-indexed ones for
+ * cap_isects/64 + C*tiles + 1 buckets), launches the sort classes for lists of up to cap_tile entries
+ * (gs_bin_emit_sort's max_tile_count = cap_tile) and zeroes info_dev[3] once.  While the guard is set (per host
+ * thread; pass NULL to clear), gs_bin_count ORs into info_dev[3]: 1 if I > cap_isects, 2 if a tile list exceeds
+ * cap_tile; and gs_bin_emit_sort, gs_blend_fwd, gs_blend_bwd, gs_project_bwd, gs_update_statistics and
+ * gs_adam_step[_dev] return at once on the device when info_dev[3] != 0: a step that does not fit -- and every
+ * step enqueued behind it -- is a no-op the host can detect later (read info_dev), re-size for, clear and replay.
+ * n_isects / n_buckets / max_tile_count arguments of those entry points may then be the capacities. */
+int gs_guard_set(const int64_t* info_dev, int64_t cap_isects, int64_t cap_tile);
+
+/* Publishes a guarded step's outcome without a copy or an event: one tiny launch writes
+ * status[0..3] = info_dev[0..3] ({I, n_buckets, max tile, flags}) and status[4] = applied_dev[0] (may be NULL).
+ * `status` may be page-locked HOST memory (hipHostMalloc'ed, device-accessible): the host then polls plain memory
+ * -- the flags are sticky and the applied-step counter monotonic, so a torn read is harmless. */
+int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied_dev, int64_t* status);
+
 /* Number of Gaussian groups per camera used by the binning kernels, and the bytes of scratch
  * `workspace` gs_bin_count / gs_bin_emit_sort need for (C, N, tiles). */
 int gs_bin_groups(int64_t N);
@@ -211,6 +229,16 @@ int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* 
                  int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
                  const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
                  float beta2, float eps, int64_t step, float grad_scale);
+
+/* Replayable form of gs_adam_step for a captured step: bias corrections and learning rates come from the device
+ * array hyper_dev[1 + n_segments] = {1/sqrt(1-beta2^t), lr_k/(1-beta1^t)...}, which gs_adam_hyper writes (values
+ * travel as kernel arguments of a one-thread launch, so successive steps cannot race on a host buffer).
+ * applied_dev (optional): device counter incremented by every launch the step guard did not skip. */
+int gs_adam_hyper(void* stream, int n_segments, const float* seg_lrs_host, float beta1, float beta2, int64_t step,
+                  float* hyper_dev);
+int gs_adam_step_dev(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq, int n_segments,
+                     const int64_t* seg_ends_host, const int64_t* seg_lens_host, const float* const* seg_grads_host,
+                     float beta1, float beta2, float eps, float grad_scale, const float* hyper_dev, int64_t* applied_dev);
 
 /* Row e: this rank's contribution to the SUM all-reduce of the view-parallel step in one pass: the four
  * geometry gradients and this view's two additive statistics (|absgrad|_2 * max_hw, visibility count)

@@ -28,6 +28,7 @@
 typedef double real;
 #define RSQRT(x) sqrt(x)
 #define REXP(x) exp(x)
+#define RLOG(x) log(x)
 #define RCEIL(x) ceil(x)
 #define RFLOOR(x) floor(x)
 #define RABS(x) fabs(x)
@@ -35,6 +36,7 @@ typedef double real;
 typedef float real;
 #define RSQRT(x) sqrtf(x)
 #define REXP(x) expf(x)
+#define RLOG(x) logf(x)
 #define RCEIL(x) ceilf(x)
 #define RFLOOR(x) floorf(x)
 #define RABS(x) fabsf(x)
@@ -378,11 +380,14 @@ int gso_blend_fwd(int C, int N, int W, int H, int tile, const real* means2d, con
  *   - the conic's own rounding moves sigma by ~1e-5 of the magnitude of its terms;
  *   - T inherits the accumulated relative error of every alpha blended before.
  * margin = gap * 1e-4 / (1e-4 + reachable relative perturbation).  Parity tests exempt pixels with
- * margin < 1e-4 from the strict bound (they must stay rare and are still bounded by one contributor's weight). */
+ * margin < 1e-4 from the strict bound (they must stay rare and are still bounded by one contributor's weight).
+ * means2d_o / conics_o (optional): the OTHER implementation's means2d / conics.  When given, the reachable
+ * perturbation of sigma is measured, not bounded: twice |sigma(other's mean, other's conic) - sigma| at this very
+ * pixel, plus the rounding of an fp32 evaluation of the form (8 ulps of the magnitude of its terms). */
 #define GSO_EPS32 ((real)1.1920929e-7)
 int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, const real* conics,
                      const real* opac, const int32_t* isect_offsets, const int32_t* flatten_ids,
-                     int64_t I, real* margin) {
+                     int64_t I, const real* means2d_o, const real* conics_o, real* margin) {
     int tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile;
     const real base = (real)1e-4;
     (void)N;
@@ -405,9 +410,20 @@ int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, 
                 if (alpha > ALPHA_MAX) alpha = ALPHA_MAX;
                 real mag = (real)0.5 * (RABS(A * dx * dx) + RABS(Cc * dy * dy)) + RABS(B * dx * dy);
                 real amax = RABS(mux) > RABS(muy) ? RABS(mux) : RABS(muy);
-                real dmu = 4 * GSO_EPS32 * (amax > 64 ? amax : 64);
-                real es = (RABS(A * dx + B * dy) + RABS(B * dx + Cc * dy)) * dmu + (real)1e-5 * mag;   /* reachable |d sigma| */
-                real ma = RABS(alpha - ALPHA_MIN) / ALPHA_MIN * base / (base + es);
+                real es;   /* reachable |d sigma| */
+                if (means2d_o && conics_o) {
+                    real dxo = means2d_o[2 * g] - px, dyo = means2d_o[2 * g + 1] - py;
+                    real so = (real)0.5 * (conics_o[3 * g] * dxo * dxo + conics_o[3 * g + 2] * dyo * dyo) + conics_o[3 * g + 1] * dxo * dyo;
+                    es = 2 * RABS(so - sigma) + 8 * GSO_EPS32 * mag;
+                } else {   /* a-priori: mean moved by a few ulps of its coordinate, conic by 1e-5, fp32 evaluation */
+                    real dmu = 4 * GSO_EPS32 * (amax > 64 ? amax : 64);
+                    es = (RABS(A * dx + B * dy) + RABS(B * dx + Cc * dy)) * dmu + ((real)1e-5 + 4 * GSO_EPS32) * mag;
+                }
+                /* gap of ln(alpha) to ln(1/255) -- in the log domain a perturbation of sigma is additive, also far from
+                 * the threshold (|sigma| ~ 1e5 at pixels a sharp splat can never reach) */
+                real ma = RABS(RLOG(opac[g] > 0 ? opac[g] : (real)1e-30) - sigma - RLOG(ALPHA_MIN));
+                if (ma > 1) ma = 1;
+                ma = ma * base / (base + es);
                 if (ma < m) m = ma;
                 /* sigma >= 0: the form is positive (semi-)definite, so only rounding inside its own evaluation can
                  * make it negative -- the gap is measured relative to the magnitude of its three terms */
@@ -418,7 +434,9 @@ int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, 
                 if (sigma < 0 || alpha < ALPHA_MIN) continue;
                 real Tn = T * (1 - alpha);
                 eT += alpha / (1 - alpha) * es;
-                real mt = RABS(Tn - T_MIN) / T_MIN * base / (base + eT);
+                real mt = RABS(RLOG(Tn > 0 ? Tn : (real)1e-30) - RLOG(T_MIN));
+                if (mt > 1) mt = 1;
+                mt = mt * base / (base + eT);
                 if (mt < m) m = mt;
                 if (Tn <= T_MIN) break;
                 T = Tn;

@@ -91,17 +91,23 @@ def render(means, quats, scales, opacities, colors, viewmats, Ks, width, height,
                              eps2d=eps2d, near_plane=near_plane, far_plane=far_plane))
 
 
-def blend_margin(fwd: Dict[str, np.ndarray]) -> np.ndarray:
-    """[C,H,W] relative distance of every pixel to the nearest blend discontinuity (see
-    gso_blend_margin); small values mark pixels where a 1-ulp difference may flip a contributor."""
+def blend_margin(fwd: Dict[str, np.ndarray], means2d_other=None, conics_other=None) -> np.ndarray:
+    """[C,H,W] normalised distance of every pixel to the nearest blend discontinuity (see gso_blend_margin); values
+    below 1e-4 mark pixels where an fp32 evaluation may legitimately flip a contributor.  With `means2d_other` /
+    `conics_other` (the implementation under test's [C,N,2] / [C,N,3] arrays) the reachable perturbation of each
+    exponent is MEASURED (twice the difference between the two implementations' sigma at that pixel, plus fp32
+    evaluation rounding) instead of bounded a priori."""
     inp = fwd["_inputs"]
     dtype = fwd["means2d"].dtype
     L = _lib(dtype)
     C, N = fwd["radii"].shape
     W, H = inp["width"], inp["height"]
     out = np.ones((C, H, W), dtype)
+    m_o = c_o = None
+    if means2d_other is not None and conics_other is not None:
+        m_o, c_o = _c(means2d_other, dtype), _c(conics_other, dtype)
     L.gso_blend_margin(C, N, W, H, inp["tile_size"], _p(fwd["means2d"]), _p(fwd["conics"]), _p(fwd["opacities"]),
-                       _p(fwd["isect_offsets"]), _p(fwd["flatten_ids"]), ct.c_int64(fwd["n_isects"]), _p(out))
+                       _p(fwd["isect_offsets"]), _p(fwd["flatten_ids"]), ct.c_int64(fwd["n_isects"]), _p(m_o), _p(c_o), _p(out))
     return out
 
 

@@ -1,0 +1,133 @@
+"""TrainStepGraph (captured, sync-free train step) against the eager step it replaces: the reference's loop body
+(/root/reference/train.py:93-157) issued through model / LossComputer / autograd / FusedAdam.  Same kernels on
+the same inputs in the same order => bitwise identical parameters, Adam moments, statistics and loss, including
+across a list-capacity overflow (skipped on the device, detected lazily, replayed) and across refinement."""
+import numpy as np
+import pytest
+import torch
+
+from easy_gaussian_splatting_amd.loss import LossComputer
+from easy_gaussian_splatting_amd.model import GaussianModel, build_optimizers
+from easy_gaussian_splatting_amd.train_graph import TrainStepGraph
+from scenes import make_scene
+
+pytestmark = pytest.mark.gpu
+LRS = (1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2)
+
+
+def _setup(n=20000, W=320, H=208, n_views=3, seed=3, sh_degree=3, dist=4.0):
+    dev = torch.device("cuda:0")
+    sc = make_scene(n, W, H, sh_degree=sh_degree, n_views=n_views, seed=seed, scale_range=(0.01, 0.08), dist=dist)
+    T = torch.from_numpy
+    op = np.clip(sc["opacities"], 1e-3, 1 - 1e-3)
+    shs = T(sc["shs"])
+
+    def make():
+        m = GaussianModel(means=T(sc["means"]), log_scales=torch.log(T(sc["scales"])), quats=T(sc["quats"]),
+                          sh_0=shs[:, :1].contiguous(), sh_rest=shs[:, 1:].contiguous(),
+                          logit_opacities=T(np.log(op / (1 - op)).astype(np.float32)), sh_degree=sh_degree, white_background=True,
+                          means_lr_schedule_max_steps=40).to(dev)
+        return m, build_optimizers(m, *LRS, fused="hip")
+
+    datas = [{"w2c": T(sc["viewmats"][v]).to(dev), "K": T(sc["Ks"][v]).to(dev), "width": W, "height": H} for v in range(n_views)]
+    g = torch.Generator().manual_seed(11)
+    gts = [torch.rand((H, W, 3), generator=g).to(dev) for _ in range(n_views)]
+    return dev, make, datas, gts
+
+
+def _eager_step(model, opt, lc, data, gt, mask=None):
+    out = model(data, clamp=False)
+    loss = lc.get_loss_dict(out["render_img"], gt, mask)
+    loss["total"].backward()
+    model.update_statistics(data, out)
+    opt.step()
+    opt.zero_grad()
+    return torch.stack([loss["l1"].detach(), loss["ssim"].detach(), loss["total"].detach()])
+
+
+def _assert_same(ma, oa, mb, ob, what=""):
+    for k in ma.param_names:
+        assert torch.equal(getattr(ma, k).detach(), getattr(mb, k).detach()), (what, k)
+        for x, y in zip(oa.moments_of(getattr(ma, k)), ob.moments_of(getattr(mb, k))):
+            assert torch.equal(x, y), (what, k, "moment")
+    for k in ("max_radii", "grad_norm_accum", "collecting_counts"):
+        assert torch.equal(getattr(ma, k), getattr(mb, k)), (what, k)
+    assert oa._step == ob._step
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_graph_step_equals_eager_step(use_graph, with_mask):
+    dev, make, datas, gts = _setup()
+    (ma, oa), (mb, ob) = make(), make()
+    lc = LossComputer(0.2, clamp_input=True)
+    mask = None
+    if with_mask:
+        mask = torch.zeros((208, 320), device=dev)
+        mask[40:90, 100:200] = 1.0
+    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], mask, use_graph=use_graph, check_every=2)
+    for it in range(7):
+        v = it % 3
+        ma.update_learning_rate(it); mb.update_learning_rate(it)
+        l_ref = _eager_step(ma, oa, lc, datas[v], gts[v], mask)
+        out = runner.step(datas[v], gts[v], mask)
+        assert torch.equal(out["loss3"], l_ref), it
+        runner.finish()
+        _assert_same(ma, oa, mb, ob, f"step {it}")
+    rep = runner.report()
+    assert rep["steps"] == 7 and rep["overflows"] == 0 and rep["graph"] == use_graph
+    assert rep["captures"] == (1 if use_graph else 0)
+
+
+def test_overflow_is_skipped_on_device_detected_lazily_and_replayed():
+    """Capacity learnt from a far-away camera, then close-up views with several times the intersections arrive while
+    the host is running ahead: the overflowing step and everything queued behind it must be device-side no-ops, and
+    after the lazy check the runner must end on exactly the eager trajectory."""
+    dev, make, datas, gts = _setup(n=30000, n_views=3, dist=4.0)
+    far = dict(datas[0])
+    w2c = far["w2c"].clone()
+    w2c[2, 3] += 14.0   # camera pulled back: splats shrink, few intersections
+    far["w2c"] = w2c
+    (ma, oa), (mb, ob) = make(), make()
+    lc = LossComputer(0.2, clamp_input=True)
+    runner = TrainStepGraph(mb, ob, lc, far, gts[0], margin=1.02, check_every=4)
+    cap0 = runner.report()["capacity_isects"]
+    seq = [far, datas[1], datas[2], far, datas[0], datas[1]]
+    for it, d in enumerate(seq):   # no finish() in between: the host keeps enqueueing behind the overflow
+        _eager_step(ma, oa, lc, d, gts[it % 3])
+        runner.step(d, gts[it % 3])
+    runner.finish()
+    rep = runner.report()
+    assert rep["overflows"] >= 1 and rep["replayed_steps"] >= 1 and rep["capacity_isects"] > cap0 and rep["steps"] == len(seq)
+    _assert_same(ma, oa, mb, ob, "after overflow")
+
+
+def test_refinement_between_graph_steps_rebuilds_the_workspace():
+    """densify_and_prune changes N (up to 3x per call in the reference, model/gaussian.py:259), reset_opacities
+    swaps the parameter storage, up_sh_degree changes the kernels' template: the runner must notice and re-capture."""
+    dev, make, datas, gts = _setup(n=8000, sh_degree=3)
+    (ma, oa), (mb, ob) = make(), make()
+    for m in (ma, mb):
+        m.active_sh_degree = 1
+        m.DENSIFY_GRAD_THRESH = 0.0   # every visible Gaussian is cloned or split: N grows ~3x
+    lc = LossComputer(0.2, clamp_input=True)
+    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], check_every=3)
+    for it in range(3):
+        _eager_step(ma, oa, lc, datas[it % 3], gts[it % 3]); runner.step(datas[it % 3], gts[it % 3])
+    runner.finish()
+    _assert_same(ma, oa, mb, ob, "before refine")
+    n0 = ma.nbr_gaussians
+    for m, seed in ((ma, 5), (mb, 5)):
+        m.densify_and_prune(generator=torch.Generator(device=dev).manual_seed(seed))
+        m.up_sh_degree()
+    assert ma.nbr_gaussians == mb.nbr_gaussians > 1.5 * n0
+    for it in range(3):
+        _eager_step(ma, oa, lc, datas[it % 3], gts[it % 3]); runner.step(datas[it % 3], gts[it % 3])
+    runner.finish()
+    _assert_same(ma, oa, mb, ob, "after densify")
+    ma.reset_opacities(); mb.reset_opacities()
+    for it in range(2):
+        _eager_step(ma, oa, lc, datas[it], gts[it]); runner.step(datas[it], gts[it])
+    runner.finish()
+    _assert_same(ma, oa, mb, ob, "after opacity reset")
+    assert runner.report()["rebuilds"] >= 3
