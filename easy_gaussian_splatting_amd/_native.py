@@ -18,6 +18,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 
 GS_TILE = 16
 GS_BUCKET = 64
+GS_UNIT = 32
 GS_REC_FLOATS = 12
 GS_ROW_FLOATS = 12
 

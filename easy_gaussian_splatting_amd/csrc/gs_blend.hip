@@ -12,17 +12,18 @@
 //
 // In training mode the forward also emits, per quadrant, the COMPACTED depth-ordered sublist of
 // the entries that touch it (ranks from popcounts of the ballots), a checkpoint of the quadrant's
-// 64 pixel states (T, accumulated rgb) every 64 sublist entries, and one work-unit descriptor per
-// such 64-entry "quadrant bucket".
+// 64 pixel states (T, accumulated rgb) every 32 sublist entries, and one work-unit descriptor per
+// such 32-entry work unit.
 //
-// Backward: GAUSSIAN-parallel, no cross-lane reductions, no atomics.  A wavefront runs four
-// independent 16-lane systolic pipelines (one DPP row each); a pipeline owns one quadrant bucket:
-// lane r keeps entries 4r..4r+3 and their 4x11 gradient sums in registers while the quadrant's 64
-// pixels stream through -- at step s lane r treats pixel s-r against its four entries in depth
-// order, receives that pixel's running (T, P = prefix colour . v_colour) from lane r-1 through
-// one DPP row_shr:1 each and hands it on; lane 0 is fed from the checkpoint.  79 steps cover
-// 64 pixels x 64 entries (19 % pipeline fill instead of the 100 % a 64-lane pipeline would pay on
-// 64 pixels), and only (entry, quadrant) pairs the forward actually walked are ever evaluated.
+// Backward: GAUSSIAN-parallel, no cross-lane reductions, no atomics.  A wavefront runs eight
+// independent 8-lane systolic pipelines (two per 16-lane DPP row); a pipeline owns one work unit =
+// 32 consecutive entries of a quadrant sublist: lane r keeps entries 4r..4r+3 and their 4x11 gradient
+// sums in registers while the quadrant's 64 pixels stream through -- at step s lane r treats pixel
+// s-r against its four entries in depth order, receives that pixel's running (T, P = prefix colour .
+// v_colour) from lane r-1 through one DPP row_shr:1 each and hands it on; the pipeline's head lane
+// is fed from the checkpoint.  71 steps cover 64 pixels x 32 entries (10 % pipeline fill; the 16-lane,
+// 64-entry form it replaces paid 19 % and wasted half a bucket per sublist on average instead of a
+// quarter), and only (entry, quadrant) pairs the forward actually walked are ever evaluated.
 // Each lane finally stores 48-byte gradient rows at rows[slot*4 + quadrant]; gs_project_bwd sums
 // the rows of every Gaussian (contiguous slots) with plain coalesced loads.
 //
@@ -44,14 +45,18 @@ struct BlendFwdArgs {
     const int32_t *isect_offsets, *bucket_offsets, *flatten_ids, *slots;
     float *out_colors, *out_alphas;
     // training-mode outputs
-    float4* ckpt;          // [4*n_buckets][64]  quadrant-bucket checkpoints
+    float4* ckpt;          // [8*n_buckets][64]  work-unit checkpoints
     int2* qlist;           // [4*I] (flatten id, row slot): per tile 4 sublists of capacity len(tile)
     int32_t* qcnt;         // [C*tiles*4]        sublist lengths
     uint8_t* qmask;        // [I] by slot        which quadrant rows of an intersection exist
     int32_t* unit_counter; // [1]
-    int2* unit_desc;       // [4*n_buckets]      (tile*4+quadrant, bucket index within the sublist)
+    int2* unit_desc;       // [8*n_buckets]      (tile*4+quadrant, unit index within the sublist)
     const int64_t* guard;  // step guard (gs_guard_set) or nullptr
 };
+
+// Work unit of the backward: kUnit consecutive entries of one quadrant sublist (half a 64-entry bucket), with a
+// checkpoint of the quadrant's 64 pixel states in front of it.
+constexpr int kUnit = 32;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -180,10 +185,10 @@ __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArg
                     const bool ok = !done[k] && sigma >= 0.f && alpha >= kAlphaMin;
                     if (CKPT) {
                         if (!__any(ok)) continue;   // no pixel of the quadrant takes it: nothing to blend, nothing to list
-                        // the sublist entry that opens a new 64-entry quadrant bucket saves the pixel states before it
+                        // the sublist entry that opens a new work unit saves the pixel states before it
                         const int pos = cnt[k] + (int)__popcll(cq[k]);
-                        if ((pos & (GS_BUCKET - 1)) == 0)
-                            a.ckpt[((size_t)4 * bucket0 + (size_t)k * nb + pos / GS_BUCKET) * 64 + lane] =
+                        if ((pos & (kUnit - 1)) == 0)
+                            a.ckpt[((size_t)8 * bucket0 + (size_t)k * (2 * nb) + pos / kUnit) * 64 + lane] =
                                 make_float4(done[k] ? -1.f : T[k], cr[k], cg[k], cb[k]);
                         cq[k] |= 1ull << j;
                     }
@@ -206,10 +211,10 @@ __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArg
         __builtin_amdgcn_wave_barrier();
     }
     if (CKPT) {
-        // publish sublist lengths and one work unit per 64-entry quadrant bucket
+        // publish sublist lengths and one work unit per kUnit sublist entries
         int nu[4], tot = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { nu[k] = (cnt[k] + GS_BUCKET - 1) / GS_BUCKET; tot += nu[k]; }
+        for (int k = 0; k < 4; ++k) { nu[k] = (cnt[k] + kUnit - 1) / kUnit; tot += nu[k]; }
         if (lane < 4) a.qcnt[4 * t + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
         int base = 0;
         if (tot > 0) {
@@ -252,19 +257,18 @@ struct BlendBwdArgs {
 };
 
 constexpr int kBwdWaves = 4;
-constexpr int kRowLanes = 16;                       // one DPP row = one pipeline
-constexpr int kPerLane = GS_BUCKET / kRowLanes;     // 4 entries per lane
-constexpr int kBwdSteps = 64 + kRowLanes - 1;       // 79
+constexpr int kPipeLanes = 8;                       // lanes per systolic pipeline (two pipelines share a 16-lane DPP row)
+constexpr int kPerLane = kUnit / kPipeLanes;        // 4 entries per lane
+constexpr int kUnitsPerWave = 64 / kPipeLanes;      // 8
+constexpr int kBwdSteps = 64 + kPipeLanes - 1;      // 71
 
 __device__ __forceinline__ float dpp_row_shr1(float v) {
     // lane r of each 16-lane row receives lane r-1's value; lane 0 keeps its own
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
 }
 
-struct PixRec {   // 32 B per pixel in LDS (+ 8 B pixel centre in a second array)
-    float4 d0;    // v_r, v_g, v_b, E
-    float4 ck;    // checkpoint T, r, g, b
-};
+// per pixel in LDS: float4 (v_r, v_g, v_b, E) and float2 (checkpoint T, P = checkpoint colour . v) in two arrays
+// (24 B; the pixel centre is recomputed from the pixel index)
 
 struct EntryState {
     float mx, my, hA, Bc, hC, op, colr, colg, colb, At, Bt, Ct;
@@ -302,38 +306,37 @@ __device__ __forceinline__ void bwd_pair(EntryState& e, const float4 d0, const f
 }
 
 __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBwdArgs a) {
-    __shared__ PixRec spix_all[kBwdWaves][4][64];   // 8 KB per wave
-    __shared__ float2 sctr_all[kBwdWaves][4][64];   // 2 KB per wave: pixel centres
+    __shared__ float4 sd0_all[kBwdWaves][kUnitsPerWave][64];   // 8 KB per wave
+    __shared__ float2 sck_all[kBwdWaves][kUnitsPerWave][64];   // 4 KB per wave
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = lane >> 4, r = lane & (kRowLanes - 1);
+    const int pipe = lane / kPipeLanes, r = lane & (kPipeLanes - 1);
     if (guard_tripped(a.guard)) return;
     const int n_units = a.unit_counter[0];
-    const int unit = ((int)blockIdx.x * kBwdWaves + wave) * 4 + row;
-    if (((int)blockIdx.x * kBwdWaves + wave) * 4 >= n_units) return;   // wave-uniform
+    const int unit = ((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave + pipe;
+    if (((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave >= n_units) return;   // wave-uniform
     const bool valid = unit < n_units;
-    PixRec* spix = spix_all[wave][row];
-    float2* sctr = sctr_all[wave][row];
+    float4* sd0 = sd0_all[wave][pipe];
+    float2* sck = sck_all[wave][pipe];
 
     int tq = 0, kb = 0;
     if (valid) { const int2 d = a.unit_desc[unit]; tq = d.x; kb = d.y; }
     const int t = tq >> 2, q = tq & 3;
     const int lo = a.isect_offsets[t], len = a.isect_offsets[t + 1] - lo;
     const int nb = (len + GS_BUCKET - 1) / GS_BUCKET, bucket0 = a.bucket_offsets[t];
-    const int n_in = valid ? min(GS_BUCKET, a.qcnt[tq] - kb * GS_BUCKET) : 0;
+    const int n_in = valid ? min(kUnit, a.qcnt[tq] - kb * kUnit) : 0;
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
     const int tyi = tt / a.tw, txi = tt - tyi * a.tw;
     const int qx0 = txi * GS_TILE + 8 * (q & 1), qy0 = tyi * GS_TILE + 8 * (q >> 1);
+    const float fx0 = (float)qx0 + 0.5f, fy0 = (float)qy0 + 0.5f;
 
-    // stage the quadrant's 64 pixels: 4 per lane
-    const float4* ckp = a.ckpt + ((size_t)4 * bucket0 + (size_t)q * nb + kb) * 64;
+    // stage the quadrant's 64 pixels: 8 per lane of the pipeline
+    const float4* ckp = a.ckpt + ((size_t)8 * bucket0 + (size_t)q * (2 * nb) + kb) * 64;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = r + kRowLanes * i;
+    for (int i = 0; i < 64 / kPipeLanes; ++i) {
+        const int p = r + kPipeLanes * i;
         const int px = qx0 + (p & 7), py = qy0 + (p >> 3);
-        PixRec pr;
-        pr.d0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        pr.ck = make_float4(-1.f, 0.f, 0.f, 0.f);
-        sctr[p] = make_float2((float)px + 0.5f, (float)py + 0.5f);
+        float4 pd0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 pck = make_float2(-1.f, 0.f);
         if (valid && px < a.W && py < a.H) {
             const size_t o = ((size_t)cam * a.H + py) * a.W + px;
             const float vr = a.v_colors[3 * o], vg = a.v_colors[3 * o + 1], vb = a.v_colors[3 * o + 2];
@@ -341,10 +344,11 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
             const float va = a.v_alphas ? a.v_alphas[o] : 0.f;
             // E = T_final * v_alpha - render_colour . v_colour  (background terms cancel)
             const float E = Tf * va - (a.out_colors[3 * o] * vr + a.out_colors[3 * o + 1] * vg + a.out_colors[3 * o + 2] * vb);
-            pr.d0 = make_float4(vr, vg, vb, E);
-            pr.ck = ckp[p];
+            const float4 ck = ckp[p];
+            pd0 = make_float4(vr, vg, vb, E);
+            pck = make_float2(ck.x, ck.y * vr + ck.z * vg + ck.w * vb);
         }
-        spix[p] = pr;
+        sd0[p] = pd0; sck[p] = pck;
     }
 
     EntryState e[kPerLane];
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         slot[i] = 0;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
         if (e[i].has) {
-            const int2 gs = a.qlist[(size_t)4 * lo + (size_t)q * len + kb * GS_BUCKET + en];
+            const int2 gs = a.qlist[(size_t)4 * lo + (size_t)q * len + kb * kUnit + en];
             slot[i] = gs.y;
             const float4* rp = a.rec + 3 * (size_t)gs.x;
             q0 = rp[0]; q1 = rp[1]; q2 = rp[2];
@@ -376,9 +380,10 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         const int p = s - r;
         const bool act = (unsigned)p < 64u;
         const int pc = min(max(p, 0), 63);
-        const float4 d0 = spix[pc].d0, ck = spix[pc].ck;
-        const float2 d1 = sctr[pc];
-        if (r == 0) { T = ck.x; P = ck.y * d0.x + ck.z * d0.y + ck.w * d0.z; }
+        const float4 d0 = sd0[pc];
+        const float2 ck = sck[pc];
+        const float2 d1 = make_float2(fx0 + (float)(pc & 7), fy0 + (float)(pc >> 3));   // pixel centre
+        if (r == 0) { T = ck.x; P = ck.y; }   // head of the pipeline: fed from the checkpoint, not from the lane below
         T = act ? T : -1.f;   // pipeline fill / drain: nothing contributes
 #pragma unroll
         for (int i = 0; i < kPerLane; ++i) bwd_pair(e[i], d0, d1, T, P);
@@ -465,8 +470,8 @@ extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const fl
     a.rows = reinterpret_cast<float4*>(rows); a.rows_color = reinterpret_cast<float4*>(rows_color);
     a.guard = current_guard().info;
     // upper bound on work units: 4 quadrant sublists per tile, each at most as long as the tile list
-    const int64_t max_units = 4 * n_buckets;
-    const unsigned grid = (unsigned)((max_units + 4 * kBwdWaves - 1) / (4 * kBwdWaves));
+    const int64_t max_units = 8 * n_buckets;
+    const unsigned grid = (unsigned)((max_units + kUnitsPerWave * kBwdWaves - 1) / (kUnitsPerWave * kBwdWaves));
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(kBwdWaves * 64), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("blend_bwd_kernel");
     return GS_OK;

@@ -180,12 +180,12 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     ckpt = qlist = qcnt = qmask = unit_counter = unit_desc = None
     if need_grad:  # what the Gaussian-parallel backward consumes (see include/gs_raster.h)
         nbk = max(n_buckets, 1)
-        ckpt = torch.empty((4 * nbk, 64, 4), **f32)
+        ckpt = torch.empty((8 * nbk, 64, 4), **f32)   # one per 32-entry work unit
         qlist = torch.empty((4 * cap, 2), **i32)
         qcnt = torch.empty((C * tiles * 4,), **i32)
         qmask = torch.empty((cap,), dtype=torch.uint8, device=dev)
         unit_counter = torch.empty((1,), **i32)
-        unit_desc = torch.empty((4 * nbk, 2), **i32)
+        unit_desc = torch.empty((8 * nbk, 2), **i32)
     _stage("gs_blend_fwd", dev, lambda: nat.check(L.gs_blend_fwd(st, C, W, H, _ptr(rec), _ptr(backgrounds), _ptr(isect_offsets),
                              _ptr(bucket_offsets), _ptr(tile_order), _ptr(flatten_ids), _ptr(slots), n_isects, _ptr(render_colors),
                              _ptr(render_alphas), _ptr(ckpt), _ptr(qlist), _ptr(qcnt), _ptr(qmask),
@@ -222,7 +222,7 @@ class _Rasterize(torch.autograd.Function):
             means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, need_grad)
         holder.meta = meta
         if holder.debug is not None:   # work-unit counters of the backward (bench.py's compute roofline)
-            holder.debug.update(unit_counter=state["unit_counter"], qcnt=state["qcnt"], unit_entries=nat.GS_BUCKET)
+            holder.debug.update(unit_counter=state["unit_counter"], qcnt=state["qcnt"], unit_entries=nat.GS_UNIT)
         ctx.cfg, ctx.holder, ctx.state = cfg, holder, state
         ctx.split = colors_rest is not None
         if need_grad:

@@ -33,6 +33,7 @@ extern "C" {
 
 #define GS_TILE 16           /* tile edge in pixels (gsplat default tile_size=16) */
 #define GS_BUCKET 64         /* entries per bucket = one wavefront */
+#define GS_UNIT 32           /* quadrant-sublist entries per work unit of gs_blend_bwd (one checkpoint each) */
 #define GS_REC_FLOATS 12     /* packed per-(camera,Gaussian) blend record */
 #define GS_ROW_FLOATS 12     /* per-intersection gradient row written by gs_blend_bwd */
 
@@ -127,11 +128,11 @@ int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, con
  *   qlist[4*I*2] i32    per tile four compacted, depth-ordered quadrant sublists of (flatten id,
  *                       gradient-row slot) pairs (sublist k of tile t starts at pair 4*lo_t + k*len_t)
  *   qcnt[C*tiles*4]     sublist lengths
- *   ckpt[4*n_buckets*64*4] f32  per 64-entry quadrant bucket: the quadrant's 64 pixel states
- *                       (T -- negative once saturated / outside the image -- and accumulated rgb)
+ *   ckpt[8*n_buckets*64*4] f32  per GS_UNIT-entry work unit of a quadrant sublist: the quadrant's 64 pixel
+ *                       states in front of it (T -- negative once saturated / outside the image -- and accumulated rgb)
  *   qmask[I] u8         by gradient-row slot: which quadrant rows of an intersection exist (fully
  *                       written: entries behind a tile's saturation point read 0)
- *   unit_counter[1], unit_desc[4*n_buckets*2] i32   work units (tile*4+quadrant, bucket) */
+ *   unit_counter[1], unit_desc[8*n_buckets*2] i32   work units (tile*4+quadrant, unit index in the sublist) */
 int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                  const float* backgrounds, const int32_t* isect_offsets,
                  const int32_t* bucket_offsets, const int32_t* tile_order, const int32_t* flatten_ids, const int32_t* slots,
@@ -139,8 +140,8 @@ int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                  int32_t* qlist, int32_t* qcnt, uint8_t* qmask, int32_t* unit_counter,
                  int32_t* unit_desc);
 
-/* B-bwd (replaces rasterize_to_pixels backward incl. absgrad).  Gaussian-parallel: four 16-lane
- * systolic pipelines per wavefront, one 64-entry quadrant bucket each; no atomics.  Writes one
+/* B-bwd (replaces rasterize_to_pixels backward incl. absgrad).  Gaussian-parallel: eight 8-lane
+ * systolic pipelines per wavefront, one GS_UNIT-entry work unit each; no atomics.  Writes one
  * 12-float row per (intersection, quadrant) at rows[(slots[i]*4 + quadrant)*12]:
  * (v_mx, v_my, |v_mx|, |v_my|, v_A, v_B, v_C, v_opacity, v_r, v_g, v_b, 0); rows[I*4*12].
  * v_render_alphas may be NULL. */

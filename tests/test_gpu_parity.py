@@ -504,7 +504,9 @@ def test_degenerate_inputs_neither_hang_nor_poison():
 @pytest.mark.parametrize("case", range(24))
 def test_randomised_configurations(case):
     """Seeded sweep over sizes / SH degree / stored K / cameras / background / splat scale / culling
-    mode / SH layout: every combination must meet the same forward and gradient tolerances."""
+    mode / SH layout: every combination must meet the same forward and gradient tolerances.  A drawn scene in which
+    more than 5 % of the pixels sit on a blend threshold (a flat, faint splat covering the image at alpha ~ 1/255) is
+    useless as a parity case: the next scene seed of the same configuration is drawn instead (at most 4, printed)."""
     from easy_gaussian_splatting_amd.rendering import rasterization
     rng = np.random.default_rng(1000 + case)
     deg = int(rng.integers(0, 4))
@@ -513,29 +515,32 @@ def test_randomised_configurations(case):
     n = int(rng.integers(1, 3000))
     W, H = int(rng.integers(17, 260)), int(rng.integers(17, 200))
     smax = float(rng.choice([0.05, 0.2, 0.8]))
-    # (the default scene seeds of cases 18 and 20 draw a flat, faint, image-covering splat whose alpha sits within 2 %
-    #  of 1/255 over a third of the pixels: a legitimate razor-edge scene, useless as a parity case -- re-seeded)
-    scene_seed = {18: 3018, 20: 3020}.get(case, 2000 + case)
-    sc = make_scene(n, W, H, sh_degree=deg, seed=scene_seed, k_store=K, n_views=C, scale_range=(0.01, smax),
-                    dist=float(rng.uniform(2.5, 6.0)), white_bg=bool(rng.integers(0, 2)))
+    dist, white = float(rng.uniform(2.5, 6.0)), bool(rng.integers(0, 2))
     use_bg, split, culling = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)) and K > 1, str(rng.choice(["tight", "gsplat"]))
-    t = to_dev(sc)
-    base = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
-    if split:
-        sh = (t["shs"][:, :1].clone().contiguous().requires_grad_(True), t["shs"][:, 1:].clone().contiguous().requires_grad_(True))
-        leaves = base + list(sh)
-    else:
-        sh = t["shs"].clone().requires_grad_(True)
-        leaves = base + [sh]
-    img, alpha, meta = rasterization(*base, sh, t["viewmats"], t["Ks"], W, H, sh_degree=deg, packed=False,
-                                     backgrounds=t["backgrounds"] if use_bg else None, absgrad=True, _tile_culling=culling)
+    for attempt in range(4):
+        sc = make_scene(n, W, H, sh_degree=deg, seed=2000 + case + 1000 * attempt, k_store=K, n_views=C, scale_range=(0.01, smax),
+                        dist=dist, white_bg=white)
+        t = to_dev(sc)
+        base = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
+        if split:
+            sh = (t["shs"][:, :1].clone().contiguous().requires_grad_(True), t["shs"][:, 1:].clone().contiguous().requires_grad_(True))
+            leaves = base + list(sh)
+        else:
+            sh = t["shs"].clone().requires_grad_(True)
+            leaves = base + [sh]
+        img, alpha, meta = rasterization(*base, sh, t["viewmats"], t["Ks"], W, H, sh_degree=deg, packed=False,
+                                         backgrounds=t["backgrounds"] if use_bg else None, absgrad=True, _tile_culling=culling)
+        fw = run_oracle(sc, use_bg=use_bg)
+        razor = float((CO.blend_margin(fw, meta["means2d"].cpu().numpy(), meta["conics"].cpu().numpy()) < 1e-4).mean())
+        if razor <= MAX_RAZOR_FRAC:
+            break
+        print(f"[parity] case {case}: scene seed {2000 + case + 1000 * attempt} is a razor-edge scene ({razor:.3f}); drawing the next")
     g = torch.Generator().manual_seed(case)
     vc, va = torch.randn(img.shape, generator=g), torch.randn(alpha.shape, generator=g)
     grads = torch.autograd.grad((img * vc.to(dev())).sum() + (alpha * va.to(dev())).sum(), leaves)
     if split:
         grads = list(grads[:4]) + [torch.cat([grads[4], grads[5]], dim=1)]
     hip = dict(img=img, alpha=alpha, meta=meta, grads=grads, vc=vc.numpy().astype(np.float64), va=va.numpy().astype(np.float64))
-    fw = run_oracle(sc, use_bg=use_bg)
     check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC, lists=culling == "gsplat")
     if fw["n_isects"] > 0:
         check_backward(hip, fw)
