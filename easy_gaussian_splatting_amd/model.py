@@ -181,12 +181,82 @@ class GaussianModel(nn.Module):
                 state["exp_avg"], state["exp_avg_sq"] = new_m[name].contiguous(), new_v[name].contiguous()
                 opt.state[group["params"][0]] = state
 
+    def _split_noise(self, generator: Optional[torch.Generator]) -> Tensor:
+        """Standard-normal samples for the split children, [NUM_SPLITS, N, 3]: drawn for EVERY Gaussian so that the
+        draw needs no count from the device (the reference draws exactly the split parents' samples after a host
+        sync, /root/reference/model/gaussian.py:164-165; same distribution)."""
+        noise = torch.randn((self.NUM_SPLITS, self.nbr_gaussians, 3), device=self.means.device, generator=generator)
+        if is_distributed():
+            # replicas must stay bitwise identical (distributed.ViewParallelStep): every rank splits with
+            # rank 0's noise, whatever state its own generator is in
+            torch.distributed.broadcast(noise, src=0)
+        return noise
+
+    @torch.no_grad()
+    def _densify_and_prune_device(self, generator: Optional[torch.Generator]) -> Dict[str, Any]:
+        """Row f-3 on the device (csrc/gs_refine.hip): decisions, one prefix scan, one gather of all six parameters
+        and both Adam moments into fresh flat buffers; ONE host read (new sizes + tb_info counters)."""
+        import ctypes as ct
+        from . import _native as nat
+        from .optim import FusedAdam
+        L, opt, dev = nat.lib(), self.optimizer, self.means.device
+        n_old, S, K = self.nbr_gaussians, int(self.NUM_SPLITS), 1 + self.sh_rest.shape[1]
+        st = torch.cuda.current_stream(dev).cuda_stream
+        noise = self._split_noise(generator)
+        flags = torch.empty((3, n_old), dtype=torch.int32, device=dev)
+        counters = torch.empty((5,), dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            nat.check(L.gs_refine_flags(st, n_old, S, float(self.DENSIFY_GRAD_THRESH), float(self.DENSIFY_SCALE_THRESH),
+                                        float(self.PRUNE_RADII_RATIO_THRESH), float(self.PRUNE_SCALE_THRESH), float(self.MIN_OPACITY),
+                                        self.grad_norm_accum.data_ptr(), self.collecting_counts.data_ptr(), self.max_radii.data_ptr(),
+                                        self.log_scales.data_ptr(), self.logit_opacities.data_ptr(), flags.data_ptr(),
+                                        counters.data_ptr()), "gs_refine_flags")
+            incl = torch.cumsum(flags, dim=1, dtype=torch.int32)
+            # the one host read: three totals (they size the new buffers) + the five tb_info counters
+            host = torch.cat([incl[:, -1].to(torch.int64) if n_old else torch.zeros(3, dtype=torch.int64, device=dev), counters]).tolist()
+            tot_old, tot_child, tot_clone, ns, nc, c0, c1, c2 = (int(v) for v in host)
+            n_new = tot_old + S * tot_child + tot_clone
+            widths = [3, 3, 4, 3, 3 * (K - 1), 1]
+            old_offs = list(opt._offs)
+            new_offs, new_ends, total = FusedAdam.flat_layout([n_new * w for w in widths])
+            f32 = dict(dtype=torch.float32, device=dev)
+            new_p, new_m, new_v = torch.empty(total, **f32), torch.empty(total, **f32), torch.empty(total, **f32)
+            for o, w, e in zip(new_offs, widths, new_ends):   # the (<= 3 float) pads between segments
+                if e > o + n_new * w:
+                    for buf in (new_p, new_m, new_v):
+                        buf[o + n_new * w:e].zero_()
+            src = torch.empty((max(n_new, 1),), dtype=torch.int32, device=dev)
+            tag = torch.empty((max(n_new, 1),), dtype=torch.int8, device=dev)
+            nat.check(L.gs_refine_apply(st, n_old, S, K, flags.data_ptr(), incl.data_ptr(), tot_old, tot_child, tot_clone,
+                                        noise.data_ptr(), opt.flat_param.data_ptr(), opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(),
+                                        (ct.c_int64 * 6)(*old_offs), new_p.data_ptr(), new_m.data_ptr(), new_v.data_ptr(),
+                                        (ct.c_int64 * 6)(*new_offs), src.data_ptr(), tag.data_ptr()), "gs_refine_apply")
+        shapes = {"means": (n_new, 3), "log_scales": (n_new, 3), "quats": (n_new, 4), "sh_0": (n_new, 1, 3),
+                  "sh_rest": (n_new, K - 1, 3), "logit_opacities": (n_new,)}
+        new_params = []
+        for name, o, w in zip(self.param_names, new_offs, widths):
+            setattr(self, name, nn.Parameter(new_p[o:o + n_new * w].view(shapes[name])))
+            new_params.append(getattr(self, name))
+        opt.adopt_flat(new_p, new_m, new_v, new_params)
+        self.grad_norm_accum = torch.zeros((n_new,), device=dev)
+        self.collecting_counts = torch.zeros((n_new,), device=dev)
+        self.max_radii = torch.zeros((n_new,), device=dev)
+        if is_distributed():
+            from .distributed import assert_replicas_identical
+            assert_replicas_identical(self.means, "means after densify_and_prune")
+        return {"train/densify": {"split": ns, "clone": nc},
+                "train/prune": {"low_opacity": c0, "large_radii": c1 - c0, "large_scale": c2 - c1},
+                "train/nbr_gaussians": n_new, "n_before": n_old}
+
     @torch.no_grad()
     def densify_and_prune(self, generator: Optional[torch.Generator] = None) -> Dict[str, Any]:
         """Clone / split high-gradient Gaussians, prune transparent / huge ones, reset statistics
-        (/root/reference/model/gaussian.py:259-349).  Decisions are taken on the device; the host reads
-        three counts (split, clone, survivors) because tensor shapes need them."""
+        (/root/reference/model/gaussian.py:259-349).  With optim.FusedAdam on the GPU the whole refinement runs on the
+        device (`_densify_and_prune_device`: one host read); otherwise -- torch.optim.Adam, CPU -- the torch path below:
+        decisions on the device, three host reads (split, clone, survivors) because tensor shapes need them."""
         from .rendering import quat_to_rotmat_torch
+        if self.means.is_cuda and hasattr(self.optimizer, "adopt_flat") and getattr(self, "device_refine", True):
+            return self._densify_and_prune_device(generator)
         n_old = self.nbr_gaussians
         avg = self.grad_norm_accum / (self.collecting_counts + 1e-8)
         avg = torch.where(torch.isnan(avg), torch.zeros_like(avg), avg)
@@ -201,11 +271,7 @@ class GaussianModel(nn.Module):
         if ns:
             rep = split_idx.repeat(self.NUM_SPLITS)            # [parents..., parents...] like .repeat(NUM_SPLITS, 1)
             scales = torch.exp(params["log_scales"][rep])
-            noise = torch.randn((rep.numel(), 3), device=scales.device, generator=generator)
-            if is_distributed():
-                # replicas must stay bitwise identical (distributed.ViewParallelStep): every rank splits with
-                # rank 0's noise, whatever state its own generator is in
-                torch.distributed.broadcast(noise, src=0)
+            noise = self._split_noise(generator)[:, split_idx, :].reshape(-1, 3)   # copy-major, like `rep`
             R = quat_to_rotmat_torch(params["quats"][rep])
             offs = torch.bmm(R, (scales * noise).unsqueeze(-1)).squeeze(-1)
             for name in self.param_names:

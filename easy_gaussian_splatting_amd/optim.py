@@ -64,6 +64,33 @@ class FusedAdam(torch.optim.Optimizer):
         if not hasattr(self, "_step"):
             self._step = 0
 
+    @staticmethod
+    def flat_layout(numels):
+        """(offsets, padded ends, total) of the flat buffers for tensors of `numels` elements: back to back, each
+        padded to a multiple of 4 floats (what gs_adam_step expects)."""
+        offs, ends, off = [], [], 0
+        for n in numels:
+            offs.append(off)
+            off = (off + n + 3) // 4 * 4
+            ends.append(off)
+        return offs, ends, off
+
+    def adopt_flat(self, flat_param, exp_avg, exp_avg_sq, new_params):
+        """Takes over flat buffers that were filled elsewhere (model.densify_and_prune's device path, gs_refine_apply):
+        `new_params` are the parameters, one per group in group order, already views of `flat_param` in
+        `flat_layout` order.  The step count is kept, as the reference keeps Adam's `step` through its state surgery."""
+        assert len(new_params) == len(self.param_groups)
+        for group, p in zip(self.param_groups, new_params):
+            group["params"] = [p]
+        self._plist = [(g, p) for g in self.param_groups for p in g["params"]]
+        self._lens = [p.numel() for _, p in self._plist]
+        self._offs, self._ends, total = self.flat_layout(self._lens)
+        assert flat_param.numel() == total == exp_avg.numel() == exp_avg_sq.numel()
+        self.flat_param, self.exp_avg, self.exp_avg_sq = flat_param, exp_avg, exp_avg_sq
+        for _, p in self._plist:
+            p.grad = None
+        self._check_views()
+
     def moments_of(self, param):
         """(exp_avg, exp_avg_sq) views shaped like `param`."""
         for i, (_, p) in enumerate(self._plist):

@@ -241,6 +241,29 @@ int gs_adam_step_dev(void* stream, int64_t n, float* params, float* exp_avg, flo
                      const int64_t* seg_ends_host, const int64_t* seg_lens_host, const float* const* seg_grads_host,
                      float beta1, float beta2, float eps, float grad_scale, const float* hyper_dev, int64_t* applied_dev);
 
+/* ---- "next" row f-3: densify / prune on the device (/root/reference/model/gaussian.py:199-349) ----
+ * gs_refine_flags: per Gaussian, the reference's decisions.  flags[3][n] (0/1): row 0 the old Gaussian survives the
+ * prune (low opacity | max_radii > ratio | largest scale > prune_scale | it was split); row 1 it is split AND its
+ * children survive (children: same opacity, scales / (0.8 S)); row 2 it is cloned AND the clone survives.
+ * counters[5] (device, zeroed here) = {split, clone, then the reference's cumulative prune counts over [old | new]:
+ * low opacity, + large radii, + large scale} -- what densify_and_prune returns as tb_info.
+ * gs_refine_apply: given the INCLUSIVE prefix scans of the three flag rows (any scan; the binding uses torch.cumsum) and
+ * their totals (the one host read of the path: they size the new buffers), fills the new flat parameter / exp_avg /
+ * exp_avg_sq buffers in the reference's order [surviving old | split children, copy-major | clones]: survivors keep
+ * their moments, new Gaussians start at zero; split children get mean + R(q)(s * noise[copy][parent]) and
+ * log(s / (0.8 S)).  Flat layout as gs_adam_step: the six tensors of param_names (means, log_scales, quats, sh_0,
+ * sh_rest, logit_opacities) at old_offsets_host[6] / new_offsets_host[6] floats.  src_scratch[n_new] i32 and
+ * tag_scratch[n_new] i8 are scratch.  noise: [S][n_old][3] standard normal. */
+int gs_refine_flags(void* stream, int64_t n, int num_splits, float densify_grad_thresh, float densify_scale_thresh,
+                    float prune_radii_ratio_thresh, float prune_scale_thresh, float min_opacity,
+                    const float* grad_norm_accum, const float* counts, const float* max_radii, const float* log_scales,
+                    const float* logit_opacities, int32_t* flags, int64_t* counters);
+int gs_refine_apply(void* stream, int64_t n_old, int num_splits, int K, const int32_t* flags, const int32_t* flags_incl,
+                    int64_t tot_old, int64_t tot_child, int64_t tot_clone, const float* noise, const float* old_params,
+                    const float* old_exp_avg, const float* old_exp_avg_sq, const int64_t* old_offsets_host, float* new_params,
+                    float* new_exp_avg, float* new_exp_avg_sq, const int64_t* new_offsets_host, int32_t* src_scratch,
+                    int8_t* tag_scratch);
+
 /* Row e: this rank's contribution to the SUM all-reduce of the view-parallel step in one pass: the four
  * geometry gradients and this view's two additive statistics (|absgrad|_2 * max_hw, visibility count)
  * packed into flat = [means 3N | log_scales 3N | quats 4N | logit_opacities N | grad_norm N | count N],
