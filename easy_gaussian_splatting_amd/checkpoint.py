@@ -1,0 +1,125 @@
+"""Checkpoint layout and camera export of the reference:
+
+    <output>/checkpoints/iterations_<N>.pth      torch.save of the whole GaussianModel module (optimizer detached
+                                                 unless save_optimizer=True)        /root/reference/utils.py:78-87
+    <output>/cameras.json                        list of Frame.to_json dicts        /root/reference/scene/scene.py:91-94
+
+`load_gaussian_model(path, iterations=None)` picks the requested or the latest `iterations_*.pth`
+(/root/reference/utils.py:48-75).  The reference pickles the module by class reference
+(`model.gaussian.GaussianModel`, with a `model.utils.LR_Scheduler` inside); this package's GaussianModel carries the
+same attribute names, so files written here under those class paths unpickle in the reference, and files written by
+the reference unpickle here -- `reference_class_paths()` installs / removes the two alias modules around the
+(un)pickling, nothing of the reference is imported.
+"""
+from __future__ import annotations
+
+import contextlib
+import json
+import sys
+import types
+from pathlib import Path
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import model as _model
+
+
+@contextlib.contextmanager
+def reference_class_paths():
+    """Temporarily exposes this package's GaussianModel / LR_Scheduler as `model.gaussian.GaussianModel` and
+    `model.utils.LR_Scheduler`, the paths the reference's pickles name (/root/reference/model/gaussian.py:14,
+    model/utils.py:19)."""
+    names = ("model", "model.gaussian", "model.utils")
+    saved = {n: sys.modules.get(n) for n in names}
+    pkg = types.ModuleType("model")
+    pkg.__path__ = []   # a package
+    gaussian = types.ModuleType("model.gaussian")
+    utils = types.ModuleType("model.utils")
+    gaussian.GaussianModel = _model.GaussianModel
+    utils.LR_Scheduler = _model.LR_Scheduler
+    pkg.gaussian, pkg.utils = gaussian, utils
+    old_names = (_model.GaussianModel.__module__, _model.LR_Scheduler.__module__)
+    sys.modules.update({"model": pkg, "model.gaussian": gaussian, "model.utils": utils})
+    _model.GaussianModel.__module__, _model.LR_Scheduler.__module__ = "model.gaussian", "model.utils"
+    try:
+        yield
+    finally:
+        _model.GaussianModel.__module__, _model.LR_Scheduler.__module__ = old_names
+        for n in names:
+            if saved[n] is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = saved[n]
+
+
+def save_gaussian_model(path: Path, gaussian_model: torch.nn.Module, save_optimizer: bool = False,
+                        reference_compatible: bool = True):
+    """`torch.save(gaussian_model, path)` with the optimizer detached unless asked for (reference behaviour).  The
+    module is written on whatever device it lives on; parameters that are views of a FusedAdam flat buffer are saved
+    as plain tensors."""
+    path = Path(path)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    tmp_optimizer = None
+    if not save_optimizer:
+        tmp_optimizer = gaussian_model.optimizer
+        gaussian_model.optimizer = None   # type: ignore
+    try:
+        with (reference_class_paths() if reference_compatible else contextlib.nullcontext()):
+            torch.save(gaussian_model, path)
+    finally:
+        if tmp_optimizer is not None:
+            gaussian_model.optimizer = tmp_optimizer
+
+
+def find_checkpoint(path: Path, iterations: Optional[int] = None) -> Path:
+    cpt_lst = list((Path(path) / "checkpoints").glob("*.pth"))
+    if iterations is not None:
+        for cpt in cpt_lst:
+            if cpt.stem == f"iterations_{iterations}":
+                return cpt
+        raise ValueError(f"cannot find checkpoint for iteration {iterations}")
+    best, best_it = None, 0
+    for cpt in cpt_lst:
+        it = int(cpt.stem.split("_")[1])
+        if it > best_it:
+            best, best_it = cpt, it
+    if best is None:
+        raise ValueError("no checkpoint found")
+    return best
+
+
+def load_gaussian_model(path: Path, iterations: Optional[int] = None, device: Optional[str] = None) -> torch.nn.Module:
+    """The reference loads to the CPU and then calls `.cuda()`; `device=None` does that when a GPU is present."""
+    target = find_checkpoint(path, iterations)
+    with reference_class_paths():
+        gaussian_model = torch.load(target, map_location="cpu", weights_only=False)
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    gaussian_model = gaussian_model.to(device)
+    for name in ("grad_norm_accum", "collecting_counts", "max_radii"):   # plain attributes in the reference's pickles
+        t = gaussian_model.__dict__.get(name)
+        if isinstance(t, torch.Tensor):
+            gaussian_model.__dict__[name] = t.to(device)
+    return gaussian_model
+
+
+class CameraState:
+    """What the reference's viewer / eval code gets from cameras.json (/root/reference/utils.py:28-46): w2c [4,4],
+    K [3,3] (principal point at the image centre), width, height."""
+
+    def __init__(self, w2c: np.ndarray, K: np.ndarray, width: int, height: int):
+        self.w2c, self.K, self.width, self.height = w2c, K, width, height
+
+
+def load_camera_states(path: Path) -> List[CameraState]:
+    camera_states = []
+    with open(Path(path) / "cameras.json", "r") as f:
+        for cam in json.load(f):
+            c2w = np.eye(4)
+            c2w[:3, :3] = np.array(cam["rotation"])
+            c2w[:3, 3] = np.array(cam["position"])
+            K = np.array([[cam["fx"], 0, cam["width"] / 2], [0, cam["fy"], cam["height"] / 2], [0, 0, 1]], dtype=np.float32)
+            camera_states.append(CameraState(np.linalg.inv(c2w), K, cam["width"], cam["height"]))
+    return camera_states

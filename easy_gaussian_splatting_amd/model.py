@@ -101,6 +101,27 @@ class GaussianModel(nn.Module):
         self.active_sh_degree = 0 if sh_degree_interval != 0 else sh_degree
         self.BACKGROUND = nn.Parameter(torch.full((3,), 1.0 if white_background else 0.0), requires_grad=False)
 
+    @classmethod
+    def from_pointcloud(cls, pc, sh_degree: int, sh_degree_interval: int = 0, **kwargs) -> "GaussianModel":
+        """The reference's constructor (/root/reference/model/gaussian.py:14-95): means = the SfM / random points,
+        isotropic scales = half the mean distance to the 3 nearest neighbours, identity rotations, SH band 0 from the
+        point colours (model/utils.py:14-16), higher bands zero, opacity 0.8.  `pc`: scene.Pointcloud; the remaining
+        keyword arguments are this class's (= the reference constructor's) hyper-parameters."""
+        import numpy as np
+        from sklearn.neighbors import NearestNeighbors   # type: ignore  (the reference's own dependency, model/utils.py:2)
+        xyzs = np.asarray(pc.xyzs)
+        dists, _ = NearestNeighbors(n_neighbors=4, metric="euclidean").fit(xyzs).kneighbors(xyzs)
+        avg_dist = np.repeat(np.mean(dists[:, 1:].astype(np.float32), axis=1, keepdims=True), repeats=3, axis=1)
+        n = xyzs.shape[0]
+        quats = torch.zeros((n, 4), dtype=torch.float32)
+        quats[:, 0] = 1.0
+        shs = torch.zeros((n, (sh_degree + 1) ** 2, 3), dtype=torch.float32)
+        shs[:, 0] = torch.tensor((np.asarray(pc.rgbs) / 255.0 - 0.5) / 0.28209479177387814, dtype=torch.float32)
+        return cls(means=torch.tensor(xyzs, dtype=torch.float32), log_scales=torch.log(torch.tensor(avg_dist, dtype=torch.float32) / 2.0),
+                   quats=quats, sh_0=shs[:, 0:1].contiguous(), sh_rest=shs[:, 1:].contiguous(),
+                   logit_opacities=torch.logit(0.8 * torch.ones((n,), dtype=torch.float32)), sh_degree=sh_degree,
+                   sh_degree_interval=sh_degree_interval, **kwargs)
+
     @property
     def nbr_gaussians(self) -> int:
         return self.means.shape[0]

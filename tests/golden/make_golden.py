@@ -45,6 +45,55 @@ def reference_vectors():
     print("ref_model_utils.npz written")
 
 
+def reference_data_class_vectors():
+    """Vectors from the reference's own scene/data_class.py (it imports standalone: numpy, PIL, torch): mask expansion,
+    RGBA compositing, downscale factor, Frame.to_data / to_json.  Inputs and outputs are stored as arrays; the image
+    files are re-created by the test."""
+    import importlib.util
+    import tempfile
+    from pathlib import Path
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("ref_data_class", "/root/reference/scene/data_class.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.default_rng(3)
+    out = {}
+    masks = [(rng.random((17, 23)) > 0.9).astype(np.uint8), (rng.random((9, 8)) > 0.7).astype(np.uint8), np.zeros((6, 6), np.uint8)]
+    masks[2][0, 0] = masks[2][5, 5] = 1
+    for i, m in enumerate(masks):
+        out[f"mask{i}"] = m
+        for e in (0, 1, 2, 5):
+            out[f"mask{i}_e{e}"] = ref.expand_mask(m.copy(), e)
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        rgba = rng.integers(0, 256, (12, 10, 4), dtype=np.uint8)
+        Image.fromarray(rgba, "RGBA").save(td / "a.png")
+        out["rgba"] = rgba
+        out["rgba_white"] = ref.get_image_arr(td / "a.png", True)
+        out["rgba_black"] = ref.get_image_arr(td / "a.png", False)
+        rgb = rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)     # stored at half the camera's nominal size
+        Image.fromarray(rgb, "RGB").save(td / "b.png")
+        mk = (rng.random((24, 32)) > 0.9).astype(np.uint8) * 255
+        Image.fromarray(mk, "L").save(td / "b_mask.png")
+        out["rgb"], out["rgb_mask"] = rgb, mk
+        w2c = np.eye(4, dtype=np.float32)
+        w2c[:3, :3] = ref_rot = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+        w2c[:3, 3] = [0.5, -1.0, 2.0]
+        fr = ref.Frame(td / "b.png", td / "b_mask.png", 2, 64, 48, 70.0, 71.0, 31.5, 24.25, w2c, False)
+        d = fr.to_data()
+        out["frame_w2c"] = w2c
+        for k in ("K", "w2c", "image", "mask"):
+            out[f"frame_{k}"] = d[k].numpy()
+        out["frame_hw"] = np.array([d["height"], d["width"]])
+        j = fr.to_json(3)
+        out["frame_json_position"], out["frame_json_rotation"] = np.array(j["position"]), np.array(j["rotation"])
+        out["frame_json_misc"] = np.array([j["id"], j["width"], j["height"], j["fx"], j["fy"]])
+    out["downscale"] = np.array([ref.get_downscale_factor(48, 64, 48, 64), ref.get_downscale_factor(48, 64, 24, 32),
+                                 ref.get_downscale_factor(1080, 1920, 675, 1200)])
+    np.savez_compressed(os.path.join(HERE, "ref_data_class.npz"), **out)
+    print("ref_data_class.npz written")
+
+
 SCENES = {
     "a": dict(n=64, width=48, height=40, sh_degree=3, n_views=1, scale_range=(0.05, 0.4), dist=4.0, white_bg=True),
     "b": dict(n=300, width=64, height=64, sh_degree=0, n_views=1, scale_range=(0.02, 0.2), dist=4.0, white_bg=False),
@@ -97,5 +146,8 @@ def oracle_scene(tag, kw):
 
 if __name__ == "__main__":
     reference_vectors()
+    reference_data_class_vectors()
+    if "--only-reference" in sys.argv:
+        sys.exit(0)
     for tag, kw in SCENES.items():
         oracle_scene(tag, kw)
