@@ -162,7 +162,7 @@ def test_checkpoint_layout_selection_and_reference_class_paths(tmp_path):
     latest = ckpt.load_gaussian_model(tmp_path, device="cpu")
     first = ckpt.load_gaussian_model(tmp_path, 7000, device="cpu")
     assert isinstance(latest, GaussianModel) and latest.optimizer is None
-    assert torch.equal(latest.means, m.means - 1.0) and torch.equal(first.means, m.means - 2.0)   # saved after 2 / 1 of the 3 increments
+    assert torch.allclose(latest.means, m.means - 1.0, atol=1e-5) and torch.allclose(first.means, m.means - 2.0, atol=1e-5)   # saved after 2 / 1 of the 3 increments
     assert latest.active_sh_degree == 0 and latest.MAX_SH_DEGREE == 3 and latest.BACKGROUND.tolist() == [1.0, 1.0, 1.0]
     assert latest.means_lr_scheduler(0) == m.means_lr_scheduler(0)
     # the pickle names the reference's class paths, so the reference's own torch.load resolves it to ITS classes
