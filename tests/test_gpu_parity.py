@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from oracle import c_oracle as CO
-from scenes import config_bench_1m, config_s1, dense_scene, make_scene
+from scenes import config_bench_1m, config_long_lists, config_s1, dense_scene, make_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -316,6 +316,19 @@ def test_large_tile_lists_hit_every_sort_class():
     assert 2048 < c2.max() <= 16384
     assert check_forward(hip2, fw2, max_razor_frac=MAX_RAZOR_FRAC)
     check_backward(hip2, fw2)
+
+
+@pytest.mark.parametrize("culling", ["gsplat", "tight"])
+def test_long_lists_heavy_tailed_footprints(culling):
+    """Real-capture-like lists: footprints of hundreds of tiles, mean list > 2 000 entries, saturating pixels (the
+    regime where emission + per-tile sort lead the forward): lists bit-exact, image and gradients within tolerance."""
+    sc = config_long_lists()
+    fw = run_oracle(sc)
+    counts = np.diff(np.append(fw["isect_offsets"].reshape(-1), fw["n_isects"]))
+    assert counts.mean() > 2000 and fw["tiles_per_gauss"].max() > 300
+    hip = run_hip(sc, culling=culling)
+    check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC, lists=culling == "gsplat")
+    check_backward(hip, fw)
 
 
 def test_depth_ties_break_by_index():
