@@ -31,14 +31,6 @@ struct AdamArgs {
     int64_t* applied;             // optional device counter of steps that were really applied (not skipped by the guard)
 };
 
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
-                                      float isbc2, float ss) {
-    m = fmaf(b1, m, (1.f - b1) * g);
-    v = fmaf(b2, v, (1.f - b2) * g * g);
-    const float denom = sqrtf(v) * isbc2 + eps;
-    p = p - ss * (m / denom);
-}
-
 __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
     if (guard_tripped(a.guard)) return;
     if (a.applied != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.applied[0] += 1;

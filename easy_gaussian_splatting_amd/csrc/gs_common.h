@@ -104,6 +104,16 @@ __device__ __forceinline__ T block_excl_scan_add(T v, T* scratch, T* total) {
     return res;
 }
 
+// One Adam update, torch's `_single_tensor_adam` arithmetic (gs_adam.hip; also applied in place by the fused
+// projection-backward + Adam kernel of gs_project.hip):  isbc2 = 1/sqrt(1-beta2^t),  ss = lr/(1-beta1^t).
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float b1, float b2, float eps,
+                                      float isbc2, float ss) {
+    m = fmaf(b1, m, (1.f - b1) * g);
+    v = fmaf(b2, v, (1.f - b2) * g * g);
+    const float denom = sqrtf(v) * isbc2 + eps;
+    p = p - ss * (m / denom);
+}
+
 // streaming (non-temporal) 16-byte accesses for data that is touched once and then dead
 #ifdef __HIPCC__
 typedef float f4v __attribute__((ext_vector_type(4)));

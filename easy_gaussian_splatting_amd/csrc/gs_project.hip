@@ -260,6 +260,14 @@ struct ProjBwdArgs {
     const float* opacities;   // raw (logit) opacities, read only when activations != 0
     int activations;
     const int64_t* guard;     // step guard (gs_guard_set) or nullptr
+    // Fused Adam (gs_project_bwd_adam): when `adam` is set no gradient is written; every parameter element is updated
+    // in place right where its gradient is formed.  Tensor order of the reference's param_names:
+    // 0 means, 1 log_scales, 2 quats, 3 sh_0, 4 sh_rest, 5 logit_opacities.
+    int adam;
+    float *ad_p[6], *ad_m[6], *ad_v[6];
+    const float* ad_hyper;    // {1/sqrt(1-beta2^t), lr_k/(1-beta1^t) x 6}  (gs_adam_hyper)
+    float ad_b1, ad_b2, ad_eps;
+    int64_t* ad_applied;
 };
 
 struct RowSum {
@@ -337,12 +345,60 @@ __device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K
         }
 }
 
+// The same walk over one block's SH-gradient tile, but as an in-place Adam update of sh_0 / sh_rest (split layout)
+// and their moments: the 48 SH gradients per Gaussian (81 % of all gradient bytes at SH3) are never written to HBM
+// nor read back by a separate optimizer pass.  (The block staged its own SH rows into LDS before the barrier in
+// front of this call, and no other block touches them, so updating in place is race-free.)
+__device__ __forceinline__ void adam_sh_tile(const float* tile, int rows, int K, int64_t n0, const ProjBwdArgs& a) {
+    const int row_f = 3 * K, stride = row_f + 1;
+    const float isbc2 = a.ad_hyper[0], ss0 = a.ad_hyper[1 + 3], ssr = a.ad_hyper[1 + 4];
+    {
+        float *p0 = a.ad_p[3] + n0 * 3, *m0 = a.ad_m[3] + n0 * 3, *v0 = a.ad_v[3] + n0 * 3;
+        for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
+            const int g = e / 3;
+            float p = p0[e], m = m0[e], v = v0[e];
+            adam1(p, tile[g * stride + (e - 3 * g)], m, v, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ss0);
+            p0[e] = p; m0[e] = m; v0[e] = v;
+        }
+    }
+    if (K > 1) {
+        const int rest_f = row_f - 3, total = rows * rest_f;
+        float *pr = a.ad_p[4] + n0 * rest_f, *mr = a.ad_m[4] + n0 * rest_f, *vr = a.ad_v[4] + n0 * rest_f;
+        // (n0 is a multiple of the block size and rest_f * kProjThreads of 4: the block's slice starts 16-byte aligned
+        //  whenever the tensor does)
+        const bool aligned = ((((uintptr_t)pr | (uintptr_t)mr | (uintptr_t)vr) & 15) == 0);
+        const int vec_end = aligned ? (total & ~3) : 0;
+        float4 *pr4 = reinterpret_cast<float4*>(pr), *mr4 = reinterpret_cast<float4*>(mr), *vr4 = reinterpret_cast<float4*>(vr);
+        for (int e4 = threadIdx.x; e4 < (vec_end >> 2); e4 += blockDim.x) {
+            float gg[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = (e4 << 2) + i, g = e / rest_f;
+                gg[i] = tile[g * stride + 3 + (e - g * rest_f)];
+            }
+            float4 p = pr4[e4], m = nt_load4(mr4 + e4), v = nt_load4(vr4 + e4);
+            adam1(p.x, gg[0], m.x, v.x, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
+            adam1(p.y, gg[1], m.y, v.y, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
+            adam1(p.z, gg[2], m.z, v.z, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
+            adam1(p.w, gg[3], m.w, v.w, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
+            pr4[e4] = p; nt_store4(m, mr4 + e4); nt_store4(v, vr4 + e4);
+        }
+        for (int e = vec_end + threadIdx.x; e < total; e += blockDim.x) {
+            const int g = e / rest_f;
+            float p = pr[e], m = mr[e], v = vr[e];
+            adam1(p, tile[g * stride + 3 + (e - g * rest_f)], m, v, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
+            pr[e] = p; mr[e] = m; vr[e] = v;
+        }
+    }
+}
+
 constexpr int kCoopRows = 48;  // Gaussians with more rows than this are summed by the whole wave
 
 template <int DEG>
 __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (guard_tripped(a.guard)) return;
+    if (a.adam && a.ad_applied != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.ad_applied[0] += 1;
     float* lds_cam = smem;
     int* vis_s = reinterpret_cast<int*>(smem + 32);
     float* tile = smem + 32 + kProjThreads;
@@ -443,7 +499,10 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
             for (int o = 0; o < row_f; ++o) my[o] = 0.f;
             if (a.v_colors_pre) { float* d = a.v_colors_pre + 3 * f; d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; }
         }
-        if (a.v_colors) {  // NULL: the caller rebuilds the SH gradients from v_colors_pre (gs_sh_grad_views)
+        if (a.adam) {
+            __syncthreads();
+            adam_sh_tile(tile, rows, a.K, n0, a);
+        } else if (a.v_colors) {  // NULL: the caller rebuilds the SH gradients from v_colors_pre (gs_sh_grad_views)
             __syncthreads();
             write_sh_tile(tile, rows, a.K, n0, a.v_colors, a.v_sh_rest, a.accumulate);
         }
@@ -475,7 +534,19 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         v_scale[0] *= sc_fac[0]; v_scale[1] *= sc_fac[1]; v_scale[2] *= sc_fac[2];
         const float v_op = s.v[7] * op_fac;
         float* vm = a.v_means + 3 * n; float* vq = a.v_quats + 4 * n; float* vs = a.v_scales + 3 * n;
-        if (a.accumulate) {
+        if (a.adam) {
+            const float isbc2 = a.ad_hyper[0];
+            auto upd = [&](int t, int64_t idx, float g) {
+                float p = a.ad_p[t][idx], m = a.ad_m[t][idx], v = a.ad_v[t][idx];
+                adam1(p, g, m, v, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, a.ad_hyper[1 + t]);
+                a.ad_p[t][idx] = p; a.ad_m[t][idx] = m; a.ad_v[t][idx] = v;
+            };
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { upd(0, 3 * n + k, v_mean[k]); upd(1, 3 * n + k, v_scale[k]); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) upd(2, 4 * n + k, v_quat[k]);
+            upd(5, n, v_op);
+        } else if (a.accumulate) {
             vm[0] += v_mean[0]; vm[1] += v_mean[1]; vm[2] += v_mean[2];
             vq[0] += v_quat[0]; vq[1] += v_quat[1]; vq[2] += v_quat[2]; vq[3] += v_quat[3];
             vs[0] += v_scale[0]; vs[1] += v_scale[1]; vs[2] += v_scale[2];
@@ -708,6 +779,8 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     GS_REQUIRE(!activations || opacities, "activations need the raw opacities");
     a.opacities = opacities; a.activations = activations != 0;
     a.guard = current_guard().info;
+    a.adam = 0; a.ad_hyper = nullptr; a.ad_applied = nullptr; a.ad_b1 = a.ad_b2 = a.ad_eps = 0.f;
+    for (int t = 0; t < 6; ++t) a.ad_p[t] = a.ad_m[t] = a.ad_v[t] = nullptr;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
     const size_t lds = proj_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;
@@ -724,5 +797,51 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
         }
         GS_LAUNCH_CHECK("project_bwd_kernel");
     }
+    return GS_OK;
+}
+
+
+// Row reduction + SH-bwd + P-bwd + Adam in ONE pass (train-step graph, single camera): gs_project_bwd with the
+// reference model's raw parameters (log-scales, logit opacities, split SH), but instead of writing the 59 gradients
+// per Gaussian and reading them back in gs_adam_step, every parameter and both of its moments are updated in place
+// where the gradient is formed.  params / exp_avg / exp_avg_sq: the flat buffers of gs_adam_step, the six tensors
+// of param_names at offsets_host[6] floats.  hyper_dev: gs_adam_hyper.  Only v_means2d_abs (the `.absgrad`
+// side channel update_statistics consumes) is still written.
+extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree, float* params, float* exp_avg, float* exp_avg_sq,
+                                   const int64_t* offsets_host, const float* viewmats, const float* Ks, int width, int height,
+                                   float eps2d, float near_plane, float far_plane, const int32_t* radii, const float* colors_post,
+                                   const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
+                                   float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev,
+                                   int64_t* applied_dev) {
+    GS_REQUIRE(N >= 0 && width > 0 && height > 0, "N>=0, positive image size");
+    GS_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16, "SH colours: 0 <= degree <= 3, (degree+1)^2 <= K <= 16");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(params && exp_avg && exp_avg_sq && offsets_host && viewmats && Ks && radii && colors_post && tiles_per_gauss &&
+               cum_tiles && rows && qmask && v_means2d_abs && hyper_dev, "null pointer");
+    ProjBwdArgs a;
+    a.C = 1; a.N = N; a.K = K; a.colors_per_camera = 0; a.W = width; a.H = height;
+    a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
+    a.means = params + offsets_host[0]; a.scales = params + offsets_host[1]; a.quats = params + offsets_host[2];
+    a.colors_in = params + offsets_host[3]; a.sh_rest = K > 1 ? params + offsets_host[4] : nullptr;
+    a.opacities = params + offsets_host[5]; a.activations = 1;
+    GS_REQUIRE(((uintptr_t)a.quats & 15) == 0, "the quaternion tensor must be 16-byte aligned");
+    a.viewmats = viewmats; a.Ks = Ks; a.colors_post = colors_post; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss;
+    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.qmask = qmask;
+    a.v_means = a.v_quats = a.v_scales = a.v_opacities = a.v_colors = a.v_sh_rest = nullptr;
+    a.v_means2d_abs = v_means2d_abs; a.v_means2d = a.v_conics = a.v_colors_post = a.v_colors_pre = nullptr;
+    a.guard = current_guard().info;
+    a.adam = 1; a.ad_hyper = hyper_dev; a.ad_applied = applied_dev; a.ad_b1 = beta1; a.ad_b2 = beta2; a.ad_eps = eps;
+    for (int t = 0; t < 6; ++t) { a.ad_p[t] = params + offsets_host[t]; a.ad_m[t] = exp_avg + offsets_host[t]; a.ad_v[t] = exp_avg_sq + offsets_host[t]; }
+    a.cam = 0; a.accumulate = 0;
+    dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
+    const size_t lds = proj_lds_bytes(K, sh_degree);
+    hipStream_t st = (hipStream_t)stream;
+    switch (sh_degree) {
+        case 0: hipLaunchKernelGGL(project_bwd_kernel<0>, grid, dim3(kProjThreads), lds, st, a); break;
+        case 1: hipLaunchKernelGGL(project_bwd_kernel<1>, grid, dim3(kProjThreads), lds, st, a); break;
+        case 2: hipLaunchKernelGGL(project_bwd_kernel<2>, grid, dim3(kProjThreads), lds, st, a); break;
+        default: hipLaunchKernelGGL(project_bwd_kernel<3>, grid, dim3(kProjThreads), lds, st, a); break;
+    }
+    GS_LAUNCH_CHECK("project_bwd_kernel (fused Adam)");
     return GS_OK;
 }

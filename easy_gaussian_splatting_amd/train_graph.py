@@ -50,7 +50,8 @@ def _p(t: Optional[Tensor]):
 
 class TrainStepGraph:
     def __init__(self, model, optimizer: FusedAdam, loss_computer, data: Dict[str, Any], gt_img: Tensor,
-                 mask: Optional[Tensor] = None, margin: float = 1.3, use_graph: bool = True, check_every: int = 16):
+                 mask: Optional[Tensor] = None, margin: float = 1.3, use_graph: bool = True, check_every: int = 16,
+                 fuse_adam: bool = True):
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("TrainStepGraph drives optim.FusedAdam (flat parameter / moment buffers)")
         if not getattr(loss_computer, "clamp_input", False) or not getattr(loss_computer, "fused", True):
@@ -59,6 +60,9 @@ class TrainStepGraph:
             raise NotImplementedError("the scale regulariser is not part of the captured step")
         self.model, self.opt, self.lc = model, optimizer, loss_computer
         self.margin, self.use_graph, self.check_every = float(margin), bool(use_graph), int(check_every)
+        # fuse_adam: gs_project_bwd_adam -- the projection / SH backward applies Adam in place where each gradient is
+        # formed (no gradient tensors, no separate optimizer pass); same update bit for bit
+        self.fuse_adam = bool(fuse_adam)
         self.dev = model.means.device
         self.W, self.H = int(data["width"]), int(data["height"])
         self.has_mask = mask is not None
@@ -130,10 +134,11 @@ class TrainStepGraph:
         b["qcnt"] = torch.empty((tiles * 4,), **i32)
         b["unit_counter"] = torch.zeros((1,), **i32)
         b["v_abs"] = torch.empty((1, N, 2), **f32)
-        self.grads = {"means": torch.empty((N, 3), **f32), "log_scales": torch.empty((N, 3), **f32),
-                      "quats": torch.empty((N, 4), **f32), "sh_0": torch.empty((N, 1, 3), **f32),
-                      "sh_rest": torch.empty((N, self.K - 1, 3), **f32) if self.K > 1 else None,
-                      "logit_opacities": torch.empty((N,), **f32)}
+        self.grads = None if self.fuse_adam else {
+            "means": torch.empty((N, 3), **f32), "log_scales": torch.empty((N, 3), **f32),
+            "quats": torch.empty((N, 4), **f32), "sh_0": torch.empty((N, 1, 3), **f32),
+            "sh_rest": torch.empty((N, self.K - 1, 3), **f32) if self.K > 1 else None,
+            "logit_opacities": torch.empty((N,), **f32)}
         b["hyper"] = torch.zeros((16,), **f32)
         self._set_inputs(data["w2c"], data["K"], gt_img, mask)
         if self.cap == 0 or min_cap or min_cap_tile:
@@ -262,23 +267,33 @@ class TrainStepGraph:
                                      _p(b["qlist"]), _p(b["qcnt"]), _p(b["unit_counter"]), _p(b["unit_desc"]), _p(b["ckpt"]),
                                      _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"]), None),
                       "gs_blend_bwd")
-            g = self.grads
-            self._ck(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
-                                       _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0, _p(b["viewmats"]), _p(b["Ks"]), W, H,
-                                       0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]),
-                                       _p(b["cum_tiles"]), _p(b["rows"]), _p(b["qmask"]), _p(g["means"]), _p(g["quats"]),
-                                       _p(g["log_scales"]), _p(g["logit_opacities"]), _p(g["sh_0"]), _p(g["sh_rest"]), _p(b["v_abs"]),
-                                       None, None, None, None, _p(m.logit_opacities), 1), "gs_project_bwd")
-            self._ck(L.gs_update_statistics(st, N, float(max(H, W)), _p(b["radii"]), _p(b["v_abs"]), _p(m.max_radii),
-                                             _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_update_statistics")
-            ns = len(opt._plist)
-            ends = (ct.c_int64 * ns)(*opt._ends)
-            lens = (ct.c_int64 * ns)(*opt._lens)
-            gptr = (ct.c_void_p * ns)(*[_p(g[grp["name"]]) for grp, _ in opt._plist])
             b1, b2 = opt.defaults["betas"]
-            self._ck(L.gs_adam_step_dev(st, opt.flat_param.numel(), _p(opt.flat_param), _p(opt.exp_avg), _p(opt.exp_avg_sq), ns,
-                                         ends, lens, gptr, float(b1), float(b2), float(opt.defaults["eps"]), 1.0, _p(b["hyper"]),
-                                         _p(b["applied"])), "gs_adam_step_dev")
+            if self.fuse_adam:
+                offs = (ct.c_int64 * 6)(*opt._offs)
+                self._ck(L.gs_project_bwd_adam(st, N, self.K, int(m.active_sh_degree), _p(opt.flat_param), _p(opt.exp_avg),
+                                               _p(opt.exp_avg_sq), offs, _p(b["viewmats"]), _p(b["Ks"]), W, H, 0.3, 0.01, 1e10,
+                                               _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]),
+                                               _p(b["rows"]), _p(b["qmask"]), _p(b["v_abs"]), float(b1), float(b2),
+                                               float(opt.defaults["eps"]), _p(b["hyper"]), _p(b["applied"])), "gs_project_bwd_adam")
+                self._ck(L.gs_update_statistics(st, N, float(max(H, W)), _p(b["radii"]), _p(b["v_abs"]), _p(m.max_radii),
+                                                _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_update_statistics")
+            else:
+                g = self.grads
+                self._ck(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
+                                          _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0, _p(b["viewmats"]), _p(b["Ks"]), W, H,
+                                          0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]),
+                                          _p(b["cum_tiles"]), _p(b["rows"]), _p(b["qmask"]), _p(g["means"]), _p(g["quats"]),
+                                          _p(g["log_scales"]), _p(g["logit_opacities"]), _p(g["sh_0"]), _p(g["sh_rest"]), _p(b["v_abs"]),
+                                          None, None, None, None, _p(m.logit_opacities), 1), "gs_project_bwd")
+                self._ck(L.gs_update_statistics(st, N, float(max(H, W)), _p(b["radii"]), _p(b["v_abs"]), _p(m.max_radii),
+                                                _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_update_statistics")
+                ns = len(opt._plist)
+                ends = (ct.c_int64 * ns)(*opt._ends)
+                lens = (ct.c_int64 * ns)(*opt._lens)
+                gptr = (ct.c_void_p * ns)(*[_p(g[grp["name"]]) for grp, _ in opt._plist])
+                self._ck(L.gs_adam_step_dev(st, opt.flat_param.numel(), _p(opt.flat_param), _p(opt.exp_avg), _p(opt.exp_avg_sq), ns,
+                                            ends, lens, gptr, float(b1), float(b2), float(opt.defaults["eps"]), 1.0, _p(b["hyper"]),
+                                            _p(b["applied"])), "gs_adam_step_dev")
             self._ck(L.gs_step_status(st, _p(b["info"]), _p(b["applied"]), self.status.data_ptr()), "gs_step_status")
         except TrainStepGraph._Stop:
             pass

@@ -55,9 +55,10 @@ def _assert_same(ma, oa, mb, ob, what=""):
     assert oa._step == ob._step
 
 
+@pytest.mark.parametrize("fuse_adam", [True, False])
 @pytest.mark.parametrize("use_graph", [True, False])
 @pytest.mark.parametrize("with_mask", [False, True])
-def test_graph_step_equals_eager_step(use_graph, with_mask):
+def test_graph_step_equals_eager_step(use_graph, with_mask, fuse_adam):
     dev, make, datas, gts = _setup()
     (ma, oa), (mb, ob) = make(), make()
     lc = LossComputer(0.2, clamp_input=True)
@@ -65,7 +66,7 @@ def test_graph_step_equals_eager_step(use_graph, with_mask):
     if with_mask:
         mask = torch.zeros((208, 320), device=dev)
         mask[40:90, 100:200] = 1.0
-    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], mask, use_graph=use_graph, check_every=2)
+    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], mask, use_graph=use_graph, check_every=2, fuse_adam=fuse_adam)
     for it in range(7):
         v = it % 3
         ma.update_learning_rate(it); mb.update_learning_rate(it)
