@@ -50,7 +50,7 @@ struct BlendFwdArgs {
     int32_t* qcnt;         // [C*tiles*4]        sublist lengths
     uint8_t* qmask;        // [I] by slot        which quadrant rows of an intersection exist
     int32_t* unit_counter; // [1]
-    int2* unit_desc;       // [8*n_buckets]      (tile*4+quadrant, unit index within the sublist)
+    int4* unit_desc;       // [8*n_buckets]      (tile*4+quadrant, entries in the unit, first qlist pair, checkpoint row)
     const int64_t* guard;  // step guard (gs_guard_set) or nullptr
 };
 
@@ -223,7 +223,10 @@ __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArg
             int off = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                for (int u = lane; u < nu[k]; u += 64) a.unit_desc[base + off + u] = make_int2(4 * t + k, u);
+                // everything the backward needs to start on the unit without a second round of dependent loads
+                for (int u = lane; u < nu[k]; u += 64)
+                    a.unit_desc[base + off + u] = make_int4(4 * t + k, min(kUnit, cnt[k] - u * kUnit), 4 * lo + k * len + u * kUnit,
+                                                            8 * bucket0 + k * (2 * nb) + u);
                 off += nu[k];
             }
         }
@@ -247,8 +250,9 @@ __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArg
 struct BlendBwdArgs {
     int C, W, H, tw, tiles;
     const float4* rec;
-    const int32_t *isect_offsets, *bucket_offsets, *qcnt, *unit_counter;
-    const int2 *qlist, *unit_desc;
+    const int32_t* unit_counter;
+    const int2* qlist;
+    const int4* unit_desc;
     const float4* ckpt;
     const float *out_colors, *out_alphas, *v_colors, *v_alphas;
     float4* rows;   // [I*4][3]
@@ -306,8 +310,8 @@ __device__ __forceinline__ void bwd_pair(EntryState& e, const float4 d0, const f
 }
 
 __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBwdArgs a) {
-    __shared__ float4 sd0_all[kBwdWaves][kUnitsPerWave][64];   // 8 KB per wave
-    __shared__ float2 sck_all[kBwdWaves][kUnitsPerWave][64];   // 4 KB per wave
+    __shared__ float4 sd0_all[kBwdWaves][kUnitsPerWave][64];   // 8 KB per wave: v_r, v_g, v_b, E of the unit's 64 pixels
+    __shared__ float2 sck_all[kBwdWaves][kUnitsPerWave][64];   // 4 KB per wave: checkpoint T, P = checkpoint colour . v
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pipe = lane / kPipeLanes, r = lane & (kPipeLanes - 1);
     if (guard_tripped(a.guard)) return;
@@ -318,19 +322,18 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
     float4* sd0 = sd0_all[wave][pipe];
     float2* sck = sck_all[wave][pipe];
 
-    int tq = 0, kb = 0;
-    if (valid) { const int2 d = a.unit_desc[unit]; tq = d.x; kb = d.y; }
+    int4 ud = make_int4(0, 0, 0, 0);
+    if (valid) ud = a.unit_desc[unit];
+    const int tq = ud.x, n_in = ud.y;
     const int t = tq >> 2, q = tq & 3;
-    const int lo = a.isect_offsets[t], len = a.isect_offsets[t + 1] - lo;
-    const int nb = (len + GS_BUCKET - 1) / GS_BUCKET, bucket0 = a.bucket_offsets[t];
-    const int n_in = valid ? min(kUnit, a.qcnt[tq] - kb * kUnit) : 0;
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
     const int tyi = tt / a.tw, txi = tt - tyi * a.tw;
     const int qx0 = txi * GS_TILE + 8 * (q & 1), qy0 = tyi * GS_TILE + 8 * (q >> 1);
     const float fx0 = (float)qx0 + 0.5f, fy0 = (float)qy0 + 0.5f;
+    // the unit's checkpoint: 64 pixel states in front of its first entry (T < 0: pixel finished or outside the image)
+    const float4* ckp = a.ckpt + (size_t)ud.w * 64;
 
     // stage the quadrant's 64 pixels: 8 per lane of the pipeline
-    const float4* ckp = a.ckpt + ((size_t)8 * bucket0 + (size_t)q * (2 * nb) + kb) * 64;
 #pragma unroll
     for (int i = 0; i < 64 / kPipeLanes; ++i) {
         const int p = r + kPipeLanes * i;
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         slot[i] = 0;
         float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
         if (e[i].has) {
-            const int2 gs = a.qlist[(size_t)4 * lo + (size_t)q * len + kb * kUnit + en];
+            const int2 gs = a.qlist[(size_t)ud.z + en];
             slot[i] = gs.y;
             const float4* rp = a.rec + 3 * (size_t)gs.x;
             q0 = rp[0]; q1 = rp[1]; q2 = rp[2];
@@ -426,7 +429,7 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     a.bucket_offsets = bucket_offsets; a.flatten_ids = flatten_ids; a.slots = slots;
     a.out_colors = render_colors; a.out_alphas = render_alphas;
     a.ckpt = reinterpret_cast<float4*>(ckpt); a.qlist = reinterpret_cast<int2*>(qlist); a.qcnt = qcnt; a.qmask = qmask;
-    a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int2*>(unit_desc);
+    a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int4*>(unit_desc);
     a.tile_order = tile_order;
     a.guard = current_guard().info;
     const unsigned n_tiles = (unsigned)(C * a.tiles);
@@ -462,9 +465,8 @@ extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const fl
     a.tw = (width + GS_TILE - 1) / GS_TILE;
     a.tiles = a.tw * ((height + GS_TILE - 1) / GS_TILE);
     a.rec = reinterpret_cast<const float4*>(rec);
-    a.isect_offsets = isect_offsets; a.bucket_offsets = bucket_offsets;
-    a.qlist = reinterpret_cast<const int2*>(qlist); a.qcnt = qcnt; a.unit_counter = unit_counter;
-    a.unit_desc = reinterpret_cast<const int2*>(unit_desc);
+    a.qlist = reinterpret_cast<const int2*>(qlist); a.unit_counter = unit_counter;
+    a.unit_desc = reinterpret_cast<const int4*>(unit_desc);
     a.ckpt = reinterpret_cast<const float4*>(ckpt); a.out_colors = render_colors;
     a.out_alphas = render_alphas; a.v_colors = v_render_colors; a.v_alphas = v_render_alphas;
     a.rows = reinterpret_cast<float4*>(rows); a.rows_color = reinterpret_cast<float4*>(rows_color);

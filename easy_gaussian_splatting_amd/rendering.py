@@ -185,7 +185,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         qcnt = torch.empty((C * tiles * 4,), **i32)
         qmask = torch.empty((cap,), dtype=torch.uint8, device=dev)
         unit_counter = torch.empty((1,), **i32)
-        unit_desc = torch.empty((8 * nbk, 2), **i32)
+        unit_desc = torch.empty((8 * nbk, 4), **i32)
     _stage("gs_blend_fwd", dev, lambda: nat.check(L.gs_blend_fwd(st, C, W, H, _ptr(rec), _ptr(backgrounds), _ptr(isect_offsets),
                              _ptr(bucket_offsets), _ptr(tile_order), _ptr(flatten_ids), _ptr(slots), n_isects, _ptr(render_colors),
                              _ptr(render_alphas), _ptr(ckpt), _ptr(qlist), _ptr(qcnt), _ptr(qmask),

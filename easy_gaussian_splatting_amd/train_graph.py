@@ -166,7 +166,7 @@ class TrainStepGraph:
         b["ckpt"] = torch.empty((8 * self.cap_buckets, 64, 4), **f32)
         b["qlist"] = torch.empty((4 * cap, 2), **i32)
         b["qmask"] = torch.empty((cap,), dtype=torch.uint8, device=dev)
-        b["unit_desc"] = torch.empty((8 * self.cap_buckets, 2), **i32)
+        b["unit_desc"] = torch.empty((8 * self.cap_buckets, 4), **i32)
         b["rows"] = torch.empty((4 * cap, nat.GS_ROW_FLOATS), **f32)
 
     def _set_inputs(self, w2c: Tensor, K: Tensor, gt: Tensor, mask: Optional[Tensor]):

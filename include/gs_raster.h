@@ -132,7 +132,8 @@ int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, con
  *                       states in front of it (T -- negative once saturated / outside the image -- and accumulated rgb)
  *   qmask[I] u8         by gradient-row slot: which quadrant rows of an intersection exist (fully
  *                       written: entries behind a tile's saturation point read 0)
- *   unit_counter[1], unit_desc[8*n_buckets*2] i32   work units (tile*4+quadrant, unit index in the sublist) */
+ *   unit_counter[1], unit_desc[8*n_buckets*4] i32   work units (tile*4+quadrant, entries in the unit, index of its
+ *                       first qlist pair, checkpoint row) */
 int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                  const float* backgrounds, const int32_t* isect_offsets,
                  const int32_t* bucket_offsets, const int32_t* tile_order, const int32_t* flatten_ids, const int32_t* slots,
