@@ -63,6 +63,7 @@ def profile_stages(enable: bool) -> Optional[Dict]:
 
 
 _tls = threading.local()
+_state_lock = threading.Lock()   # guards the two module-level dicts below (entry points are called from any thread)
 _cap_hint: Dict[int, int] = {}   # per device: list capacity to pre-allocate (last intersection count + 25 %)
 # host-side diagnostics: time spent blocked on the list-size read-back (bench.py reports it; a wait
 # near zero means the host, not the GPU, paces the loop)
@@ -153,7 +154,8 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     # device needed (+25 %): the window between the host waking up and the emit kernel being queued is
     # what the colour pass has to cover, and six allocator calls do not belong in it.
     hint_key = dev.index if dev.index is not None else torch.cuda.current_device()
-    cap = _cap_hint.get(hint_key, 0)
+    with _state_lock:
+        cap = _cap_hint.get(hint_key, 0)
 
     def alloc_lists(c):
         return (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32),
@@ -163,13 +165,15 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     lists = alloc_lists(cap) if cap > 0 else None
     t_wait = time.perf_counter_ns()
     ready.synchronize()
-    stats["sync_wait_ns"] += time.perf_counter_ns() - t_wait
-    stats["calls"] += 1
+    waited = time.perf_counter_ns() - t_wait
     n_isects, n_buckets, max_tile = (int(v) for v in info_host[:3].tolist())
     if lists is None or n_isects > cap:
         cap = max(n_isects, 1)
         lists = alloc_lists(cap)
-    _cap_hint[hint_key] = n_isects + (n_isects >> 2) + 1024
+    with _state_lock:
+        stats["sync_wait_ns"] += waited
+        stats["calls"] += 1
+        _cap_hint[hint_key] = n_isects + (n_isects >> 2) + 1024
     keys_tmp, slot_gid, isect_ids, flatten_ids, slots = lists
     _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, _ptr(bbox), _ptr(depths), _ptr(workspace), ws_bytes,
                                  _ptr(isect_offsets), n_isects, max_tile, _ptr(keys_tmp), _ptr(slot_gid),

@@ -94,3 +94,28 @@ def test_fused_adam_detects_detached_parameters_and_rejects_group_betas():
     p = torch.nn.Parameter(torch.zeros(8, device=dev))
     with pytest.raises(NotImplementedError):
         FusedAdam([{"params": [p], "lr": 1e-3, "betas": (0.5, 0.9), "name": "x"}])
+
+
+def test_checkpoint_round_trip_of_a_fused_adam_model(tmp_path):
+    """save_gaussian_model / load_gaussian_model (reference layout, /root/reference/utils.py:48-87) with parameters that
+    are views of FusedAdam's flat buffer, with and without the optimizer; training resumes on the loaded model."""
+    from easy_gaussian_splatting_amd import checkpoint as ckpt
+    dev = torch.device("cuda:0")
+    m = _model(300, dev, 8)
+    opt = build_optimizers(m, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused="hip")
+    for name in m.param_names:
+        getattr(m, name).grad = torch.randn_like(getattr(m, name))
+    opt.step(); opt.zero_grad()
+    ckpt.save_gaussian_model(tmp_path / "checkpoints" / "iterations_10.pth", m)
+    ckpt.save_gaussian_model(tmp_path / "checkpoints" / "iterations_20.pth", m, save_optimizer=True)
+    assert m.optimizer is opt
+    a = ckpt.load_gaussian_model(tmp_path, 10)
+    b = ckpt.load_gaussian_model(tmp_path)          # latest: iterations_20, with optimizer
+    assert a.optimizer is None and b.optimizer is not None and a.means.is_cuda
+    for name in m.param_names:
+        assert torch.equal(getattr(a, name), getattr(m, name)) and torch.equal(getattr(b, name), getattr(m, name))
+    # resume on the checkpoint without optimizer: a fresh FusedAdam over the loaded parameters steps fine
+    oa = build_optimizers(a, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused="hip")
+    for name in a.param_names:
+        getattr(a, name).grad = torch.randn_like(getattr(a, name))
+    oa.step()
