@@ -144,7 +144,7 @@ class FusedAdam(torch.optim.Optimizer):
         `model.to(...)` / `p.data = ...` silently detaches them from what `step` updates)."""
         base = self.flat_param.data_ptr()
         for (_, p), o in zip(self._plist, self._offs):
-            if p.data_ptr() != base + 4 * o:
+            if p.numel() and p.data_ptr() != base + 4 * o:   # (an empty tensor, e.g. sh_rest at SH degree 0, has no address)
                 raise RuntimeError("FusedAdam: a parameter no longer aliases the flat buffer (moved or re-assigned "
                                    "after the optimizer was built); rebuild the optimizer")
 

@@ -119,3 +119,18 @@ def test_checkpoint_round_trip_of_a_fused_adam_model(tmp_path):
     for name in a.param_names:
         getattr(a, name).grad = torch.randn_like(getattr(a, name))
     oa.step()
+
+
+def test_fused_adam_with_an_empty_parameter_tensor():
+    """SH degree 0: sh_rest is [N, 0, 3] -- an empty segment must neither trip the view check nor the kernel."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=g)
+    m = GaussianModel(means=r(100, 3), log_scales=r(100, 3), quats=r(100, 4), sh_0=r(100, 1, 3), sh_rest=torch.zeros(100, 0, 3),
+                      logit_opacities=r(100), sh_degree=0).to(dev)
+    opt = build_optimizers(m, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3, fused="hip")
+    before = m.means.detach().clone()
+    for name in m.param_names:
+        getattr(m, name).grad = torch.ones_like(getattr(m, name))
+    opt.step(); opt.zero_grad()
+    assert float((m.means.detach() - before).abs().max()) > 0 and m.sh_rest.shape == (100, 0, 3)

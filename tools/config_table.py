@@ -5,7 +5,8 @@ import os, sys, time, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-from easy_gaussian_splatting_amd.synthetic import make_scene, config_s1
+from easy_gaussian_splatting_amd.synthetic import config_s1, config_s2, config_s3, config_s5
+from easy_gaussian_splatting_amd.train_graph import TrainStepGraph
 from easy_gaussian_splatting_amd.model import GaussianModel, build_optimizers
 from easy_gaussian_splatting_amd.loss import LossComputer
 from oracle import c_oracle as CO
@@ -13,9 +14,9 @@ from oracle import c_oracle as CO
 dev = torch.device("cuda:0")
 CFG = {
     "S1 10k 256x256 SH0": config_s1(),
-    "S2 300k 800x800 SH3": make_scene(300_000, 800, 800, sh_degree=3, seed=42, extent=(2, 2, 2), scale_range=(0.003, 0.03), dist=5.0, white_bg=True),
-    "S3 2M 1920x1080 SH3": make_scene(2_000_000, 1920, 1080, sh_degree=3, seed=42, extent=(4, 2.25, 4), scale_range=(0.003, 0.03), dist=8.0, white_bg=False),
-    "S5 5M 3840x2160 SH3": make_scene(5_000_000, 3840, 2160, sh_degree=3, seed=42, extent=(4, 2.25, 4), scale_range=(0.002, 0.02), dist=8.0, white_bg=False),
+    "S2 300k 800x800 SH3": config_s2(),
+    "S3 2M 1920x1080 SH3": config_s3(),
+    "S5 5M 3840x2160 SH3": config_s5(),
 }
 
 def timed(fn, reps):
@@ -27,8 +28,8 @@ def timed(fn, reps):
         torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
     return statistics.median(ts)
 
-print("| config | N_vis | I (tight) | forward ms | fwd+bwd ms | train step ms | it/s | peak GiB |")
-print("|---|---|---|---|---|---|---|---|")
+print("| config | N_vis | I (tight) | forward ms | fwd+bwd ms | train step ms (eager) | train step ms (hipGraph) | it/s (hipGraph) | peak GiB |")
+print("|---|---|---|---|---|---|---|---|---|")
 for name, sc in CFG.items():
     T = lambda a: torch.from_numpy(a).to(dev)
     W, H, deg = sc["width"], sc["height"], sc["sh_degree"]
@@ -52,10 +53,17 @@ for name, sc in CFG.items():
     out = model(data)
     from easy_gaussian_splatting_amd.rendering import rasterization
     with torch.no_grad():
-        _, _, meta = rasterization(model.means, model.quats, model.scales, model.opacities, (model.sh_0, model.sh_rest), data["w2c"][None], data["K"][None], W, H, sh_degree=deg, packed=False)
+        _, _, meta = rasterization(model.means, model.quats, model.scales, model.opacities, (model.sh_0, model.sh_rest), data["w2c"][None], data["K"][None], W, H, sh_degree=deg, packed=False, _tile_culling="tight")
     reps = 20 if sc["means"].shape[0] <= 2_000_000 else 8
     f, fb, st = timed(fwd, reps), timed(fwdbwd, reps), timed(step, reps)
-    print(f"| {name} | {int((meta['radii']>0).sum())} | {meta['flatten_ids'].numel()} | {f:.3f} | {fb:.3f} | {st:.3f} | {1e3/st:.0f} | {torch.cuda.max_memory_allocated()/2**30:.1f} |", flush=True)
+    runner = TrainStepGraph(model, opt, LossComputer(0.2, clamp_input=True), data, gt, None)
+    def gstep():
+        for _ in range(5):
+            runner.step()
+    sg = timed(gstep, max(reps // 2, 3)) / 5
+    runner.finish()
+    print(f"| {name} | {int((meta['radii']>0).sum())} | {meta['flatten_ids'].numel()} | {f:.3f} | {fb:.3f} | {st:.3f} | {sg:.3f} | {1e3/sg:.0f} | {torch.cuda.max_memory_allocated()/2**30:.1f} |", flush=True)
+    del runner
     if name.startswith("S1"):
         cores = os.cpu_count()
         ts_f, ts_fb = [], []
