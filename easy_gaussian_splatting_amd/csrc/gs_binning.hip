@@ -612,7 +612,7 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     const unsigned grid = (unsigned)(C * tiles);
     // size classes, each launched only if some tile needs it (the host knows max_tile_count):
     //   radix (two key buffers + 2 x 1 KB of counters per wave):
-    //     <= 1024: 256 threads, 24 KB | <= 4096: 256 thr, 72 KB | <= 8192: 512 thr, 144 KB
+    //     <= 1024: 256 threads, 24 KB | <= 4096: 256 thr, 72 KB | <= 8192: 768 thr, 152 KB
     //   bitonic: <= 16384: 1024 thr, 128 KB | beyond: in-place global network
     int lo_excl = 0;
     auto radix = [&](auto kernel, int threads, int hi) -> int {
@@ -628,7 +628,7 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     };
     if (int rc = radix(tile_radix_sort_kernel<256>, 256, 1024)) return rc;
     if (int rc = radix(tile_radix_sort_kernel<256>, 256, 4096)) return rc;
-    if (int rc = radix(tile_radix_sort_kernel<512>, 512, 8192)) return rc;
+    if (int rc = radix(tile_radix_sort_kernel<768>, 768, 8192)) return rc;
     if (max_tile_count > lo_excl) {
         a.lo_excl = lo_excl; a.hi_incl = kSortLarge;
         const size_t lds_k = sizeof(uint64_t) * (size_t)kSortLarge;
