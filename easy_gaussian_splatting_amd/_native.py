@@ -60,7 +60,8 @@ SIGNATURES = {
     "gs_adam_step_dev": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P, _P]),
     "gs_refine_flags": (_I, [_P, _L, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_refine_apply": (_I, [_P, _L, _I, _I, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gs_project_bwd_adam": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P]),
+    "gs_project_bwd_adam": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P,
+                                  _P, _P, _P]),
     "gs_adam_step": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F]),
 }
 

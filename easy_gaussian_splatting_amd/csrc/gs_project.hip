@@ -268,6 +268,10 @@ struct ProjBwdArgs {
     const float* ad_hyper;    // {1/sqrt(1-beta2^t), lr_k/(1-beta1^t) x 6}  (gs_adam_hyper)
     float ad_b1, ad_b2, ad_eps;
     int64_t* ad_applied;
+    // ... and update_statistics (/root/reference/model/gaussian.py:188-197) for the single camera, from the radius and
+    // the absgrad this thread holds anyway (optional: NULL = not fused)
+    float *st_max_radii, *st_grad_norm, *st_counts;
+    float st_max_hw;
 };
 
 struct RowSum {
@@ -546,6 +550,11 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
 #pragma unroll
             for (int k = 0; k < 4; ++k) upd(2, 4 * n + k, v_quat[k]);
             upd(5, n, v_op);
+            if (a.st_max_radii != nullptr && vis) {   // same arithmetic as update_statistics_kernel
+                a.st_max_radii[n] = fmaxf(a.st_max_radii[n], (float)a.radii[f] / a.st_max_hw);
+                a.st_grad_norm[n] += sqrtf(s.v[2] * s.v[2] + s.v[3] * s.v[3]) * a.st_max_hw;
+                a.st_counts[n] += 1.f;
+            }
         } else if (a.accumulate) {
             vm[0] += v_mean[0]; vm[1] += v_mean[1]; vm[2] += v_mean[2];
             vq[0] += v_quat[0]; vq[1] += v_quat[1]; vq[2] += v_quat[2]; vq[3] += v_quat[3];
@@ -780,6 +789,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.opacities = opacities; a.activations = activations != 0;
     a.guard = current_guard().info;
     a.adam = 0; a.ad_hyper = nullptr; a.ad_applied = nullptr; a.ad_b1 = a.ad_b2 = a.ad_eps = 0.f;
+    a.st_max_radii = a.st_grad_norm = a.st_counts = nullptr; a.st_max_hw = 1.f;
     for (int t = 0; t < 6; ++t) a.ad_p[t] = a.ad_m[t] = a.ad_v[t] = nullptr;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
     const size_t lds = proj_lds_bytes(K, sh_degree);
@@ -806,13 +816,13 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
 // per Gaussian and reading them back in gs_adam_step, every parameter and both of its moments are updated in place
 // where the gradient is formed.  params / exp_avg / exp_avg_sq: the flat buffers of gs_adam_step, the six tensors
 // of param_names at offsets_host[6] floats.  hyper_dev: gs_adam_hyper.  Only v_means2d_abs (the `.absgrad`
-// side channel update_statistics consumes) is still written.
+// side channel) is still written; with max_radii / grad_norm_accum / counts given, update_statistics is applied too.
 extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree, float* params, float* exp_avg, float* exp_avg_sq,
                                    const int64_t* offsets_host, const float* viewmats, const float* Ks, int width, int height,
                                    float eps2d, float near_plane, float far_plane, const int32_t* radii, const float* colors_post,
                                    const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
                                    float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev,
-                                   int64_t* applied_dev) {
+                                   int64_t* applied_dev, float* max_radii, float* grad_norm_accum, float* counts) {
     GS_REQUIRE(N >= 0 && width > 0 && height > 0, "N>=0, positive image size");
     GS_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16, "SH colours: 0 <= degree <= 3, (degree+1)^2 <= K <= 16");
     if (N == 0) return GS_OK;
@@ -831,6 +841,10 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     a.v_means2d_abs = v_means2d_abs; a.v_means2d = a.v_conics = a.v_colors_post = a.v_colors_pre = nullptr;
     a.guard = current_guard().info;
     a.adam = 1; a.ad_hyper = hyper_dev; a.ad_applied = applied_dev; a.ad_b1 = beta1; a.ad_b2 = beta2; a.ad_eps = eps;
+    GS_REQUIRE((max_radii == nullptr) == (grad_norm_accum == nullptr) && (max_radii == nullptr) == (counts == nullptr),
+               "the three statistics buffers come together or not at all");
+    a.st_max_radii = max_radii; a.st_grad_norm = grad_norm_accum; a.st_counts = counts;
+    a.st_max_hw = (float)(width > height ? width : height);
     for (int t = 0; t < 6; ++t) { a.ad_p[t] = params + offsets_host[t]; a.ad_m[t] = exp_avg + offsets_host[t]; a.ad_v[t] = exp_avg_sq + offsets_host[t]; }
     a.cam = 0; a.accumulate = 0;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));

@@ -274,9 +274,8 @@ class TrainStepGraph:
                                                _p(opt.exp_avg_sq), offs, _p(b["viewmats"]), _p(b["Ks"]), W, H, 0.3, 0.01, 1e10,
                                                _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]),
                                                _p(b["rows"]), _p(b["qmask"]), _p(b["v_abs"]), float(b1), float(b2),
-                                               float(opt.defaults["eps"]), _p(b["hyper"]), _p(b["applied"])), "gs_project_bwd_adam")
-                self._ck(L.gs_update_statistics(st, N, float(max(H, W)), _p(b["radii"]), _p(b["v_abs"]), _p(m.max_radii),
-                                                _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_update_statistics")
+                                               float(opt.defaults["eps"]), _p(b["hyper"]), _p(b["applied"]), _p(m.max_radii),
+                                               _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_project_bwd_adam")
             else:
                 g = self.grads
                 self._ck(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),

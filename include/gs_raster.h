@@ -270,12 +270,14 @@ int gs_refine_apply(void* stream, int64_t n_old, int num_splits, int K, const in
  * gradient is written; each parameter element and its two moments are updated in place where its gradient is
  * formed (saves writing and re-reading 59 floats per Gaussian).  params / exp_avg / exp_avg_sq and offsets_host[6]
  * (means, log_scales, quats, sh_0, sh_rest, logit_opacities; floats) describe the flat buffers of gs_adam_step.
- * Same update, bit for bit, as gs_project_bwd followed by gs_adam_step_dev.  Honours the step guard. */
+ * Same update, bit for bit, as gs_project_bwd followed by gs_adam_step_dev.  Honours the step guard.
+ * max_radii / grad_norm_accum / counts (optional, all three or none): gs_update_statistics is applied in the same pass. */
 int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree, float* params, float* exp_avg, float* exp_avg_sq,
                         const int64_t* offsets_host, const float* viewmats, const float* Ks, int width, int height, float eps2d,
                         float near_plane, float far_plane, const int32_t* radii, const float* colors_post,
                         const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
-                        float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev, int64_t* applied_dev);
+                        float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev, int64_t* applied_dev,
+                        float* max_radii, float* grad_norm_accum, float* counts);
 
 /* Row e: this rank's contribution to the SUM all-reduce of the view-parallel step in one pass: the four
  * geometry gradients and this view's two additive statistics (|absgrad|_2 * max_hw, visibility count)
