@@ -29,19 +29,26 @@ extern "C" int gs_guard_set(const int64_t* info_dev, int64_t cap_isects, int64_t
 
 namespace gs {
 __global__ void step_status_kernel(const int64_t* __restrict__ info, const int64_t* __restrict__ applied,
-                                   volatile int64_t* __restrict__ status) {
+                                   volatile int64_t* __restrict__ status, const float* __restrict__ loss3,
+                                   float* __restrict__ loss_ring, int ring_len) {
     if (threadIdx.x < 4) status[threadIdx.x] = info[threadIdx.x];
     if (threadIdx.x == 4) status[4] = applied ? applied[0] : 0;
+    // per-step loss log: slot (applied - 1) mod ring_len, written only by steps the guard did not skip, so a replayed
+    // step overwrites nothing but its own slot
+    if (loss_ring != nullptr && applied != nullptr && info[3] == 0 && threadIdx.x < 3 && applied[0] > 0)
+        loss_ring[3 * ((applied[0] - 1) % ring_len) + threadIdx.x] = loss3[threadIdx.x];
     __threadfence_system();
 }
 }  // namespace gs
 
-extern "C" int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied_dev, int64_t* status) {
-    if (!info_dev || !status) {
-        gs::set_error("invalid argument: null pointer");
+extern "C" int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied_dev, int64_t* status,
+                              const float* loss3_dev, float* loss_ring_dev, int ring_len) {
+    if (!info_dev || !status || (loss_ring_dev && (!loss3_dev || ring_len <= 0))) {
+        gs::set_error("invalid argument: null pointer / empty ring");
         return GS_ERR_ARG;
     }
-    hipLaunchKernelGGL(gs::step_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info_dev, applied_dev, status);
+    hipLaunchKernelGGL(gs::step_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info_dev, applied_dev, status, loss3_dev,
+                       loss_ring_dev, ring_len);
     GS_LAUNCH_CHECK("step_status_kernel");
     return GS_OK;
 }

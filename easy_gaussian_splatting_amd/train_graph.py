@@ -129,6 +129,7 @@ class TrainStepGraph:
         b["render_alphas"] = torch.empty((1, H, W, 1), **f32)
         b["loss_ws"] = torch.empty((int(L.gs_loss_workspace_floats(H, W)),), **f32)
         b["loss3"] = torch.zeros((3,), **f32)
+        b["loss_ring"] = torch.zeros((self.LOSS_RING, 3), **f32)
         b["one"] = torch.ones((), **f32)
         b["v_render"] = torch.empty((H, W, 3), **f32)
         b["qcnt"] = torch.empty((tiles * 4,), **i32)
@@ -293,7 +294,8 @@ class TrainStepGraph:
                 self._ck(L.gs_adam_step_dev(st, opt.flat_param.numel(), _p(opt.flat_param), _p(opt.exp_avg), _p(opt.exp_avg_sq), ns,
                                             ends, lens, gptr, float(b1), float(b2), float(opt.defaults["eps"]), 1.0, _p(b["hyper"]),
                                             _p(b["applied"])), "gs_adam_step_dev")
-            self._ck(L.gs_step_status(st, _p(b["info"]), _p(b["applied"]), self.status.data_ptr()), "gs_step_status")
+            self._ck(L.gs_step_status(st, _p(b["info"]), _p(b["applied"]), self.status.data_ptr(), _p(b["loss3"]), _p(b["loss_ring"]),
+                                      self.LOSS_RING), "gs_step_status")
         except TrainStepGraph._Stop:
             pass
         finally:
@@ -408,6 +410,17 @@ class TrainStepGraph:
         """Blocks until every issued step is known to be applied (replaying overflowed ones)."""
         while self.pending:
             self._poll(block=True)
+
+    LOSS_RING = 4096   # steps of loss history kept on the device
+
+    def loss_history(self, last_n: int) -> Tensor:
+        """[last_n, 3] = {l1, 1-ssim, total} of the last `last_n` APPLIED steps since the latest (re-)build, oldest first
+        (one device read; call after `finish()`).  The `loss3` tensor `step()` returns is only the latest launch's value and
+        is meaningless for a step the guard skipped -- this log is written by applied steps only."""
+        applied = int(self.buf["applied"].item())
+        n = max(0, min(int(last_n), applied, self.LOSS_RING))
+        idx = (torch.arange(applied - n, applied, device=self.dev)) % self.LOSS_RING
+        return self.buf["loss_ring"][idx]
 
     def report(self) -> Dict[str, Any]:
         return dict(self.stats, capacity_isects=self.cap, capacity_tile_list=self.cap_tile, steps=self.confirmed,

@@ -62,8 +62,11 @@ int gs_guard_set(const int64_t* info_dev, int64_t cap_isects, int64_t cap_tile);
 /* Publishes a guarded step's outcome without a copy or an event: one tiny launch writes
  * status[0..3] = info_dev[0..3] ({I, n_buckets, max tile, flags}) and status[4] = applied_dev[0] (may be NULL).
  * `status` may be page-locked HOST memory (hipHostMalloc'ed, device-accessible): the host then polls plain memory
- * -- the flags are sticky and the applied-step counter monotonic, so a torn read is harmless. */
-int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied_dev, int64_t* status);
+ * -- the flags are sticky and the applied-step counter monotonic, so a torn read is harmless.
+ * loss_ring_dev (optional, with loss3_dev = gs_l1_ssim_fwd's out3): a device ring of ring_len x 3 floats; an APPLIED step
+ * n (counted from 1) logs its {l1, 1-ssim, total} in slot (n-1) mod ring_len, a skipped step logs nothing. */
+int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied_dev, int64_t* status,
+                   const float* loss3_dev, float* loss_ring_dev, int ring_len);
 
 /* Number of Gaussian groups per camera used by the binning kernels, and the bytes of scratch
  * `workspace` gs_bin_count / gs_bin_emit_sort need for (C, N, tiles). */

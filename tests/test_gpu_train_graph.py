@@ -94,13 +94,17 @@ def test_overflow_is_skipped_on_device_detected_lazily_and_replayed():
     runner = TrainStepGraph(mb, ob, lc, far, gts[0], margin=1.02, check_every=4)
     cap0 = runner.report()["capacity_isects"]
     seq = [far, datas[1], datas[2], far, datas[0], datas[1]]
+    ref_losses = []
     for it, d in enumerate(seq):   # no finish() in between: the host keeps enqueueing behind the overflow
-        _eager_step(ma, oa, lc, d, gts[it % 3])
+        ref_losses.append(_eager_step(ma, oa, lc, d, gts[it % 3]))
         runner.step(d, gts[it % 3])
     runner.finish()
     rep = runner.report()
     assert rep["overflows"] >= 1 and rep["replayed_steps"] >= 1 and rep["capacity_isects"] > cap0 and rep["steps"] == len(seq)
     _assert_same(ma, oa, mb, ob, "after overflow")
+    # the device-side loss log holds the APPLIED steps' losses (skipped launches log nothing)
+    hist = runner.loss_history(3)
+    assert hist.shape == (min(3, int(runner.buf["applied"].item())), 3) and torch.equal(hist[-1], ref_losses[-1])
 
 
 def test_refinement_between_graph_steps_rebuilds_the_workspace():

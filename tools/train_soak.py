@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Soak run of the whole train loop (forward, fused loss, backward, statistics, fused Adam, densify/prune every 100
-steps, opacity reset) at a mid-size synthetic scene: finite values, decreasing loss, bounded memory."""
+steps, opacity reset, means-LR schedule) at a mid-size synthetic scene: finite values, decreasing loss, bounded memory.
+    tools/train_soak.py [eager|graph]     graph: every step through train_graph.TrainStepGraph (changing cameras,
+                                          re-capture after each refinement, overflow replay if a view needs more room)"""
 import os, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -27,25 +29,39 @@ with torch.no_grad():
 del ref
 model = model_from(sc, 1.0, 1)
 opt = build_optimizers(model, 1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2, fused="hip")
-lc = LossComputer(0.2)
+mode = sys.argv[1] if len(sys.argv) > 1 else "eager"
+lc = LossComputer(0.2, clamp_input=(mode == "graph"))
+runner = None
+if mode == "graph":
+    from easy_gaussian_splatting_amd.train_graph import TrainStepGraph
+    runner = TrainStepGraph(model, opt, lc, datas[0], targets[0], None)
 losses, t0 = [], time.time()
 for it in range(1, 701):
     v = it % V
-    out = model(datas[v])
-    loss = lc.get_loss_dict(out["render_img"], targets[v])["total"]
-    loss.backward()
-    model.update_statistics(datas[v], out)
-    opt.step(); opt.zero_grad()
-    losses.append(loss.detach())
+    model.update_learning_rate(it)
+    if runner is not None:
+        losses.append(runner.step(datas[v], targets[v])["loss3"][2].clone())
+    else:
+        out = model(datas[v])
+        loss = lc.get_loss_dict(out["render_img"], targets[v])["total"]
+        loss.backward()
+        model.update_statistics(datas[v], out)
+        opt.step(); opt.zero_grad()
+        losses.append(loss.detach())
     if it % 100 == 0:
+        if runner is not None:
+            runner.finish()
         if it == 400:
             model.reset_opacities()
         else:
             model.densify_and_prune()
         torch.cuda.synchronize()
-        l = torch.stack(losses[-50:]).mean().item()
+        l = (runner.loss_history(50)[:, 2] if runner is not None else torch.stack(losses[-50:])).mean().item()
         print(f"it {it}: N={model.nbr_gaussians} loss(mean last 50)={l:.5f} mem={torch.cuda.max_memory_allocated() / 2**30:.2f} GiB "
               f"{(time.time() - t0) / it * 1e3:.2f} ms/it", flush=True)
 ls = torch.stack(losses).cpu().numpy()
 assert np.isfinite(ls).all()
 print("first/last 50:", ls[:50].mean(), ls[-50:].mean())
+if runner is not None:
+    runner.finish()
+    print("runner:", runner.report())
