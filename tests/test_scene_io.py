@@ -190,3 +190,11 @@ def test_model_from_pointcloud_follows_reference_initialisation():
     assert np.allclose(m.scales.detach().numpy(), np.repeat(exp[:, None], 3, 1), rtol=1e-5)
     assert np.allclose(m.sh_0[:, 0].detach().numpy(), (pc.rgbs / 255.0 - 0.5) / 0.28209479177387814, atol=1e-6)
     assert m.active_sh_degree == 0
+
+
+def test_loader_quaternion_convention_matches_reference_fixture():
+    """The COLMAP reader's own wxyz -> rotation routine against vectors captured from the reference's
+    model/utils.py:31-55 (the convention pyquaternion's `rotation_matrix` shares), un-normalised inputs included."""
+    z = np.load(Path(__file__).parent / "golden" / "ref_model_utils.npz")
+    for q, R in zip(z["quats"], z["rotmats"]):
+        assert np.allclose(S.quat_wxyz_to_rotmat(q), R, atol=1e-12)
