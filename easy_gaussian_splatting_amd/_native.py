@@ -13,7 +13,8 @@ import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsraster.so")
+# (GS_LIB_PATH: a tuning variant of the same library, tools/tune_variants.sh; the product loads the in-tree build)
+LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsraster.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 GS_TILE = 16

@@ -626,7 +626,10 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
         lo_excl = hi;
         return GS_OK;
     };
-    if (int rc = radix(tile_radix_sort_kernel<256>, 256, 1024)) return rc;
+#ifndef GS_SORT1K_THREADS
+#define GS_SORT1K_THREADS 256
+#endif
+    if (int rc = radix(tile_radix_sort_kernel<GS_SORT1K_THREADS>, GS_SORT1K_THREADS, 1024)) return rc;
     if (int rc = radix(tile_radix_sort_kernel<256>, 256, 4096)) return rc;
     if (int rc = radix(tile_radix_sort_kernel<768>, 768, 8192)) return rc;
     if (max_tile_count > lo_excl) {

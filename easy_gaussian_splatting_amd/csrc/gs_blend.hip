@@ -260,7 +260,10 @@ struct BlendBwdArgs {
     const int64_t* guard;
 };
 
-constexpr int kBwdWaves = 4;
+#ifndef GS_BWD_WAVES
+#define GS_BWD_WAVES 4
+#endif
+constexpr int kBwdWaves = GS_BWD_WAVES;
 constexpr int kPipeLanes = 8;                       // lanes per systolic pipeline (two pipelines share a 16-lane DPP row)
 constexpr int kPerLane = kUnit / kPipeLanes;        // 4 entries per lane
 constexpr int kUnitsPerWave = 64 / kPipeLanes;      // 8
@@ -309,7 +312,12 @@ __device__ __forceinline__ void bwd_pair(EntryState& e, const float4 d0, const f
     P = Pn;
 }
 
-__global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBwdArgs a) {
+#ifdef GS_BWD_WAVES_PER_EU
+#define GS_BWD_ATTR __attribute__((amdgpu_waves_per_eu(GS_BWD_WAVES_PER_EU, GS_BWD_WAVES_PER_EU)))
+#else
+#define GS_BWD_ATTR
+#endif
+__global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(const BlendBwdArgs a) {
     __shared__ float4 sd0_all[kBwdWaves][kUnitsPerWave][64];   // 8 KB per wave: v_r, v_g, v_b, E of the unit's 64 pixels
     __shared__ float2 sck_all[kBwdWaves][kUnitsPerWave][64];   // 4 KB per wave: checkpoint T, P = checkpoint colour . v
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -378,6 +386,9 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
     __builtin_amdgcn_wave_barrier();
 
     float T_out = -1.f, P_out = 0.f;
+#ifdef GS_BWD_UNROLL
+#pragma unroll GS_BWD_UNROLL
+#endif
     for (int s = 0; s < kBwdSteps; ++s) {
         float T = dpp_row_shr1(T_out), P = dpp_row_shr1(P_out);
         const int p = s - r;
@@ -437,7 +448,10 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     // 4 tiles (waves) per workgroup: measured equal to single-wave workgroups (0.33-0.36 ms at the bench
     // size).  One box of the pool ran the single-wave form at 0.63 ms with every other kernel at its usual
     // time; the cause was not established, a quarter of the workgroups is the conservative launch shape.
-    constexpr int kFwdWaves = 4;
+#ifndef GS_FWD_WAVES
+#define GS_FWD_WAVES 4
+#endif
+    constexpr int kFwdWaves = GS_FWD_WAVES;
     const dim3 grid((n_tiles + kFwdWaves - 1) / kFwdWaves), block(64 * kFwdWaves);
     if (train) {
         GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));

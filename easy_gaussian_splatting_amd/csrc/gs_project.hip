@@ -9,7 +9,10 @@
 
 namespace gs {
 
-constexpr int kProjThreads = 256;
+#ifndef GS_PROJ_THREADS
+#define GS_PROJ_THREADS 256
+#endif
+constexpr int kProjThreads = GS_PROJ_THREADS;
 
 struct ProjFwdArgs {
     int C, K, colors_per_camera, W, H, tw, th, tight, activations;
