@@ -37,6 +37,7 @@ struct Splat2D {
     float A, B, C;   // conic
     float cxx, cyy;  // diagonal of the blurred 2-D covariance (for opacity-aware extents)
     int radius;      // 0 => culled
+    int x0, x1, y0, y1;  // tile rectangle of the 3-sigma square (project_gaussian with tile > 0)
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -54,53 +55,78 @@ GS_HD void alpha_extent(float opacity, float cxx, float cyy, float& ex, float& e
     ey = sqrtf(tau2 * cyy) * 1.0005f + 0.02f;
 }
 
-// Intermediates the VJP needs again; recomputed in backward rather than stored.
-struct ProjChain {
-    float qw, qx, qy, qz, qinv;           // normalised quaternion, 1/|q|
-    float R[9];                           // rotation of the Gaussian
-    float M[9];                           // R diag(s)
-    float cc00, cc01, cc02, cc11, cc12, cc22;  // camera-space covariance
-    float x, y, z;                        // camera-space mean
-    float tx, ty;                         // clamped x, y used inside J
-    int clampx, clampy;                   // -1 / 0 / +1
-    float j00, j02, j11, j12;
-    float a, b, c, det;                   // blurred 2-D covariance and determinant
-};
+// Arithmetic type of the per-Gaussian projection chain (mean -> camera space -> covariance -> conic, its VJP, the
+// radius and the tile rectangle).  fp64 by default: CDNA4 issues vector fp64 at half the fp32 rate, the chain is
+// ~10^3 flops per Gaussian against ~10^5 per Gaussian in the blend, and its inverse (det = ac - b^2 of a 60:1 needle
+// loses 3 digits, twice in the VJP) is the one badly conditioned step of the whole path.  Inputs and outputs stay fp32.
+#ifndef GS_PROJ_REAL
+#define GS_PROJ_REAL double
+#endif
+typedef GS_PROJ_REAL preal;
 
+GS_HD float r_sqrt(float x) { return sqrtf(x); }
+GS_HD double r_sqrt(double x) { return sqrt(x); }
+GS_HD float r_ceil(float x) { return ceilf(x); }
+GS_HD double r_ceil(double x) { return ceil(x); }
+GS_HD float r_floor(float x) { return floorf(x); }
+GS_HD double r_floor(double x) { return floor(x); }
+GS_HD float r_max(float x, float y) { return fmaxf(x, y); }
+GS_HD double r_max(double x, double y) { return fmax(x, y); }
+GS_HD float r_min(float x, float y) { return fminf(x, y); }
+GS_HD double r_min(double x, double y) { return fmin(x, y); }
+
+// Intermediates the VJP needs again; recomputed in backward rather than stored.
+template <typename T>
+struct ProjChainT {
+    T qw, qx, qy, qz, qinv;           // normalised quaternion, 1/|q|
+    T R[9];                           // rotation of the Gaussian
+    T M[9];                           // R diag(s)
+    T cc00, cc01, cc02, cc11, cc12, cc22;  // camera-space covariance
+    T x, y, z;                        // camera-space mean
+    T tx, ty;                         // clamped x, y used inside J
+    int clampx, clampy;               // -1 / 0 / +1
+    T j00, j02, j11, j12;
+    T a, b, c, det;                   // blurred 2-D covariance and determinant
+};
+typedef ProjChainT<preal> ProjChain;
+
+template <typename T>
 GS_HD bool project_chain(const float* mean, const float* quat, const float* scale,
                          const Camera& cam, float eps2d, float near_p, float far_p,
-                         ProjChain& o) {
-    const float px = mean[0], py = mean[1], pz = mean[2];
-    o.x = cam.R[0] * px + cam.R[1] * py + cam.R[2] * pz + cam.t[0];
-    o.y = cam.R[3] * px + cam.R[4] * py + cam.R[5] * pz + cam.t[1];
-    o.z = cam.R[6] * px + cam.R[7] * py + cam.R[8] * pz + cam.t[2];
-    if (o.z < near_p || o.z > far_p) return false;
+                         ProjChainT<T>& o) {
+    const T px = mean[0], py = mean[1], pz = mean[2];
+    T V[9];
+    for (int i = 0; i < 9; ++i) V[i] = (T)cam.R[i];
+    o.x = V[0] * px + V[1] * py + V[2] * pz + (T)cam.t[0];
+    o.y = V[3] * px + V[4] * py + V[5] * pz + (T)cam.t[1];
+    o.z = V[6] * px + V[7] * py + V[8] * pz + (T)cam.t[2];
+    if (o.z < (T)near_p || o.z > (T)far_p) return false;
 
-    const float qn2 = quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3];
-    o.qinv = 1.0f / sqrtf(qn2);
-    const float w = quat[0] * o.qinv, x = quat[1] * o.qinv, y = quat[2] * o.qinv, z = quat[3] * o.qinv;
+    const T q0 = quat[0], q1 = quat[1], q2 = quat[2], q3 = quat[3];
+    const T qn2 = q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3;
+    o.qinv = T(1) / r_sqrt(qn2);
+    const T w = q0 * o.qinv, x = q1 * o.qinv, y = q2 * o.qinv, z = q3 * o.qinv;
     o.qw = w; o.qx = x; o.qy = y; o.qz = z;
-    float* R = o.R;
-    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - w * z); R[2] = 2.f * (x * z + w * y);
-    R[3] = 2.f * (x * y + w * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - w * x);
-    R[6] = 2.f * (x * z - w * y); R[7] = 2.f * (y * z + w * x); R[8] = 1.f - 2.f * (x * x + y * y);
-    float* M = o.M;
-    const float s0 = scale[0], s1 = scale[1], s2 = scale[2];
+    T* R = o.R;
+    R[0] = T(1) - T(2) * (y * y + z * z); R[1] = T(2) * (x * y - w * z); R[2] = T(2) * (x * z + w * y);
+    R[3] = T(2) * (x * y + w * z); R[4] = T(1) - T(2) * (x * x + z * z); R[5] = T(2) * (y * z - w * x);
+    R[6] = T(2) * (x * z - w * y); R[7] = T(2) * (y * z + w * x); R[8] = T(1) - T(2) * (x * x + y * y);
+    T* M = o.M;
+    const T s0 = scale[0], s1 = scale[1], s2 = scale[2];
     M[0] = R[0] * s0; M[1] = R[1] * s1; M[2] = R[2] * s2;
     M[3] = R[3] * s0; M[4] = R[4] * s1; M[5] = R[5] * s2;
     M[6] = R[6] * s0; M[7] = R[7] * s1; M[8] = R[8] * s2;
     // world covariance (symmetric)
-    const float c00 = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
-    const float c01 = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
-    const float c02 = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
-    const float c11 = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
-    const float c12 = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
-    const float c22 = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+    const T c00 = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+    const T c01 = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+    const T c02 = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+    const T c11 = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+    const T c12 = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+    const T c22 = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
     // T = Rv * cov
-    const float* V = cam.R;
-    const float t00 = V[0] * c00 + V[1] * c01 + V[2] * c02, t01 = V[0] * c01 + V[1] * c11 + V[2] * c12, t02 = V[0] * c02 + V[1] * c12 + V[2] * c22;
-    const float t10 = V[3] * c00 + V[4] * c01 + V[5] * c02, t11 = V[3] * c01 + V[4] * c11 + V[5] * c12, t12 = V[3] * c02 + V[4] * c12 + V[5] * c22;
-    const float t20 = V[6] * c00 + V[7] * c01 + V[8] * c02, t21 = V[6] * c01 + V[7] * c11 + V[8] * c12, t22 = V[6] * c02 + V[7] * c12 + V[8] * c22;
+    const T t00 = V[0] * c00 + V[1] * c01 + V[2] * c02, t01 = V[0] * c01 + V[1] * c11 + V[2] * c12, t02 = V[0] * c02 + V[1] * c12 + V[2] * c22;
+    const T t10 = V[3] * c00 + V[4] * c01 + V[5] * c02, t11 = V[3] * c01 + V[4] * c11 + V[5] * c12, t12 = V[3] * c02 + V[4] * c12 + V[5] * c22;
+    const T t20 = V[6] * c00 + V[7] * c01 + V[8] * c02, t21 = V[6] * c01 + V[7] * c11 + V[8] * c12, t22 = V[6] * c02 + V[7] * c12 + V[8] * c22;
     o.cc00 = t00 * V[0] + t01 * V[1] + t02 * V[2];
     o.cc01 = t00 * V[3] + t01 * V[4] + t02 * V[5];
     o.cc02 = t00 * V[6] + t01 * V[7] + t02 * V[8];
@@ -108,55 +134,65 @@ GS_HD bool project_chain(const float* mean, const float* quat, const float* scal
     o.cc12 = t10 * V[6] + t11 * V[7] + t12 * V[8];
     o.cc22 = t20 * V[6] + t21 * V[7] + t22 * V[8];
 
-    const float rz = 1.0f / o.z;
-    const float rx = o.x * rz, ry = o.y * rz;
-    o.clampx = rx > cam.limx ? 1 : (rx < -cam.limx ? -1 : 0);
-    o.clampy = ry > cam.limy ? 1 : (ry < -cam.limy ? -1 : 0);
-    o.tx = o.z * (o.clampx > 0 ? cam.limx : (o.clampx < 0 ? -cam.limx : rx));
-    o.ty = o.z * (o.clampy > 0 ? cam.limy : (o.clampy < 0 ? -cam.limy : ry));
-    o.j00 = cam.fx * rz; o.j11 = cam.fy * rz;
-    o.j02 = -cam.fx * o.tx * rz * rz; o.j12 = -cam.fy * o.ty * rz * rz;
-    o.a = o.j00 * o.j00 * o.cc00 + 2.f * o.j00 * o.j02 * o.cc02 + o.j02 * o.j02 * o.cc22 + eps2d;
+    const T fx = cam.fx, fy = cam.fy, limx = cam.limx, limy = cam.limy;
+    const T rz = T(1) / o.z;
+    const T rx = o.x * rz, ry = o.y * rz;
+    o.clampx = rx > limx ? 1 : (rx < -limx ? -1 : 0);
+    o.clampy = ry > limy ? 1 : (ry < -limy ? -1 : 0);
+    o.tx = o.z * (o.clampx > 0 ? limx : (o.clampx < 0 ? -limx : rx));
+    o.ty = o.z * (o.clampy > 0 ? limy : (o.clampy < 0 ? -limy : ry));
+    o.j00 = fx * rz; o.j11 = fy * rz;
+    o.j02 = -fx * o.tx * rz * rz; o.j12 = -fy * o.ty * rz * rz;
+    o.a = o.j00 * o.j00 * o.cc00 + T(2) * o.j00 * o.j02 * o.cc02 + o.j02 * o.j02 * o.cc22 + (T)eps2d;
     o.b = o.j00 * o.j11 * o.cc01 + o.j00 * o.j12 * o.cc02 + o.j02 * o.j11 * o.cc12 + o.j02 * o.j12 * o.cc22;
-    o.c = o.j11 * o.j11 * o.cc11 + 2.f * o.j11 * o.j12 * o.cc12 + o.j12 * o.j12 * o.cc22 + eps2d;
+    o.c = o.j11 * o.j11 * o.cc11 + T(2) * o.j11 * o.j12 * o.cc12 + o.j12 * o.j12 * o.cc22 + (T)eps2d;
     o.det = o.a * o.c - o.b * o.b;
     return true;
 }
 
-// Appendix A.1: full forward projection of one Gaussian for one camera.
-GS_HD Splat2D project_gaussian(const float* mean, const float* quat, const float* scale,
-                               const Camera& cam, int W, int H, float eps2d, float near_p,
-                               float far_p, float radius_clip) {
+// Appendix A.3: tile rectangle [x0,x1) x [y0,y1) touched by the 3-sigma square.
+template <typename T>
+GS_HD void tile_rect(T mx, T my, int radius, int tile, int tw, int th, int& x0, int& x1, int& y0, int& y1) {
+    const T inv = T(1) / (T)tile;  // exact for power-of-two tiles; division kept for others
+    const T r = (tile & (tile - 1)) ? (T)radius / (T)tile : (T)radius * inv;
+    const T cx = (tile & (tile - 1)) ? mx / (T)tile : mx * inv;
+    const T cy = (tile & (tile - 1)) ? my / (T)tile : my * inv;
+    const T fx0 = r_floor(cx - r), fx1 = r_ceil(cx + r), fy0 = r_floor(cy - r), fy1 = r_ceil(cy + r);
+    x0 = (int)r_min(r_max(fx0, T(0)), (T)tw); x1 = (int)r_min(r_max(fx1, T(0)), (T)tw);
+    y0 = (int)r_min(r_max(fy0, T(0)), (T)th); y1 = (int)r_min(r_max(fy1, T(0)), (T)th);
+}
+
+// Appendix A.1: full forward projection of one Gaussian for one camera.  With tile > 0 the tile rectangle of the
+// 3-sigma square is taken from the unrounded centre as well (s.x0..s.y1).
+template <typename T>
+GS_HD Splat2D project_gaussian_t(const float* mean, const float* quat, const float* scale,
+                                 const Camera& cam, int W, int H, float eps2d, float near_p,
+                                 float far_p, float radius_clip, int tile, int tw, int th) {
     Splat2D s;
     s.mx = s.my = s.depth = s.A = s.B = s.C = s.cxx = s.cyy = 0.f;
-    s.radius = 0;
-    ProjChain p;
-    if (!project_chain(mean, quat, scale, cam, eps2d, near_p, far_p, p)) return s;
-    if (!(p.det > 0.f)) return s;
-    const float mid = 0.5f * (p.a + p.c);
-    const float lam = mid + sqrtf(fmaxf(kRadiusDiscFloor, mid * mid - p.det));
-    const float radius = ceilf(3.0f * sqrtf(lam));
-    if (radius <= radius_clip) return s;
-    const float mx = cam.fx * p.x / p.z + cam.cx, my = cam.fy * p.y / p.z + cam.cy;
-    if (mx + radius <= 0.f || mx - radius >= (float)W || my + radius <= 0.f || my - radius >= (float)H) return s;
-    const float rdet = 1.0f / p.det;
-    s.mx = mx; s.my = my; s.depth = p.z;
-    s.A = p.c * rdet; s.B = -p.b * rdet; s.C = p.a * rdet;
-    s.cxx = p.a; s.cyy = p.c;
+    s.radius = 0; s.x0 = s.x1 = s.y0 = s.y1 = 0;
+    ProjChainT<T> p;
+    if (!project_chain<T>(mean, quat, scale, cam, eps2d, near_p, far_p, p)) return s;
+    if (!(p.det > T(0))) return s;
+    const T mid = T(0.5) * (p.a + p.c);
+    const T lam = mid + r_sqrt(r_max((T)kRadiusDiscFloor, mid * mid - p.det));
+    const T radius = r_ceil(T(3) * r_sqrt(lam));
+    if (radius <= (T)radius_clip) return s;
+    const T mx = (T)cam.fx * p.x / p.z + (T)cam.cx, my = (T)cam.fy * p.y / p.z + (T)cam.cy;
+    if (mx + radius <= T(0) || mx - radius >= (T)W || my + radius <= T(0) || my - radius >= (T)H) return s;
+    const T rdet = T(1) / p.det;
+    s.mx = (float)mx; s.my = (float)my; s.depth = (float)p.z;
+    s.A = (float)(p.c * rdet); s.B = (float)(-p.b * rdet); s.C = (float)(p.a * rdet);
+    s.cxx = (float)p.a; s.cyy = (float)p.c;
     s.radius = (int)radius;
+    if (tile > 0) tile_rect<T>(mx, my, s.radius, tile, tw, th, s.x0, s.x1, s.y0, s.y1);
     return s;
 }
 
-// Appendix A.3: tile rectangle [x0,x1) x [y0,y1) touched by the 3-sigma square.
-GS_HD void tile_rect(float mx, float my, int radius, int tile, int tw, int th, int& x0, int& x1,
-                     int& y0, int& y1) {
-    const float inv = 1.0f / (float)tile;  // exact for power-of-two tiles; division kept for others
-    const float r = (tile & (tile - 1)) ? (float)radius / (float)tile : (float)radius * inv;
-    const float cx = (tile & (tile - 1)) ? mx / (float)tile : mx * inv;
-    const float cy = (tile & (tile - 1)) ? my / (float)tile : my * inv;
-    const float fx0 = floorf(cx - r), fx1 = ceilf(cx + r), fy0 = floorf(cy - r), fy1 = ceilf(cy + r);
-    x0 = (int)fminf(fmaxf(fx0, 0.f), (float)tw); x1 = (int)fminf(fmaxf(fx1, 0.f), (float)tw);
-    y0 = (int)fminf(fmaxf(fy0, 0.f), (float)th); y1 = (int)fminf(fmaxf(fy1, 0.f), (float)th);
+GS_HD Splat2D project_gaussian(const float* mean, const float* quat, const float* scale,
+                               const Camera& cam, int W, int H, float eps2d, float near_p,
+                               float far_p, float radius_clip, int tile = 0, int tw = 0, int th = 0) {
+    return project_gaussian_t<preal>(mean, quat, scale, cam, W, H, eps2d, near_p, far_p, radius_clip, tile, tw, th);
 }
 
 // Minimum of the positive-definite form a dx^2 + b dx dy + c dy^2 over the axis-aligned
@@ -284,72 +320,76 @@ GS_HD void sh_vjp(int degree, const float* sh, const float* rgb, const float* v_
 }
 
 // Appendix A.6 projection VJP for one (camera, Gaussian): adds into v_mean[3], v_quat[4], v_scale[3].
-GS_HD void project_vjp(const float* scale, const Camera& cam, const ProjChain& p, float v_mx,
-                       float v_my, float vA, float vB, float vC, float v_depth, float* v_mean,
+template <typename T>
+GS_HD void project_vjp(const float* scale, const Camera& cam, const ProjChainT<T>& p, float v_mx_f,
+                       float v_my_f, float vA_f, float vB_f, float vC_f, float v_depth_f, float* v_mean,
                        float* v_quat, float* v_scale) {
+    const T v_mx = v_mx_f, v_my = v_my_f, vA = vA_f, vB = vB_f, vC = vC_f, v_depth = v_depth_f;
+    const T fx = cam.fx, fy = cam.fy, limx = cam.limx, limy = cam.limy;
+    T V[9];
+    for (int i = 0; i < 9; ++i) V[i] = (T)cam.R[i];
     // conic = inverse(cov2'); G = -X V X with V = [[vA, vB/2],[vB/2, vC]]
-    const float rdet = 1.0f / p.det;
-    const float X00 = p.c * rdet, X01 = -p.b * rdet, X11 = p.a * rdet;
-    const float h = 0.5f * vB;
-    const float xv00 = X00 * vA + X01 * h, xv01 = X00 * h + X01 * vC;
-    const float xv10 = X01 * vA + X11 * h, xv11 = X01 * h + X11 * vC;
-    const float g00 = -(xv00 * X00 + xv01 * X01);
-    const float g01 = -(xv00 * X01 + xv01 * X11);
-    const float g11 = -(xv10 * X01 + xv11 * X11);
-    const float j00 = p.j00, j02 = p.j02, j11 = p.j11, j12 = p.j12;
+    const T rdet = T(1) / p.det;
+    const T X00 = p.c * rdet, X01 = -p.b * rdet, X11 = p.a * rdet;
+    const T h = T(0.5) * vB;
+    const T xv00 = X00 * vA + X01 * h, xv01 = X00 * h + X01 * vC;
+    const T xv10 = X01 * vA + X11 * h, xv11 = X01 * h + X11 * vC;
+    const T g00 = -(xv00 * X00 + xv01 * X01);
+    const T g01 = -(xv00 * X01 + xv01 * X11);
+    const T g11 = -(xv10 * X01 + xv11 * X11);
+    const T j00 = p.j00, j02 = p.j02, j11 = p.j11, j12 = p.j12;
     // GJ (2x3)
-    const float a0 = g00 * j00, a1 = g01 * j11, a2 = g00 * j02 + g01 * j12;
-    const float b0 = g01 * j00, b1 = g11 * j11, b2 = g01 * j02 + g11 * j12;
+    const T a0 = g00 * j00, a1 = g01 * j11, a2 = g00 * j02 + g01 * j12;
+    const T b0 = g01 * j00, b1 = g11 * j11, b2 = g01 * j02 + g11 * j12;
     // v_covc = J^T G J (symmetric)
-    const float vc00 = j00 * a0, vc01 = j00 * a1, vc02 = j00 * a2;
-    const float vc11 = j11 * b1, vc12 = j11 * b2, vc22 = j02 * a2 + j12 * b2;
+    const T vc00 = j00 * a0, vc01 = j00 * a1, vc02 = j00 * a2;
+    const T vc11 = j11 * b1, vc12 = j11 * b2, vc22 = j02 * a2 + j12 * b2;
     // v_J = 2 (GJ) covc ; only the four non-constant entries
-    const float vJ00 = 2.f * (a0 * p.cc00 + a1 * p.cc01 + a2 * p.cc02);
-    const float vJ02 = 2.f * (a0 * p.cc02 + a1 * p.cc12 + a2 * p.cc22);
-    const float vJ11 = 2.f * (b0 * p.cc01 + b1 * p.cc11 + b2 * p.cc12);
-    const float vJ12 = 2.f * (b0 * p.cc02 + b1 * p.cc12 + b2 * p.cc22);
-    const float rz = 1.0f / p.z, rz2 = rz * rz, rz3 = rz2 * rz;
-    float vx = 0.f, vy = 0.f;
-    float vz = -vJ00 * cam.fx * rz2 - vJ11 * cam.fy * rz2 + 2.f * vJ02 * cam.fx * p.tx * rz3 + 2.f * vJ12 * cam.fy * p.ty * rz3;
-    const float v_tx = -vJ02 * cam.fx * rz2, v_ty = -vJ12 * cam.fy * rz2;
-    if (p.clampx == 0) vx += v_tx; else vz += v_tx * (p.clampx > 0 ? cam.limx : -cam.limx);
-    if (p.clampy == 0) vy += v_ty; else vz += v_ty * (p.clampy > 0 ? cam.limy : -cam.limy);
-    vx += v_mx * cam.fx * rz; vy += v_my * cam.fy * rz;
-    vz += -(v_mx * cam.fx * p.x + v_my * cam.fy * p.y) * rz2 + v_depth;
-    const float* V = cam.R;
-    v_mean[0] += V[0] * vx + V[3] * vy + V[6] * vz;
-    v_mean[1] += V[1] * vx + V[4] * vy + V[7] * vz;
-    v_mean[2] += V[2] * vx + V[5] * vy + V[8] * vz;
+    const T vJ00 = T(2) * (a0 * p.cc00 + a1 * p.cc01 + a2 * p.cc02);
+    const T vJ02 = T(2) * (a0 * p.cc02 + a1 * p.cc12 + a2 * p.cc22);
+    const T vJ11 = T(2) * (b0 * p.cc01 + b1 * p.cc11 + b2 * p.cc12);
+    const T vJ12 = T(2) * (b0 * p.cc02 + b1 * p.cc12 + b2 * p.cc22);
+    const T rz = T(1) / p.z, rz2 = rz * rz, rz3 = rz2 * rz;
+    T vx = T(0), vy = T(0);
+    T vz = -vJ00 * fx * rz2 - vJ11 * fy * rz2 + T(2) * vJ02 * fx * p.tx * rz3 + T(2) * vJ12 * fy * p.ty * rz3;
+    const T v_tx = -vJ02 * fx * rz2, v_ty = -vJ12 * fy * rz2;
+    if (p.clampx == 0) vx += v_tx; else vz += v_tx * (p.clampx > 0 ? limx : -limx);
+    if (p.clampy == 0) vy += v_ty; else vz += v_ty * (p.clampy > 0 ? limy : -limy);
+    vx += v_mx * fx * rz; vy += v_my * fy * rz;
+    vz += -(v_mx * fx * p.x + v_my * fy * p.y) * rz2 + v_depth;
+    v_mean[0] += (float)(V[0] * vx + V[3] * vy + V[6] * vz);
+    v_mean[1] += (float)(V[1] * vx + V[4] * vy + V[7] * vz);
+    v_mean[2] += (float)(V[2] * vx + V[5] * vy + V[8] * vz);
     // v_cov = V^T v_covc V (symmetric): first U = v_covc V
-    const float u00 = vc00 * V[0] + vc01 * V[3] + vc02 * V[6], u01 = vc00 * V[1] + vc01 * V[4] + vc02 * V[7], u02 = vc00 * V[2] + vc01 * V[5] + vc02 * V[8];
-    const float u10 = vc01 * V[0] + vc11 * V[3] + vc12 * V[6], u11 = vc01 * V[1] + vc11 * V[4] + vc12 * V[7], u12 = vc01 * V[2] + vc11 * V[5] + vc12 * V[8];
-    const float u20 = vc02 * V[0] + vc12 * V[3] + vc22 * V[6], u21 = vc02 * V[1] + vc12 * V[4] + vc22 * V[7], u22 = vc02 * V[2] + vc12 * V[5] + vc22 * V[8];
-    const float w00 = V[0] * u00 + V[3] * u10 + V[6] * u20;
-    const float w01 = V[0] * u01 + V[3] * u11 + V[6] * u21;
-    const float w02 = V[0] * u02 + V[3] * u12 + V[6] * u22;
-    const float w11 = V[1] * u01 + V[4] * u11 + V[7] * u21;
-    const float w12 = V[1] * u02 + V[4] * u12 + V[7] * u22;
-    const float w22 = V[2] * u02 + V[5] * u12 + V[8] * u22;
+    const T u00 = vc00 * V[0] + vc01 * V[3] + vc02 * V[6], u01 = vc00 * V[1] + vc01 * V[4] + vc02 * V[7], u02 = vc00 * V[2] + vc01 * V[5] + vc02 * V[8];
+    const T u10 = vc01 * V[0] + vc11 * V[3] + vc12 * V[6], u11 = vc01 * V[1] + vc11 * V[4] + vc12 * V[7], u12 = vc01 * V[2] + vc11 * V[5] + vc12 * V[8];
+    const T u20 = vc02 * V[0] + vc12 * V[3] + vc22 * V[6], u21 = vc02 * V[1] + vc12 * V[4] + vc22 * V[7], u22 = vc02 * V[2] + vc12 * V[5] + vc22 * V[8];
+    const T w00 = V[0] * u00 + V[3] * u10 + V[6] * u20;
+    const T w01 = V[0] * u01 + V[3] * u11 + V[6] * u21;
+    const T w02 = V[0] * u02 + V[3] * u12 + V[6] * u22;
+    const T w11 = V[1] * u01 + V[4] * u11 + V[7] * u21;
+    const T w12 = V[1] * u02 + V[4] * u12 + V[7] * u22;
+    const T w22 = V[2] * u02 + V[5] * u12 + V[8] * u22;
     // v_M = 2 v_cov M
-    const float* M = p.M;
-    float vM[9];
-    vM[0] = 2.f * (w00 * M[0] + w01 * M[3] + w02 * M[6]); vM[1] = 2.f * (w00 * M[1] + w01 * M[4] + w02 * M[7]); vM[2] = 2.f * (w00 * M[2] + w01 * M[5] + w02 * M[8]);
-    vM[3] = 2.f * (w01 * M[0] + w11 * M[3] + w12 * M[6]); vM[4] = 2.f * (w01 * M[1] + w11 * M[4] + w12 * M[7]); vM[5] = 2.f * (w01 * M[2] + w11 * M[5] + w12 * M[8]);
-    vM[6] = 2.f * (w02 * M[0] + w12 * M[3] + w22 * M[6]); vM[7] = 2.f * (w02 * M[1] + w12 * M[4] + w22 * M[7]); vM[8] = 2.f * (w02 * M[2] + w12 * M[5] + w22 * M[8]);
-    const float* R = p.R;
-    v_scale[0] += vM[0] * R[0] + vM[3] * R[3] + vM[6] * R[6];
-    v_scale[1] += vM[1] * R[1] + vM[4] * R[4] + vM[7] * R[7];
-    v_scale[2] += vM[2] * R[2] + vM[5] * R[5] + vM[8] * R[8];
-    float vR[9];
-    for (int i = 0; i < 3; ++i) { vR[3 * i] = vM[3 * i] * scale[0]; vR[3 * i + 1] = vM[3 * i + 1] * scale[1]; vR[3 * i + 2] = vM[3 * i + 2] * scale[2]; }
-    const float w = p.qw, x = p.qx, y = p.qy, z = p.qz;
-    const float vq0 = 2.f * (-z * vR[1] + y * vR[2] + z * vR[3] - x * vR[5] - y * vR[6] + x * vR[7]);
-    const float vq1 = 2.f * (y * vR[1] + z * vR[2] + y * vR[3] - 2.f * x * vR[4] - w * vR[5] + z * vR[6] + w * vR[7] - 2.f * x * vR[8]);
-    const float vq2 = 2.f * (-2.f * y * vR[0] + x * vR[1] + w * vR[2] + x * vR[3] + z * vR[5] - w * vR[6] + z * vR[7] - 2.f * y * vR[8]);
-    const float vq3 = 2.f * (-2.f * z * vR[0] - w * vR[1] + x * vR[2] + w * vR[3] - 2.f * z * vR[4] + y * vR[5] + x * vR[6] + y * vR[7]);
-    const float dot = w * vq0 + x * vq1 + y * vq2 + z * vq3;
-    v_quat[0] += (vq0 - w * dot) * p.qinv; v_quat[1] += (vq1 - x * dot) * p.qinv;
-    v_quat[2] += (vq2 - y * dot) * p.qinv; v_quat[3] += (vq3 - z * dot) * p.qinv;
+    const T* M = p.M;
+    T vM[9];
+    vM[0] = T(2) * (w00 * M[0] + w01 * M[3] + w02 * M[6]); vM[1] = T(2) * (w00 * M[1] + w01 * M[4] + w02 * M[7]); vM[2] = T(2) * (w00 * M[2] + w01 * M[5] + w02 * M[8]);
+    vM[3] = T(2) * (w01 * M[0] + w11 * M[3] + w12 * M[6]); vM[4] = T(2) * (w01 * M[1] + w11 * M[4] + w12 * M[7]); vM[5] = T(2) * (w01 * M[2] + w11 * M[5] + w12 * M[8]);
+    vM[6] = T(2) * (w02 * M[0] + w12 * M[3] + w22 * M[6]); vM[7] = T(2) * (w02 * M[1] + w12 * M[4] + w22 * M[7]); vM[8] = T(2) * (w02 * M[2] + w12 * M[5] + w22 * M[8]);
+    const T* R = p.R;
+    v_scale[0] += (float)(vM[0] * R[0] + vM[3] * R[3] + vM[6] * R[6]);
+    v_scale[1] += (float)(vM[1] * R[1] + vM[4] * R[4] + vM[7] * R[7]);
+    v_scale[2] += (float)(vM[2] * R[2] + vM[5] * R[5] + vM[8] * R[8]);
+    T vR[9];
+    for (int i = 0; i < 3; ++i) { vR[3 * i] = vM[3 * i] * (T)scale[0]; vR[3 * i + 1] = vM[3 * i + 1] * (T)scale[1]; vR[3 * i + 2] = vM[3 * i + 2] * (T)scale[2]; }
+    const T w = p.qw, x = p.qx, y = p.qy, z = p.qz;
+    const T vq0 = T(2) * (-z * vR[1] + y * vR[2] + z * vR[3] - x * vR[5] - y * vR[6] + x * vR[7]);
+    const T vq1 = T(2) * (y * vR[1] + z * vR[2] + y * vR[3] - T(2) * x * vR[4] - w * vR[5] + z * vR[6] + w * vR[7] - T(2) * x * vR[8]);
+    const T vq2 = T(2) * (-T(2) * y * vR[0] + x * vR[1] + w * vR[2] + x * vR[3] + z * vR[5] - w * vR[6] + z * vR[7] - T(2) * y * vR[8]);
+    const T vq3 = T(2) * (-T(2) * z * vR[0] - w * vR[1] + x * vR[2] + w * vR[3] - T(2) * z * vR[4] + y * vR[5] + x * vR[6] + y * vR[7]);
+    const T dot = w * vq0 + x * vq1 + y * vq2 + z * vq3;
+    v_quat[0] += (float)((vq0 - w * dot) * p.qinv); v_quat[1] += (float)((vq1 - x * dot) * p.qinv);
+    v_quat[2] += (float)((vq2 - y * dot) * p.qinv); v_quat[3] += (float)((vq3 - z * dot) * p.qinv);
 }
 
 // Camera constants from raw viewmat[16] / K[9] (row-major), incl. the general 3x3 inverse for the

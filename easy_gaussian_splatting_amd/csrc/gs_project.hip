@@ -165,19 +165,19 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
     bool vis = false;
     if (STAGE != 2) {
         Splat2D s;
-        s.radius = 0; s.mx = s.my = s.depth = s.A = s.B = s.C = s.cxx = s.cyy = 0.f;
+        s.radius = 0; s.mx = s.my = s.depth = s.A = s.B = s.C = s.cxx = s.cyy = 0.f; s.x0 = s.x1 = s.y0 = s.y1 = 0;
         if (in_range) {
             const float4 q4 = reinterpret_cast<const float4*>(a.quats)[n];
             const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
             const float scale[3] = {act_scale(a.scales[3 * n], a.activations), act_scale(a.scales[3 * n + 1], a.activations),
                                     act_scale(a.scales[3 * n + 2], a.activations)};
-            s = project_gaussian(mean, quat, scale, cam, a.W, a.H, a.eps2d, a.near_p, a.far_p, a.radius_clip);
+            s = project_gaussian(mean, quat, scale, cam, a.W, a.H, a.eps2d, a.near_p, a.far_p, a.radius_clip, GS_TILE, a.tw, a.th);
         }
         vis = s.radius > 0;
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
         float op = 0.f, ex = -1.f, ey = -1.f;
         if (vis) {
-            tile_rect(s.mx, s.my, s.radius, GS_TILE, a.tw, a.th, x0, x1, y0, y1);
+            x0 = s.x0; x1 = s.x1; y0 = s.y0; y1 = s.y1;   // from the unrounded centre (gs_math.h: preal)
             op = act_opacity(a.opacities[n], a.activations);
             alpha_extent(op, s.cxx, s.cyy, ex, ey);
             // tight mode: keep only the tiles of the 3-sigma rectangle that hold a pixel centre where
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
                                 act_scale(a.scales[3 * n + 2], a.activations)};
         if (a.activations) { sc_fac[0] = scale[0]; sc_fac[1] = scale[1]; sc_fac[2] = scale[2]; }
         ProjChain p;
-        if (project_chain(mean, quat, scale, cam, a.eps2d, a.near_p, a.far_p, p))
-            project_vjp(scale, cam, p, s.v[0], s.v[1], s.v[4], s.v[5], s.v[6], 0.f, v_mean, v_quat, v_scale);
+        if (project_chain<preal>(mean, quat, scale, cam, a.eps2d, a.near_p, a.far_p, p))
+            project_vjp<preal>(scale, cam, p, s.v[0], s.v[1], s.v[4], s.v[5], s.v[6], 0.f, v_mean, v_quat, v_scale);
     }
     if (in_range) {
         if (a.activations && vis) { const float o = act_opacity(a.opacities[n], 1); op_fac = o * (1.f - o); }

@@ -18,7 +18,7 @@ int hm_forward(int C, int N, int K, int degree, const float* means, const float*
         for (int n = 0; n < N; ++n) {
             const long f = (long)c * N + n;
             gs::Splat2D s = gs::project_gaussian(means + 3 * n, quats + 4 * n, scales + 3 * n, cam, W, H,
-                                                 eps2d, near_p, far_p, radius_clip);
+                                                 eps2d, near_p, far_p, radius_clip, tile, tw, th);
             radii[f] = s.radius; means2d[2 * f] = s.mx; means2d[2 * f + 1] = s.my; depths[f] = s.depth;
             conics[3 * f] = s.A; conics[3 * f + 1] = s.B; conics[3 * f + 2] = s.C;
             float rgb[3] = {0.5f, 0.5f, 0.5f};
@@ -27,9 +27,7 @@ int hm_forward(int C, int N, int K, int degree, const float* means, const float*
                 float ux, uy, uz;
                 gs::view_dir(means + 3 * n, cam, ux, uy, uz);
                 gs::sh_to_rgb(degree, shs + (long)n * K * 3, ux, uy, uz, rgb);
-                int x0, x1, y0, y1;
-                gs::tile_rect(s.mx, s.my, s.radius, tile, tw, th, x0, x1, y0, y1);
-                cnt = (x1 - x0) * (y1 - y0);
+                cnt = (s.x1 - s.x0) * (s.y1 - s.y0);
             }
             colors[3 * f] = rgb[0]; colors[3 * f + 1] = rgb[1]; colors[3 * f + 2] = rgb[2];
             tiles_per_gauss[f] = cnt;
@@ -54,12 +52,12 @@ int hm_backward(int C, int N, int K, int degree, const float* means, const float
             const long f = (long)c * N + n;
             if (radii[f] <= 0) continue;
             gs::ProjChain p;
-            if (!gs::project_chain(means + 3 * n, quats + 4 * n, scales + 3 * n, cam, eps2d, near_p, far_p, p)) continue;
+            if (!gs::project_chain<gs::preal>(means + 3 * n, quats + 4 * n, scales + 3 * n, cam, eps2d, near_p, far_p, p)) continue;
             float ux, uy, uz;
             const float dn = gs::view_dir(means + 3 * n, cam, ux, uy, uz);
             gs::sh_vjp(degree, shs + (long)n * K * 3, colors + 3 * f, v_colors + 3 * f, ux, uy, uz, dn,
                        v_shs + (long)n * K * 3, v_means + 3 * n, true);
-            gs::project_vjp(scales + 3 * n, cam, p, v_means2d[2 * f], v_means2d[2 * f + 1], v_conics[3 * f],
+            gs::project_vjp<gs::preal>(scales + 3 * n, cam, p, v_means2d[2 * f], v_means2d[2 * f + 1], v_conics[3 * f],
                             v_conics[3 * f + 1], v_conics[3 * f + 2], 0.f, v_means + 3 * n, v_quats + 4 * n,
                             v_scales + 3 * n);
         }
@@ -76,7 +74,7 @@ extern "C" int hm_extents(int n, const float* opac, const float* cxx, const floa
     for (int i = 0; i < n; ++i) {
         gs::alpha_extent(opac[i], cxx[i], cyy[i], ex[i], ey[i]);
         int x0, x1, y0, y1;
-        gs::tile_rect(mx[i], my[i], radius[i], tile, tw, th, x0, x1, y0, y1);
+        gs::tile_rect<float>(mx[i], my[i], radius[i], tile, tw, th, x0, x1, y0, y1);
         rect_gsplat[4 * i] = x0; rect_gsplat[4 * i + 1] = x1; rect_gsplat[4 * i + 2] = y0; rect_gsplat[4 * i + 3] = y1;
         gs::tile_rect_tight(mx[i], my[i], ex[i], ey[i], W, H, tile, x0, x1, y0, y1);
         rect_tight[4 * i] = x0; rect_tight[4 * i + 1] = x1; rect_tight[4 * i + 2] = y0; rect_tight[4 * i + 3] = y1;

@@ -1,34 +1,67 @@
-import sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+#!/usr/bin/env python3
+"""Reproduce one configuration of tests/test_gpu_parity.py::test_randomised_configurations outside pytest and print where
+the HIP path and the oracle (fp64 and fp32 builds) disagree most: tools/debug_case.py <case> [attempt]."""
+import os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
-from scenes import make_scene
 from oracle import c_oracle as CO
 from easy_gaussian_splatting_amd.rendering import rasterization
+import test_gpu_parity as TP
+
 case = int(sys.argv[1]) if len(sys.argv) > 1 else 7
-rng = np.random.default_rng(1000 + case)
-deg = int(rng.integers(0, 4)); K = int(rng.choice([(deg + 1) ** 2, 16])); C = int(rng.integers(1, 4)); n = int(rng.integers(1, 3000))
-W, H = int(rng.integers(17, 260)), int(rng.integers(17, 200)); smax = float(rng.choice([0.05, 0.2, 0.8]))
-sc = make_scene(n, W, H, sh_degree=deg, seed=2000 + case, k_store=K, n_views=C, scale_range=(0.01, smax), dist=float(rng.uniform(2.5, 6.0)), white_bg=bool(rng.integers(0, 2)))
-use_bg, split, culling = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)) and K > 1, str(rng.choice(["tight", "gsplat"]))
-print(dict(deg=deg, K=K, C=C, n=n, W=W, H=H, smax=smax, use_bg=use_bg, split=split, culling=culling))
+attempt = int(sys.argv[2]) if len(sys.argv) > 2 else None
 dev = torch.device("cuda:0")
-t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
+if attempt is None:   # the scene seed the test settles on: the first whose razor fraction is within bounds
+    for attempt in range(8):
+        sc, (deg, W, H, use_bg, split, culling) = TP.fuzz_case(case, attempt)
+        t = TP.to_dev(sc)
+        _, _, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"], t["Ks"], W, H, sh_degree=deg,
+                                   packed=False, _tile_culling=culling)
+        fw = TP.run_oracle(sc, use_bg=use_bg)
+        if (CO.blend_margin(fw, meta["means2d"].cpu().numpy(), meta["conics"].cpu().numpy()) < 1e-4).mean() <= TP.MAX_RAZOR_FRAC:
+            break
+    print("attempt", attempt)
+sc, (deg, W, H, use_bg, split, culling) = TP.fuzz_case(case, attempt)
+n, C = sc["means"].shape[0], sc["viewmats"].shape[0]
+print(dict(deg=deg, C=C, n=n, W=W, H=H, use_bg=use_bg, split=split, culling=culling))
+t = TP.to_dev(sc)
 base = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
 dbg = {}
-img, alpha, meta = rasterization(*base, t["viewmats"], t["Ks"], W, H, sh_degree=deg, packed=False, backgrounds=t["backgrounds"] if use_bg else None, absgrad=True, _tile_culling=culling, _debug=dbg)
+img, alpha, meta = rasterization(*base, t["viewmats"], t["Ks"], W, H, sh_degree=deg, packed=False,
+                                 backgrounds=t["backgrounds"] if use_bg else None, absgrad=True, _tile_culling=culling, _debug=dbg)
+fw = TP.run_oracle(sc, use_bg=use_bg)
+m2 = meta["means2d"].cpu().numpy()
+e = np.abs(m2 - fw["means2d"]).max(-1); c, i = np.unravel_index(e.argmax(), e.shape)
+print(f"means2d: worst abs err {e.max():.3e} at cam {c} gaussian {i}: hip {m2[c, i]} oracle {fw['means2d'][c, i]} depth {fw['depths'][c, i]} radius {fw['radii'][c, i]}")
+try:
+    rep = TP.forward_report(meta, fw, lists=culling == "gsplat")
+except AssertionError as ex:
+    print("forward_report:", str(ex).splitlines()[0]); sys.exit(0)
+print("razor", rep["razor"].mean(), "loose", rep["loose"].mean(), "exact lists", rep["exact_lists"])
 g = torch.Generator().manual_seed(case)
-vc, va = torch.randn(img.shape, generator=g), torch.randn(alpha.shape, generator=g)
+keep = torch.from_numpy(~rep["loose"])[..., None]
+vc, va = torch.randn(img.shape, generator=g) * keep, torch.randn(alpha.shape, generator=g) * keep
 grads = torch.autograd.grad((img * vc.to(dev)).sum() + (alpha * va.to(dev)).sum(), base)
+names = ["v_means", "v_quats", "v_scales", "v_opacities", "v_colors"]
 for dt in (np.float64, np.float32):
-    fw = CO.render(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["shs"], sc["viewmats"], sc["Ks"], W, H, sh_degree=deg, backgrounds=sc["backgrounds"] if use_bg else None, dtype=dt)
-    bw = CO.backward(fw, vc.numpy().astype(dt), va.numpy().astype(dt))
-    print("oracle", dt.__name__, "I", fw["n_isects"])
-    for nm, gg in zip(["v_means", "v_quats", "v_scales", "v_opacities", "v_colors"], grads):
-        e = np.abs(gg.cpu().numpy() - bw[nm]); i = np.unravel_index(e.argmax(), e.shape)
-        print("  ", nm, "rel", e.max() / np.abs(bw[nm]).max(), "at", i, "hip", gg.cpu().numpy()[i], "ref", bw[nm][i], "max", np.abs(bw[nm]).max())
-    for nm, key in (("v_means2d", "v_means2d"), ("v_conics", "v_conics"), ("v_colors_post", "v_colors_post")):
-        e = np.abs(dbg[nm].cpu().numpy() - bw[key]); i = np.unravel_index(e.argmax(), e.shape)
-        print("  [2D]", nm, "rel", e.max() / np.abs(bw[key]).max(), "at", i, dbg[nm].cpu().numpy()[i], bw[key][i])
+    f = fw if dt == np.float64 else TP.run_oracle(sc, use_bg=use_bg, dtype=np.float32)
+    bw = CO.backward(f, vc.numpy().astype(dt), va.numpy().astype(dt))
+    print("oracle", dt.__name__, "I", f["n_isects"])
+    for nm, gg in zip(names, grads):
+        er = np.abs(gg.cpu().numpy() - bw[nm]); idx = np.unravel_index(er.argmax(), er.shape)
+        print(f"   {nm}: rel {er.max() / np.abs(bw[nm]).max():.3e} at {idx} hip {gg.cpu().numpy()[idx]:.6e} ref {bw[nm][idx]:.6e} max {np.abs(bw[nm]).max():.3e}")
+    for nm in ("v_means2d", "v_conics", "v_colors_post"):
+        er = np.abs(dbg[nm].cpu().numpy() - bw[nm]); idx = np.unravel_index(er.argmax(), er.shape)
+        print(f"   [2D] {nm}: rel {er.max() / np.abs(bw[nm]).max():.3e} at {idx} hip {dbg[nm].cpu().numpy()[idx]:.6e} ref {bw[nm][idx]:.6e}")
     if dt == np.float64:
-        gi = int(np.unravel_index(np.abs(grads[0].cpu().numpy() - bw["v_means"]).argmax(), (n, 3))[0])
-        print("   worst gaussian", gi, "scales", sc["scales"][gi], "mean", sc["means"][gi], "radii", fw["radii"][:, gi], "depth", fw["depths"][:, gi], "means2d", fw["means2d"][:, gi], "conic", fw["conics"][:, gi], "opac", sc["opacities"][gi])
+        bw64 = bw
+for nm, gg in zip(names[:3], grads[:3]):
+    er = np.abs(gg.cpu().numpy() - bw64[nm]).reshape(n, -1).max(-1); gi = int(er.argmax())
+    print(f"worst gaussian for {nm}: {gi} scales {sc['scales'][gi]} quat {sc['quats'][gi]} opac {sc['opacities'][gi]:.4f} radii {fw['radii'][:, gi]} "
+          f"depth {fw['depths'][:, gi]} means2d {fw['means2d'][:, gi].tolist()} conic {fw['conics'][:, gi].tolist()}")
+gi = int(np.abs(grads[2].cpu().numpy() - bw64["v_scales"]).max(-1).argmax())
+for c in range(C):
+    for nm in ("v_conics", "v_means2d"):
+        h, r = dbg[nm].cpu().numpy()[c, gi], bw64[nm][c, gi]
+        print(f"gaussian {gi} cam {c} {nm}: hip {h} ref {r} rel-to-own {np.abs(h - r).max() / (np.abs(r).max() + 1e-30):.2e} tiles {fw['tiles_per_gauss'][c, gi]}")
