@@ -136,7 +136,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
     int n_tiles_total, int n_groups_total, const uint32_t* __restrict__ tile_cnt,
     const uint32_t* __restrict__ grp_tot, int32_t* __restrict__ isect_offsets,
     int32_t* __restrict__ bucket_offsets, uint32_t* __restrict__ grp_base,
-    int64_t* __restrict__ info, int32_t* __restrict__ tile_order, int64_t cap_isects, int64_t cap_tile) {
+    int64_t* __restrict__ info, int32_t* __restrict__ tile_order, int64_t cap_isects, int64_t cap_tile,
+    int64_t keep_mask) {
     __shared__ unsigned long long scratch[17];
     unsigned long long carry_i = 0, carry_b = 0;
     uint32_t max_cnt = 0;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
             const int64_t f = ((int64_t)carry_i > cap_isects ? 1 : 0) | ((int64_t)mm > cap_tile ? 2 : 0);
             if (f) info[3] |= f;
         } else {
-            info[3] = 0;
+            info[3] = keep_mask ? (info[3] & keep_mask) : 0;   // (two-level binning: the coarse stage's overflow bit survives)
         }
     }
     __syncthreads();
@@ -199,32 +200,35 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
         if (n_tiles_total > chunk) {
             for (int i = threadIdx.x; i < n_tiles_total; i += kBinThreads) tile_order[i] = i;
         } else {
-            __shared__ uint32_t cls_cnt[64], cls_base[64];
+            // per-wave counters: 16 x fewer lanes contend for one LDS word than with a single set of 64
+            constexpr int kW = kBinThreads / 64;
+            __shared__ uint32_t cls_cnt[64][kW + 1];   // [class][wave] (+1: stride 17, no bank aliasing down a class)
             auto cls_of = [](uint32_t x) -> int {   // 4 * floor(log2 x) + the next two bits, 0 for x < 2
                 if (x < 2u) return 0;
                 const int lg = 31 - __clz((int)x);
                 return min(63, (lg << 2) | (int)((x << (31 - lg)) >> 29 & 3u));
             };
-            if (threadIdx.x < 64) cls_cnt[threadIdx.x] = 0u;
+            const int wv = threadIdx.x >> 6;
+            for (int i = threadIdx.x; i < 64 * (kW + 1); i += kBinThreads) (&cls_cnt[0][0])[i] = 0u;
             __syncthreads();
             const int first = threadIdx.x * kScanItems;
 #pragma unroll
             for (int k = 0; k < kScanItems; ++k)
-                if (first + k < n_tiles_total) atomicAdd(&cls_cnt[cls_of(v[k])], 1u);
+                if (first + k < n_tiles_total) atomicAdd(&cls_cnt[cls_of(v[k])][wv], 1u);
             __syncthreads();
-            if (threadIdx.x < 64) {   // descending classes: lane l owns class 63 - l
+            if (threadIdx.x < 64) {   // descending classes: lane l owns class 63 - l; waves in order inside a class
                 const int c = 63 - (int)threadIdx.x;
-                const uint32_t n = cls_cnt[c];
-                cls_base[c] = wave_incl_scan_add(n) - n;
-                cls_cnt[c] = 0u;
+                uint32_t n = 0, cw[kW];
+#pragma unroll
+                for (int w = 0; w < kW; ++w) { cw[w] = cls_cnt[c][w]; n += cw[w]; }
+                uint32_t run = wave_incl_scan_add(n) - n;
+#pragma unroll
+                for (int w = 0; w < kW; ++w) { cls_cnt[c][w] = run; run += cw[w]; }
             }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < kScanItems; ++k)
-                if (first + k < n_tiles_total) {
-                    const int c = cls_of(v[k]);
-                    tile_order[cls_base[c] + atomicAdd(&cls_cnt[c], 1u)] = first + k;
-                }
+                if (first + k < n_tiles_total) tile_order[atomicAdd(&cls_cnt[cls_of(v[k])][wv], 1u)] = first + k;
         }
     }
     // group bases (few thousand values at most): serial chunks of kBinThreads
@@ -354,6 +358,7 @@ struct SortArgs {
     int32_t* flatten_ids;
     int32_t* slots;
     const int64_t* guard;
+    int coarse;   // two-level binning: the lists are coarse-bin lists of (depth bits << 32 | flatten id) keys, sorted in place
 };
 
 template <bool IN_LDS>
@@ -373,6 +378,10 @@ __global__ void tile_sort_kernel(const SortArgs a) {
         bitonic_sort_keys(skeys, n, P);
     } else {
         bitonic_sort_keys(gk, n, P);
+    }
+    if (a.coarse) {
+        if (IN_LDS) for (int i = threadIdx.x; i < n; i += blockDim.x) gk[i] = skeys[i];
+        return;
     }
     const int cam = t / a.tiles, tid = t - cam * a.tiles;
     const long long hi_bits = ((long long)cam << (32 + a.tile_bits)) | ((long long)tid << 32);
@@ -498,6 +507,11 @@ __global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
         while (P < n) P <<= 1;
         bitonic_sort_keys(src, n, P);
     }
+    if (a.coarse) {
+        unsigned long long* out = a.keys + lo;
+        for (int i = tid; i < n; i += T) out[i] = src[i];
+        return;
+    }
     const int cam = tile / a.tiles, tix = tile - cam * a.tiles;
     const long long hi_bits = ((long long)cam << (32 + a.tile_bits)) | ((long long)tix << 32);
     for (int i = tid; i < n; i += T) {
@@ -507,6 +521,429 @@ __global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
         a.flatten_ids[lo + i] = a.slot_gid[slot];
         a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
     }
+}
+
+
+// ================================================================================================
+// Two-level binning (gs_bins_count / gs_bins_lists).  The per-tile pipeline above sorts every one of the I list
+// entries (3-4 LDS passes each); with footprints of tens to hundreds of tiles (real captures) that is most of the
+// forward.  Here only the COARSE lists are sorted: a bin is 4x4 (or 2x2) tiles, a Gaussian enters every bin its
+// rectangle touches (I' entries, 1.4-17 per Gaussian instead of 3-190), each bin's list is depth-sorted by the same
+// LDS radix kernels on (depth bits << 32 | flatten id) keys, and every tile then takes its own list out of its bin's
+// sorted list by an ORDERED compaction (ballot + popcount: no atomics, no second sort, depth and tie order inherited):
+//   bins_hist_kernel    per (camera, Gaussian group): LDS histogram over bins
+//   bin_colscan_kernel  (shared)  per bin: exclusive scan down the group axis
+//   bins_scan_kernel    one block: bin offsets, group bases, {I', longest bin list}, coarse overflow flag
+//   bins_emit_kernel    per group: LDS cursors -> keys into the bin segments; cum_tiles (gradient-row slot bases)
+//   tile_radix_sort_kernel / tile_sort_kernel (shared, coarse mode): bins sorted in place
+//   bins_refine_kernel<false>  one block per bin, one wave per tile: per-tile counts
+//   bin_tilescan_kernel (shared)  isect_offsets, bucket_offsets, tile_order, {I, n_buckets, max list}
+//   bins_refine_kernel<true>   the same walk, writing flatten_ids / isect_ids / slots at the scanned offsets
+struct BinsLayout {
+    int groups, shift, bw, bh, nbins;
+    int64_t per_group;
+    size_t hist_off;      // u32 [C*groups][nbins]
+    size_t bin_cnt_off;   // u32 [C*nbins]
+    size_t grp_tot_off;   // u32 [C*groups]   fine intersections of each group (for cum_tiles)
+    size_t grp_base_off;  // u32 [C*groups]
+    size_t coff_off;      // i32 [C*nbins+1]  bin offsets into the coarse key buffer
+    size_t choff_off;     // i32 [C*nbins+1]  exclusive scan of the bins' chunk counts (chunk = 64 << 2*shift entries)
+    size_t tile_cnt_off;  // u32 [C*tiles]
+    size_t chunk_bin_off; // int4 [max_chunks]  {bin, first entry, entries, -} of each chunk
+    int chunk_shift;
+    size_t rec_off;       // uint4 [C*N]  footprint with the slot base in place of the count (one gather instead of two)
+    size_t staged_off;    // uint4 [coarse_cap]  the same records in sorted bin order (written by pass 1, read by pass 2)
+    size_t cnt_ct_off;    // u32 [max_chunks][tiles per bin]  per-chunk tile counts -> exclusive prefix inside a tile
+    int64_t max_chunks;
+    size_t total;
+};
+
+static BinsLayout bins_layout(int C, int64_t N, int tw, int th, int bin_shift, int64_t coarse_cap) {
+    BinsLayout L;
+    int64_t g = (N + 4095) / 4096;
+    if (g < 1) g = 1;
+    if (g > 256) g = 256;
+    L.groups = (int)g;
+    L.per_group = (N + g - 1) / g;
+    // 4x4-tile bins unless that puts more than ~2500 Gaussians per bin on average (sort classes above 4096 entries
+    // run one block per CU): then 2x2
+    const int64_t nb2 = (int64_t)((tw + 3) / 4) * ((th + 3) / 4);
+    L.shift = bin_shift ? bin_shift : ((N / nb2 > 2500) ? 1 : 2);
+    const int B = 1 << L.shift;
+    L.bw = (tw + B - 1) / B; L.bh = (th + B - 1) / B; L.nbins = L.bw * L.bh;
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    L.hist_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * L.groups * L.nbins);
+    L.bin_cnt_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * L.nbins);
+    L.grp_tot_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * L.groups);
+    L.grp_base_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * L.groups);
+    L.coff_off = off; off = align(off + sizeof(int32_t) * ((size_t)C * L.nbins + 1));
+    L.choff_off = off; off = align(off + sizeof(int32_t) * ((size_t)C * L.nbins + 1));
+    L.tile_cnt_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * tw * th);
+    L.chunk_shift = 10 + (L.shift - 1);   // chunk = 1024 entries (2x2-tile bins) / 2048 (4x4)
+    L.max_chunks = (coarse_cap >> L.chunk_shift) + (int64_t)C * L.nbins;   // sum of ceil(n_b / chunk) can not exceed this
+    L.chunk_bin_off = off; off = align(off + sizeof(int4) * (size_t)L.max_chunks);
+    L.rec_off = off; off = align(off + sizeof(uint4) * (size_t)C * (size_t)N);
+    L.staged_off = off; off = align(off + sizeof(uint4) * (size_t)coarse_cap);
+    L.cnt_ct_off = off; off = align(off + sizeof(uint32_t) * (size_t)L.max_chunks * B * B);
+    L.total = off;
+    return L;
+}
+
+// bins touched by a footprint (tile rectangle, possibly with a tile mask: the rectangle is what counts here -- a bin
+// none of whose tiles is in the mask just yields no entry in the refinement)
+__device__ __forceinline__ void coarse_rect(uint4 fp, int shift, int& cx0, int& cw, int& cy0, int& crect) {
+    int x0, x1, y0, y1;
+    unpack_bbox(fp, x0, x1, y0, y1);
+    if (fp.w == 0u) { cx0 = cy0 = cw = crect = 0; return; }
+    const int r = (1 << shift) - 1;
+    cx0 = x0 >> shift; cy0 = y0 >> shift;
+    cw = ((x1 + r) >> shift) - cx0;
+    crect = cw * (((y1 + r) >> shift) - cy0);
+}
+
+__global__ __launch_bounds__(kBinThreads) void bins_hist_kernel(int64_t N, int shift, int bw, int nbins, int64_t per_group,
+                                                                const uint4* __restrict__ bbox,
+                                                                uint32_t* __restrict__ hist_mat,
+                                                                uint32_t* __restrict__ grp_tot) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* hist = lds;               // [nbins]
+    uint32_t* scratch = lds + nbins;    // [32]
+    const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
+    for (int t = threadIdx.x; t < nbins; t += blockDim.x) hist[t] = 0;
+    __syncthreads();
+    const int64_t g0 = grp * per_group, g1 = min(N, g0 + per_group);
+    uint32_t local = 0;
+    for (int64_t base = g0; base < g1; base += blockDim.x) {
+        const int64_t n = base + threadIdx.x;
+        uint4 fp = make_uint4(0u, 0u, 0u, 0u);
+        if (n < g1) fp = bbox[(int64_t)c * N + n];
+        int cx0, cw, cy0, crect;
+        coarse_rect(fp, shift, cx0, cw, cy0, crect);
+        local += fp.w;
+        if (crect <= kCoopTiles)
+            for (int i = 0, xx = 0, row = cy0 * bw + cx0; i < crect; ++i) {
+                atomicAdd(&hist[row + xx], 1u);
+                if (++xx == cw) { xx = 0; row += bw; }
+            }
+        unsigned long long big = __ballot(crect > kCoopTiles);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const int bx0 = __shfl(cx0, src, 64), by0 = __shfl(cy0, src, 64), bcw = __shfl(cw, src, 64), bcnt = __shfl(crect, src, 64);
+            for (int i = lane_id(); i < bcnt; i += 64) {
+                const int yy = i / bcw;
+                atomicAdd(&hist[(by0 + yy) * bw + bx0 + (i - yy * bcw)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* out = hist_mat + ((size_t)c * G + grp) * nbins;
+    for (int t = threadIdx.x; t < nbins; t += blockDim.x) out[t] = hist[t];
+    uint32_t wsum = wave_reduce_add(local);
+    if (lane_id() == 0) scratch[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += scratch[i];
+        grp_tot[c * G + grp] = s;
+    }
+}
+
+// per (camera, bin): exclusive scan over the groups, one wave per bin (G <= 256: four strided elements per lane)
+__global__ __launch_bounds__(256) void bins_colscan_kernel(int C, int G, int nbins, uint32_t* __restrict__ hist_mat,
+                                                          uint32_t* __restrict__ bin_cnt) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= (int64_t)C * nbins) return;
+    const int c = (int)(i / nbins), t = (int)(i % nbins), lane = lane_id();
+    uint32_t* col = hist_mat + (size_t)c * G * nbins + t;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int g = 64 * k + lane; v[k] = g < G ? col[(size_t)g * nbins] : 0u; }
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t incl = wave_incl_scan_add(v[k]);
+        const int g = 64 * k + lane;
+        if (g < G) col[(size_t)g * nbins] = carry + incl - v[k];
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) bin_cnt[i] = carry;
+}
+
+// one block: bin offsets (exclusive scan of the bin totals), group bases, info[4] = I', info[5] = longest bin list,
+// coarse overflow -> flags bit 4 (sticky under a step guard, fresh otherwise)
+__global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total, int n_groups_total,
+                                                                const uint32_t* __restrict__ bin_cnt,
+                                                                const uint32_t* __restrict__ grp_tot,
+                                                                int32_t* __restrict__ coff, int32_t* __restrict__ choff,
+                                                                int4* __restrict__ chunk_desc, int64_t max_chunks,
+                                                                int chunk_shift, uint32_t* __restrict__ grp_base,
+                                                                int64_t* __restrict__ info, int64_t coarse_cap, int64_t list_cap,
+                                                                int guarded) {
+    __shared__ unsigned long long scratch[17];
+    __shared__ uint32_t smax[16];
+    unsigned long long carry = 0, ccarry = 0;
+    uint32_t max_cnt = 0;
+    const int chunk = kBinThreads * kScanItems;
+    for (int base = 0; base < n_bins_total; base += chunk) {
+        const int first = base + threadIdx.x * kScanItems;
+        uint32_t v[kScanItems];
+        unsigned long long si = 0, sc = 0;
+        const uint32_t cmask = (1u << chunk_shift) - 1u;
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            v[k] = (first + k < n_bins_total) ? bin_cnt[first + k] : 0u;
+            si += v[k];
+            sc += (v[k] + cmask) >> chunk_shift;
+            max_cnt = max(max_cnt, v[k]);
+        }
+        // entries (< 2^31) in the low word, chunks in the high word of one 64-bit scan
+        unsigned long long total;
+        const unsigned long long ex = block_excl_scan_add(si | (sc << 36), scratch, &total);
+        unsigned long long run = carry + (ex & ((1ull << 36) - 1)), crun = ccarry + (ex >> 36);
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            const uint32_t nch = (v[k] + cmask) >> chunk_shift;
+            if (first + k < n_bins_total) {
+                coff[first + k] = (int32_t)min(run, (unsigned long long)0x7fffffff);
+                choff[first + k] = (int32_t)crun;
+                for (uint32_t j = 0; j < nch; ++j)   // (bounded by the buffer even when the coarse capacity is exceeded)
+                    if ((int64_t)(crun + j) < max_chunks)
+                        chunk_desc[crun + j] = make_int4(first + k, (int)(run + ((unsigned long long)j << chunk_shift)),
+                                                         (int)min(v[k] - (j << chunk_shift), 1u << chunk_shift), 0);
+            }
+            run += v[k];
+            crun += nch;
+        }
+        carry += total & ((1ull << 36) - 1);
+        ccarry += total >> 36;
+    }
+    uint32_t m = max_cnt;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+    if (lane_id() == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t mm = 0;
+        for (int i = 0; i < kBinThreads / 64; ++i) mm = max(mm, smax[i]);
+        coff[n_bins_total] = (int32_t)min(carry, (unsigned long long)0x7fffffff);
+        choff[n_bins_total] = (int32_t)ccarry;
+        info[4] = (int64_t)carry; info[5] = (int64_t)mm; info[6] = (int64_t)ccarry;
+        const int64_t f = ((int64_t)carry > coarse_cap ? 4 : 0) | ((int64_t)mm > list_cap ? 8 : 0);
+        if (guarded) { if (f) info[3] |= f; }
+        else info[3] = f;
+    }
+    unsigned long long gcarry = 0;
+    for (int base = 0; base < n_groups_total; base += kBinThreads) {
+        const int i = base + threadIdx.x;
+        unsigned long long v = i < n_groups_total ? grp_tot[i] : 0ull, total;
+        unsigned long long ex = block_excl_scan_add(v, scratch, &total);
+        if (i < n_groups_total) grp_base[i] = (uint32_t)(gcarry + ex);
+        gcarry += total;
+    }
+}
+
+__global__ __launch_bounds__(kBinThreads) void bins_emit_kernel(
+    int64_t N, int shift, int bw, int nbins, int64_t per_group, const uint4* __restrict__ bbox,
+    const float* __restrict__ depths, const uint32_t* __restrict__ hist_mat, const int32_t* __restrict__ coff,
+    const uint32_t* __restrict__ grp_base, unsigned long long* __restrict__ keys, int32_t* __restrict__ cum_tiles,
+    uint4* __restrict__ rec, const int64_t* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (info[3] != 0) return;
+    uint32_t* cursor = lds;             // [nbins]
+    uint32_t* scratch = lds + nbins;    // [32]
+    const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
+    const uint32_t* mine = hist_mat + ((size_t)c * G + grp) * nbins;
+    const int32_t* boff = coff + (size_t)c * nbins;
+    for (int t0 = 0; t0 < nbins; t0 += 8 * (int)blockDim.x) {   // loads batched ahead of the LDS stores
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * (int)blockDim.x + (int)threadIdx.x;
+            v[k] = t < nbins ? mine[t] + (uint32_t)boff[t] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + k * (int)blockDim.x + (int)threadIdx.x;
+            if (t < nbins) cursor[t] = v[k];
+        }
+    }
+    __syncthreads();
+    uint32_t running = grp_base[c * G + grp];
+    const int64_t g0 = grp * per_group, g1 = min(N, g0 + per_group);
+    uint4 fp_next = make_uint4(0u, 0u, 0u, 0u);
+    float d_next = 0.f;
+    if (g0 + threadIdx.x < g1) { fp_next = bbox[(int64_t)c * N + g0 + threadIdx.x]; d_next = depths[(int64_t)c * N + g0 + threadIdx.x]; }
+    for (int64_t base = g0; base < g1; base += blockDim.x) {
+        const int64_t n = base + threadIdx.x;
+        const int64_t f = (int64_t)c * N + n;
+        const uint4 fp = fp_next;
+        const float dcur = d_next;
+        int cx0, cw, cy0, crect;
+        coarse_rect(n < g1 ? fp : make_uint4(0u, 0u, 0u, 0u), shift, cx0, cw, cy0, crect);
+        uint32_t total;
+        const uint32_t slot0 = running + block_excl_scan_add(n < g1 ? fp.w : 0u, scratch, &total);
+        running += total;
+        fp_next = make_uint4(0u, 0u, 0u, 0u);
+        if (n + blockDim.x < g1) { fp_next = bbox[f + blockDim.x]; d_next = depths[f + blockDim.x]; }
+        if (n < g1) {
+            cum_tiles[f] = (int32_t)slot0;
+            rec[f] = make_uint4(fp.x, fp.y, fp.z, slot0);
+        }
+        const unsigned long long key = ((unsigned long long)__float_as_uint(dcur) << 32) | (unsigned long long)(uint32_t)f;
+        if (crect <= kCoopTiles)
+            for (int i = 0, xx = 0, row = cy0 * bw + cx0; i < crect; ++i) {
+                keys[atomicAdd(&cursor[row + xx], 1u)] = key;
+                if (++xx == cw) { xx = 0; row += bw; }
+            }
+        unsigned long long big = __ballot(crect > kCoopTiles);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const int bx0 = __shfl(cx0, src, 64), by0 = __shfl(cy0, src, 64), bcw = __shfl(cw, src, 64), bcnt = __shfl(crect, src, 64);
+            const unsigned long long bkey = __shfl(key, src, 64);
+            for (int i = lane_id(); i < bcnt; i += 64) {
+                const int yy = i / bcw;
+                keys[atomicAdd(&cursor[(by0 + yy) * bw + bx0 + (i - yy * bcw)], 1u)] = bkey;
+            }
+        }
+    }
+}
+
+struct RefineArgs {
+    int tw, th, tiles, tile_bits, bw, nbins, n_bins_total;
+    const int32_t* coff;
+    const int32_t* choff;
+    const int4* chunk_desc;
+    const unsigned long long* keys;   // sorted bin lists
+    const uint4* rec;                 // [C*N] footprint + slot base
+    uint4* staged;                    // [I'] the same in sorted bin order
+    uint32_t* cnt_ct;                 // [chunk][tiles per bin]
+    uint32_t* tile_cnt;
+    const int32_t* isect_offsets;
+    int64_t* isect_ids;
+    int32_t* flatten_ids;
+    int32_t* slots;
+    const int64_t* info;
+};
+
+// One block per CHUNK (64 << 2*SHIFT consecutive entries of one bin's sorted list), one wave per tile of the bin.  The
+// chunk is staged in LDS (key, footprint, slot base: each read from memory once); every wave walks it 64 entries per
+// step and keeps those whose footprint holds ITS tile.  Pass 1 (WRITE = false) leaves the per-(chunk, tile) counts;
+// bins_chunkscan_kernel turns them into each chunk's start inside the tile's list; pass 2 repeats the walk and writes:
+// position = tile offset + chunk start + running count + popcount of the lower lanes' hits, so the bin's (depth, flatten
+// id) order is the tile's.  The slot of an entry is the Gaussian's first gradient row + the rank of this tile inside its
+// footprint (row-major over the rectangle / the set mask bits).  Chunks are independent: no serial walk down a long bin.
+template <bool WRITE, int SHIFT>
+__global__ __launch_bounds__(64 << (2 * SHIFT)) void bins_refine_kernel(const RefineArgs a) {
+    constexpr int B = 1 << SHIFT, T = 64 * B * B, E = 1024 << (SHIFT - 1), PER = E / T;
+    __shared__ uint4 s_box[E];
+    __shared__ uint32_t s_d[WRITE ? E : 1], s_cum[WRITE ? E : 1];
+    const int chunk = blockIdx.x;
+    // (three independent loads, then the tests: a block's life is a chain of memory latencies, keep it short)
+    const int64_t flags = a.info[3];
+    const int n_chunks = a.choff[a.n_bins_total];
+    const int4 desc = a.chunk_desc[chunk];
+    if (flags != 0 || chunk >= n_chunks) return;
+    const int bin = desc.x, base = desc.y, m = desc.z;
+    const int cam = bin / a.nbins, b = bin - cam * a.nbins;
+    const int by = b / a.bw, bx = b - by * a.bw;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = bx * B + (wave & (B - 1)), ty = by * B + (wave >> SHIFT);
+    const bool tile_ok = tx < a.tw && ty < a.th;
+    const int tile = cam * a.tiles + ty * a.tw + tx;
+    int64_t out = 0;
+    if (WRITE && tile_ok) out = (int64_t)a.isect_offsets[tile] + (int64_t)a.cnt_ct[(size_t)chunk * (B * B) + wave];
+    // pass 1 gathers the footprint records by flatten id (the one random access of the refinement: a 128-byte line per
+    // entry) and leaves them in sorted order; pass 2 streams them
+    unsigned long long key[PER];
+    uint4 fp[PER];
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        const int e = p * T + (int)threadIdx.x;
+        key[p] = e < m ? a.keys[base + e] : 0ull;
+        if (WRITE) fp[p] = e < m ? a.staged[base + e] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (!WRITE) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const int e = p * T + (int)threadIdx.x;
+            fp[p] = e < m ? a.rec[(uint32_t)key[p]] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        const int e = p * T + (int)threadIdx.x;
+        if (e < m) {
+            if (!WRITE) a.staged[base + e] = fp[p];
+            if (WRITE) { s_cum[e] = fp[p].w; s_d[e] = (uint32_t)(key[p] >> 32); }
+            fp[p].w = (uint32_t)key[p];   // the flatten id rides in the fourth word from here on
+            s_box[e] = fp[p];
+        }
+    }
+    __syncthreads();
+    if (!tile_ok) return;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const long long hi_bits = ((long long)cam << (32 + a.tile_bits)) | ((long long)(ty * a.tw + tx) << 32);
+    uint32_t count = 0;
+    for (int j = 0; j < m; j += 64) {
+        const int e = j + lane;
+        bool hit = false;
+        int k = 0;
+        uint32_t f = 0;
+        if (e < m) {
+            const uint4 q = s_box[e];
+            int x0, x1, y0, y1;
+            unpack_bbox(q, x0, x1, y0, y1);
+            f = q.w;
+            if (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) {
+                const int w = x1 - x0, idx = (ty - y0) * w + (tx - x0);
+                if (w * (y1 - y0) <= kCoopTiles) { hit = (q.z >> idx) & 1u; k = __popc(q.z & ((1u << idx) - 1u)); }
+                else { hit = true; k = idx; }
+            }
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (WRITE) {
+            if (hit) {
+                const int64_t pos = out + __popcll(bal & lt_mask);
+                a.flatten_ids[pos] = (int32_t)f;
+                a.isect_ids[pos] = hi_bits | (long long)s_d[e];
+                a.slots[pos] = (int32_t)(s_cum[e] + (uint32_t)k);
+            }
+            out += __popcll(bal);
+        } else {
+            count += (uint32_t)__popcll(bal);
+        }
+    }
+    if (!WRITE && lane == 0) a.cnt_ct[(size_t)chunk * (B * B) + wave] = count;
+}
+
+// per tile: exclusive scan of its counts down the chunks of its bin (in place) -> tile_cnt
+template <int SHIFT>
+__global__ __launch_bounds__(256) void bins_chunkscan_kernel(const RefineArgs a, int C) {
+    constexpr int B = 1 << SHIFT;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * a.tiles) return;
+    if (a.info[3] != 0) return;
+    const int cam = i / a.tiles, t = i - cam * a.tiles;
+    const int ty = t / a.tw, tx = t - ty * a.tw;
+    const int bin = cam * a.nbins + (ty >> SHIFT) * a.bw + (tx >> SHIFT);
+    const int w = ((ty & (B - 1)) << SHIFT) | (tx & (B - 1));
+    const int c0 = a.choff[bin], c1 = a.choff[bin + 1];
+    uint32_t run = 0;
+    constexpr int kBatch = 8;   // loads batched ahead of the in-place stores (see bin_colscan_kernel)
+    for (int c = c0; c < c1; c += kBatch) {
+        uint32_t v[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) v[k] = c + k < c1 ? a.cnt_ct[(size_t)(c + k) * (B * B) + w] : 0u;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            if (c + k < c1) a.cnt_ct[(size_t)(c + k) * (B * B) + w] = run;
+            run += v[k];
+        }
+    }
+    a.tile_cnt[i] = run;
 }
 
 constexpr int kSortLarge = 16384;
@@ -535,6 +972,48 @@ static int ensure_lds(const void* fn, size_t bytes) {
             GS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
             have = bytes;
         }
+    }
+    return GS_OK;
+}
+
+// Size classes of the per-list sort, each launched only if some list needs it (max_count: the longest list, known to
+// the host -- or an upper bound / INT64_MAX when it is not; blocks whose list is outside a class return at once):
+//   radix (two key buffers + 2 x 1 KB of counters per wave):
+//     <= 1024: 256 threads, 24 KB | <= 4096: 256 thr, 72 KB | <= 8192: 768 thr, 152 KB
+//   bitonic: <= 16384: 1024 thr, 128 KB | beyond: in-place global network
+static int launch_list_sorts(hipStream_t st, SortArgs& a, unsigned grid, int64_t max_tile_count) {
+    int lo_excl = 0;
+    auto radix = [&](auto kernel, int threads, int hi) -> int {
+        if (max_tile_count > lo_excl) {
+            a.lo_excl = lo_excl; a.hi_incl = hi;
+            const size_t lds_k = 2 * sizeof(uint64_t) * (size_t)hi + 2 * sizeof(uint32_t) * 256 * (size_t)(threads / 64);
+            if (int rc = ensure_lds((const void*)kernel, lds_k)) return rc;
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_k, st, a);
+            GS_LAUNCH_CHECK("tile_radix_sort_kernel");
+        }
+        lo_excl = hi;
+        return GS_OK;
+    };
+#ifndef GS_SORT1K_THREADS
+#define GS_SORT1K_THREADS 256
+#endif
+#ifndef GS_SORT4K_THREADS
+#define GS_SORT4K_THREADS 256
+#endif
+    if (int rc = radix(tile_radix_sort_kernel<GS_SORT1K_THREADS>, GS_SORT1K_THREADS, 1024)) return rc;
+    if (int rc = radix(tile_radix_sort_kernel<GS_SORT4K_THREADS>, GS_SORT4K_THREADS, 4096)) return rc;
+    if (int rc = radix(tile_radix_sort_kernel<768>, 768, 8192)) return rc;
+    if (max_tile_count > lo_excl) {
+        a.lo_excl = lo_excl; a.hi_incl = kSortLarge;
+        const size_t lds_k = sizeof(uint64_t) * (size_t)kSortLarge;
+        if (int rc = ensure_lds((const void*)tile_sort_kernel<true>, lds_k)) return rc;
+        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(1024), lds_k, st, a);
+        GS_LAUNCH_CHECK("tile_sort_kernel<lds>");
+    }
+    if (max_tile_count > kSortLarge) {
+        a.lo_excl = kSortLarge; a.hi_incl = 0x7fffffff;
+        hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(grid), dim3(1024), 0, st, a);
+        GS_LAUNCH_CHECK("tile_sort_kernel<global>");
     }
     return GS_OK;
 }
@@ -568,7 +1047,8 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
     const Guard gd = current_guard();
     GS_REQUIRE(gd.info == nullptr || gd.info == info_dev, "the guard set by gs_guard_set must be this call's info_dev");
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(kBinThreads), 0, st, (int)ct, C * L.groups, tile_cnt,
-                       grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev, tile_order, gd.cap_isects, gd.cap_tile);
+                       grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev, tile_order, gd.cap_isects, gd.cap_tile,
+                       (int64_t)0);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
     if (info_host) {
         GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -609,40 +1089,134 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     a.isect_offsets = isect_offsets; a.keys = (unsigned long long*)keys_tmp; a.slot_gid = slot_gid;
     a.isect_ids = isect_ids; a.flatten_ids = flatten_ids; a.slots = slots;
     a.guard = current_guard().info;
-    const unsigned grid = (unsigned)(C * tiles);
-    // size classes, each launched only if some tile needs it (the host knows max_tile_count):
-    //   radix (two key buffers + 2 x 1 KB of counters per wave):
-    //     <= 1024: 256 threads, 24 KB | <= 4096: 256 thr, 72 KB | <= 8192: 768 thr, 152 KB
-    //   bitonic: <= 16384: 1024 thr, 128 KB | beyond: in-place global network
-    int lo_excl = 0;
-    auto radix = [&](auto kernel, int threads, int hi) -> int {
-        if (max_tile_count > lo_excl) {
-            a.lo_excl = lo_excl; a.hi_incl = hi;
-            const size_t lds_k = 2 * sizeof(uint64_t) * (size_t)hi + 2 * sizeof(uint32_t) * 256 * (size_t)(threads / 64);
-            if (int rc = ensure_lds((const void*)kernel, lds_k)) return rc;
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_k, st, a);
-            GS_LAUNCH_CHECK("tile_radix_sort_kernel");
-        }
-        lo_excl = hi;
-        return GS_OK;
-    };
-#ifndef GS_SORT1K_THREADS
-#define GS_SORT1K_THREADS 256
-#endif
-    if (int rc = radix(tile_radix_sort_kernel<GS_SORT1K_THREADS>, GS_SORT1K_THREADS, 1024)) return rc;
-    if (int rc = radix(tile_radix_sort_kernel<256>, 256, 4096)) return rc;
-    if (int rc = radix(tile_radix_sort_kernel<768>, 768, 8192)) return rc;
-    if (max_tile_count > lo_excl) {
-        a.lo_excl = lo_excl; a.hi_incl = kSortLarge;
-        const size_t lds_k = sizeof(uint64_t) * (size_t)kSortLarge;
-        if (int rc = ensure_lds((const void*)tile_sort_kernel<true>, lds_k)) return rc;
-        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(1024), lds_k, st, a);
-        GS_LAUNCH_CHECK("tile_sort_kernel<lds>");
+    a.coarse = 0;
+    return launch_list_sorts(st, a, (unsigned)(C * tiles), max_tile_count);
+}
+
+// ------------------------------------------------------------------------------------------------ two-level binning
+extern "C" size_t gs_bins_workspace_bytes(int C, int64_t N, int tile_w, int tile_h, int bin_shift, int64_t coarse_cap) {
+    if (bin_shift < 0 || bin_shift > 2 || coarse_cap < 0) return 0;
+    return bins_layout(C, N, tile_w, tile_h, bin_shift, coarse_cap).total;
+}
+
+template <bool WRITE>
+static int launch_refine(hipStream_t st, const BinsLayout& L, const RefineArgs& a) {
+    const unsigned grid = (unsigned)L.max_chunks;   // upper bound; blocks past the last chunk return at once
+    if (L.shift == 2) hipLaunchKernelGGL((bins_refine_kernel<WRITE, 2>), dim3(grid), dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((bins_refine_kernel<WRITE, 1>), dim3(grid), dim3(256), 0, st, a);
+    GS_LAUNCH_CHECK("bins_refine_kernel");
+    return GS_OK;
+}
+
+static void fill_refine_args(RefineArgs& r, const BinsLayout& L, int C, int tile_w, int tile_h, char* ws, const uint64_t* coarse_keys,
+                             const uint32_t* bbox, const int64_t* info_dev) {
+    r.tw = tile_w; r.th = tile_h; r.tiles = tile_w * tile_h; r.n_bins_total = C * L.nbins;
+    r.choff = (const int32_t*)(ws + L.choff_off);
+    r.chunk_desc = (const int4*)(ws + L.chunk_bin_off);
+    r.cnt_ct = (uint32_t*)(ws + L.cnt_ct_off);
+    int tb = 0;
+    for (int v = r.tiles; v > 0; v >>= 1) ++tb;
+    r.tile_bits = tb; r.bw = L.bw; r.nbins = L.nbins;
+    r.coff = (const int32_t*)(ws + L.coff_off);
+    r.keys = (const unsigned long long*)coarse_keys;
+    r.rec = (const uint4*)(ws + L.rec_off);
+    r.staged = (uint4*)(ws + L.staged_off);
+    r.tile_cnt = (uint32_t*)(ws + L.tile_cnt_off);
+    r.isect_offsets = nullptr; r.isect_ids = nullptr; r.flatten_ids = nullptr; r.slots = nullptr;
+    r.info = info_dev;
+}
+
+extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int tile_h, int bin_shift, const uint32_t* bbox,
+                             const float* depths, void* workspace, size_t workspace_bytes, uint64_t* coarse_keys,
+                             int64_t coarse_cap, int64_t coarse_list_cap,
+                             int32_t* cum_tiles, int32_t* isect_offsets, int32_t* bucket_offsets, int32_t* tile_order,
+                             int64_t* info_dev, int64_t* info_host) {
+    GS_REQUIRE(C >= 1 && N >= 0 && tile_w > 0 && tile_h > 0, "C>=1, N>=0, positive tile grid");
+    const int tiles = tile_w * tile_h;
+    GS_REQUIRE((int64_t)C * tiles < (1ll << 31) && (int64_t)C * N < (1ll << 31), "too many tiles or flatten ids");
+    GS_REQUIRE(bin_shift >= 0 && bin_shift <= 2, "bin_shift: 0 (library default), 1 (2x2 tiles) or 2 (4x4 tiles)");
+    GS_REQUIRE(coarse_cap >= 0 && coarse_cap < (1ll << 31) && (coarse_cap == 0 || coarse_keys), "coarse key buffer");
+    const BinsLayout L = bins_layout(C, N, tile_w, tile_h, bin_shift, coarse_cap);
+    GS_REQUIRE((size_t)L.nbins * 4 + 128 <= 160 * 1024, "tile grid too large for the LDS bin histogram");
+    GS_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small (see gs_bins_workspace_bytes)");
+    GS_REQUIRE(isect_offsets && bucket_offsets && info_dev, "null output pointer");
+    GS_REQUIRE(N == 0 || (bbox && depths && cum_tiles), "null bbox / depths / cum_tiles");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    uint32_t* hist = (uint32_t*)(ws + L.hist_off);
+    uint32_t* bin_cnt = (uint32_t*)(ws + L.bin_cnt_off);
+    uint32_t* grp_tot = (uint32_t*)(ws + L.grp_tot_off);
+    uint32_t* grp_base = (uint32_t*)(ws + L.grp_base_off);
+    int32_t* coff = (int32_t*)(ws + L.coff_off);
+    uint32_t* tile_cnt = (uint32_t*)(ws + L.tile_cnt_off);
+    const Guard gd = current_guard();
+    GS_REQUIRE(gd.info == nullptr || gd.info == info_dev, "the guard set by gs_guard_set must be this call's info_dev");
+    // sort classes launched: up to the one that holds coarse_list_cap (<= 0: all of them); a longer bin list raises
+    // flags bit 8 and nothing is emitted
+    int64_t list_cap = 0x7fffffff;
+    if (coarse_list_cap > 0) list_cap = coarse_list_cap <= 1024 ? 1024 : coarse_list_cap <= 4096 ? 4096 : coarse_list_cap <= 8192 ? 8192
+                                        : coarse_list_cap <= kSortLarge ? kSortLarge : 0x7fffffff;
+    const size_t lds = sizeof(uint32_t) * ((size_t)L.nbins + 32);
+    if (int rc = ensure_lds((const void*)bins_hist_kernel, lds)) return rc;
+    hipLaunchKernelGGL(bins_hist_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, L.shift, L.bw, L.nbins, L.per_group,
+                       (const uint4*)bbox, hist, grp_tot);
+    GS_LAUNCH_CHECK("bins_hist_kernel");
+    const int64_t cb = (int64_t)C * L.nbins;
+    hipLaunchKernelGGL(bins_colscan_kernel, dim3((unsigned)((cb + 3) / 4)), dim3(256), 0, st, C, L.groups, L.nbins, hist, bin_cnt);
+    GS_LAUNCH_CHECK("bins_colscan_kernel");
+    hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(kBinThreads), 0, st, (int)cb, C * L.groups, bin_cnt, grp_tot, coff,
+                       (int32_t*)(ws + L.choff_off), (int4*)(ws + L.chunk_bin_off), L.max_chunks, L.chunk_shift, grp_base,
+                       info_dev, coarse_cap, list_cap,
+                       gd.info != nullptr ? 1 : 0);
+    GS_LAUNCH_CHECK("bins_scan_kernel");
+    if (N > 0) {
+        if (int rc = ensure_lds((const void*)bins_emit_kernel, lds)) return rc;
+        hipLaunchKernelGGL(bins_emit_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, L.shift, L.bw, L.nbins, L.per_group,
+                           (const uint4*)bbox, depths, hist, coff, grp_base, (unsigned long long*)coarse_keys, cum_tiles,
+                           (uint4*)(ws + L.rec_off), (const int64_t*)info_dev);
+        GS_LAUNCH_CHECK("bins_emit_kernel");
+        SortArgs a;
+        a.tiles = L.nbins; a.tile_bits = 0;
+        a.isect_offsets = coff; a.keys = (unsigned long long*)coarse_keys; a.slot_gid = nullptr;
+        a.isect_ids = nullptr; a.flatten_ids = nullptr; a.slots = nullptr;
+        a.guard = info_dev; a.coarse = 1;
+        // (the longest bin list is not known to the host here: every class is launched, the blocks of the classes a
+        //  list does not belong to return at once; a list can never be longer than the key buffer)
+        if (int rc = launch_list_sorts(st, a, (unsigned)cb, list_cap < coarse_cap ? list_cap : coarse_cap)) return rc;
     }
-    if (max_tile_count > kSortLarge) {
-        a.lo_excl = kSortLarge; a.hi_incl = 0x7fffffff;
-        hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(grid), dim3(1024), 0, st, a);
-        GS_LAUNCH_CHECK("tile_sort_kernel<global>");
+    RefineArgs r;
+    fill_refine_args(r, L, C, tile_w, tile_h, ws, coarse_keys, bbox, info_dev);
+    if (int rc = launch_refine<false>(st, L, r)) return rc;
+    {
+        const unsigned g = (unsigned)(((int64_t)C * tiles + 255) / 256);
+        if (L.shift == 2) hipLaunchKernelGGL(bins_chunkscan_kernel<2>, dim3(g), dim3(256), 0, st, r, C);
+        else hipLaunchKernelGGL(bins_chunkscan_kernel<1>, dim3(g), dim3(256), 0, st, r, C);
+        GS_LAUNCH_CHECK("bins_chunkscan_kernel");
+    }
+    hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(kBinThreads), 0, st, C * tiles, 0, tile_cnt, (const uint32_t*)nullptr,
+                       isect_offsets, bucket_offsets, (uint32_t*)nullptr, info_dev, tile_order, gd.cap_isects,
+                       (int64_t)0x7fffffffffffffffll, (int64_t)12);
+    GS_LAUNCH_CHECK("bin_tilescan_kernel");
+    if (info_host) {
+        GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        GS_HIP_CHECK(hipStreamSynchronize(st));
     }
     return GS_OK;
+}
+
+extern "C" int gs_bins_lists(void* stream, int C, int64_t N, int tile_w, int tile_h, int bin_shift, const uint32_t* bbox, void* workspace,
+                             size_t workspace_bytes, const uint64_t* coarse_keys, int64_t coarse_cap, const int32_t* cum_tiles,
+                             const int32_t* isect_offsets, int64_t* isect_ids, int32_t* flatten_ids, int32_t* slots,
+                             const int64_t* info_dev) {
+    GS_REQUIRE(C >= 1 && N >= 0 && tile_w > 0 && tile_h > 0, "C>=1, N>=0, positive tile grid");
+    GS_REQUIRE(bin_shift >= 0 && bin_shift <= 2 && coarse_cap >= 0, "bin_shift: 0, 1 or 2; coarse_cap as given to gs_bins_count");
+    const BinsLayout L = bins_layout(C, N, tile_w, tile_h, bin_shift, coarse_cap);
+    GS_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small (see gs_bins_workspace_bytes)");
+    GS_REQUIRE(info_dev && isect_offsets, "null pointer");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(cum_tiles && bbox && isect_ids && flatten_ids && slots, "null list buffer");
+    RefineArgs r;
+    fill_refine_args(r, L, C, tile_w, tile_h, (char*)workspace, coarse_keys, bbox, info_dev);
+    r.isect_offsets = isect_offsets; r.isect_ids = isect_ids; r.flatten_ids = flatten_ids; r.slots = slots;
+    return launch_refine<true>((hipStream_t)stream, L, r);
 }

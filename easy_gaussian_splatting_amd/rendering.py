@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as _ct
 import math
+import os
 import threading
 import time
 import weakref
@@ -65,20 +66,55 @@ def profile_stages(enable: bool) -> Optional[Dict]:
 _tls = threading.local()
 _state_lock = threading.Lock()   # guards the two module-level dicts below (entry points are called from any thread)
 _cap_hint: Dict[int, int] = {}   # per device: list capacity to pre-allocate (last intersection count + 25 %)
+_coarse_hint: Dict[int, dict] = {}   # per device: what the last two-level binning needed (entries, longest bin list, footprint)
+
+
+def bin_shift_for(footprint) -> int:
+    """Bin size of the two-level binning from the mean footprint (tile-list entries per Gaussian) of the previous call:
+    2x2-tile bins (1) while Gaussians cover a few tiles, 4x4 (2) beyond; 0 = library default (first call).
+    GS_BINS_SHIFT overrides."""
+    env = os.environ.get("GS_BINS_SHIFT")
+    if env:
+        return int(env)
+    if footprint is None:
+        return 0
+    return 1 if footprint < 8.0 else 2
+
+
+def binning_mode() -> str:
+    """GS_BINNING: "auto" (default), "bins" (two-level binning: coarse-bin lists sorted, tiles refined out of them in order)
+    or "tiles" (every tile list emitted and sorted on its own).  Both yield bit-identical lists."""
+    mode = os.environ.get("GS_BINNING", "auto")
+    if mode not in ("auto", "bins", "tiles"):
+        raise ValueError(f"GS_BINNING must be 'auto', 'bins' or 'tiles', got {mode!r}")
+    return mode
+
+
+BINS_FROM_FOOTPRINT = 6.0   # mean tile-list entries per Gaussian from which sorting coarse bins beats sorting tiles
+
+
+def binning_choice(footprint) -> str:
+    """The pipeline for a scene whose Gaussians cover `footprint` tiles on average (None: unknown -> per-tile)."""
+    mode = binning_mode()
+    if mode != "auto":
+        return mode
+    return "bins" if footprint is not None and footprint >= BINS_FROM_FOOTPRINT else "tiles"
+
+
 # host-side diagnostics: time spent blocked on the list-size read-back (bench.py reports it; a wait
 # near zero means the host, not the GPU, paces the loop)
 stats = {"sync_wait_ns": 0, "calls": 0}
 
 
 def _pinned_info(device: torch.device) -> Tensor:
-    """Page-locked 4 x int64 landing buffer for the list sizes, one per (host thread, device)."""
+    """Page-locked 8 x int64 landing buffer for the list sizes, one per (host thread, device)."""
     cache = getattr(_tls, "pinned", None)
     if cache is None:
         cache = _tls.pinned = {}
     key = device.index if device.index is not None else torch.cuda.current_device()
     buf = cache.get(key)
     if buf is None:
-        buf = cache[key] = torch.empty((4,), dtype=torch.int64, pin_memory=True)
+        buf = cache[key] = torch.empty((8,), dtype=torch.int64, pin_memory=True)
     return buf
 
 
@@ -137,14 +173,38 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     # queued right behind the count kernels and the SH colour pass behind the copy, so the host
     # wakes on the copy's event while the GPU is still busy with SH: no idle gap.
     project(1, "gs_project_fwd")
-    ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
-    workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    info_dev = torch.empty((8,), dtype=torch.int64, device=dev)
     isect_offsets = torch.empty((C * tiles + 1,), **i32)
     bucket_offsets = torch.empty((C * tiles + 1,), **i32)
-    info_dev = torch.empty((4,), dtype=torch.int64, device=dev)
     tile_order = torch.empty((C * tiles,), **i32)   # launch order of the blend forward: longest lists first
-    _stage("gs_bin_count", dev, lambda: nat.check(L.gs_bin_count(st, C, N, tw, th, _ptr(bbox), _ptr(workspace), ws_bytes, _ptr(isect_offsets),
-                             _ptr(bucket_offsets), _ptr(tile_order), _ptr(info_dev), None), "gs_bin_count"))
+    cum_tiles = torch.empty((C * N,), **i32)
+    hint_key = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _state_lock:
+        hint = dict(_coarse_hint.get(hint_key, {}))
+    two_level = binning_choice(hint.get("footprint")) == "bins"
+    if two_level:
+        # two-level binning (include/gs_raster.h): coarse-bin lists are emitted and sorted, tiles are counted out of them.
+        # Sizes the host cannot know yet come from the previous call on this device (+25 %); a miss raises a flag in
+        # info[3], nothing is emitted, and the count is repeated with the sizes it reported.
+        shift = bin_shift_for(hint.get("footprint"))
+        coarse_cap = max(hint.get("entries", 0), 2 * C * N + 1024)
+        list_cap = [hint.get("longest", 0)]   # 0: launch every sort class
+        bufs = {}
+
+        def alloc_coarse(n):
+            bufs["keys"] = torch.empty((n,), dtype=torch.int64, device=dev)
+            bufs["ws"] = torch.empty((int(L.gs_bins_workspace_bytes(C, N, tw, th, shift, n)),), dtype=torch.uint8, device=dev)
+
+        alloc_coarse(coarse_cap)
+        count = lambda: nat.check(L.gs_bins_count(st, C, N, tw, th, shift, _ptr(bbox), _ptr(depths), _ptr(bufs["ws"]), bufs["ws"].numel(),
+                                                  _ptr(bufs["keys"]), bufs["keys"].numel(), list_cap[0], _ptr(cum_tiles), _ptr(isect_offsets),
+                                                  _ptr(bucket_offsets), _ptr(tile_order), _ptr(info_dev), None), "gs_bins_count")
+    else:
+        ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
+        workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        count = lambda: nat.check(L.gs_bin_count(st, C, N, tw, th, _ptr(bbox), _ptr(workspace), ws_bytes, _ptr(isect_offsets),
+                                                 _ptr(bucket_offsets), _ptr(tile_order), _ptr(info_dev), None), "gs_bin_count")
+    _stage("gs_bin_count", dev, count)
     info_host = _pinned_info(dev)
     info_host.copy_(info_dev, non_blocking=True)
     ready = torch.cuda.Event()
@@ -153,19 +213,26 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     # The list buffers are allocated BEFORE the host blocks, from the size the previous call on this
     # device needed (+25 %): the window between the host waking up and the emit kernel being queued is
     # what the colour pass has to cover, and six allocator calls do not belong in it.
-    hint_key = dev.index if dev.index is not None else torch.cuda.current_device()
     with _state_lock:
         cap = _cap_hint.get(hint_key, 0)
 
     def alloc_lists(c):
-        return (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32),
-                torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32), torch.empty((c,), **i32))
+        scratch = () if two_level else (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32))
+        return scratch + (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32), torch.empty((c,), **i32))
 
-    cum_tiles = torch.empty((C * N,), **i32)
     lists = alloc_lists(cap) if cap > 0 else None
     t_wait = time.perf_counter_ns()
     ready.synchronize()
     waited = time.perf_counter_ns() - t_wait
+    while two_level and int(info_host[3]) & 12:
+        # the coarse key buffer was too small or a bin list longer than the sort classes launched (first call on this
+        # device, or the scene changed): nothing was emitted; re-run the count with the sizes it reported
+        if int(info_host[3]) & 4:
+            alloc_coarse(int(info_host[4]) + (int(info_host[4]) >> 2) + 1024)
+        list_cap[0] = 0
+        count()
+        info_host.copy_(info_dev, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
     n_isects, n_buckets, max_tile = (int(v) for v in info_host[:3].tolist())
     if lists is None or n_isects > cap:
         cap = max(n_isects, 1)
@@ -174,10 +241,22 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         stats["sync_wait_ns"] += waited
         stats["calls"] += 1
         _cap_hint[hint_key] = n_isects + (n_isects >> 2) + 1024
-    keys_tmp, slot_gid, isect_ids, flatten_ids, slots = lists
-    _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, _ptr(bbox), _ptr(depths), _ptr(workspace), ws_bytes,
-                                 _ptr(isect_offsets), n_isects, max_tile, _ptr(keys_tmp), _ptr(slot_gid),
-                                 _ptr(cum_tiles), _ptr(isect_ids), _ptr(flatten_ids), _ptr(slots)), "gs_bin_emit_sort"))
+        if two_level:
+            _coarse_hint[hint_key] = dict(entries=int(info_host[4]) + (int(info_host[4]) >> 2) + 1024,
+                                          longest=int(info_host[5]) + (int(info_host[5]) >> 2) + 64,
+                                          footprint=n_isects / max(1, C * N))
+        else:
+            _coarse_hint[hint_key] = dict(footprint=n_isects / max(1, C * N))
+    if two_level:
+        isect_ids, flatten_ids, slots = lists
+        _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bins_lists(st, C, N, tw, th, shift, _ptr(bbox), _ptr(bufs["ws"]), bufs["ws"].numel(),
+                                     _ptr(bufs["keys"]), bufs["keys"].numel(), _ptr(cum_tiles), _ptr(isect_offsets), _ptr(isect_ids),
+                                     _ptr(flatten_ids), _ptr(slots), _ptr(info_dev)), "gs_bins_lists"))
+    else:
+        keys_tmp, slot_gid, isect_ids, flatten_ids, slots = lists
+        _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, _ptr(bbox), _ptr(depths), _ptr(workspace), ws_bytes,
+                                     _ptr(isect_offsets), n_isects, max_tile, _ptr(keys_tmp), _ptr(slot_gid),
+                                     _ptr(cum_tiles), _ptr(isect_ids), _ptr(flatten_ids), _ptr(slots)), "gs_bin_emit_sort"))
 
     render_colors = torch.empty((C, H, W, 3), **f32)
     render_alphas = torch.empty((C, H, W, 1), **f32)

@@ -118,12 +118,10 @@ class TrainStepGraph:
         b["bbox"] = torch.empty((N, 4), **i32)
         b["tiles_per_gauss"] = torch.empty((1, N), **i32)
         b["cum_tiles"] = torch.empty((N,), **i32)
-        self.ws_bytes = int(L.gs_bin_workspace_bytes(1, N, self.tw, self.th))
-        b["ws"] = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
         b["isect_offsets"] = torch.empty((tiles + 1,), **i32)
         b["bucket_offsets"] = torch.empty((tiles + 1,), **i32)
         b["tile_order"] = torch.empty((tiles,), **i32)
-        b["info"] = torch.zeros((4,), dtype=torch.int64, device=dev)
+        b["info"] = torch.zeros((8,), dtype=torch.int64, device=dev)
         b["applied"] = torch.zeros((1,), dtype=torch.int64, device=dev)
         b["render_colors"] = torch.empty((1, H, W, 3), **f32)
         b["render_alphas"] = torch.empty((1, H, W, 1), **f32)
@@ -147,11 +145,27 @@ class TrainStepGraph:
             self.cap = max(int(max(n_isects, min_cap) * self.margin) + 4096, self.cap)
             need_tile = max(int(max(max_tile, min_cap_tile) * 1.5), self.cap_tile)
             self.cap_tile = next((c for c in _SORT_CLASSES if c >= need_tile), 1 << 30)
+        self._alloc_binning()
         self._alloc_lists()
         self._key = self._state_key()
         # eager warm-up of the guarded pipeline (raises every kernel attribute; also a functional check before capture)
         self._capture()
         self.stats["rebuilds"] += 1
+
+    def _alloc_binning(self):
+        """Workspace of the binning pipeline the probe chose (rendering.binning_mode): per-tile lists sorted one by one
+        ("tiles") or coarse-bin lists sorted and refined ("bins"; capacities for the coarse entries and the longest bin
+        list learnt from the probe, overflow flagged on the device like the list capacity)."""
+        L, b, dev = nat.lib(), self.buf, self.dev
+        if self.binning == "bins":
+            ws = int(L.gs_bins_workspace_bytes(1, self.N, self.tw, self.th, self.bin_shift, self.cap_coarse))
+            b["coarse_keys"] = torch.empty((self.cap_coarse,), dtype=torch.int64, device=dev)
+        else:
+            ws = int(L.gs_bin_workspace_bytes(1, self.N, self.tw, self.th))
+            b["keys_tmp"] = torch.empty((self.cap,), dtype=torch.int64, device=dev)
+            b["slot_gid"] = torch.empty((self.cap,), dtype=torch.int32, device=dev)
+        self.ws_bytes = ws
+        b["ws"] = torch.empty((ws,), dtype=torch.uint8, device=dev)
 
     def _alloc_lists(self):
         b, dev, cap = self.buf, self.dev, self.cap
@@ -159,8 +173,6 @@ class TrainStepGraph:
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.cap_buckets = cap // nat.GS_BUCKET + tiles + 1
-        b["keys_tmp"] = torch.empty((cap,), dtype=torch.int64, device=dev)
-        b["slot_gid"] = torch.empty((cap,), **i32)
         b["isect_ids"] = torch.empty((cap,), dtype=torch.int64, device=dev)
         b["flatten_ids"] = torch.empty((cap,), **i32)
         b["slots"] = torch.empty((cap,), **i32)
@@ -223,25 +235,57 @@ class TrainStepGraph:
         if self.debug_sync and not torch.cuda.is_current_stream_capturing():
             self.stream.synchronize()
 
-    def _project_and_count(self):
+    def _project(self):
         L, b, m = nat.lib(), self.buf, self.model
-        st = self._st()
         culling = {"gsplat": 0, "tight": 1}[getattr(m, "tile_culling", "tight")]
-        self._ck(L.gs_project_fwd(st, 1, self.N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
+        self._ck(L.gs_project_fwd(self._st(), 1, self.N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
                                    _p(m.logit_opacities), _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0,
                                    _p(b["viewmats"]), _p(b["Ks"]), self.W, self.H, 0.3, 0.01, 1e10, 0.0, culling, 0, 1,
                                    _p(b["radii"]), _p(b["means2d"]), _p(b["depths"]), _p(b["conics"]), _p(b["colors_post"]),
                                    _p(b["rec"]), _p(b["bbox"]), _p(b["tiles_per_gauss"])), "gs_project_fwd")
-        self._ck(L.gs_bin_count(st, 1, self.N, self.tw, self.th, _p(b["bbox"]), _p(b["ws"]), self.ws_bytes, _p(b["isect_offsets"]),
-                                 _p(b["bucket_offsets"]), _p(b["tile_order"]), _p(b["info"]), None), "gs_bin_count")
+
+    def _count(self):
+        L, b = nat.lib(), self.buf
+        if self.binning == "bins":
+            self._ck(L.gs_bins_count(self._st(), 1, self.N, self.tw, self.th, self.bin_shift, _p(b["bbox"]), _p(b["depths"]), _p(b["ws"]),
+                                      self.ws_bytes, _p(b["coarse_keys"]), self.cap_coarse, self.cap_coarse_list, _p(b["cum_tiles"]),
+                                      _p(b["isect_offsets"]), _p(b["bucket_offsets"]), _p(b["tile_order"]), _p(b["info"]), None),
+                     "gs_bins_count")
+        else:
+            self._ck(L.gs_bin_count(self._st(), 1, self.N, self.tw, self.th, _p(b["bbox"]), _p(b["ws"]), self.ws_bytes,
+                                     _p(b["isect_offsets"]), _p(b["bucket_offsets"]), _p(b["tile_order"]), _p(b["info"]), None),
+                     "gs_bin_count")
 
     def _probe(self):
-        """One blocking read of {I, max tile list} for the current inputs (build time only)."""
-        with torch.cuda.device(self.dev), self._on_stream():
-            self._project_and_count()
-        info = self.buf["info"].tolist()
-        self.buf["info"].zero_()
-        return int(info[0]), int(info[2])
+        """Blocking reads of the list sizes for the current inputs (build time only): {I, longest tile list} from the
+        per-tile count, then -- if the footprints call for the two-level binning -- {coarse entries, longest bin list}."""
+        from .rendering import bin_shift_for, binning_choice
+        L, b, dev = nat.lib(), self.buf, self.dev
+        self.binning = "tiles"
+        self.ws_bytes = int(L.gs_bin_workspace_bytes(1, self.N, self.tw, self.th))
+        b["ws"] = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev), self._on_stream():
+            self._project()
+            self._count()
+        info = b["info"].tolist()
+        n_isects, max_tile = int(info[0]), int(info[2])
+        footprint = n_isects / max(1, self.N)
+        self.binning = binning_choice(footprint)
+        if self.binning == "bins":
+            self.bin_shift = bin_shift_for(footprint) or 2
+            self.cap_coarse, self.cap_coarse_list = 2 * self.N + 1024, 0
+            while True:
+                self._alloc_binning()
+                with torch.cuda.device(dev), self._on_stream():
+                    self._count()
+                info = b["info"].tolist()
+                if not int(info[3]) & 12:
+                    break
+                self.cap_coarse = int(int(info[4]) * self.margin) + 4096
+            self.cap_coarse = int(int(info[4]) * self.margin) + 4096
+            self.cap_coarse_list = int(int(info[5]) * 1.5) + 64
+        b["info"].zero_()
+        return n_isects, max_tile
 
     def _enqueue_step(self):
         """The whole step on the current stream, guarded; nothing here allocates or synchronises."""
@@ -251,10 +295,16 @@ class TrainStepGraph:
         nat.check(L.gs_guard_set(_p(b["info"]), self.cap, self.cap_tile), "gs_guard_set")
         self._stage_no = 0
         try:
-            self._project_and_count()
-            self._ck(L.gs_bin_emit_sort(st, 1, N, self.tw, self.th, _p(b["bbox"]), _p(b["depths"]), _p(b["ws"]), self.ws_bytes,
-                                         _p(b["isect_offsets"]), self.cap, self.cap_tile, _p(b["keys_tmp"]), _p(b["slot_gid"]),
-                                         _p(b["cum_tiles"]), _p(b["isect_ids"]), _p(b["flatten_ids"]), _p(b["slots"])), "gs_bin_emit_sort")
+            self._project()
+            self._count()
+            if self.binning == "bins":
+                self._ck(L.gs_bins_lists(st, 1, N, self.tw, self.th, self.bin_shift, _p(b["bbox"]), _p(b["ws"]), self.ws_bytes,
+                                          _p(b["coarse_keys"]), self.cap_coarse, _p(b["cum_tiles"]), _p(b["isect_offsets"]),
+                                          _p(b["isect_ids"]), _p(b["flatten_ids"]), _p(b["slots"]), _p(b["info"])), "gs_bins_lists")
+            else:
+                self._ck(L.gs_bin_emit_sort(st, 1, N, self.tw, self.th, _p(b["bbox"]), _p(b["depths"]), _p(b["ws"]), self.ws_bytes,
+                                             _p(b["isect_offsets"]), self.cap, self.cap_tile, _p(b["keys_tmp"]), _p(b["slot_gid"]),
+                                             _p(b["cum_tiles"]), _p(b["isect_ids"]), _p(b["flatten_ids"]), _p(b["slots"])), "gs_bin_emit_sort")
             self._ck(L.gs_blend_fwd(st, 1, W, H, _p(b["rec"]), _p(b["bg"]), _p(b["isect_offsets"]), _p(b["bucket_offsets"]),
                                      _p(b["tile_order"]), _p(b["flatten_ids"]), _p(b["slots"]), self.cap, _p(b["render_colors"]),
                                      _p(b["render_alphas"]), _p(b["ckpt"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["qmask"]),
@@ -423,5 +473,5 @@ class TrainStepGraph:
         return self.buf["loss_ring"][idx]
 
     def report(self) -> Dict[str, Any]:
-        return dict(self.stats, capacity_isects=self.cap, capacity_tile_list=self.cap_tile, steps=self.confirmed,
+        return dict(self.stats, binning=self.binning, capacity_isects=self.cap, capacity_tile_list=self.cap_tile, steps=self.confirmed,
                     graph=self.graph is not None)

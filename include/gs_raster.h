@@ -124,6 +124,31 @@ int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, con
                      uint64_t* keys_tmp, int32_t* slot_gid, int32_t* cum_tiles, int64_t* isect_ids,
                      int32_t* flatten_ids, int32_t* slots);
 
+/* Two-level binning: the same outputs as gs_bin_count + gs_bin_emit_sort (bit for bit), built differently.  A bin is
+ * 2x2 (bin_shift 1) or 4x4 (2) tiles (0: the library picks from N and the tile grid).  gs_bins_count emits every
+ * Gaussian into the bins its tile rectangle touches as a (depth bits << 32 | flatten id) key -- I' entries, 1.4-17 per
+ * Gaussian where the tile lists hold 3-190 --, depth-sorts each bin's list in LDS, and counts each tile's entries out
+ * of its bin's sorted list; gs_bins_lists repeats that walk and writes the per-tile lists by ordered compaction (ballot
+ * + popcount: no atomics, no second sort; depth and tie order are inherited from the bin).  The per-tile pipeline sorts
+ * I entries, this one I'; it pays from ~6 tile-list entries per Gaussian upwards (real captures: tens to hundreds).
+ *   coarse_keys[coarse_cap] u64   scratch for the bin lists (kept between the two calls)
+ *   coarse_list_cap               longest bin list the sort classes launched must take (<= 0: launch every class)
+ *   info_dev[8]                   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, -}
+ *                                 flags: 1 I > guard capacity | 4 I' > coarse_cap | 8 a bin list > coarse_list_cap;
+ *                                 with flags != 0 nothing was emitted: repeat gs_bins_count with the sizes reported
+ *   cum_tiles[C*N]                exclusive scan of tiles_per_gauss (first gradient-row slot of each flatten id)
+ * workspace: gs_bins_workspace_bytes(C, N, tile_w, tile_h, bin_shift, coarse_cap), same arguments in both calls.
+ * If info_host != NULL the eight values are copied there and the stream is synchronised. */
+size_t gs_bins_workspace_bytes(int C, int64_t N, int tile_w, int tile_h, int bin_shift, int64_t coarse_cap);
+int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int tile_h, int bin_shift, const uint32_t* bbox,
+                  const float* depths, void* workspace, size_t workspace_bytes, uint64_t* coarse_keys,
+                  int64_t coarse_cap, int64_t coarse_list_cap, int32_t* cum_tiles, int32_t* isect_offsets,
+                  int32_t* bucket_offsets, int32_t* tile_order, int64_t* info_dev, int64_t* info_host);
+int gs_bins_lists(void* stream, int C, int64_t N, int tile_w, int tile_h, int bin_shift, const uint32_t* bbox,
+                  void* workspace, size_t workspace_bytes, const uint64_t* coarse_keys, int64_t coarse_cap,
+                  const int32_t* cum_tiles, const int32_t* isect_offsets, int64_t* isect_ids, int32_t* flatten_ids,
+                  int32_t* slots, const int64_t* info_dev);
+
 /* B-fwd (replaces gsplat rasterize_to_pixels forward).  backgrounds[C,3] may be NULL.
  * Outputs render_colors[C,H,W,3], render_alphas[C,H,W,1].  One wavefront per 16x16 tile, each
  * lane owning one pixel of each 8x8 quadrant.  Inference: pass ckpt = NULL (and NULL for every
