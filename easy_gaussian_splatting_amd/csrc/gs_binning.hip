@@ -45,6 +45,7 @@ BinLayout bin_layout(int C, int64_t N, int tiles) {
     L.tile_cnt_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * tiles);
     L.grp_tot_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * L.groups);
     L.grp_base_off = off; off = align(off + sizeof(uint32_t) * (size_t)C * L.groups);
+    L.items_off = off; off = align(off + sizeof(int32_t) * (64 + (size_t)10 * (size_t)C * tiles));   // == sort_items_bytes(C * tiles)
     L.total = off;
     return L;
 }
@@ -359,7 +360,12 @@ struct SortArgs {
     int32_t* slots;
     const int64_t* guard;
     int coarse;   // two-level binning: the lists are coarse-bin lists of (depth bits << 32 | flatten id) keys, sorted in place
+    int seg;      // > 0: segment mode -- block b sorts segment b % kSegMax (kSegLen keys) of list b / kSegMax, in place
+    unsigned long long* merged;   // segment mode, coarse lists: where seg_merge_kernel leaves the merged list
 };
+
+constexpr int kSegLen = 8192;   // the largest LDS radix class
+constexpr int kSegMax = 8;      // lists of up to 65536 keys: sorted segment by segment, then rank-merged
 
 template <bool IN_LDS>
 __global__ void tile_sort_kernel(const SortArgs a) {
@@ -407,14 +413,19 @@ __global__ void tile_sort_kernel(const SortArgs a) {
 // arrive in arbitrary order: a tile in which an equal-depth pair is out of order -- practically
 // never -- is re-sorted on the full 64-bit key by the bitonic network.
 template <int T>
-__global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
+__device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vblock) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     constexpr int W = T / 64;
-    const int tile = blockIdx.x;
-    if (guard_tripped(a.guard)) return;
-    const int lo = a.isect_offsets[tile], n = a.isect_offsets[tile + 1] - lo;
+    const int tile = a.seg ? vblock / kSegMax : vblock;
+    int lo = a.isect_offsets[tile], n = a.isect_offsets[tile + 1] - lo;
     if (n <= a.lo_excl || n > a.hi_incl) return;
-    const int cap = a.hi_incl;
+    if (a.seg) {   // this block's slice of a list in (kSegLen, kSegMax * kSegLen]
+        const int sg = vblock - tile * kSegMax;
+        lo += sg * kSegLen;
+        n = min(kSegLen, n - sg * kSegLen);
+        if (n <= 0) return;
+    }
+    const int cap = a.seg ? kSegLen : a.hi_incl;
     unsigned long long* src = skeys;
     unsigned long long* dst = skeys + cap;
     uint32_t* cnt = reinterpret_cast<uint32_t*>(skeys + 2 * cap);   // [W][256]: counts, then offsets, of this pass
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
         while (P < n) P <<= 1;
         bitonic_sort_keys(src, n, P);
     }
-    if (a.coarse) {
+    if (a.coarse || a.seg) {
         unsigned long long* out = a.keys + lo;
         for (int i = tid; i < n; i += T) out[i] = src[i];
         return;
@@ -521,6 +532,48 @@ __global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
         a.flatten_ids[lo + i] = a.slot_gid[slot];
         a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
     }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
+    if (guard_tripped(a.guard)) return;
+    radix_sort_list<T>(a, blockIdx.x);
+}
+
+// The same sort over a compacted work list (class_items_kernel): the classes above 1024 keys need 72-152 KB of LDS per
+// block, so a block that only finds out that its list belongs to another class still has to wait for that much LDS to
+// come free -- thousands of them serialise behind the real work.  Here a fixed number of blocks strides over the items.
+template <int T>
+__global__ __launch_bounds__(T) void tile_radix_sort_items_kernel(const SortArgs a, const int32_t* __restrict__ items,
+                                                                  const int32_t* __restrict__ n_items) {
+    if (guard_tripped(a.guard)) return;
+    const int n = *n_items;
+    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        radix_sort_list<T>(a, items[it]);
+        __syncthreads();
+    }
+}
+
+// Work lists of the sort classes above 1024 keys: items[0] lists of (1024, 4096], items[1] of (4096, 8192], items[2] the
+// (list * kSegMax + segment) pairs of the lists of (8192, 65536].  counts[3] zeroed by the caller.
+__global__ __launch_bounds__(256) void class_items_kernel(int n_lists, const int32_t* __restrict__ offsets,
+                                                          int32_t* __restrict__ items, int32_t* __restrict__ counts,
+                                                          const int64_t* __restrict__ guard) {
+    if (guard_tripped(guard)) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lists) return;
+    const int n = offsets[i + 1] - offsets[i];
+    if (n > 1024 && n <= 4096) items[atomicAdd(&counts[0], 1)] = i;
+    else if (n > 4096 && n <= kSegLen) items[n_lists + atomicAdd(&counts[1], 1)] = i;
+    else if (n > kSegLen && n <= kSegLen * kSegMax) {
+        const int ns = (n + kSegLen - 1) / kSegLen;
+        const int p = atomicAdd(&counts[2], ns);
+        for (int sg = 0; sg < ns; ++sg) items[2 * n_lists + p + sg] = i * kSegMax + sg;
+    }
+}
+
+static size_t sort_items_bytes(int64_t n_lists) {   // work lists of launch_list_sorts: 3 counters + items of three classes
+    return sizeof(int32_t) * (64 + (size_t)(2 + kSegMax) * (size_t)n_lists);
 }
 
 
@@ -554,6 +607,7 @@ struct BinsLayout {
     size_t rec_off;       // uint4 [C*N]  footprint with the slot base in place of the count (one gather instead of two)
     size_t staged_off;    // uint4 [coarse_cap]  the same records in sorted bin order (written by pass 1, read by pass 2)
     size_t cnt_ct_off;    // u32 [max_chunks][tiles per bin]  per-chunk tile counts -> exclusive prefix inside a tile
+    size_t items_off;     // i32 work lists of the sort classes above 1024 keys
     int64_t max_chunks;
     size_t total;
 };
@@ -586,6 +640,7 @@ static BinsLayout bins_layout(int C, int64_t N, int tw, int th, int bin_shift, i
     L.rec_off = off; off = align(off + sizeof(uint4) * (size_t)C * (size_t)N);
     L.staged_off = off; off = align(off + sizeof(uint4) * (size_t)coarse_cap);
     L.cnt_ct_off = off; off = align(off + sizeof(uint32_t) * (size_t)L.max_chunks * B * B);
+    L.items_off = off; off = align(off + sort_items_bytes((int64_t)C * L.nbins));
     L.total = off;
     return L;
 }
@@ -946,7 +1001,63 @@ __global__ __launch_bounds__(256) void bins_chunkscan_kernel(const RefineArgs a,
     a.tile_cnt[i] = run;
 }
 
-constexpr int kSortLarge = 16384;
+// Lists of (kSegLen, kSegMax * kSegLen] keys: every kSegLen-segment has been sorted in place (tile_radix_sort_kernel in
+// segment mode); the keys are unique, so the position of a key in the merged list is its index in its own segment plus,
+// for every other segment, the number of keys there that are smaller (one binary search each).  Per-tile lists are
+// written out directly (slots / flatten ids / isect ids); coarse-bin lists go to `merged` and seg_copy_kernel takes
+// them back.  (The bitonic network this replaces moved every key ~100 times through LDS: 229 us for 9 k-key bins.)
+__global__ __launch_bounds__(1024) void seg_merge_kernel(const SortArgs a, const int32_t* __restrict__ items,
+                                                         const int32_t* __restrict__ n_items) {
+    if (guard_tripped(a.guard)) return;
+    const int n_it = *n_items;
+    for (int it = blockIdx.x; it < n_it; it += gridDim.x) {
+    const int vblock = items[it];
+    const int list = vblock / kSegMax, sg = vblock - list * kSegMax;
+    const int lo = a.isect_offsets[list], n = a.isect_offsets[list + 1] - lo;
+    const int s_lo = sg * kSegLen, s_n = min(kSegLen, n - s_lo);
+    const int n_seg = (n + kSegLen - 1) / kSegLen;
+    const unsigned long long* gk = a.keys + lo;
+    const int cam = list / max(a.tiles, 1), tix = list - cam * a.tiles;
+    const long long hi_bits = ((long long)cam << (32 + a.tile_bits)) | ((long long)tix << 32);
+    for (int i = threadIdx.x; i < s_n; i += blockDim.x) {
+        const unsigned long long k = gk[s_lo + i];
+        int pos = i;
+        for (int o = 0; o < n_seg; ++o) {
+            if (o == sg) continue;
+            const unsigned long long* seg = gk + o * kSegLen;
+            int l = 0, r = min(kSegLen, n - o * kSegLen);   // first index with seg[idx] > k  (== count of smaller keys)
+            while (l < r) {
+                const int mid = (l + r) >> 1;
+                if (seg[mid] < k) l = mid + 1; else r = mid;
+            }
+            pos += l;
+        }
+        if (a.coarse) {
+            a.merged[lo + pos] = k;
+        } else {
+            const uint32_t slot = (uint32_t)k;
+            a.slots[lo + pos] = (int32_t)slot;
+            a.flatten_ids[lo + pos] = a.slot_gid[slot];
+            a.isect_ids[lo + pos] = hi_bits | (long long)(k >> 32);
+        }
+    }
+    }
+}
+
+__global__ __launch_bounds__(1024) void seg_copy_kernel(const SortArgs a, const int32_t* __restrict__ items,
+                                                        const int32_t* __restrict__ n_items) {
+    if (guard_tripped(a.guard)) return;
+    const int n_it = *n_items;
+    for (int it = blockIdx.x; it < n_it; it += gridDim.x) {
+        const int vblock = items[it];
+        const int list = vblock / kSegMax, sg = vblock - list * kSegMax;
+        const int lo = a.isect_offsets[list], n = a.isect_offsets[list + 1] - lo;
+        const int s_lo = sg * kSegLen, s_n = min(kSegLen, n - s_lo);
+        for (int i = threadIdx.x; i < s_n; i += blockDim.x) a.keys[lo + s_lo + i] = a.merged[lo + s_lo + i];
+    }
+}
+
+constexpr int kSortLarge = kSegLen * kSegMax;   // beyond: bitonic network in place in global memory
 
 }  // namespace gs
 
@@ -976,45 +1087,70 @@ static int ensure_lds(const void* fn, size_t bytes) {
     return GS_OK;
 }
 
-// Size classes of the per-list sort, each launched only if some list needs it (max_count: the longest list, known to
-// the host -- or an upper bound / INT64_MAX when it is not; blocks whose list is outside a class return at once):
-//   radix (two key buffers + 2 x 1 KB of counters per wave):
-//     <= 1024: 256 threads, 24 KB | <= 4096: 256 thr, 72 KB | <= 8192: 768 thr, 152 KB
-//   bitonic: <= 16384: 1024 thr, 128 KB | beyond: in-place global network
-static int launch_list_sorts(hipStream_t st, SortArgs& a, unsigned grid, int64_t max_tile_count) {
-    int lo_excl = 0;
-    auto radix = [&](auto kernel, int threads, int hi) -> int {
-        if (max_tile_count > lo_excl) {
-            a.lo_excl = lo_excl; a.hi_incl = hi;
-            const size_t lds_k = 2 * sizeof(uint64_t) * (size_t)hi + 2 * sizeof(uint32_t) * 256 * (size_t)(threads / 64);
-            if (int rc = ensure_lds((const void*)kernel, lds_k)) return rc;
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds_k, st, a);
-            GS_LAUNCH_CHECK("tile_radix_sort_kernel");
-        }
-        lo_excl = hi;
-        return GS_OK;
-    };
 #ifndef GS_SORT1K_THREADS
 #define GS_SORT1K_THREADS 256
 #endif
 #ifndef GS_SORT4K_THREADS
 #define GS_SORT4K_THREADS 256
 #endif
-    if (int rc = radix(tile_radix_sort_kernel<GS_SORT1K_THREADS>, GS_SORT1K_THREADS, 1024)) return rc;
-    if (int rc = radix(tile_radix_sort_kernel<GS_SORT4K_THREADS>, GS_SORT4K_THREADS, 4096)) return rc;
-    if (int rc = radix(tile_radix_sort_kernel<768>, 768, 8192)) return rc;
-    if (max_tile_count > lo_excl) {
-        a.lo_excl = lo_excl; a.hi_incl = kSortLarge;
-        const size_t lds_k = sizeof(uint64_t) * (size_t)kSortLarge;
-        if (int rc = ensure_lds((const void*)tile_sort_kernel<true>, lds_k)) return rc;
-        hipLaunchKernelGGL(tile_sort_kernel<true>, dim3(grid), dim3(1024), lds_k, st, a);
-        GS_LAUNCH_CHECK("tile_sort_kernel<lds>");
+// Size classes of the per-list sort (max_count: the longest list, known to the host, or an upper bound):
+//   <= 1024 keys: one block per list, 256 threads, 24 KB of LDS
+//   (1024, 4096] 72 KB | (4096, 8192] 768 threads, 152 KB | (8192, 65536] 8192-key segments + rank merge: over compacted
+//   work lists (class_items_kernel), a fixed number of blocks striding over the items
+//   beyond: bitonic network in place in global memory
+static int launch_list_sorts(hipStream_t st, SortArgs& a, unsigned grid, int64_t max_tile_count, int32_t* items_ws) {
+    int lo_excl = 0;
+    int32_t* counts = items_ws;
+    int32_t* items = items_ws + 64;
+    const size_t radix_lds = 2 * sizeof(uint32_t) * 256;
+    a.lo_excl = 0; a.hi_incl = 1024;
+    if (max_tile_count > 0) {   // lists of up to 1024 keys: one block per list (24 KB of LDS: a block of another class costs nothing)
+        const size_t lds_k = 2 * sizeof(uint64_t) * 1024 + radix_lds * (GS_SORT1K_THREADS / 64);
+        hipLaunchKernelGGL(tile_radix_sort_kernel<GS_SORT1K_THREADS>, dim3(grid), dim3(GS_SORT1K_THREADS), lds_k, st, a);
+        GS_LAUNCH_CHECK("tile_radix_sort_kernel");
+    }
+    if (max_tile_count <= 1024) return GS_OK;
+    GS_HIP_CHECK(hipMemsetAsync(counts, 0, 64 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(class_items_kernel, dim3((grid + 255) / 256), dim3(256), 0, st, (int)grid, a.isect_offsets, items, counts, a.guard);
+    GS_LAUNCH_CHECK("class_items_kernel");
+    {   // (1024, 4096]: 72 KB -> two blocks per CU
+        a.lo_excl = 1024; a.hi_incl = 4096;
+        const size_t lds_k = 2 * sizeof(uint64_t) * 4096 + radix_lds * (GS_SORT4K_THREADS / 64);
+        if (int rc = ensure_lds((const void*)tile_radix_sort_items_kernel<GS_SORT4K_THREADS>, lds_k)) return rc;
+        hipLaunchKernelGGL(tile_radix_sort_items_kernel<GS_SORT4K_THREADS>, dim3(grid < 512u ? grid : 512u), dim3(GS_SORT4K_THREADS), lds_k, st, a,
+                           (const int32_t*)items, (const int32_t*)counts);
+        GS_LAUNCH_CHECK("tile_radix_sort_items_kernel<4096>");
+    }
+    if (max_tile_count > 4096) {   // (4096, 8192]: 152 KB -> one block per CU
+        a.lo_excl = 4096; a.hi_incl = kSegLen;
+        const size_t lds_k = 2 * sizeof(uint64_t) * (size_t)kSegLen + radix_lds * (768 / 64);
+        if (int rc = ensure_lds((const void*)tile_radix_sort_items_kernel<768>, lds_k)) return rc;
+        hipLaunchKernelGGL(tile_radix_sort_items_kernel<768>, dim3(grid < 256u ? grid : 256u), dim3(768), lds_k, st, a,
+                           (const int32_t*)(items + grid), (const int32_t*)(counts + 1));
+        GS_LAUNCH_CHECK("tile_radix_sort_items_kernel<8192>");
+    }
+    if (max_tile_count > kSegLen) {   // (8192, 65536]: segments sorted in LDS, then rank-merged
+        a.lo_excl = kSegLen; a.hi_incl = kSortLarge; a.seg = 1;
+        const size_t lds_k = 2 * sizeof(uint64_t) * (size_t)kSegLen + radix_lds * (768 / 64);
+        if (int rc = ensure_lds((const void*)tile_radix_sort_items_kernel<768>, lds_k)) return rc;
+        const int32_t* it = items + 2 * (size_t)grid;
+        const int32_t* nit = counts + 2;
+        hipLaunchKernelGGL(tile_radix_sort_items_kernel<768>, dim3(256), dim3(768), lds_k, st, a, it, nit);
+        GS_LAUNCH_CHECK("tile_radix_sort_items_kernel<segments>");
+        hipLaunchKernelGGL(seg_merge_kernel, dim3(512), dim3(1024), 0, st, a, it, nit);
+        GS_LAUNCH_CHECK("seg_merge_kernel");
+        if (a.coarse) {
+            hipLaunchKernelGGL(seg_copy_kernel, dim3(512), dim3(1024), 0, st, a, it, nit);
+            GS_LAUNCH_CHECK("seg_copy_kernel");
+        }
+        a.seg = 0;
     }
     if (max_tile_count > kSortLarge) {
         a.lo_excl = kSortLarge; a.hi_incl = 0x7fffffff;
         hipLaunchKernelGGL(tile_sort_kernel<false>, dim3(grid), dim3(1024), 0, st, a);
         GS_LAUNCH_CHECK("tile_sort_kernel<global>");
     }
+    (void)lo_excl;
     return GS_OK;
 }
 
@@ -1089,8 +1225,9 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     a.isect_offsets = isect_offsets; a.keys = (unsigned long long*)keys_tmp; a.slot_gid = slot_gid;
     a.isect_ids = isect_ids; a.flatten_ids = flatten_ids; a.slots = slots;
     a.guard = current_guard().info;
-    a.coarse = 0;
-    return launch_list_sorts(st, a, (unsigned)(C * tiles), max_tile_count);
+    a.coarse = 0; a.seg = 0; a.merged = nullptr;
+    static_assert(2 + kSegMax == 10, "bin_layout sizes the work lists for kSegMax == 8");
+    return launch_list_sorts(st, a, (unsigned)(C * tiles), max_tile_count, (int32_t*)(ws + L.items_off));
 }
 
 // ------------------------------------------------------------------------------------------------ two-level binning
@@ -1154,7 +1291,7 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     // sort classes launched: up to the one that holds coarse_list_cap (<= 0: all of them); a longer bin list raises
     // flags bit 8 and nothing is emitted
     int64_t list_cap = 0x7fffffff;
-    if (coarse_list_cap > 0) list_cap = coarse_list_cap <= 1024 ? 1024 : coarse_list_cap <= 4096 ? 4096 : coarse_list_cap <= 8192 ? 8192
+    if (coarse_list_cap > 0) list_cap = coarse_list_cap <= 1024 ? 1024 : coarse_list_cap <= 4096 ? 4096 : coarse_list_cap <= kSegLen ? kSegLen
                                         : coarse_list_cap <= kSortLarge ? kSortLarge : 0x7fffffff;
     const size_t lds = sizeof(uint32_t) * ((size_t)L.nbins + 32);
     if (int rc = ensure_lds((const void*)bins_hist_kernel, lds)) return rc;
@@ -1179,10 +1316,11 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
         a.tiles = L.nbins; a.tile_bits = 0;
         a.isect_offsets = coff; a.keys = (unsigned long long*)coarse_keys; a.slot_gid = nullptr;
         a.isect_ids = nullptr; a.flatten_ids = nullptr; a.slots = nullptr;
-        a.guard = info_dev; a.coarse = 1;
+        a.guard = info_dev; a.coarse = 1; a.seg = 0;
+        a.merged = (unsigned long long*)(ws + L.staged_off);   // (free until the refinement's first pass fills it)
         // (the longest bin list is not known to the host here: every class is launched, the blocks of the classes a
         //  list does not belong to return at once; a list can never be longer than the key buffer)
-        if (int rc = launch_list_sorts(st, a, (unsigned)cb, list_cap < coarse_cap ? list_cap : coarse_cap)) return rc;
+        if (int rc = launch_list_sorts(st, a, (unsigned)cb, list_cap < coarse_cap ? list_cap : coarse_cap, (int32_t*)(ws + L.items_off))) return rc;
     }
     RefineArgs r;
     fill_refine_args(r, L, C, tile_w, tile_h, ws, coarse_keys, bbox, info_dev);

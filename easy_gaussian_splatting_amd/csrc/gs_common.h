@@ -60,6 +60,7 @@ struct BinLayout {
     size_t tile_cnt_off; // u32 [C*tiles]
     size_t grp_tot_off;  // u32 [C*groups]          intersections emitted by each group
     size_t grp_base_off; // u32 [C*groups]          exclusive scan of the above
+    size_t items_off;    // i32 work lists of the sort classes above 1024 keys (gs_binning.hip: class_items_kernel)
     size_t total;
 };
 BinLayout bin_layout(int C, int64_t N, int tiles);

@@ -103,7 +103,7 @@ def binning_choice(footprint) -> str:
 
 # host-side diagnostics: time spent blocked on the list-size read-back (bench.py reports it; a wait
 # near zero means the host, not the GPU, paces the loop)
-stats = {"sync_wait_ns": 0, "calls": 0}
+stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0}
 
 
 def _pinned_info(device: torch.device) -> Tensor:
@@ -230,6 +230,8 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         if int(info_host[3]) & 4:
             alloc_coarse(int(info_host[4]) + (int(info_host[4]) >> 2) + 1024)
         list_cap[0] = 0
+        with _state_lock:
+            stats["coarse_retries"] += 1
         count()
         info_host.copy_(info_dev, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()

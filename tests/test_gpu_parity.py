@@ -603,12 +603,15 @@ def fuzz_case(case, attempt=0):
 
 # GS_FUZZ_CASES=N widens the sweep (tools / ad-hoc hunting; the committed suite runs 24 cases)
 @pytest.mark.parametrize("case", range(int(os.environ.get("GS_FUZZ_CASES", "24"))))
-def test_randomised_configurations(case):
+def test_randomised_configurations(case, monkeypatch):
     """Seeded sweep over sizes / SH degree / stored K / cameras / background / splat scale / culling
     mode / SH layout: every combination must meet the same forward and gradient tolerances.  A drawn scene in which
     more than 5 % of the pixels sit on a blend threshold (a flat, faint splat covering the image at alpha ~ 1/255) is
     useless as a parity case: the next scene seed of the same configuration is drawn instead (at most 8, printed)."""
     from easy_gaussian_splatting_amd.rendering import rasterization
+    # the binning pipeline alternates with the case: per-tile sort / two-level with 2x2- and 4x4-tile bins
+    monkeypatch.setenv("GS_BINNING", ("tiles", "bins", "bins")[case % 3])
+    monkeypatch.setenv("GS_BINS_SHIFT", ("", "1", "2")[case % 3])
     for attempt in range(8):
         sc, (deg, W, H, use_bg, split, culling) = fuzz_case(case, attempt)
         t = to_dev(sc)
@@ -641,10 +644,113 @@ def test_randomised_configurations(case):
         check_backward(hip, fw)
 
 
-@pytest.mark.parametrize("n,lo,hi", [(250, 64, 1024), (1500, 1024, 4096), (5000, 4096, 8192), (10000, 8192, 16384)])
-def test_every_sort_size_class_orders_like_a_stable_global_sort(n, lo, hi):
-    """One scene per size class of the per-tile sort (radix <= 1024 / 4096 / 8192, bitonic <= 16384):
-    inside every tile the ids must be ordered by (depth bits, flatten id), every id exactly once."""
+def _binning_scenes():
+    big = make_scene(2500, 320, 208, sh_degree=1, seed=61, k_store=4, n_views=2, scale_range=(0.05, 0.6), dist=5.0)   # footprints of 20+ tiles
+    return {"long_lists": config_long_lists(), "dense_3000": dense_scene(3000, 13), "two_views_big": big,
+            "tiny": make_scene(50, 40, 24, sh_degree=3, seed=1, scale_range=(0.05, 0.4), dist=4.0),
+            "ragged": make_scene(1237, 333, 77, sh_degree=1, seed=3, k_store=4, scale_range=(0.02, 0.3), dist=4.0)}
+
+
+@pytest.mark.parametrize("culling", ["gsplat", "tight"])
+@pytest.mark.parametrize("name", ["long_lists", "dense_3000", "two_views_big", "tiny", "ragged"])
+def test_binning_pipelines_agree_bit_for_bit(name, culling, monkeypatch):
+    """The per-tile pipeline (every tile list emitted and sorted) and the two-level one (coarse bins sorted, tiles refined
+    out of them; 2x2- and 4x4-tile bins) must produce the same lists, offsets, gradient-row slots, image and gradients --
+    bit for bit -- including the first call on a device, whose coarse buffer is too small and is re-run."""
+    from easy_gaussian_splatting_amd import rendering
+    sc = _binning_scenes()[name]
+    runs = {}
+    for mode, shift in (("tiles", ""), ("bins", "1"), ("bins", "2")):
+        monkeypatch.setenv("GS_BINNING", mode)
+        monkeypatch.setenv("GS_BINS_SHIFT", shift)
+        rendering._coarse_hint.clear()
+        retries = rendering.stats["coarse_retries"]
+        dbg = {}
+        hip = run_hip(sc, culling=culling, dbg=dbg)
+        if mode == "bins" and name == "long_lists":
+            assert rendering.stats["coarse_retries"] > retries, "the first call must have outgrown the default coarse buffer"
+            hip2 = run_hip(sc, culling=culling)   # second call: sized from the hint, no retry
+            assert torch.equal(hip2["meta"]["flatten_ids"], hip["meta"]["flatten_ids"]) and torch.equal(hip2["img"], hip["img"])
+        runs[(mode, shift)] = hip
+    ref = runs[("tiles", "")]
+    for key, hip in runs.items():
+        for k in ("flatten_ids", "isect_ids", "isect_offsets", "tiles_per_gauss", "radii"):
+            assert torch.equal(hip["meta"][k], ref["meta"][k]), (key, k)
+        assert torch.equal(hip["img"], ref["img"]) and torch.equal(hip["alpha"], ref["alpha"]), key
+        for a, b in zip(hip["grads"], ref["grads"]):
+            assert torch.equal(a, b), key
+        assert torch.equal(hip["meta"]["means2d"].absgrad, ref["meta"]["means2d"].absgrad)
+
+
+def test_two_level_binning_flags_and_capacities():
+    """C-ABI contract of gs_bins_count: a coarse key buffer or a sort-class bound that is too small raises flags 4 / 8 in
+    info[3], reports the sizes needed in info[4] / info[5], and emits nothing; the repeated call with those sizes succeeds
+    and agrees with the per-tile count."""
+    import ctypes as ct
+    from easy_gaussian_splatting_amd import _native as nat
+    d = dev()
+    sc = config_long_lists()
+    t = to_dev(sc)
+    L = nat.lib()
+    C, N = 1, sc["means"].shape[0]
+    W, H = int(sc["width"]), int(sc["height"])
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    tiles = tw * th
+    i32 = dict(dtype=torch.int32, device=d); f32 = dict(dtype=torch.float32, device=d)
+    radii = torch.empty((C, N), **i32); m2 = torch.empty((C, N, 2), **f32); dep = torch.empty((C, N), **f32)
+    con = torch.empty((C, N, 3), **f32); col = torch.empty((C, N, 3), **f32); rec = torch.empty((C * N, 12), **f32)
+    bbox = torch.empty((C * N, 4), **i32); tpg = torch.empty((C, N), **i32)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda x: x.data_ptr()
+    nat.check(L.gs_project_fwd(st, C, N, 16, 3, P(t["means"]), P(t["quats"]), P(t["scales"]), P(t["opacities"]), P(t["shs"]), None, 0,
+                               P(t["viewmats"]), P(t["Ks"]), W, H, 0.3, 0.01, 1e10, 0.0, 0, 1, 0, P(radii), P(m2), P(dep),
+                               P(con), P(col), P(rec), P(bbox), P(tpg)), "gs_project_fwd")
+    off = torch.empty((tiles + 1,), **i32); boff = torch.empty((tiles + 1,), **i32); order = torch.empty((tiles,), **i32)
+    cum = torch.empty((C * N,), **i32)
+    info = torch.zeros((8,), dtype=torch.int64, device=d)
+    host = (ct.c_int64 * 8)()
+
+    def count(cap, list_cap, shift=2):
+        keys = torch.empty((max(cap, 1),), dtype=torch.int64, device=d)
+        ws = torch.empty((int(L.gs_bins_workspace_bytes(C, N, tw, th, shift, cap)),), dtype=torch.uint8, device=d)
+        nat.check(L.gs_bins_count(st, C, N, tw, th, shift, P(bbox), P(dep), P(ws), ws.numel(), P(keys), cap, list_cap, P(cum), P(off),
+                                  P(boff), P(order), P(info), host), "gs_bins_count")
+        return [int(v) for v in host]
+
+    h = count(1000, 0)
+    assert h[3] & 4 and h[4] > 1000, h
+    need, longest = h[4], h[5]
+    assert longest > 1024
+    h = count(need, 1024)
+    assert h[3] == 8 and h[5] == longest, h
+    h = count(need, longest)
+    assert h[3] == 0 and h[4] == need and h[0] == int(tpg.sum()), h
+    assert torch.equal(torch.diff(off.long()), torch.bincount(_tile_of_entries(bbox, tw), minlength=tiles))
+
+
+def _tile_of_entries(bbox, tw):
+    """Tile index of every (Gaussian, tile) pair of the footprints in `bbox` (rectangles; masks for <= 32 tiles)."""
+    b = bbox.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    out = []
+    for x, y, mask, cnt in b:
+        if cnt == 0:
+            continue
+        x0, x1, y0, y1 = x & 0xFFFF, x >> 16, y & 0xFFFF, y >> 16
+        w = x1 - x0
+        for i in range(w * (y1 - y0)):
+            if w * (y1 - y0) > 32 or (mask >> i) & 1:
+                out.append((y0 + i // w) * tw + x0 + i % w)
+    return torch.tensor(out, dtype=torch.int64, device=bbox.device)
+
+
+@pytest.mark.parametrize("binning", ["tiles", "bins"])
+@pytest.mark.parametrize("n,lo,hi", [(250, 64, 1024), (1500, 1024, 4096), (5000, 4096, 8192), (10000, 8192, 16384),
+                                     (30000, 16384, 65536), (70000, 65536, 1 << 20)])
+def test_every_sort_size_class_orders_like_a_stable_global_sort(n, lo, hi, binning, monkeypatch):
+    """One scene per size class of the list sort (LDS radix <= 1024 / 4096 / 8192, 8192-key segments + rank merge <= 65536,
+    global bitonic network beyond), per-tile and coarse-bin lists alike: inside every tile the ids must be ordered by
+    (depth bits, flatten id), every id exactly once."""
+    monkeypatch.setenv("GS_BINNING", binning)
     sc = dense_scene(n, 100 + n)
     hip = run_hip(sc, bwd=False)
     meta = hip["meta"]
