@@ -418,6 +418,7 @@ def run_rank(args) -> int:
                 st_ll = rendering.profile_stages(False) or {}
                 n_ll = int(meta_ll["flatten_ids"].shape[0])
                 out_ll[mode] = {"n_isects": n_ll, "mean_list": round(n_ll / (120 * 68), 1), "fwd_bwd_ms": _percentiles(ms_ll),
+                                "binning": rendering.last_binning(device),
                                 "stage_ms": {k[3:]: round(float(np.mean(v)), 4) for k, v in sorted(st_ll.items())}}
             extras["long_lists"] = dict(out_ll, workload="200000 heavy-tailed splats (scale 0.02-0.3), 1920x1080, SH3: rasterization fwd+bwd, eager")
             del tt, ins, sh0, shr, vc

@@ -71,14 +71,14 @@ _coarse_hint: Dict[int, dict] = {}   # per device: what the last two-level binni
 
 def bin_shift_for(footprint) -> int:
     """Bin size of the two-level binning from the mean footprint (tile-list entries per Gaussian) of the previous call:
-    2x2-tile bins (1) while Gaussians cover a few tiles, 4x4 (2) beyond; 0 = library default (first call).
-    GS_BINS_SHIFT overrides."""
+    4x4-tile bins (2) from the footprint at which the two-level binning is chosen at all, 2x2 (1) below (only reached
+    when GS_BINNING forces it); 0 = library default (first call).  GS_BINS_SHIFT overrides."""
     env = os.environ.get("GS_BINS_SHIFT")
     if env:
         return int(env)
     if footprint is None:
         return 0
-    return 1 if footprint < 8.0 else 2
+    return 1 if footprint < BINS_FROM_FOOTPRINT else 2   # (tools/binning_sweep.py: 4x4 wins wherever the two-level binning does)
 
 
 def binning_mode() -> str:
@@ -90,7 +90,16 @@ def binning_mode() -> str:
     return mode
 
 
-BINS_FROM_FOOTPRINT = 6.0   # mean tile-list entries per Gaussian from which sorting coarse bins beats sorting tiles
+# mean tile-list entries per Gaussian from which sorting coarse bins beats sorting tiles (tools/binning_sweep.py on MI355X,
+# 1080p: 0.22 vs 0.23 ms at 4.8, 0.27 vs 0.23 at 9.5, 0.42 vs 0.23 at 21, 1.10 vs 0.30 at 106)
+BINS_FROM_FOOTPRINT = 6.0
+
+
+def last_binning(device=None) -> Optional[str]:
+    """"tiles" / "bins": the pipeline the last eager rasterization on `device` went through (None before the first)."""
+    key = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
+    with _state_lock:
+        return _coarse_hint.get(key, {}).get("mode")
 
 
 def binning_choice(footprint) -> str:
@@ -246,9 +255,9 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         if two_level:
             _coarse_hint[hint_key] = dict(entries=int(info_host[4]) + (int(info_host[4]) >> 2) + 1024,
                                           longest=int(info_host[5]) + (int(info_host[5]) >> 2) + 64,
-                                          footprint=n_isects / max(1, C * N))
+                                          footprint=n_isects / max(1, C * N), mode="bins")
         else:
-            _coarse_hint[hint_key] = dict(footprint=n_isects / max(1, C * N))
+            _coarse_hint[hint_key] = dict(footprint=n_isects / max(1, C * N), mode="tiles")
     if two_level:
         isect_ids, flatten_ids, slots = lists
         _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bins_lists(st, C, N, tw, th, shift, _ptr(bbox), _ptr(bufs["ws"]), bufs["ws"].numel(),
