@@ -352,6 +352,9 @@ __device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K
         }
 }
 
+#ifndef GS_ADAM_BATCH
+#define GS_ADAM_BATCH 3
+#endif
 // The same walk over one block's SH-gradient tile, but as an in-place Adam update of sh_0 / sh_rest (split layout)
 // and their moments: the 48 SH gradients per Gaussian (81 % of all gradient bytes at SH3) are never written to HBM
 // nor read back by a separate optimizer pass.  (The block staged its own SH rows into LDS before the barrier in
@@ -376,19 +379,35 @@ __device__ __forceinline__ void adam_sh_tile(const float* tile, int rows, int K,
         const bool aligned = ((((uintptr_t)pr | (uintptr_t)mr | (uintptr_t)vr) & 15) == 0);
         const int vec_end = aligned ? (total & ~3) : 0;
         float4 *pr4 = reinterpret_cast<float4*>(pr), *mr4 = reinterpret_cast<float4*>(mr), *vr4 = reinterpret_cast<float4*>(vr);
-        for (int e4 = threadIdx.x; e4 < (vec_end >> 2); e4 += blockDim.x) {
-            float gg[4];
+        // kAdamBatch iterations' worth of parameters and moments are requested before the first update is stored: the
+        // in-place stores may alias the next loads as far as the compiler can tell, and a thread would otherwise pay one
+        // HBM round trip per 16 bytes x 3
+        constexpr int kAdamBatch = GS_ADAM_BATCH;
+        const int n4 = vec_end >> 2;
+        for (int e0 = threadIdx.x; e0 < n4; e0 += kAdamBatch * (int)blockDim.x) {
+            float4 p[kAdamBatch], m[kAdamBatch], v[kAdamBatch];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = (e4 << 2) + i, g = e / rest_f;
-                gg[i] = tile[g * stride + 3 + (e - g * rest_f)];
+            for (int u = 0; u < kAdamBatch; ++u) {
+                const int e4 = e0 + u * (int)blockDim.x;
+                if (e4 < n4) { p[u] = pr4[e4]; m[u] = nt_load4(mr4 + e4); v[u] = nt_load4(vr4 + e4); }
             }
-            float4 p = pr4[e4], m = nt_load4(mr4 + e4), v = nt_load4(vr4 + e4);
-            adam1(p.x, gg[0], m.x, v.x, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
-            adam1(p.y, gg[1], m.y, v.y, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
-            adam1(p.z, gg[2], m.z, v.z, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
-            adam1(p.w, gg[3], m.w, v.w, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
-            pr4[e4] = p; nt_store4(m, mr4 + e4); nt_store4(v, vr4 + e4);
+#pragma unroll
+            for (int u = 0; u < kAdamBatch; ++u) {
+                const int e4 = e0 + u * (int)blockDim.x;
+                if (e4 < n4) {
+                    float gg[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = (e4 << 2) + i, g = e / rest_f;
+                        gg[i] = tile[g * stride + 3 + (e - g * rest_f)];
+                    }
+                    adam1(p[u].x, gg[0], m[u].x, v[u].x, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
+                    adam1(p[u].y, gg[1], m[u].y, v[u].y, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
+                    adam1(p[u].z, gg[2], m[u].z, v[u].z, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
+                    adam1(p[u].w, gg[3], m[u].w, v[u].w, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, ssr);
+                    pr4[e4] = p[u]; nt_store4(m[u], mr4 + e4); nt_store4(v[u], vr4 + e4);
+                }
+            }
         }
         for (int e = vec_end + threadIdx.x; e < total; e += blockDim.x) {
             const int g = e / rest_f;
