@@ -49,6 +49,7 @@ struct BlendFwdArgs {
     int2* qlist;           // [4*I] (flatten id, row slot): per tile 4 sublists of capacity len(tile)
     int32_t* qcnt;         // [C*tiles*4]        sublist lengths
     uint8_t* qmask;        // [I] by slot        which quadrant rows of an intersection exist
+    int tail_clear;        // 1: a tile that stops early zeroes the masks of the rest of its list itself
     int32_t* unit_counter; // [1]
     int4* unit_desc;       // [8*n_buckets]      (tile*4+quadrant, entries in the unit, first qlist pair, checkpoint row)
     const int64_t* guard;  // step guard (gs_guard_set) or nullptr
@@ -122,7 +123,9 @@ __global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArg
         if (!(qa[0] || qa[1] || qa[2] || qa[3])) {
             // every pixel of the tile is finished: the rest of the list contributes nothing, but its
             // quadrant masks must still read "no rows" (this replaces a memset of the whole array)
-            if (CKPT)
+            // (long lists: the host has cleared the array instead -- the slots of a tile's abandoned tail are scattered, and
+            //  tens of millions of scattered byte stores cost several times the rest of the kernel)
+            if (CKPT && a.tail_clear)
                 for (int i = lo + b * GS_BUCKET + lane; i < hi; i += 64) a.qmask[a.slots[i]] = 0;
             break;
         }
@@ -453,7 +456,11 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
 #endif
     constexpr int kFwdWaves = GS_FWD_WAVES;
     const dim3 grid((n_tiles + kFwdWaves - 1) / kFwdWaves), block(64 * kFwdWaves);
+    // mean list of 1024 entries or more (opaque captures stop after a few per cent of such lists): one streaming clear of
+    // the quadrant masks instead of scattered byte stores over every abandoned tail
+    a.tail_clear = !(train && n_isects / (int64_t)n_tiles >= 1024);
     if (train) {
+        if (!a.tail_clear) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
         GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves>), grid, block, 0, st, a);
     } else {

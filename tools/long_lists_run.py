@@ -21,3 +21,17 @@ torch.cuda.synchronize()
 cnt = torch.diff(torch.cat([meta["isect_offsets"].reshape(-1), torch.tensor([meta["flatten_ids"].numel()], device=dev, dtype=torch.int32)]))
 print(f"{mode}: I={meta['flatten_ids'].numel()} mean list {float(cnt.float().mean()):.0f} max list {int(cnt.max())} "
       f"lists >1024: {int((cnt > 1024).sum())} >4096: {int((cnt > 4096).sum())} >8192: {int((cnt > 8192).sum())} >16384: {int((cnt > 16384).sum())} of {cnt.numel()}")
+dbg = {}
+img, alpha, meta = rasterization(*ins, t["viewmats"], t["Ks"], W, H, sh_degree=int(sc["sh_degree"]), packed=False,
+                                 backgrounds=t["backgrounds"], absgrad=True, _tile_culling=mode, _debug=dbg)
+torch.cuda.synchronize()
+q = int(dbg["qcnt"].sum()); u = int(dbg["unit_counter"][0])
+print(f"quadrant entries kept for the backward {q} ({q / (4 * meta['flatten_ids'].numel()):.3f} of 4 I), work units {u}; saturated pixels {float((alpha > 1 - 2e-4).float().mean()):.3f}")
+import time
+with torch.no_grad():
+    for _ in range(3):
+        rasterization(*ins, t["viewmats"], t["Ks"], W, H, sh_degree=int(sc["sh_degree"]), packed=False, backgrounds=t["backgrounds"], _tile_culling=mode)
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(10):
+        rasterization(*ins, t["viewmats"], t["Ks"], W, H, sh_degree=int(sc["sh_degree"]), packed=False, backgrounds=t["backgrounds"], _tile_culling=mode)
+    torch.cuda.synchronize(); print(f"inference forward {(time.time() - t0) * 100:.3f} ms")
