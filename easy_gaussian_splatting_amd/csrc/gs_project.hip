@@ -475,20 +475,65 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
             bits1 = bits2;
         }
     }
+    // Gaussians with many rows: the whole wave sums one of them at a time.  The quadrant masks of the NEXT one are
+    // requested before the rows of the current one are read (a wave holds up to 64 such Gaussians and would otherwise
+    // pay two dependent round trips for each in turn), and a Gaussian none of whose listed entries any pixel took --
+    // most of them behind an opaque surface -- costs no reduction at all.  Per lane the rows are still added in slot
+    // order (fixed order -> reproducible sums).
+    constexpr int kPre = 4;   // 256 slots' masks ahead
+    auto fetch_masks = [&](int bbase, int bcnt, int (&mk)[kPre]) {
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) { const int r = lane_id() + 64 * k; mk[k] = r < bcnt ? (int)a.qmask[bbase + r] : 0; }
+    };
+    auto add_bits = [&](RowSum& p, int64_t slot, int bits) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (bits & (1 << q)) {
+                const float4* r = a.rows + 3 * (slot * 4 + q);
+                const float4 x = r[0], y = r[1], z = r[2];
+                p.v[0] += x.x; p.v[1] += x.y; p.v[2] += x.z; p.v[3] += x.w;
+                p.v[4] += y.x; p.v[5] += y.y; p.v[6] += y.z; p.v[7] += y.w;
+                p.v[8] += z.x; p.v[9] += z.y; p.v[10] += z.z;
+            }
+        }
+    };
     unsigned long long big = __ballot(cnt > kCoopRows);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
+    int cur = -1, ccnt = 0, cbase = 0, cmk[kPre], nmk[kPre];
+    if (big) {
+        cur = __ffsll((long long)big) - 1;
         big &= big - 1;
-        const int bcnt = __shfl(cnt, src, 64), bbase = __shfl(base, src, 64);
+        ccnt = __shfl(cnt, cur, 64); cbase = __shfl(base, cur, 64);
+        fetch_masks(cbase, ccnt, cmk);
+    }
+    while (cur >= 0) {
+        int nxt = -1, ncnt = 0, nbase = 0;
+        if (big) {
+            nxt = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            ncnt = __shfl(cnt, nxt, 64); nbase = __shfl(base, nxt, 64);
+            fetch_masks(nbase, ncnt, nmk);
+        }
         RowSum p;
 #pragma unroll
         for (int i = 0; i < 12; ++i) p.v[i] = 0.f;
-        for (int r = lane_id(); r < bcnt; r += 64) row_add(p, a.rows, a.qmask, (int64_t)(bbase + r));
+        bool any_rows = false;
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            const float t = wave_reduce_add(p.v[i]);
-            if (lane_id() == src) s.v[i] = t;
+        for (int k = 0; k < kPre; ++k)
+            if (cmk[k]) { add_bits(p, (int64_t)(cbase + lane_id() + 64 * k), cmk[k]); any_rows = true; }
+        for (int r = lane_id() + 64 * kPre; r < ccnt; r += 64) {
+            const int bits = a.qmask[cbase + r];
+            if (bits) { add_bits(p, (int64_t)(cbase + r), bits); any_rows = true; }
         }
+        if (__any(any_rows)) {
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                const float t = wave_reduce_add(p.v[i]);
+                if (lane_id() == cur) s.v[i] = t;
+            }
+        }
+        cur = nxt; ccnt = ncnt; cbase = nbase;
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) cmk[k] = nmk[k];
     }
 
     // ---- 2. colour path
