@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU-box call that regenerates everything under profiles/ for a round:  tools/final_profiles.sh r02
+# (SQ counters and HBM traffic first: bench.py quotes them in its roofline objects)
+tag=${1:-r02}
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 600 bash tools/prof_sq.sh $tag > gpurun_out/${tag}_sq.log 2>&1
+timeout 400 bash tools/prof_pmc.sh $tag > gpurun_out/${tag}_pmc.log 2>&1
+cp gpurun_out/${tag}_sq_counters.json gpurun_out/${tag}_pmc_traffic.json profiles/ 2>/dev/null
+timeout 300 bash tools/prof_bench.sh ${tag}_bench > gpurun_out/${tag}_prof_bench.log 2>&1
+timeout 600 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
+for m in tight gsplat; do
+  timeout 200 bash tools/prof_cmd.sh ${tag}_longlists_$m tools/long_lists_run.py $m 10 > /dev/null 2>&1
+  grep -v "amdgpu.ids\|^W2026\|^E2026" /tmp/${tag}_longlists_$m.log > gpurun_out/${tag}_longlists_$m.txt
+done
+GS_BINNING=bins timeout 300 bash tools/prof_pmc.sh ${tag}_longlists tools/long_lists_run.py tight 3 > /dev/null 2>&1
+timeout 900 python tools/config_table.py > gpurun_out/${tag}_configs.md 2> gpurun_out/${tag}_configs.err
+timeout 200 python tools/binning_sweep.py 2>/dev/null > gpurun_out/${tag}_binning_sweep.txt
+head -c 600 gpurun_out/${tag}_bench_line.json; echo; tail -3 gpurun_out/${tag}_bench.err

@@ -13,11 +13,15 @@ sc = config_long_lists(n=200_000, width=1920, height=1080)
 t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
 W, H = int(sc["width"]), int(sc["height"])
 ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+from easy_gaussian_splatting_amd import rendering
 for it in range(iters + 2):
+    if it == 2:
+        rendering.profile_stages(True)
     img, alpha, meta = rasterization(*ins, t["viewmats"], t["Ks"], W, H, sh_degree=int(sc["sh_degree"]), packed=False,
                                      backgrounds=t["backgrounds"], absgrad=True, _tile_culling=mode)
     img.sum().backward()
-torch.cuda.synchronize()
+st_ms = rendering.profile_stages(False)
+print("stages (ms):", {k[3:]: round(float(np.mean(v)), 4) for k, v in sorted(st_ms.items())}, "total", round(sum(float(np.mean(v)) for v in st_ms.values()), 4))
 cnt = torch.diff(torch.cat([meta["isect_offsets"].reshape(-1), torch.tensor([meta["flatten_ids"].numel()], device=dev, dtype=torch.int32)]))
 print(f"{mode}: I={meta['flatten_ids'].numel()} mean list {float(cnt.float().mean()):.0f} max list {int(cnt.max())} "
       f"lists >1024: {int((cnt > 1024).sum())} >4096: {int((cnt > 4096).sum())} >8192: {int((cnt > 8192).sum())} >16384: {int((cnt > 16384).sum())} of {cnt.numel()}")
