@@ -84,8 +84,14 @@ __device__ __forceinline__ void blend_pair(const float alpha, const bool ok, con
     T = Tn;
 }
 
+// The training instantiation needs 96 VGPRs left to itself (5 waves / SIMD: the 8160 tile-waves of a 1080p frame then run
+// in 1.6 rounds); held to 80 (11 spilled) it keeps 6 resident and is 3 % faster.  The inference one fits 8 waves / SIMD.
+#ifndef GS_FWD_TRAIN_WAVES_PER_EU
+#define GS_FWD_TRAIN_WAVES_PER_EU 6
+#endif
+#define GS_FWD_ATTR __attribute__((amdgpu_waves_per_eu(CKPT ? GS_FWD_TRAIN_WAVES_PER_EU : 8, 8)))
 template <bool CKPT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void blend_fwd_kernel(const BlendFwdArgs a) {
+__global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const BlendFwdArgs a) {
     __shared__ float4 srec_all[WAVES][GS_BUCKET * 3];
     float4* srec = srec_all[threadIdx.x >> 6];
     const int ti = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
