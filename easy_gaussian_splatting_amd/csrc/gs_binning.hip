@@ -11,13 +11,14 @@
 //                       group bases, {I, n_buckets, max_tile}
 //   bin_emit_kernel     same blocks as hist: per-tile write cursor in LDS (returning ds_add),
 //                       emits (depth bits << 32 | row slot) into its tile's segment
-//   tile_radix_sort_kernel  one block per tile (lists up to 8192 entries): four stable 8-bit LDS
-//                       counting passes on the depth word -> depth order; ties by flatten index
-//                       (slot order == flatten order), as the stable global sort of the reference
-//                       yields, restored by the bitonic network in the rare tile that has
-//                       out-of-order equal depths.
-//   tile_sort_kernel    bitonic network on the 64-bit keys, in LDS (<= 16384 entries) or in place
-//                       in global memory beyond that.
+//   tile_radix_sort_kernel  one block per list of <= 1024 keys: four stable 8-bit LDS counting passes on the depth word ->
+//                       depth order; ties by flatten index (slot order == flatten order), as the stable global sort of
+//                       the reference yields, restored by a bitonic network in the rare list that has out-of-order
+//                       equal depths.  Longer lists: the same sort over compacted work lists (class_items_kernel,
+//                       tile_radix_sort_items_kernel: <= 4096 and <= 8192 keys), 8192-key segments + a rank merge up to
+//                       65536 keys (seg_merge_kernel), a bitonic network in place in global memory beyond.
+// Second half of the file: the two-level binning (gs_bins_count / gs_bins_lists) for scenes whose Gaussians cover many
+// tiles -- coarse bins sorted with the same kernels, tiles refined out of them by ordered compaction.
 // The "slot" carried in the key's low word is the index of this intersection's gradient row
 // (cum_tiles[f] + k): rows of one Gaussian are contiguous, which lets the backward reduce them
 // with plain coalesced loads instead of float atomics.

@@ -83,3 +83,23 @@ def test_camera_gradients_are_refused_not_dropped():
     K = torch.eye(3)[None]
     with pytest.raises(NotImplementedError):
         rasterization(z(2, 3), z(2, 4), z(2, 3), z(2), z(2, 3), V, K, 16, 16, packed=False)
+
+
+def test_binning_choice_host_logic(monkeypatch):
+    """rendering.binning_choice / bin_shift_for: the pipeline and bin size from the previous call's mean footprint, the
+    environment overrides, and a loud error for an unknown mode (host logic only: no GPU)."""
+    from easy_gaussian_splatting_amd import rendering as R
+    monkeypatch.delenv("GS_BINNING", raising=False)
+    monkeypatch.delenv("GS_BINS_SHIFT", raising=False)
+    assert R.binning_choice(None) == "tiles" and R.binning_choice(2.8) == "tiles"
+    assert R.binning_choice(R.BINS_FROM_FOOTPRINT) == "bins" and R.binning_choice(105.9) == "bins"
+    assert R.bin_shift_for(None) == 0 and R.bin_shift_for(3.0) == 1 and R.bin_shift_for(40.0) == 2
+    monkeypatch.setenv("GS_BINNING", "bins")
+    assert R.binning_choice(1.0) == "bins"
+    monkeypatch.setenv("GS_BINNING", "tiles")
+    assert R.binning_choice(500.0) == "tiles"
+    monkeypatch.setenv("GS_BINS_SHIFT", "1")
+    assert R.bin_shift_for(500.0) == 1
+    monkeypatch.setenv("GS_BINNING", "quadtree")
+    with pytest.raises(ValueError):
+        R.binning_choice(3.0)
