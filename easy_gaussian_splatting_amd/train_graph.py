@@ -452,7 +452,8 @@ class TrainStepGraph:
         self.stats["overflows"] += 1
         self.stats["replayed_steps"] += len(redo)
         first = redo[0]
-        self._build({"w2c": first[2], "K": first[3]}, first[4], first[5], min_cap=n_isects, min_cap_tile=max_tile)
+        # (min_cap >= 1 forces a fresh probe even when only a coarse-bin capacity was exceeded and the list sizes read 0)
+        self._build({"w2c": first[2], "K": first[3]}, first[4], first[5], min_cap=max(n_isects, 1), min_cap_tile=max_tile)
         for e in redo:
             self._issue(e)
 

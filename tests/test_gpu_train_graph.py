@@ -55,10 +55,12 @@ def _assert_same(ma, oa, mb, ob, what=""):
     assert oa._step == ob._step
 
 
+@pytest.mark.parametrize("binning", ["tiles", "bins"])
 @pytest.mark.parametrize("fuse_adam", [True, False])
 @pytest.mark.parametrize("use_graph", [True, False])
 @pytest.mark.parametrize("with_mask", [False, True])
-def test_graph_step_equals_eager_step(use_graph, with_mask, fuse_adam):
+def test_graph_step_equals_eager_step(use_graph, with_mask, fuse_adam, binning, monkeypatch):
+    monkeypatch.setenv("GS_BINNING", binning)   # per-tile lists / two-level binning (coarse capacities under the step guard)
     dev, make, datas, gts = _setup()
     (ma, oa), (mb, ob) = make(), make()
     lc = LossComputer(0.2, clamp_input=True)
@@ -80,10 +82,12 @@ def test_graph_step_equals_eager_step(use_graph, with_mask, fuse_adam):
     assert rep["captures"] == (1 if use_graph else 0)
 
 
-def test_overflow_is_skipped_on_device_detected_lazily_and_replayed():
+@pytest.mark.parametrize("binning", ["tiles", "bins"])
+def test_overflow_is_skipped_on_device_detected_lazily_and_replayed(binning, monkeypatch):
     """Capacity learnt from a far-away camera, then close-up views with several times the intersections arrive while
     the host is running ahead: the overflowing step and everything queued behind it must be device-side no-ops, and
     after the lazy check the runner must end on exactly the eager trajectory."""
+    monkeypatch.setenv("GS_BINNING", binning)
     dev, make, datas, gts = _setup(n=30000, n_views=3, dist=4.0)
     far = dict(datas[0])
     w2c = far["w2c"].clone()
@@ -101,6 +105,7 @@ def test_overflow_is_skipped_on_device_detected_lazily_and_replayed():
     runner.finish()
     rep = runner.report()
     assert rep["overflows"] >= 1 and rep["replayed_steps"] >= 1 and rep["capacity_isects"] > cap0 and rep["steps"] == len(seq)
+    assert rep["binning"] == binning
     _assert_same(ma, oa, mb, ob, "after overflow")
     # the device-side loss log holds the APPLIED steps' losses (skipped launches log nothing)
     hist = runner.loss_history(3)
