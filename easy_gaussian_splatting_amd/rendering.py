@@ -102,9 +102,15 @@ def last_binning(device=None) -> Optional[str]:
         return _coarse_hint.get(key, {}).get("mode")
 
 
-def binning_choice(footprint) -> str:
-    """The pipeline for a scene whose Gaussians cover `footprint` tiles on average (None: unknown -> per-tile)."""
+MAX_TILES_PER_TILE_PIPELINE = 40928   # the per-tile pipeline keeps a histogram over every tile of a camera in 160 KB of LDS
+
+
+def binning_choice(footprint, tiles: int = 0) -> str:
+    """The pipeline for a scene whose Gaussians cover `footprint` tiles on average (None: unknown -> per-tile).  Images of
+    more than 40928 tiles per camera (beyond ~4K x 2.5K) always take the two-level binning, whose LDS histogram is over bins."""
     mode = binning_mode()
+    if tiles > MAX_TILES_PER_TILE_PIPELINE and mode != "tiles":
+        return "bins"
     if mode != "auto":
         return mode
     return "bins" if footprint is not None and footprint >= BINS_FROM_FOOTPRINT else "tiles"
@@ -190,7 +196,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     hint_key = dev.index if dev.index is not None else torch.cuda.current_device()
     with _state_lock:
         hint = dict(_coarse_hint.get(hint_key, {}))
-    two_level = binning_choice(hint.get("footprint")) == "bins"
+    two_level = binning_choice(hint.get("footprint"), tiles) == "bins"
     if two_level:
         # two-level binning (include/gs_raster.h): coarse-bin lists are emitted and sorted, tiles are counted out of them.
         # Sizes the host cannot know yet come from the previous call on this device (+25 %); a miss raises a flag in

@@ -259,18 +259,25 @@ class TrainStepGraph:
     def _probe(self):
         """Blocking reads of the list sizes for the current inputs (build time only): {I, longest tile list} from the
         per-tile count, then -- if the footprints call for the two-level binning -- {coarse entries, longest bin list}."""
-        from .rendering import bin_shift_for, binning_choice
+        from .rendering import MAX_TILES_PER_TILE_PIPELINE, bin_shift_for, binning_choice
         L, b, dev = nat.lib(), self.buf, self.dev
-        self.binning = "tiles"
-        self.ws_bytes = int(L.gs_bin_workspace_bytes(1, self.N, self.tw, self.th))
-        b["ws"] = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), self._on_stream():
-            self._project()
-            self._count()
-        info = b["info"].tolist()
-        n_isects, max_tile = int(info[0]), int(info[2])
-        footprint = n_isects / max(1, self.N)
-        self.binning = binning_choice(footprint)
+        tiles = self.tw * self.th
+        n_isects = max_tile = 0
+        footprint = None
+        if tiles <= MAX_TILES_PER_TILE_PIPELINE:
+            self.binning = "tiles"
+            self.ws_bytes = int(L.gs_bin_workspace_bytes(1, self.N, self.tw, self.th))
+            b["ws"] = torch.empty((self.ws_bytes,), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev), self._on_stream():
+                self._project()
+                self._count()
+            info = b["info"].tolist()
+            n_isects, max_tile = int(info[0]), int(info[2])
+            footprint = n_isects / max(1, self.N)
+        else:
+            with torch.cuda.device(dev), self._on_stream():
+                self._project()
+        self.binning = binning_choice(footprint, tiles)
         if self.binning == "bins":
             self.bin_shift = bin_shift_for(footprint) or 2
             self.cap_coarse, self.cap_coarse_list = 2 * self.N + 1024, 0
@@ -284,6 +291,7 @@ class TrainStepGraph:
                 self.cap_coarse = int(int(info[4]) * self.margin) + 4096
             self.cap_coarse = int(int(info[4]) * self.margin) + 4096
             self.cap_coarse_list = int(int(info[5]) * 1.5) + 64
+            n_isects, max_tile = int(info[0]), int(info[2])
         b["info"].zero_()
         return n_isects, max_tile
 
