@@ -397,7 +397,7 @@ __global__ void tile_sort_kernel(const SortArgs a) {
         const uint32_t slot = (uint32_t)k;
         a.slots[lo + i] = (int32_t)slot;
         a.flatten_ids[lo + i] = a.slot_gid[slot];
-        a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
+        if (a.isect_ids) a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
     }
 }
 
@@ -531,7 +531,7 @@ __device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vbl
         const uint32_t slot = (uint32_t)k;
         a.slots[lo + i] = (int32_t)slot;
         a.flatten_ids[lo + i] = a.slot_gid[slot];
-        a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
+        if (a.isect_ids) a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
     }
 }
 
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(64 << (2 * SHIFT)) void bins_refine_kernel(const Re
             if (hit) {
                 const int64_t pos = out + __popcll(bal & lt_mask);
                 a.flatten_ids[pos] = (int32_t)f;
-                a.isect_ids[pos] = hi_bits | (long long)s_d[e];
+                if (a.isect_ids) a.isect_ids[pos] = hi_bits | (long long)s_d[e];
                 a.slots[pos] = (int32_t)(s_cum[e] + (uint32_t)k);
             }
             out += __popcll(bal);
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(1024) void seg_merge_kernel(const SortArgs a, const
             const uint32_t slot = (uint32_t)k;
             a.slots[lo + pos] = (int32_t)slot;
             a.flatten_ids[lo + pos] = a.slot_gid[slot];
-            a.isect_ids[lo + pos] = hi_bits | (long long)(k >> 32);
+            if (a.isect_ids) a.isect_ids[lo + pos] = hi_bits | (long long)(k >> 32);
         }
     }
     }
@@ -1206,7 +1206,7 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     GS_REQUIRE(n_isects >= 0 && n_isects < (1ll << 31), "intersection count must fit int32");
     if (N == 0) return GS_OK;
     GS_REQUIRE(bbox && depths && isect_offsets && cum_tiles, "null pointer");
-    GS_REQUIRE(n_isects == 0 || (keys_tmp && slot_gid && isect_ids && flatten_ids && slots), "null intersection buffer");
+    GS_REQUIRE(n_isects == 0 || (keys_tmp && slot_gid && flatten_ids && slots), "null intersection buffer");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     const uint32_t* hist = (const uint32_t*)(ws + L.hist_off);
@@ -1353,7 +1353,7 @@ extern "C" int gs_bins_lists(void* stream, int C, int64_t N, int tile_w, int til
     GS_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small (see gs_bins_workspace_bytes)");
     GS_REQUIRE(info_dev && isect_offsets, "null pointer");
     if (N == 0) return GS_OK;
-    GS_REQUIRE(cum_tiles && bbox && isect_ids && flatten_ids && slots, "null list buffer");
+    GS_REQUIRE(cum_tiles && bbox && flatten_ids && slots, "null list buffer");
     RefineArgs r;
     fill_refine_args(r, L, C, tile_w, tile_h, (char*)workspace, coarse_keys, bbox, info_dev);
     r.isect_offsets = isect_offsets; r.isect_ids = isect_ids; r.flatten_ids = flatten_ids; r.slots = slots;

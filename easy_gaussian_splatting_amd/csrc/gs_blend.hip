@@ -89,7 +89,7 @@ __device__ __forceinline__ void blend_pair(const float alpha, const bool ok, con
 #ifndef GS_FWD_TRAIN_WAVES_PER_EU
 #define GS_FWD_TRAIN_WAVES_PER_EU 6
 #endif
-#define GS_FWD_ATTR __attribute__((amdgpu_waves_per_eu(CKPT ? GS_FWD_TRAIN_WAVES_PER_EU : 8, 8)))
+#define GS_FWD_ATTR __attribute__((amdgpu_waves_per_eu(CKPT ? GS_FWD_TRAIN_WAVES_PER_EU : 1, 8)))
 template <bool CKPT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const BlendFwdArgs a) {
     __shared__ float4 srec_all[WAVES][GS_BUCKET * 3];

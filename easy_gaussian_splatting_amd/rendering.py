@@ -133,6 +133,51 @@ def _pinned_info(device: torch.device) -> Tensor:
     return buf
 
 
+class _LazyMeta(dict):
+    """gsplat's meta dict with `isect_ids` built on first access.  The sorted (camera | tile | depth bits) keys are a function
+    of the other entries -- camera | tile from `isect_offsets`, depth bits from `depths[flatten_ids]` -- and writing them was
+    half of the list bytes of every forward although nothing downstream of the reference reads them
+    (/root/reference/model/gaussian.py:368-375 takes `means2d` and `radii`)."""
+    PENDING = object()
+
+    def _isect_ids(self) -> Tensor:
+        C, tiles = self["n_cameras"], self["tile_width"] * self["tile_height"]
+        fid = dict.__getitem__(self, "flatten_ids")
+        off = dict.__getitem__(self, "isect_offsets").reshape(-1).long()
+        counts = torch.diff(off, append=off.new_tensor([fid.numel()]))
+        tile = torch.repeat_interleave(torch.arange(C * tiles, device=fid.device), counts, output_size=fid.numel())
+        tile_bits = int(tiles).bit_length()
+        dbits = dict.__getitem__(self, "depths").reshape(-1).view(torch.int32)[fid.long()].long() & 0xFFFFFFFF
+        return ((tile // tiles) << (32 + tile_bits)) | ((tile % tiles) << 32) | dbits
+
+    def __getitem__(self, key):
+        v = dict.__getitem__(self, key)
+        if v is _LazyMeta.PENDING:
+            v = self._isect_ids()
+            dict.__setitem__(self, key, v)
+        return v
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __iter__(self):   # (defined so that dict(meta) / {**meta} go through keys() + __getitem__, not the raw storage)
+        return dict.__iter__(self)
+
+    def items(self):
+        return [(k, self[k]) for k in dict.keys(self)]
+
+    def values(self):
+        return [self[k] for k in dict.keys(self)]
+
+    def pop(self, key, *default):
+        if key in self:
+            self[key]
+        return dict.pop(self, key, *default)
+
+    def copy(self):
+        return dict(self.items())
+
+
 class _Holder:
     """Carries non-tensor state between `rasterization()` and the autograd node without making
     the node own its own output (the weak reference lets backward attach `.absgrad` to the very
@@ -231,9 +276,12 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     with _state_lock:
         cap = _cap_hint.get(hint_key, 0)
 
+    eager_ids = os.environ.get("GS_EAGER_ISECT_IDS") == "1"   # (default: meta builds isect_ids on first access, _LazyMeta)
+
     def alloc_lists(c):
         scratch = () if two_level else (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32))
-        return scratch + (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32), torch.empty((c,), **i32))
+        ids = torch.empty((c,), dtype=torch.int64, device=dev) if eager_ids else None
+        return scratch + (ids, torch.empty((c,), **i32), torch.empty((c,), **i32))
 
     lists = alloc_lists(cap) if cap > 0 else None
     t_wait = time.perf_counter_ns()
@@ -291,15 +339,15 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
                              _ptr(render_alphas), _ptr(ckpt), _ptr(qlist), _ptr(qcnt), _ptr(qmask),
                              _ptr(unit_counter), _ptr(unit_desc)), "gs_blend_fwd"))
 
-    meta = {
+    meta = _LazyMeta({
         "camera_ids": None, "gaussian_ids": None,
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
         "opacities": opacities[None, :].expand(C, N),
         "tile_width": tw, "tile_height": th, "tiles_per_gauss": tiles_per_gauss,
-        "isect_ids": isect_ids[:n_isects], "flatten_ids": flatten_ids[:n_isects],
+        "isect_ids": _LazyMeta.PENDING if isect_ids is None else isect_ids[:n_isects], "flatten_ids": flatten_ids[:n_isects],
         "isect_offsets": isect_offsets[: C * tiles].view(C, th, tw),
         "width": W, "height": H, "tile_size": _TILE, "n_cameras": C,
-    }
+    })
     state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, n_isects=n_isects, n_buckets=n_buckets,
                  radii=radii, colors_post=colors_post, rec=rec, tiles_per_gauss=tiles_per_gauss,
                  cum_tiles=cum_tiles, isect_offsets=isect_offsets, bucket_offsets=bucket_offsets,

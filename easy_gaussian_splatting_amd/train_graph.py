@@ -173,7 +173,6 @@ class TrainStepGraph:
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.cap_buckets = cap // nat.GS_BUCKET + tiles + 1
-        b["isect_ids"] = torch.empty((cap,), dtype=torch.int64, device=dev)
         b["flatten_ids"] = torch.empty((cap,), **i32)
         b["slots"] = torch.empty((cap,), **i32)
         b["ckpt"] = torch.empty((8 * self.cap_buckets, 64, 4), **f32)
@@ -308,11 +307,11 @@ class TrainStepGraph:
             if self.binning == "bins":
                 self._ck(L.gs_bins_lists(st, 1, N, self.tw, self.th, self.bin_shift, _p(b["bbox"]), _p(b["ws"]), self.ws_bytes,
                                           _p(b["coarse_keys"]), self.cap_coarse, _p(b["cum_tiles"]), _p(b["isect_offsets"]),
-                                          _p(b["isect_ids"]), _p(b["flatten_ids"]), _p(b["slots"]), _p(b["info"])), "gs_bins_lists")
+                                          None, _p(b["flatten_ids"]), _p(b["slots"]), _p(b["info"])), "gs_bins_lists")
             else:
                 self._ck(L.gs_bin_emit_sort(st, 1, N, self.tw, self.th, _p(b["bbox"]), _p(b["depths"]), _p(b["ws"]), self.ws_bytes,
                                              _p(b["isect_offsets"]), self.cap, self.cap_tile, _p(b["keys_tmp"]), _p(b["slot_gid"]),
-                                             _p(b["cum_tiles"]), _p(b["isect_ids"]), _p(b["flatten_ids"]), _p(b["slots"])), "gs_bin_emit_sort")
+                                             _p(b["cum_tiles"]), None, _p(b["flatten_ids"]), _p(b["slots"])), "gs_bin_emit_sort")
             self._ck(L.gs_blend_fwd(st, 1, W, H, _p(b["rec"]), _p(b["bg"]), _p(b["isect_offsets"]), _p(b["bucket_offsets"]),
                                      _p(b["tile_order"]), _p(b["flatten_ids"]), _p(b["slots"]), self.cap, _p(b["render_colors"]),
                                      _p(b["render_alphas"]), _p(b["ckpt"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["qmask"]),

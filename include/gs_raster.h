@@ -116,7 +116,8 @@ int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile_h, const u
 /* I-emit + per-tile depth sort (replaces the emitting half of isect_tiles and the global
  * cub::DeviceRadixSort).  Needs the workspace as left by gs_bin_count.  keys_tmp[I] u64 and
  * slot_gid[I] i32 are scratch.  Outputs: cum_tiles[C*N] (exclusive scan of tiles_per_gauss =
- * first gradient-row slot of each flatten id), isect_ids[I] i64 (cam | tile | depth bits, sorted),
+ * first gradient-row slot of each flatten id), isect_ids[I] i64 (cam | tile | depth bits, sorted; may be NULL: it is
+ * a function of the other outputs -- cam | tile from isect_offsets, depth bits from depths[flatten_ids] -- and half of the list bytes),
  * flatten_ids[I] i32 (sorted), slots[I] i32 (gradient-row slot of each sorted entry). */
 int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, const uint32_t* bbox,
                      const float* depths, void* workspace, size_t workspace_bytes,
@@ -137,6 +138,7 @@ int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, con
  *                                 flags: 1 I > guard capacity | 4 I' > coarse_cap | 8 a bin list > coarse_list_cap;
  *                                 with flags != 0 nothing was emitted: repeat gs_bins_count with the sizes reported
  *   cum_tiles[C*N]                exclusive scan of tiles_per_gauss (first gradient-row slot of each flatten id)
+ *   isect_ids                     may be NULL (see gs_bin_emit_sort)
  * workspace: gs_bins_workspace_bytes(C, N, tile_w, tile_h, bin_shift, coarse_cap), same arguments in both calls.
  * If info_host != NULL the eight values are copied there and the stream is synchronised. */
 size_t gs_bins_workspace_bytes(int C, int64_t N, int tile_w, int tile_h, int bin_shift, int64_t coarse_cap);

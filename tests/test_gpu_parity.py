@@ -744,6 +744,21 @@ def test_two_level_binning_flags_and_capacities():
     h = count(need, longest)
     assert h[3] == 0 and h[4] == need and h[0] == int(tpg.sum()), h
     assert torch.equal(torch.diff(off.long()), torch.bincount(_tile_of_entries(bbox, tw), minlength=tiles))
+    # the list pass with an explicit isect_ids buffer (rasterization() passes NULL and derives the keys on demand): the
+    # kernel-written keys must equal the derived ones
+    from easy_gaussian_splatting_amd.rendering import _LazyMeta
+    I = h[0]
+    keys = torch.empty((need,), dtype=torch.int64, device=d)
+    ws = torch.empty((int(L.gs_bins_workspace_bytes(C, N, tw, th, 2, need)),), dtype=torch.uint8, device=d)
+    nat.check(L.gs_bins_count(st, C, N, tw, th, 2, P(bbox), P(dep), P(ws), ws.numel(), P(keys), need, 0, P(cum), P(off), P(boff), P(order),
+                              P(info), host), "gs_bins_count")
+    ids = torch.empty((I,), dtype=torch.int64, device=d); fid = torch.empty((I,), **i32); slots = torch.empty((I,), **i32)
+    nat.check(L.gs_bins_lists(st, C, N, tw, th, 2, P(bbox), P(ws), ws.numel(), P(keys), need, P(cum), P(off), P(ids), P(fid), P(slots), P(info)),
+              "gs_bins_lists")
+    lazy = _LazyMeta({"n_cameras": C, "tile_width": tw, "tile_height": th, "flatten_ids": fid, "isect_offsets": off[:tiles].view(C, th, tw),
+                      "depths": dep, "isect_ids": _LazyMeta.PENDING})
+    assert torch.equal(ids, lazy["isect_ids"])
+    assert bool((ids[1:] >= ids[:-1]).all()) and torch.equal(torch.sort(slots.long()).values, torch.arange(I, device=d))
 
 
 def _tile_of_entries(bbox, tw):
