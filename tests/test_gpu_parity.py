@@ -588,11 +588,12 @@ def test_degenerate_inputs_neither_hang_nor_poison():
 def fuzz_case(case, attempt=0):
     """The sweep's configuration `case` (scene seed number `attempt`): scene dict + (deg, W, H, use_bg, split, culling)."""
     rng = np.random.default_rng(1000 + case)
+    big = int(os.environ.get("GS_FUZZ_SCALE", "1"))   # ad-hoc hunting: GS_FUZZ_SCALE=4 draws up to 48 k Gaussians at ~1000 x 800
     deg = int(rng.integers(0, 4))
     K = int(rng.choice([(deg + 1) ** 2, 16]))
     C = int(rng.integers(1, 4))
-    n = int(rng.integers(1, 3000))
-    W, H = int(rng.integers(17, 260)), int(rng.integers(17, 200))
+    n = int(rng.integers(1, 3000 * big * big))
+    W, H = int(rng.integers(17, 260 * big)), int(rng.integers(17, 200 * big))
     smax = float(rng.choice([0.05, 0.2, 0.8]))
     dist, white = float(rng.uniform(2.5, 6.0)), bool(rng.integers(0, 2))
     use_bg, split, culling = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)) and K > 1, str(rng.choice(["tight", "gsplat"]))
