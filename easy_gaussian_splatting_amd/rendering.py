@@ -91,8 +91,9 @@ def binning_mode() -> str:
 
 
 # mean tile-list entries per Gaussian from which sorting coarse bins beats sorting tiles (tools/binning_sweep.py on MI355X,
-# 1080p: 0.22 vs 0.23 ms at 4.8, 0.27 vs 0.23 at 9.5, 0.42 vs 0.23 at 21, 1.10 vs 0.30 at 106)
-BINS_FROM_FOOTPRINT = 6.0
+# 1080p, per-tile vs two-level: 0.22 vs 0.23 ms at 4.8, 0.27 vs 0.23 at 9.5, 0.42 vs 0.23 at 21, 1.10 vs 0.30 at 106;
+# tools/stage_profile_s3_s5.py: 2 M Gaussians at 5.4 0.54 vs 0.47, 5 M at 4K and 7.6 1.86 vs 0.89)
+BINS_FROM_FOOTPRINT = 5.0
 
 
 def last_binning(device=None) -> Optional[str]:
