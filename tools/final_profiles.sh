@@ -7,6 +7,13 @@ mkdir -p gpurun_out
 timeout 600 bash tools/prof_sq.sh $tag > gpurun_out/${tag}_sq.log 2>&1
 timeout 400 bash tools/prof_pmc.sh $tag > gpurun_out/${tag}_pmc.log 2>&1
 cp gpurun_out/${tag}_sq_counters.json gpurun_out/${tag}_pmc_traffic.json profiles/ 2>/dev/null
+python3 - $tag <<'PY'   # the blend kernels' counters on their own (what VERDICT r1 #2 asked for by name)
+import json, sys
+tag = sys.argv[1]
+d = json.load(open(f"gpurun_out/{tag}_sq_counters.json"))
+for part in ("fwd", "bwd"):
+    json.dump({k: v for k, v in d.items() if f"blend_{part}" in k}, open(f"gpurun_out/{tag}_sq_blend_{part}.json", "w"), indent=1)
+PY
 timeout 300 bash tools/prof_bench.sh ${tag}_bench > gpurun_out/${tag}_prof_bench.log 2>&1
 timeout 600 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
 for m in tight gsplat; do
