@@ -212,40 +212,47 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
     const float cnt = (float)(a.H - 2 * kHalo) * (float)(a.W - 2 * kHalo) * 3.f;
     const float k_ssim = -g * a.lambda_ssim / cnt;                     // d(1 - mean ssim)
     const float k_l1 = g * (1.f - a.lambda_ssim) / ((float)a.H * (float)a.W * 3.f);
-    for (int ch = 0; ch < 3; ++ch) {
-        {   // loads first, LDS stores after; row-wise mapping as in the forward kernel: a tile row of one
-            // channel's derivative maps is one contiguous run of 42 x 3 floats
-            constexpr int kRowsPer = kLR / 2;
-            const int half = tid >> 7, j = tid & 127;
-            const int col = j / 3, mi = j - col * 3;
-            const int gx = x0 - kHalo + col;
-            const bool lane_on = j < kLR * 3 && gx >= 0 && gx < a.W;
-            float v[kRowsPer];
+    // Row-wise mapping as in the forward kernel: a tile row of one channel's derivative maps is one contiguous run of
+    // 42 x 3 floats.  The NEXT channel's maps are requested while this channel's two passes run (a block is a chain of
+    // three load -> stage -> filter rounds otherwise: 68 us for 22 us worth of HBM traffic).
+    constexpr int kRowsPer = kLR / 2;
+    const int half = tid >> 7, jj = tid & 127;
+    const int scol = jj / 3, smi = jj - scol * 3;
+    const int sgx = x0 - kHalo + scol;
+    const bool lane_on = jj < kLR * 3 && sgx >= 0 && sgx < a.W;
+    float v[kRowsPer];
+    auto fetch = [&](int ch) {
 #pragma unroll
-            for (int i = 0; i < kRowsPer; ++i) {
-                const int gy = y0 - kHalo + half + 2 * i;
-                v[i] = 0.f;   // derivative maps are zero outside the image (and outside the interior)
-                if (lane_on && gy >= 0 && gy < a.H) v[i] = a.maps[((size_t)ch * plane + (size_t)gy * a.W + gx) * 3 + mi];
-            }
-            if (j < kLR * 3) {
-                float* d = sm + (mi * kLR + half) * kLRP + col;
-#pragma unroll
-                for (int i = 0; i < kRowsPer; ++i) d[2 * i * kLRP] = v[i];
-            }
+        for (int i = 0; i < kRowsPer; ++i) {
+            const int gy = y0 - kHalo + half + 2 * i;
+            v[i] = 0.f;   // derivative maps are zero outside the image (and outside the interior)
+            if (lane_on && gy >= 0 && gy < a.H) v[i] = a.maps[((size_t)ch * plane + (size_t)gy * a.W + sgx) * 3 + smi];
         }
+    };
+    fetch(0);
+    for (int ch = 0; ch < 3; ++ch) {
+        if (jj < kLR * 3) {
+            float* d = sm + (smi * kLR + half) * kLRP + scol;
+#pragma unroll
+            for (int i = 0; i < kRowsPer; ++i) d[2 * i * kLRP] = v[i];
+        }
+#ifndef GS_LOSS_BWD_PREFETCH
+#define GS_LOSS_BWD_PREFETCH 1
+#endif
+        if (GS_LOSS_BWD_PREFETCH && ch < 2) fetch(ch + 1);
         __syncthreads();
         if (tid < kLR * (kLT / 8)) {   // horizontal pass, sliding window: one row x 8 columns per thread
             const int g = tid / kLR, row = tid - g * kLR, c0 = 8 * g;
 #pragma unroll
             for (int mi = 0; mi < 3; ++mi) {
-                float v[18];
+                float w[18];
 #pragma unroll
-                for (int i = 0; i < 18; ++i) v[i] = sm[(mi * kLR + row) * kLRP + c0 + i];
+                for (int i = 0; i < 18; ++i) w[i] = sm[(mi * kLR + row) * kLRP + c0 + i];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float acc = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) acc = fmaf(kWin[k], v[j + k], acc);
+                    for (int k = 0; k < 11; ++k) acc = fmaf(kWin[k], w[j + k], acc);
                     hp[mi * kLR * kHP + row * kHP + c0 + j] = acc;
                 }
             }
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
                 a.v_render[o] = keep * (k_ssim * (c[0][j] + 2.f * r * c[1][j] + gtv * c[2][j]) + k_l1 * sgn);
             }
         }
+        if (!GS_LOSS_BWD_PREFETCH && ch < 2) fetch(ch + 1);
         __syncthreads();
     }
 }
