@@ -132,7 +132,11 @@ __global__ void bin_colscan_kernel(int C, int G, int tiles, uint32_t* __restrict
     tile_cnt[i] = run;
 }
 
-// single block: scans over tiles and groups
+// Three independent single-block jobs in one launch (they used to run one after the other in a single block, 23 us of
+// barrier and memory latency on the critical path of every forward):
+//   block 0  exclusive scans of the tile counts -> isect_offsets, bucket_offsets; {I, n_buckets, longest list}, flags
+//   block 1  launch order of the blend forward (longest lists first)
+//   block 2  group bases (exclusive scan of the groups' intersection totals)
 constexpr int kScanItems = 16;
 __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
     int n_tiles_total, int n_groups_total, const uint32_t* __restrict__ tile_cnt,
@@ -141,12 +145,67 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
     int64_t* __restrict__ info, int32_t* __restrict__ tile_order, int64_t cap_isects, int64_t cap_tile,
     int64_t keep_mask) {
     __shared__ unsigned long long scratch[17];
+    const int chunk = kBinThreads * kScanItems;
+    if (blockIdx.x == 2) {   // group bases (few thousand values at most): serial chunks of kBinThreads
+        unsigned long long gcarry = 0;
+        for (int base = 0; base < n_groups_total; base += kBinThreads) {
+            const int i = base + threadIdx.x;
+            unsigned long long v = i < n_groups_total ? grp_tot[i] : 0ull, total;
+            unsigned long long ex = block_excl_scan_add(v, scratch, &total);
+            if (i < n_groups_total) grp_base[i] = (uint32_t)(gcarry + ex);
+            gcarry += total;
+        }
+        return;
+    }
+    if (blockIdx.x == 1) {
+        // Launch order for the blend forward (one wave per tile): longest lists first, so that the short
+        // ones fill the gaps at the end instead of the long ones sticking out (-10 % on its run time).
+        // Counting sort into 64 quarter-octave length classes with LDS atomics -- the order inside a class
+        // is arbitrary, which only permutes independent work.  One register-resident chunk only.
+        if (!tile_order) return;
+        if (n_tiles_total > chunk) {
+            for (int i = threadIdx.x; i < n_tiles_total; i += kBinThreads) tile_order[i] = i;
+            return;
+        }
+        // per-wave counters: 16 x fewer lanes contend for one LDS word than with a single set of 64
+        constexpr int kW = kBinThreads / 64;
+        __shared__ uint32_t cls_cnt[64][kW + 1];   // [class][wave] (+1: stride 17, no bank aliasing down a class)
+        auto cls_of = [](uint32_t x) -> int {   // 4 * floor(log2 x) + the next two bits, 0 for x < 2
+            if (x < 2u) return 0;
+            const int lg = 31 - __clz((int)x);
+            return min(63, (lg << 2) | (int)((x << (31 - lg)) >> 29 & 3u));
+        };
+        const int wv = threadIdx.x >> 6;
+        const int first = threadIdx.x * kScanItems;
+        uint32_t v[kScanItems];
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) v[k] = (first + k < n_tiles_total) ? tile_cnt[first + k] : 0u;
+        for (int i = threadIdx.x; i < 64 * (kW + 1); i += kBinThreads) (&cls_cnt[0][0])[i] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k)
+            if (first + k < n_tiles_total) atomicAdd(&cls_cnt[cls_of(v[k])][wv], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64) {   // descending classes: lane l owns class 63 - l; waves in order inside a class
+            const int c = 63 - (int)threadIdx.x;
+            uint32_t n = 0, cw[kW];
+#pragma unroll
+            for (int w = 0; w < kW; ++w) { cw[w] = cls_cnt[c][w]; n += cw[w]; }
+            uint32_t run = wave_incl_scan_add(n) - n;
+#pragma unroll
+            for (int w = 0; w < kW; ++w) { cls_cnt[c][w] = run; run += cw[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k)
+            if (first + k < n_tiles_total) tile_order[atomicAdd(&cls_cnt[cls_of(v[k])][wv], 1u)] = first + k;
+        return;
+    }
     unsigned long long carry_i = 0, carry_b = 0;
     uint32_t max_cnt = 0;
-    const int chunk = kBinThreads * kScanItems;
-    uint32_t v[kScanItems];   // (the last chunk's counts stay in registers for the launch order below)
     for (int base = 0; base < n_tiles_total; base += chunk) {
         const int first = base + threadIdx.x * kScanItems;
+        uint32_t v[kScanItems];
         unsigned long long si = 0, sb = 0;
 #pragma unroll
         for (int k = 0; k < kScanItems; ++k) {
@@ -192,55 +251,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
         } else {
             info[3] = keep_mask ? (info[3] & keep_mask) : 0;   // (two-level binning: the coarse stage's overflow bit survives)
         }
-    }
-    __syncthreads();
-    // Launch order for the blend forward (one wave per tile): longest lists first, so that the short
-    // ones fill the gaps at the end instead of the long ones sticking out (-10 % on its run time).
-    // Counting sort into 64 quarter-octave length classes with LDS atomics -- the order inside a class
-    // is arbitrary, which only permutes independent work.  One register-resident chunk only.
-    if (tile_order) {
-        if (n_tiles_total > chunk) {
-            for (int i = threadIdx.x; i < n_tiles_total; i += kBinThreads) tile_order[i] = i;
-        } else {
-            // per-wave counters: 16 x fewer lanes contend for one LDS word than with a single set of 64
-            constexpr int kW = kBinThreads / 64;
-            __shared__ uint32_t cls_cnt[64][kW + 1];   // [class][wave] (+1: stride 17, no bank aliasing down a class)
-            auto cls_of = [](uint32_t x) -> int {   // 4 * floor(log2 x) + the next two bits, 0 for x < 2
-                if (x < 2u) return 0;
-                const int lg = 31 - __clz((int)x);
-                return min(63, (lg << 2) | (int)((x << (31 - lg)) >> 29 & 3u));
-            };
-            const int wv = threadIdx.x >> 6;
-            for (int i = threadIdx.x; i < 64 * (kW + 1); i += kBinThreads) (&cls_cnt[0][0])[i] = 0u;
-            __syncthreads();
-            const int first = threadIdx.x * kScanItems;
-#pragma unroll
-            for (int k = 0; k < kScanItems; ++k)
-                if (first + k < n_tiles_total) atomicAdd(&cls_cnt[cls_of(v[k])][wv], 1u);
-            __syncthreads();
-            if (threadIdx.x < 64) {   // descending classes: lane l owns class 63 - l; waves in order inside a class
-                const int c = 63 - (int)threadIdx.x;
-                uint32_t n = 0, cw[kW];
-#pragma unroll
-                for (int w = 0; w < kW; ++w) { cw[w] = cls_cnt[c][w]; n += cw[w]; }
-                uint32_t run = wave_incl_scan_add(n) - n;
-#pragma unroll
-                for (int w = 0; w < kW; ++w) { cls_cnt[c][w] = run; run += cw[w]; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kScanItems; ++k)
-                if (first + k < n_tiles_total) tile_order[atomicAdd(&cls_cnt[cls_of(v[k])][wv], 1u)] = first + k;
-        }
-    }
-    // group bases (few thousand values at most): serial chunks of kBinThreads
-    unsigned long long gcarry = 0;
-    for (int base = 0; base < n_groups_total; base += kBinThreads) {
-        const int i = base + threadIdx.x;
-        unsigned long long v = i < n_groups_total ? grp_tot[i] : 0ull, total;
-        unsigned long long ex = block_excl_scan_add(v, scratch, &total);
-        if (i < n_groups_total) grp_base[i] = (uint32_t)(gcarry + ex);
-        gcarry += total;
     }
 }
 
@@ -1183,7 +1193,7 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
     GS_LAUNCH_CHECK("bin_colscan_kernel");
     const Guard gd = current_guard();
     GS_REQUIRE(gd.info == nullptr || gd.info == info_dev, "the guard set by gs_guard_set must be this call's info_dev");
-    hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(kBinThreads), 0, st, (int)ct, C * L.groups, tile_cnt,
+    hipLaunchKernelGGL(bin_tilescan_kernel, dim3(3), dim3(kBinThreads), 0, st, (int)ct, C * L.groups, tile_cnt,
                        grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev, tile_order, gd.cap_isects, gd.cap_tile,
                        (int64_t)0);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
@@ -1332,7 +1342,7 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
         else hipLaunchKernelGGL(bins_chunkscan_kernel<1>, dim3(g), dim3(256), 0, st, r, C);
         GS_LAUNCH_CHECK("bins_chunkscan_kernel");
     }
-    hipLaunchKernelGGL(bin_tilescan_kernel, dim3(1), dim3(kBinThreads), 0, st, C * tiles, 0, tile_cnt, (const uint32_t*)nullptr,
+    hipLaunchKernelGGL(bin_tilescan_kernel, dim3(2), dim3(kBinThreads), 0, st, C * tiles, 0, tile_cnt, (const uint32_t*)nullptr,
                        isect_offsets, bucket_offsets, (uint32_t*)nullptr, info_dev, tile_order, gd.cap_isects,
                        (int64_t)0x7fffffffffffffffll, (int64_t)12);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
