@@ -737,8 +737,8 @@ __global__ __launch_bounds__(256) void bins_colscan_kernel(int C, int G, int nbi
     if (lane == 0) bin_cnt[i] = carry;
 }
 
-// one block: bin offsets (exclusive scan of the bin totals), group bases, info[4] = I', info[5] = longest bin list,
-// coarse overflow -> flags bit 4 (sticky under a step guard, fresh otherwise)
+// block 0: bin offsets (exclusive scan of the bin totals), chunk descriptors, info[4] = I', info[5] = longest bin list,
+// coarse overflow -> flags bit 4 (sticky under a step guard, fresh otherwise); block 1: group bases
 __global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total, int n_groups_total,
                                                                 const uint32_t* __restrict__ bin_cnt,
                                                                 const uint32_t* __restrict__ grp_tot,
@@ -749,6 +749,17 @@ __global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total
                                                                 int guarded) {
     __shared__ unsigned long long scratch[17];
     __shared__ uint32_t smax[16];
+    if (blockIdx.x == 1) {   // second block of the launch: group bases, beside the bin scan
+        unsigned long long gcarry = 0;
+        for (int base = 0; base < n_groups_total; base += kBinThreads) {
+            const int i = base + threadIdx.x;
+            unsigned long long v = i < n_groups_total ? grp_tot[i] : 0ull, total;
+            unsigned long long ex = block_excl_scan_add(v, scratch, &total);
+            if (i < n_groups_total) grp_base[i] = (uint32_t)(gcarry + ex);
+            gcarry += total;
+        }
+        return;
+    }
     unsigned long long carry = 0, ccarry = 0;
     uint32_t max_cnt = 0;
     const int chunk = kBinThreads * kScanItems;
@@ -799,14 +810,6 @@ __global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total
         const int64_t f = ((int64_t)carry > coarse_cap ? 4 : 0) | ((int64_t)mm > list_cap ? 8 : 0);
         if (guarded) { if (f) info[3] |= f; }
         else info[3] = f;
-    }
-    unsigned long long gcarry = 0;
-    for (int base = 0; base < n_groups_total; base += kBinThreads) {
-        const int i = base + threadIdx.x;
-        unsigned long long v = i < n_groups_total ? grp_tot[i] : 0ull, total;
-        unsigned long long ex = block_excl_scan_add(v, scratch, &total);
-        if (i < n_groups_total) grp_base[i] = (uint32_t)(gcarry + ex);
-        gcarry += total;
     }
 }
 
@@ -1312,7 +1315,7 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     const int64_t cb = (int64_t)C * L.nbins;
     hipLaunchKernelGGL(bins_colscan_kernel, dim3((unsigned)((cb + 3) / 4)), dim3(256), 0, st, C, L.groups, L.nbins, hist, bin_cnt);
     GS_LAUNCH_CHECK("bins_colscan_kernel");
-    hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(kBinThreads), 0, st, (int)cb, C * L.groups, bin_cnt, grp_tot, coff,
+    hipLaunchKernelGGL(bins_scan_kernel, dim3(2), dim3(kBinThreads), 0, st, (int)cb, C * L.groups, bin_cnt, grp_tot, coff,
                        (int32_t*)(ws + L.choff_off), (int4*)(ws + L.chunk_bin_off), L.max_chunks, L.chunk_shift, grp_base,
                        info_dev, coarse_cap, list_cap,
                        gd.info != nullptr ? 1 : 0);
