@@ -143,10 +143,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
     const uint32_t* __restrict__ grp_tot, int32_t* __restrict__ isect_offsets,
     int32_t* __restrict__ bucket_offsets, uint32_t* __restrict__ grp_base,
     int64_t* __restrict__ info, int32_t* __restrict__ tile_order, int64_t cap_isects, int64_t cap_tile,
-    int64_t keep_mask) {
+    int64_t keep_mask, int32_t* __restrict__ sort_counts) {
     __shared__ unsigned long long scratch[17];
     const int chunk = kBinThreads * kScanItems;
     if (blockIdx.x == 2) {   // group bases (few thousand values at most): serial chunks of kBinThreads
+        if (sort_counts && threadIdx.x < 64) sort_counts[threadIdx.x] = 0;   // work-list counters of the sort that follows
         unsigned long long gcarry = 0;
         for (int base = 0; base < n_groups_total; base += kBinThreads) {
             const int i = base + threadIdx.x;
@@ -746,10 +747,11 @@ __global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total
                                                                 int4* __restrict__ chunk_desc, int64_t max_chunks,
                                                                 int chunk_shift, uint32_t* __restrict__ grp_base,
                                                                 int64_t* __restrict__ info, int64_t coarse_cap, int64_t list_cap,
-                                                                int guarded) {
+                                                                int guarded, int32_t* __restrict__ sort_counts) {
     __shared__ unsigned long long scratch[17];
     __shared__ uint32_t smax[16];
     if (blockIdx.x == 1) {   // second block of the launch: group bases, beside the bin scan
+        if (threadIdx.x < 64) sort_counts[threadIdx.x] = 0;   // work-list counters of the coarse sort
         unsigned long long gcarry = 0;
         for (int base = 0; base < n_groups_total; base += kBinThreads) {
             const int i = base + threadIdx.x;
@@ -1124,7 +1126,7 @@ static int launch_list_sorts(hipStream_t st, SortArgs& a, unsigned grid, int64_t
         GS_LAUNCH_CHECK("tile_radix_sort_kernel");
     }
     if (max_tile_count <= 1024) return GS_OK;
-    GS_HIP_CHECK(hipMemsetAsync(counts, 0, 64 * sizeof(int32_t), st));
+    // (counts were zeroed by the scan kernel of the count stage: bin_tilescan_kernel block 2 / bins_scan_kernel block 1)
     hipLaunchKernelGGL(class_items_kernel, dim3((grid + 255) / 256), dim3(256), 0, st, (int)grid, a.isect_offsets, items, counts, a.guard);
     GS_LAUNCH_CHECK("class_items_kernel");
     {   // (1024, 4096]: 72 KB -> two blocks per CU
@@ -1198,7 +1200,7 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
     GS_REQUIRE(gd.info == nullptr || gd.info == info_dev, "the guard set by gs_guard_set must be this call's info_dev");
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(3), dim3(kBinThreads), 0, st, (int)ct, C * L.groups, tile_cnt,
                        grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev, tile_order, gd.cap_isects, gd.cap_tile,
-                       (int64_t)0);
+                       (int64_t)0, (int32_t*)(ws + L.items_off));
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
     if (info_host) {
         GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -1318,7 +1320,7 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     hipLaunchKernelGGL(bins_scan_kernel, dim3(2), dim3(kBinThreads), 0, st, (int)cb, C * L.groups, bin_cnt, grp_tot, coff,
                        (int32_t*)(ws + L.choff_off), (int4*)(ws + L.chunk_bin_off), L.max_chunks, L.chunk_shift, grp_base,
                        info_dev, coarse_cap, list_cap,
-                       gd.info != nullptr ? 1 : 0);
+                       gd.info != nullptr ? 1 : 0, (int32_t*)(ws + L.items_off));
     GS_LAUNCH_CHECK("bins_scan_kernel");
     if (N > 0) {
         if (int rc = ensure_lds((const void*)bins_emit_kernel, lds)) return rc;
@@ -1347,7 +1349,7 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     }
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(2), dim3(kBinThreads), 0, st, C * tiles, 0, tile_cnt, (const uint32_t*)nullptr,
                        isect_offsets, bucket_offsets, (uint32_t*)nullptr, info_dev, tile_order, gd.cap_isects,
-                       (int64_t)0x7fffffffffffffffll, (int64_t)12);
+                       (int64_t)0x7fffffffffffffffll, (int64_t)12, (int32_t*)nullptr);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
     if (info_host) {
         GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));

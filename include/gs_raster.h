@@ -114,7 +114,8 @@ int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile_h, const u
                  int32_t* bucket_offsets, int32_t* tile_order, int64_t* info_dev, int64_t* info_host);
 
 /* I-emit + per-tile depth sort (replaces the emitting half of isect_tiles and the global
- * cub::DeviceRadixSort).  Needs the workspace as left by gs_bin_count.  keys_tmp[I] u64 and
+ * cub::DeviceRadixSort).  Needs the workspace as left by gs_bin_count and consumes it (the sort's work-list counters
+ * are zeroed by the count): one gs_bin_emit_sort per gs_bin_count, in that order.  keys_tmp[I] u64 and
  * slot_gid[I] i32 are scratch.  Outputs: cum_tiles[C*N] (exclusive scan of tiles_per_gauss =
  * first gradient-row slot of each flatten id), isect_ids[I] i64 (cam | tile | depth bits, sorted; may be NULL: it is
  * a function of the other outputs -- cam | tile from isect_offsets, depth bits from depths[flatten_ids] -- and half of the list bytes),

@@ -683,22 +683,20 @@ def test_binning_pipelines_agree_bit_for_bit(name, culling, monkeypatch):
         assert torch.equal(hip["meta"]["means2d"].absgrad, ref["meta"]["means2d"].absgrad)
 
 
-def test_image_beyond_the_per_tile_histogram_takes_the_two_level_binning():
+def test_image_beyond_the_per_tile_histogram_takes_the_two_level_binning(monkeypatch):
     """5120 x 2880 = 57 600 tiles: more than the per-tile pipeline's LDS histogram holds (40 928); rasterization() must
     take the two-level binning by itself and agree with the oracle; the per-tile entry point must refuse loudly."""
     from easy_gaussian_splatting_amd import rendering
+    monkeypatch.delenv("GS_BINNING", raising=False)   # the automatic choice is what is under test
     sc = make_scene(3000, 5120, 2880, sh_degree=1, seed=91, k_store=4, scale_range=(0.01, 0.2), dist=5.0)
     fw = run_oracle(sc)
     hip = run_hip(sc, fw=fw)
     assert rendering.last_binning(dev()) == "bins"
     check_forward(hip, fw)
     check_backward(hip, fw)
-    os.environ["GS_BINNING"] = "tiles"
-    try:
-        with pytest.raises(ValueError, match="tile grid too large"):
-            run_hip(sc, bwd=False)
-    finally:
-        del os.environ["GS_BINNING"]
+    monkeypatch.setenv("GS_BINNING", "tiles")
+    with pytest.raises(ValueError, match="tile grid too large"):
+        run_hip(sc, bwd=False)
 
 
 def test_two_level_binning_flags_and_capacities():
