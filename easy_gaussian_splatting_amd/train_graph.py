@@ -73,6 +73,7 @@ class TrainStepGraph:
         # need the runtime knob.)
         self.stream = torch.cuda.Stream(self.dev)
         self.cap = 0
+        self.probed = (0, 0)
         self.cap_tile = _SORT_CLASSES[0]
         self.pending: deque = deque()     # steps issued but not yet confirmed applied: (t, lrs, w2c, K, gt, mask)
         # {I, n_buckets, max tile, flags, applied} of the latest finished step, written by the device (gs_step_status)
@@ -142,8 +143,9 @@ class TrainStepGraph:
         self._set_inputs(data["w2c"], data["K"], gt_img, mask)
         if self.cap == 0 or min_cap or min_cap_tile:
             n_isects, max_tile = self._probe()
+            self.probed = (n_isects, max_tile)
             self.cap = max(int(max(n_isects, min_cap) * self.margin) + 4096, self.cap)
-            need_tile = max(int(max(max_tile, min_cap_tile) * 1.5), self.cap_tile)
+            need_tile = max(int(max(max_tile, min_cap_tile) * self.margin), self.cap_tile)   # (same head-room as the lists)
             self.cap_tile = next((c for c in _SORT_CLASSES if c >= need_tile), 1 << 30)
         self._alloc_binning()
         self._alloc_lists()
@@ -481,5 +483,6 @@ class TrainStepGraph:
         return self.buf["loss_ring"][idx]
 
     def report(self) -> Dict[str, Any]:
-        return dict(self.stats, binning=self.binning, capacity_isects=self.cap, capacity_tile_list=self.cap_tile, steps=self.confirmed,
+        return dict(self.stats, binning=self.binning, probed_isects=self.probed[0], probed_longest_list=self.probed[1],
+                    capacity_isects=self.cap, capacity_tile_list=self.cap_tile, steps=self.confirmed,
                     graph=self.graph is not None)
