@@ -311,8 +311,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
             for (uint32_t mb = fp.z; mb; mb &= mb - 1, ++k) {
                 const int i = __ffs((int)mb) - 1, yy = i / w;
                 const uint32_t pos = atomicAdd(&cursor[(y0 + yy) * tw + x0 + (i - yy * w)], 1u);
-                keys[pos] = ((unsigned long long)dbits << 32) | (slot0 + k);
-                slot_gid[slot0 + k] = (int32_t)f;
+                keys[pos] = ((unsigned long long)dbits << 32) | (slot_gid ? slot0 + k : (uint32_t)f);
+                if (slot_gid) slot_gid[slot0 + k] = (int32_t)f;
             }
         }
         unsigned long long big = __ballot(rect > kCoopTiles);
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
             for (int i = lane_id(); i < bcnt; i += 64) {
                 const int yy = i / bw;
                 const uint32_t pos = atomicAdd(&cursor[(by0 + yy) * tw + bx0 + (i - yy * bw)], 1u);
-                keys[pos] = ((unsigned long long)bd << 32) | (bslot + i);
-                slot_gid[bslot + i] = bf;
+                keys[pos] = ((unsigned long long)bd << 32) | (slot_gid ? bslot + i : (uint32_t)bf);
+                if (slot_gid) slot_gid[bslot + i] = bf;
             }
         }
     }
@@ -406,8 +406,8 @@ __global__ void tile_sort_kernel(const SortArgs a) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const unsigned long long k = IN_LDS ? skeys[i] : gk[i];
         const uint32_t slot = (uint32_t)k;
-        a.slots[lo + i] = (int32_t)slot;
-        a.flatten_ids[lo + i] = a.slot_gid[slot];
+        if (a.slot_gid) { a.slots[lo + i] = (int32_t)slot; a.flatten_ids[lo + i] = a.slot_gid[slot]; }
+        else a.flatten_ids[lo + i] = (int32_t)slot;   // inference lists: the key's low word is the flatten id itself
         if (a.isect_ids) a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
     }
 }
@@ -540,8 +540,8 @@ __device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vbl
     for (int i = tid; i < n; i += T) {
         const unsigned long long k = src[i];
         const uint32_t slot = (uint32_t)k;
-        a.slots[lo + i] = (int32_t)slot;
-        a.flatten_ids[lo + i] = a.slot_gid[slot];
+        if (a.slot_gid) { a.slots[lo + i] = (int32_t)slot; a.flatten_ids[lo + i] = a.slot_gid[slot]; }
+        else a.flatten_ids[lo + i] = (int32_t)slot;   // inference lists: the key's low word is the flatten id itself
         if (a.isect_ids) a.isect_ids[lo + i] = hi_bits | (long long)(k >> 32);
     }
 }
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(64 << (2 * SHIFT)) void bins_refine_kernel(const Re
                 const int64_t pos = out + __popcll(bal & lt_mask);
                 a.flatten_ids[pos] = (int32_t)f;
                 if (a.isect_ids) a.isect_ids[pos] = hi_bits | (long long)s_d[e];
-                a.slots[pos] = (int32_t)(s_cum[e] + (uint32_t)k);
+                if (a.slots) a.slots[pos] = (int32_t)(s_cum[e] + (uint32_t)k);
             }
             out += __popcll(bal);
         } else {
@@ -1052,8 +1052,8 @@ __global__ __launch_bounds__(1024) void seg_merge_kernel(const SortArgs a, const
             a.merged[lo + pos] = k;
         } else {
             const uint32_t slot = (uint32_t)k;
-            a.slots[lo + pos] = (int32_t)slot;
-            a.flatten_ids[lo + pos] = a.slot_gid[slot];
+            if (a.slot_gid) { a.slots[lo + pos] = (int32_t)slot; a.flatten_ids[lo + pos] = a.slot_gid[slot]; }
+            else a.flatten_ids[lo + pos] = (int32_t)slot;
             if (a.isect_ids) a.isect_ids[lo + pos] = hi_bits | (long long)(k >> 32);
         }
     }
@@ -1221,7 +1221,8 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     GS_REQUIRE(n_isects >= 0 && n_isects < (1ll << 31), "intersection count must fit int32");
     if (N == 0) return GS_OK;
     GS_REQUIRE(bbox && depths && isect_offsets && cum_tiles, "null pointer");
-    GS_REQUIRE(n_isects == 0 || (keys_tmp && slot_gid && flatten_ids && slots), "null intersection buffer");
+    GS_REQUIRE(n_isects == 0 || (keys_tmp && flatten_ids), "null intersection buffer");
+    GS_REQUIRE((slot_gid == nullptr) == (slots == nullptr), "slot_gid and slots: both (training lists) or neither (inference lists)");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     const uint32_t* hist = (const uint32_t*)(ws + L.hist_off);
@@ -1368,7 +1369,7 @@ extern "C" int gs_bins_lists(void* stream, int C, int64_t N, int tile_w, int til
     GS_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small (see gs_bins_workspace_bytes)");
     GS_REQUIRE(info_dev && isect_offsets, "null pointer");
     if (N == 0) return GS_OK;
-    GS_REQUIRE(cum_tiles && bbox && flatten_ids && slots, "null list buffer");
+    GS_REQUIRE(cum_tiles && bbox && flatten_ids, "null list buffer");
     RefineArgs r;
     fill_refine_args(r, L, C, tile_w, tile_h, (char*)workspace, coarse_keys, bbox, info_dev);
     r.isect_offsets = isect_offsets; r.isect_ids = isect_ids; r.flatten_ids = flatten_ids; r.slots = slots;

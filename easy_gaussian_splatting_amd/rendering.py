@@ -279,10 +279,12 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
 
     eager_ids = os.environ.get("GS_EAGER_ISECT_IDS") == "1"   # (default: meta builds isect_ids on first access, _LazyMeta)
 
+    want_slots = need_grad   # inference: no gradient-row slots, no slot -> id map (the sort keys carry the flatten id)
+
     def alloc_lists(c):
-        scratch = () if two_level else (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32))
+        scratch = () if two_level else (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32) if want_slots else None)
         ids = torch.empty((c,), dtype=torch.int64, device=dev) if eager_ids else None
-        return scratch + (ids, torch.empty((c,), **i32), torch.empty((c,), **i32))
+        return scratch + (ids, torch.empty((c,), **i32), torch.empty((c,), **i32) if want_slots else None)
 
     lists = alloc_lists(cap) if cap > 0 else None
     t_wait = time.perf_counter_ns()

@@ -119,7 +119,8 @@ int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile_h, const u
  * slot_gid[I] i32 are scratch.  Outputs: cum_tiles[C*N] (exclusive scan of tiles_per_gauss =
  * first gradient-row slot of each flatten id), isect_ids[I] i64 (cam | tile | depth bits, sorted; may be NULL: it is
  * a function of the other outputs -- cam | tile from isect_offsets, depth bits from depths[flatten_ids] -- and half of the list bytes),
- * flatten_ids[I] i32 (sorted), slots[I] i32 (gradient-row slot of each sorted entry). */
+ * flatten_ids[I] i32 (sorted), slots[I] i32 (gradient-row slot of each sorted entry).  Inference lists: pass slot_gid =
+ * slots = NULL -- the keys then carry the flatten id itself (no slot map is written or gathered; same order). */
 int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int tile_h, const uint32_t* bbox,
                      const float* depths, void* workspace, size_t workspace_bytes,
                      const int32_t* isect_offsets, int64_t n_isects, int64_t max_tile_count,
