@@ -62,6 +62,8 @@ SIGNATURES = {
     "gs_step_status": (_I, [_P, _P, _P, _P, _P, _P, _I]),
     "gs_adam_hyper": (_I, [_P, _I, _P, _F, _F, _L, _P]),
     "gs_adam_step_dev": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P, _P]),
+    "gs_scan_rows_workspace_ints": (_Z, [_I, _L]),
+    "gs_scan_rows_i32": (_I, [_P, _I, _L, _P, _P, _P]),
     "gs_refine_flags": (_I, [_P, _L, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_refine_apply": (_I, [_P, _L, _I, _I, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_project_bwd_adam": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P,

@@ -232,7 +232,9 @@ class GaussianModel(nn.Module):
                                         self.grad_norm_accum.data_ptr(), self.collecting_counts.data_ptr(), self.max_radii.data_ptr(),
                                         self.log_scales.data_ptr(), self.logit_opacities.data_ptr(), flags.data_ptr(),
                                         counters.data_ptr()), "gs_refine_flags")
-            incl = torch.cumsum(flags, dim=1, dtype=torch.int32)
+            incl = torch.empty_like(flags)
+            scan_ws = torch.empty((int(L.gs_scan_rows_workspace_ints(3, n_old)),), dtype=torch.int32, device=dev)
+            nat.check(L.gs_scan_rows_i32(st, 3, n_old, flags.data_ptr(), incl.data_ptr(), scan_ws.data_ptr()), "gs_scan_rows_i32")
             # the one host read: three totals (they size the new buffers) + the five tb_info counters
             host = torch.cat([incl[:, -1].to(torch.int64) if n_old else torch.zeros(3, dtype=torch.int64, device=dev), counters]).tolist()
             tot_old, tot_child, tot_clone, ns, nc, c0, c1, c2 = (int(v) for v in host)

@@ -280,13 +280,16 @@ int gs_adam_step_dev(void* stream, int64_t n, float* params, float* exp_avg, flo
  * children survive (children: same opacity, scales / (0.8 S)); row 2 it is cloned AND the clone survives.
  * counters[5] (device, zeroed here) = {split, clone, then the reference's cumulative prune counts over [old | new]:
  * low opacity, + large radii, + large scale} -- what densify_and_prune returns as tb_info.
- * gs_refine_apply: given the INCLUSIVE prefix scans of the three flag rows (any scan; the binding uses torch.cumsum) and
+ * gs_refine_apply: given the INCLUSIVE prefix scans of the three flag rows (gs_scan_rows_i32) and
  * their totals (the one host read of the path: they size the new buffers), fills the new flat parameter / exp_avg /
  * exp_avg_sq buffers in the reference's order [surviving old | split children, copy-major | clones]: survivors keep
  * their moments, new Gaussians start at zero; split children get mean + R(q)(s * noise[copy][parent]) and
  * log(s / (0.8 S)).  Flat layout as gs_adam_step: the six tensors of param_names (means, log_scales, quats, sh_0,
  * sh_rest, logit_opacities) at old_offsets_host[6] / new_offsets_host[6] floats.  src_scratch[n_new] i32 and
  * tag_scratch[n_new] i8 are scratch.  noise: [S][n_old][3] standard normal. */
+/* Inclusive prefix scan of every row of an int32 [rows][n] array.  workspace: gs_scan_rows_workspace_ints(rows, n) int32. */
+size_t gs_scan_rows_workspace_ints(int rows, int64_t n);
+int gs_scan_rows_i32(void* stream, int rows, int64_t n, const int32_t* in, int32_t* out, int32_t* workspace);
 int gs_refine_flags(void* stream, int64_t n, int num_splits, float densify_grad_thresh, float densify_scale_thresh,
                     float prune_radii_ratio_thresh, float prune_scale_thresh, float min_opacity,
                     const float* grad_norm_accum, const float* counts, const float* max_radii, const float* log_scales,

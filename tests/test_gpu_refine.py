@@ -102,3 +102,15 @@ def test_device_refine_nothing_to_do_and_everything_pruned():
     m.MIN_OPACITY = 2.0                  # everything is "transparent": all pruned
     info = m.densify_and_prune()
     assert info["train/nbr_gaussians"] == 0 and m.means.shape == (0, 3) and m.sh_rest.shape == (0, 15, 3)
+
+
+@pytest.mark.parametrize("n", [1, 63, 16384, 16385, 1_000_003])
+def test_row_scan_equals_cumsum(n):
+    """gs_scan_rows_i32 (the refinement's prefix scans): every row's inclusive scan, block and chunk boundaries included."""
+    from easy_gaussian_splatting_amd import _native as nat
+    L, d = nat.lib(), torch.device("cuda:0")
+    x = torch.randint(0, 3, (3, n), dtype=torch.int32, device=d, generator=torch.Generator(device=d).manual_seed(n))
+    out = torch.empty_like(x)
+    ws = torch.empty((int(L.gs_scan_rows_workspace_ints(3, n)),), dtype=torch.int32, device=d)
+    nat.check(L.gs_scan_rows_i32(torch.cuda.current_stream().cuda_stream, 3, n, x.data_ptr(), out.data_ptr(), ws.data_ptr()), "gs_scan_rows_i32")
+    assert torch.equal(out, torch.cumsum(x, 1, dtype=torch.int32))
