@@ -54,23 +54,54 @@ def reference_class_paths():
                 sys.modules[n] = saved[n]
 
 
+def as_torch_adam(optimizer) -> torch.optim.Adam:
+    """A `torch.optim.Adam` over the same parameter objects with the same groups, step count and moments (copies) --
+    what the reference's pickles hold (/root/reference/model/gaussian.py:389-412).  `optim.FusedAdam.state_dict()` is
+    already in Adam's layout, so this is a plain load."""
+    if isinstance(optimizer, torch.optim.Adam):
+        return optimizer
+    groups = [{"params": list(g["params"]), "lr": g["lr"], "name": g.get("name")} for g in optimizer.param_groups]
+    adam = torch.optim.Adam(groups, betas=tuple(optimizer.defaults["betas"]), eps=optimizer.defaults["eps"])
+    adam.load_state_dict(optimizer.state_dict())
+    return adam
+
+
+def as_fused_adam(optimizer):
+    """The reverse: an `optim.FusedAdam` over the parameters of a `torch.optim.Adam` (they become views of its flat
+    buffer, wherever they live now), moments and step count restored."""
+    from .optim import FusedAdam
+    groups = [{"params": list(g["params"]), "lr": g["lr"], "name": g.get("name")} for g in optimizer.param_groups]
+    state = optimizer.state_dict()
+    fused = FusedAdam(groups, betas=tuple(optimizer.defaults["betas"]), eps=optimizer.defaults["eps"])
+    fused.load_state_dict(state)
+    return fused
+
+
 def save_gaussian_model(path: Path, gaussian_model: torch.nn.Module, save_optimizer: bool = False,
                         reference_compatible: bool = True):
-    """`torch.save(gaussian_model, path)` with the optimizer detached unless asked for (reference behaviour).  The
-    module is written on whatever device it lives on; parameters that are views of a FusedAdam flat buffer are saved
-    as plain tensors."""
+    """`torch.save(gaussian_model, path)` with the optimizer detached unless asked for (reference behaviour,
+    /root/reference/utils.py:78-87).  With `reference_compatible` the file names the reference's class paths and holds
+    only what the reference's classes know: `MAX_SCALE_RATIO` as a tensor (the reference calls
+    `torch.max(ratio, self.MAX_SCALE_RATIO)`, model/gaussian.py:380-382) and, with `save_optimizer`, a
+    `torch.optim.Adam` carrying this optimizer's state (an `optim.FusedAdam` object would name a class the reference
+    cannot import)."""
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
-    tmp_optimizer = None
-    if not save_optimizer:
-        tmp_optimizer = gaussian_model.optimizer
-        gaussian_model.optimizer = None   # type: ignore
+    live_optimizer = gaussian_model.optimizer
+    live_ratio = gaussian_model.__dict__.get("MAX_SCALE_RATIO")
     try:
+        if not save_optimizer:
+            gaussian_model.optimizer = None   # type: ignore
+        elif reference_compatible and live_optimizer is not None:
+            gaussian_model.optimizer = as_torch_adam(live_optimizer)
+        if reference_compatible and live_ratio is not None and not isinstance(live_ratio, torch.Tensor):
+            gaussian_model.MAX_SCALE_RATIO = torch.tensor(float(live_ratio), dtype=torch.float32, device=gaussian_model.means.device)
         with (reference_class_paths() if reference_compatible else contextlib.nullcontext()):
             torch.save(gaussian_model, path)
     finally:
-        if tmp_optimizer is not None:
-            gaussian_model.optimizer = tmp_optimizer
+        gaussian_model.optimizer = live_optimizer
+        if live_ratio is not None:
+            gaussian_model.MAX_SCALE_RATIO = live_ratio
 
 
 def find_checkpoint(path: Path, iterations: Optional[int] = None) -> Path:
@@ -90,18 +121,39 @@ def find_checkpoint(path: Path, iterations: Optional[int] = None) -> Path:
     return best
 
 
-def load_gaussian_model(path: Path, iterations: Optional[int] = None, device: Optional[str] = None) -> torch.nn.Module:
-    """The reference loads to the CPU and then calls `.cuda()`; `device=None` does that when a GPU is present."""
+def load_gaussian_model(path: Path, iterations: Optional[int] = None, device: Optional[str] = None,
+                        optimizer: str = "keep") -> torch.nn.Module:
+    """The reference loads to the CPU and then calls `.cuda()` (/root/reference/utils.py:48-75); `device=None` does that
+    when a GPU is present.  Works on files written here and on files written by the reference (whose objects lack this
+    package's extra attributes: they fall back to the class defaults of `model.GaussianModel`; their statistics and
+    `MAX_SCALE_RATIO` are plain tensor attributes that `Module.to` does not move).
+    A pickled optimizer (`save_optimizer=True`) is made steppable on `device`: `optimizer="keep"` leaves a
+    `torch.optim.Adam` an Adam (state moved to the device), `"hip"` turns it into `optim.FusedAdam`; an
+    `optim.FusedAdam` object found in an older file of this package is always rebuilt over the moved parameters."""
+    if optimizer not in ("keep", "hip"):
+        raise ValueError("optimizer: 'keep' or 'hip'")
     target = find_checkpoint(path, iterations)
     with reference_class_paths():
         gaussian_model = torch.load(target, map_location="cpu", weights_only=False)
     if device is None:
         device = "cuda" if torch.cuda.is_available() else "cpu"
+    opt = gaussian_model.__dict__.get("optimizer")
+    opt_state = None if opt is None else opt.state_dict()   # (before .to(): FusedAdam reads its flat CPU buffers here)
     gaussian_model = gaussian_model.to(device)
-    for name in ("grad_norm_accum", "collecting_counts", "max_radii"):   # plain attributes in the reference's pickles
+    for name in ("grad_norm_accum", "collecting_counts", "max_radii", "MAX_SCALE_RATIO"):   # plain attributes in the reference's pickles
         t = gaussian_model.__dict__.get(name)
         if isinstance(t, torch.Tensor):
             gaussian_model.__dict__[name] = t.to(device)
+    if opt is not None:
+        from .optim import FusedAdam
+        groups = [{"params": list(g["params"]), "lr": g["lr"], "name": g.get("name")} for g in opt.param_groups]
+        betas, eps = tuple(opt.defaults["betas"]), opt.defaults["eps"]
+        want_fused = optimizer == "hip" or isinstance(opt, FusedAdam)
+        if want_fused and torch.device(device).type != "cuda":
+            want_fused = False   # (FusedAdam steps on the GPU only; on the CPU the state stays a torch.optim.Adam)
+        new = FusedAdam(groups, betas=betas, eps=eps) if want_fused else torch.optim.Adam(groups, betas=betas, eps=eps)
+        new.load_state_dict(opt_state)   # (torch casts the moments to each parameter's device)
+        gaussian_model.optimizer = new
     return gaussian_model
 
 

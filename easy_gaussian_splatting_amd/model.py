@@ -70,6 +70,15 @@ class LR_Scheduler:
 
 
 class GaussianModel(nn.Module):
+    # Defaults of this package's own attributes, at class level: an object unpickled from a file the REFERENCE wrote
+    # (checkpoint.load_gaussian_model) has none of them in its __dict__ and takes these.
+    fuse_sh_cat = True          # hand (sh_0, sh_rest) to the rasterizer, no per-step torch.cat
+    fuse_activations = True     # exp / sigmoid inside the projection kernels (GPU)
+    tile_culling = "tight"      # render-equivalent shorter lists ("gsplat": meta's list arrays bit-exact)
+    sh_grads = "dense"
+    on_colors_pre = None
+    device_refine = True
+
     def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, sh_0: Tensor, sh_rest: Tensor,
                  logit_opacities: Tensor, sh_degree: int, sh_degree_interval: int = 0,
                  white_background: bool = False, fuse_sh_cat: bool = True,
@@ -167,7 +176,8 @@ class GaussianModel(nn.Module):
         if self.USE_SCALE_REGULARIZATION:
             scales = self.scales
             ratio = scales.amax(dim=1) / scales.amin(dim=1)
-            reg["scale_reg"] = torch.mean(torch.clamp(ratio, min=self.MAX_SCALE_RATIO) - self.MAX_SCALE_RATIO)
+            max_ratio = float(self.MAX_SCALE_RATIO)   # (a 0-d tensor in files the reference wrote)
+            reg["scale_reg"] = torch.mean(torch.clamp(ratio, min=max_ratio) - max_ratio)
         return reg
 
     # ---------------------------------------------------------------- refinement (row f-3)

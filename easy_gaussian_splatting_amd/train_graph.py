@@ -87,10 +87,13 @@ class TrainStepGraph:
         self._build(data, gt_img, mask)
 
     # ------------------------------------------------------------------------------------------ workspace
-    def _state_key(self):
+    def _state_key(self, W: Optional[int] = None, H: Optional[int] = None):
+        """What the captured graph is specialised on.  `W` / `H`: the size of the frame about to be rendered (the
+        reference takes it per frame from `Frame.to_data`, e.g. multi-camera COLMAP sets); default = the built size."""
         m = self.model
         return (m.means.shape[0], self.opt.flat_param.data_ptr(), m.max_radii.data_ptr(), m.grad_norm_accum.data_ptr(),
-                m.collecting_counts.data_ptr(), m.active_sh_degree, getattr(m, "tile_culling", "tight"), self.W, self.H)
+                m.collecting_counts.data_ptr(), m.active_sh_degree, getattr(m, "tile_culling", "tight"),
+                self.W if W is None else int(W), self.H if H is None else int(H))
 
     def _build(self, data, gt_img, mask, min_cap: int = 0, min_cap_tile: int = 0):
         """(Re-)allocates the workspace for the model as it is now, learns the capacities from one blocking probe
@@ -183,18 +186,33 @@ class TrainStepGraph:
         b["unit_desc"] = torch.empty((8 * self.cap_buckets, 4), **i32)
         b["rows"] = torch.empty((4 * cap, nat.GS_ROW_FLOATS), **f32)
 
+    def _protect_pending(self, static: Tensor):
+        """`static` (one of the runner's input buffers) is about to be overwritten: steps still pending that were issued
+        with "same as the buffer holds" get a snapshot of it first (enqueued ahead of the overwrite on the same stream)."""
+        snap = None
+        for e in self.pending:
+            for i in range(2, 6):
+                if isinstance(e[i], Tensor) and e[i].data_ptr() == static.data_ptr():
+                    if snap is None:
+                        snap = static.clone()
+                    e[i] = snap[0] if (e[i].dim() < static.dim()) else snap
+
     def _set_inputs(self, w2c: Tensor, K: Tensor, gt: Tensor, mask: Optional[Tensor]):
         b = self.buf
         if w2c.data_ptr() != b["viewmats"].data_ptr():   # (the static buffer itself = "same as last step")
+            self._protect_pending(b["viewmats"])
             b["viewmats"][0].copy_(w2c, non_blocking=True)
         if K.data_ptr() != b["Ks"].data_ptr():
+            self._protect_pending(b["Ks"])
             b["Ks"][0].copy_(K, non_blocking=True)
         if gt.data_ptr() != b["gt"].data_ptr():
+            self._protect_pending(b["gt"])
             b["gt"].copy_(gt, non_blocking=True)
         if self.has_mask:
             if mask is None:
                 raise ValueError("this runner was built with a mask; pass one every step")
             if mask.data_ptr() != b["mask"].data_ptr():
+                self._protect_pending(b["mask"])
                 b["mask"].copy_(mask, non_blocking=True)
 
     def _st(self) -> int:
@@ -414,11 +432,19 @@ class TrainStepGraph:
     def step(self, data: Optional[Dict[str, Any]] = None, gt_img: Optional[Tensor] = None, mask: Optional[Tensor] = None):
         """One training iteration.  `data` / `gt_img` / `mask` default to the previous step's (static buffers are
         re-used as they are).  Returns the runner's static output tensors (valid until the next step)."""
-        if self._state_key() != self._key:
+        W, H = (self.W, self.H) if data is None else (int(data["width"]), int(data["height"]))
+        if self._state_key(W, H) != self._key:
             self.finish()
-            cur = self._last_inputs if data is None else (data["w2c"], data["K"], gt_img if gt_img is not None else self.buf["gt"], mask)
-            if data is not None:
-                self.W, self.H = int(data["width"]), int(data["height"])
+            if (W, H) != (self.W, self.H):
+                # another frame size: the static image buffers are re-allocated, so the frame must bring its own target
+                if gt_img is None or (self.has_mask and mask is None):
+                    raise ValueError("TrainStepGraph.step: a change of image size needs gt_img (and mask) of the new size")
+                cur = (data["w2c"], data["K"], gt_img, mask)
+                self.W, self.H = W, H
+            else:
+                cur = self._last_inputs if data is None else (data["w2c"], data["K"], gt_img if gt_img is not None else self.buf["gt"],
+                                                              mask if mask is not None else self.buf.get("mask"))
+                # (old static buffers named here stay alive through `cur` until the new ones have been filled from them)
             self.cap = 0
             self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None)
         b = self.buf
@@ -429,7 +455,11 @@ class TrainStepGraph:
         self._last_inputs = (w2c, K, gt, mk)
         opt = self.opt
         opt._step += 1
-        self._issue((opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk))
+        # The queued entry is what an overflow recovery replays.  Inputs are kept by reference: a caller must not write
+        # into a camera / target / mask tensor it has handed in before `finish()` (or `check_every` further steps).  Entries
+        # that alias the runner's OWN static buffers (data=None / gt_img=None steps) are snapshotted right before a later
+        # step overwrites those buffers (`_protect_pending`), so a skipped step is always replayed with its own inputs.
+        self._issue([opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk])
         if self.issued % self.check_every == 0:
             self._poll(block=False)
         return {"render_img": b["render_colors"][0], "loss3": b["loss3"], "batch_radii": b["radii"], "absgrad": b["v_abs"]}

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from easy_gaussian_splatting_amd.model import GaussianModel, build_optimizers
+from easy_gaussian_splatting_amd.optim import FusedAdam
 
 pytestmark = pytest.mark.gpu
 
@@ -119,6 +120,20 @@ def test_checkpoint_round_trip_of_a_fused_adam_model(tmp_path):
     for name in a.param_names:
         getattr(a, name).grad = torch.randn_like(getattr(a, name))
     oa.step()
+    # resume WITH the pickled optimizer state: the file holds a torch.optim.Adam in the reference's layout;
+    # loaded as it is ("keep") and as FusedAdam ("hip"), the next step must equal the original optimizer's next step
+    assert isinstance(b.optimizer, torch.optim.Adam)
+    c = ckpt.load_gaussian_model(tmp_path, optimizer="hip")
+    assert isinstance(c.optimizer, FusedAdam) and c.optimizer._step == opt._step == 1
+    grads = {name: torch.randn_like(getattr(m, name)) for name in m.param_names}
+    for mod in (m, b, c):
+        for name in m.param_names:
+            getattr(mod, name).grad = grads[name].clone()
+        mod.optimizer.step()
+    for name in m.param_names:
+        assert torch.equal(getattr(c, name), getattr(m, name)), name                       # same kernel, same state
+        assert torch.allclose(getattr(b, name), getattr(m, name), rtol=1e-5, atol=1e-7), name   # torch's Adam on the same state
+    c.optimizer._check_views()
 
 
 def test_fused_adam_with_an_empty_parameter_tensor():

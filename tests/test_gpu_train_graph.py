@@ -141,3 +141,56 @@ def test_refinement_between_graph_steps_rebuilds_the_workspace():
     runner.finish()
     _assert_same(ma, oa, mb, ob, "after opacity reset")
     assert runner.report()["rebuilds"] >= 3
+
+
+def test_frames_of_two_image_sizes_alternate():
+    """The reference takes width / height per frame (`Frame.to_data`; multi-camera COLMAP sets mix sizes): a frame of
+    another size must re-build the workspace and re-capture, and the trajectory must stay the eager one."""
+    dev, make, datas, gts = _setup(n=6000, W=320, H=208)
+    small = []
+    g = torch.Generator().manual_seed(5)
+    for d in datas:   # the same cameras at 240 x 160 (intrinsics scaled)
+        K = d["K"].clone()
+        K[0] *= 240 / 320
+        K[1] *= 160 / 208
+        small.append(({"w2c": d["w2c"], "K": K, "width": 240, "height": 160}, torch.rand((160, 240, 3), generator=g).to(dev)))
+    (ma, oa), (mb, ob) = make(), make()
+    lc = LossComputer(0.2, clamp_input=True)
+    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], check_every=2)
+    seq = [(datas[0], gts[0]), small[1], small[2], (datas[1], gts[1]), small[0], (datas[2], gts[2])]
+    for it, (d, gt) in enumerate(seq):
+        l_ref = _eager_step(ma, oa, lc, d, gt)
+        out = runner.step(d, gt)
+        assert out["render_img"].shape == (d["height"], d["width"], 3)
+        runner.finish()
+        assert torch.equal(out["loss3"], l_ref), it
+    _assert_same(ma, oa, mb, ob, "two image sizes")
+    assert runner.report()["rebuilds"] >= 5
+    with pytest.raises(ValueError):   # a new size without a target image of that size
+        runner.step(small[0][0])
+
+
+def test_skipped_step_that_reused_the_static_inputs_is_replayed_with_its_own_inputs():
+    """`step()` without arguments renders "the same frame again" out of the runner's static buffers.  If such a step is
+    skipped behind an overflow and a LATER step has meanwhile overwritten those buffers, the replay must still use the
+    frame the skipped step was issued with (pending entries held the static buffers by reference)."""
+    dev, make, datas, gts = _setup(n=30000, n_views=3, dist=4.0)
+    far = dict(datas[0])
+    w2c = far["w2c"].clone()
+    w2c[2, 3] += 14.0
+    far["w2c"] = w2c
+    (ma, oa), (mb, ob) = make(), make()
+    lc = LossComputer(0.2, clamp_input=True)
+    runner = TrainStepGraph(mb, ob, lc, far, gts[0], margin=1.02, check_every=8)
+    eager_seq = [(far, gts[0]), (datas[1], gts[1]), (datas[1], gts[1]), (datas[2], gts[2]), (datas[2], gts[2])]
+    for d, gt in eager_seq:
+        _eager_step(ma, oa, lc, d, gt)
+    runner.step(far, gts[0])
+    runner.step(datas[1], gts[1])   # overflows the far view's capacity: skipped on the device
+    runner.step()                   # "same frame again" (static buffers), queued behind the overflow
+    runner.step(datas[2], gts[2])   # overwrites the static buffers
+    runner.step()
+    runner.finish()
+    rep = runner.report()
+    assert rep["overflows"] >= 1 and rep["steps"] == 5
+    _assert_same(ma, oa, mb, ob, "static-input replay")

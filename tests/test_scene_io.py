@@ -178,6 +178,81 @@ def test_checkpoint_layout_selection_and_reference_class_paths(tmp_path):
     assert full.optimizer is not None and [g["name"] for g in full.optimizer.param_groups] == m.param_names
 
 
+def test_checkpoint_written_by_the_reference_loads_renders_and_resumes(tmp_path):
+    """A file as the REFERENCE writes it: an object of class `model.gaussian.GaussianModel` that carries exactly the
+    reference's attribute set (/root/reference/model/gaussian.py:31-92: statistics as plain tensor attributes,
+    MAX_SCALE_RATIO a 0-d tensor, a torch.optim.Adam inside, none of this package's extra attributes).  It must unpickle
+    into this package's class, fall back to the class defaults (`fuse_sh_cat`), and its optimizer must step."""
+    import types
+    n = 30
+    g = torch.Generator().manual_seed(1)
+    r = lambda *sh: torch.randn(*sh, generator=g)
+    # stand-in classes under the reference's module paths, with the reference's attribute names only
+    pkg, gmod, umod = types.ModuleType("model"), types.ModuleType("model.gaussian"), types.ModuleType("model.utils")
+    pkg.__path__ = []
+
+    class LR_Scheduler:   # noqa: N801  (the reference's name)
+        def __init__(self, lr_init, lr_final, max_steps):
+            self.lr_init, self.lr_final, self.max_steps = lr_init, lr_final, max_steps
+
+    class RefGaussianModel(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            P = torch.nn.Parameter
+            self.means, self.log_scales, self.quats = P(r(n, 3)), P(r(n, 3) * 0.1 - 3), P(r(n, 4))
+            self.sh_0, self.sh_rest, self.logit_opacities = P(r(n, 1, 3)), P(r(n, 15, 3)), P(r(n))
+            self.grad_norm_accum, self.collecting_counts, self.max_radii = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+            self.optimizer = None
+            self.active_sh_degree = 2
+            self.means_lr_scheduler = LR_Scheduler(1.6e-4, 1.6e-6, 30000)
+            self.MAX_SH_DEGREE = 3
+            self.DENSIFY_GRAD_THRESH, self.DENSIFY_SCALE_THRESH, self.NUM_SPLITS = 0.0002, 0.01, 2
+            self.PRUNE_RADII_RATIO_THRESH, self.PRUNE_SCALE_THRESH, self.MIN_OPACITY = 0.15, 0.1, 0.005
+            self.USE_SCALE_REGULARIZATION = True
+            self.MAX_SCALE_RATIO = torch.tensor(10.0)
+            self.BACKGROUND = P(torch.zeros(3), requires_grad=False)
+
+    LR_Scheduler.__module__, LR_Scheduler.__qualname__ = "model.utils", "LR_Scheduler"
+    RefGaussianModel.__module__, RefGaussianModel.__qualname__, RefGaussianModel.__name__ = "model.gaussian", "GaussianModel", "GaussianModel"
+    gmod.GaussianModel, umod.LR_Scheduler = RefGaussianModel, LR_Scheduler
+    ref = RefGaussianModel()
+    names = ["means", "log_scales", "quats", "sh_0", "sh_rest", "logit_opacities"]
+    ref.optimizer = torch.optim.Adam([{"params": [getattr(ref, k)], "lr": 1e-3 * (i + 1), "name": k} for i, k in enumerate(names)])
+    for k in names:
+        getattr(ref, k).grad = torch.ones_like(getattr(ref, k))
+    ref.optimizer.step()
+    sys.modules.update({"model": pkg, "model.gaussian": gmod, "model.utils": umod})
+    try:
+        (tmp_path / "checkpoints").mkdir()
+        torch.save(ref, tmp_path / "checkpoints" / "iterations_100.pth")
+    finally:
+        for k in ("model", "model.gaussian", "model.utils"):
+            sys.modules.pop(k)
+    m = ckpt.load_gaussian_model(tmp_path, device="cpu")
+    assert type(m) is GaussianModel and "fuse_sh_cat" not in m.__dict__ and m.fuse_sh_cat is True and m.tile_culling == "tight"
+    assert torch.equal(m.means, ref.means) and m.active_sh_degree == 2 and isinstance(m.max_radii, torch.Tensor)
+    assert abs(m.means_lr_scheduler(15000) - 1.6e-5) < 1e-9                      # this package's __call__ on the reference's fields
+    assert float(m.get_regularization_dict()["scale_reg"]) >= 0.0                # MAX_SCALE_RATIO is a tensor in such files
+    assert isinstance(m.optimizer, torch.optim.Adam) and [g["name"] for g in m.optimizer.param_groups] == names
+    before = m.means.detach().clone()
+    for k in names:
+        getattr(m, k).grad = torch.ones_like(getattr(m, k))
+    m.optimizer.step()                                                           # the pickled state resumes (step 2 of Adam)
+    st = m.optimizer.state[m.means]
+    assert float(st["step"]) == 2.0 and not torch.equal(m.means.detach(), before)
+    # and the way back: what this package writes holds only what the reference's classes can hold
+    m.USE_SCALE_REGULARIZATION, m.MAX_SCALE_RATIO = True, 10.0
+    ckpt.save_gaussian_model(tmp_path / "checkpoints" / "iterations_200.pth", m, save_optimizer=True)
+    assert m.MAX_SCALE_RATIO == 10.0 and isinstance(m.optimizer, torch.optim.Adam)
+    import zipfile
+    with zipfile.ZipFile(tmp_path / "checkpoints" / "iterations_200.pth") as z:
+        pkl = z.read([nm for nm in z.namelist() if nm.endswith("data.pkl")][0])
+    assert b"easy_gaussian_splatting_amd" not in pkl                              # no class of this package is named
+    with ckpt.reference_class_paths():
+        raw = torch.load(tmp_path / "checkpoints" / "iterations_200.pth", map_location="cpu", weights_only=False)
+    assert isinstance(raw.MAX_SCALE_RATIO, torch.Tensor) and float(torch.max(torch.tensor([3.0, 30.0]), raw.MAX_SCALE_RATIO)[0]) == 10.0
+
+
 def test_model_from_pointcloud_follows_reference_initialisation():
     rng = np.random.default_rng(0)
     pc = S.Pointcloud(rng.standard_normal((200, 3)).astype(np.float32), rng.integers(0, 256, (200, 3), dtype=np.uint8))
