@@ -68,6 +68,8 @@ SIGNATURES = {
     "gs_refine_apply": (_I, [_P, _L, _I, _I, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_project_bwd_adam": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P,
                                   _P, _P, _P]),
+    "gs_workspace_query": (_I, [_I, _L, _I, _I, _L, _L, _I, _I, _P, _P]),
+    "gs_workspace_bind": (_I, [_P, _P, _L, _P, _L, _P, _P]),
     "gs_adam_step": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F]),
 }
 

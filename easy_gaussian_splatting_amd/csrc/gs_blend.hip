@@ -441,6 +441,8 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     GS_REQUIRE(isect_offsets && bucket_offsets && render_colors && render_alphas, "null pointer");
     const bool train = ckpt != nullptr;
     GS_REQUIRE(!train || (qlist && qcnt && qmask && unit_counter && unit_desc && slots), "training mode needs every list output");
+    // work-unit descriptors carry the index of a unit's first qlist pair (< 4 * I) as int32
+    GS_REQUIRE(!train || 4 * n_isects <= (int64_t)INT32_MAX, "training mode holds at most 2^29 intersections per call (int32 work-unit descriptors)");
     BlendFwdArgs a;
     a.C = C; a.W = width; a.H = height;
     a.tw = (width + GS_TILE - 1) / GS_TILE;

@@ -34,6 +34,11 @@ def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def group_ready() -> bool:
+    """A process group exists (possibly of one rank)."""
+    return dist.is_available() and dist.is_initialized()
+
+
 class GradBucket:
     """Persistent flat gradient buffer: parameters' `.grad` become views into it, so autograd
     accumulates straight into the bucket and the all-reduce needs no pack/unpack copies."""
@@ -52,8 +57,9 @@ class GradBucket:
     def zero_(self):
         self.flat.zero_()
 
-    def all_reduce_mean(self, group=None, async_op: bool = False):
-        if not is_distributed():
+    def all_reduce_mean(self, group=None, async_op: bool = False, force: bool = False):
+        """`force`: issue the collective even in a one-rank group (exercises the transport: RCCL smoke test)."""
+        if not (is_distributed() or (force and group_ready())):
             return None
         world = dist.get_world_size(group)
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
@@ -63,11 +69,11 @@ class GradBucket:
         return None
 
 
-def all_reduce_param_grads(params: Iterable[torch.nn.Parameter], group=None) -> None:
+def all_reduce_param_grads(params: Iterable[torch.nn.Parameter], group=None, force: bool = False) -> None:
     """Mean of `.grad` over ranks without a staging bucket: one async all-reduce per parameter
     tensor, largest first (sh_rest is 76 % of the bytes at SH3), then one wait and the 1/world scale.
-    Used with optim.FusedAdam, whose gradients are the rasterizer's own output tensors."""
-    if not is_distributed():
+    Used with optim.FusedAdam, whose gradients are the rasterizer's own output tensors.  `force`: also in a one-rank group."""
+    if not (is_distributed() or (force and group_ready())):
         return
     world = dist.get_world_size(group)
     grads = sorted((p.grad for p in params if p.requires_grad and p.grad is not None), key=lambda g: -g.numel())
@@ -88,38 +94,45 @@ class ViewParallelStep:
     replaces `model.update_statistics(data, out); optimizer.step(); optimizer.zero_grad()` of the
     reference loop (/root/reference/train.py:36-43, 57-58).  The update equals the single-process
     step on the batch of all ranks' views with a mean-over-views loss.  With one rank it is exactly
-    the reference sequence."""
+    the reference sequence -- unless `force_exchange` is set: then a one-rank group still goes through every
+    collective of the scheme (camera all-gather, radii MAX, colour-gradient all-gather from inside `backward()`,
+    geometry all-reduce, split Adam), which is how the RCCL path is exercised on a one-GPU box."""
 
     SH = ("sh_0", "sh_rest")
     GEOMETRY = ("means", "log_scales", "quats", "logit_opacities")
 
-    def __init__(self, model, optimizer, group=None, sh_grad_fn=None):
+    def __init__(self, model, optimizer, group=None, sh_grad_fn=None, force_exchange: bool = False):
         self.model, self.opt, self.group = model, optimizer, group
-        self.world = dist.get_world_size(group) if is_distributed() else 1
-        if self.world > 1 and not hasattr(optimizer, "moments_of"):
+        self.world = dist.get_world_size(group) if group_ready() else 1
+        if force_exchange and not group_ready():
+            raise RuntimeError("ViewParallelStep(force_exchange=True) needs an initialised process group")
+        self.exchange = self.world > 1 or bool(force_exchange)
+        if self.exchange and not hasattr(optimizer, "moments_of"):
             raise TypeError("ViewParallelStep drives optim.FusedAdam (partial steps, folded 1/world scale)")
         if sh_grad_fn is None:
             from .rendering import sh_grad_views as sh_grad_fn
         self.sh_grad_fn = sh_grad_fn
         self._cams = self._rad = self._pre = None
-        if self.world > 1:   # started from inside backward(), as soon as the colour gradient exists
+        self.collectives = 0   # collectives issued so far (diagnostics / tests)
+        if self.exchange:   # started from inside backward(), as soon as the colour gradient exists
             model.on_colors_pre = self._gather_colors_pre
-        model.sh_grads = "colors_pre" if self.world > 1 else "dense"
+        model.sh_grads = "colors_pre" if self.exchange else "dense"
 
     # Optional hooks that move the two small collectives off the end of the step (every rank must make
     # the same calls in the same order; `step` issues whatever was not issued before).
     def begin_step(self, data) -> None:
         """Before the forward: exchange the cameras (64 B per rank)."""
-        if self.world == 1 or self._cams is not None:
+        if not self.exchange or self._cams is not None:
             return
         dt, dev = self.model.means.dtype, self.model.means.device
         cams = torch.empty(self.world * 16, dtype=dt, device=dev)
         work = dist.all_gather_into_tensor(cams, data["w2c"].to(dt).reshape(-1).contiguous(), group=self.group, async_op=True)
         self._cams = (cams, work)
+        self.collectives += 1
 
     def after_forward(self, data, out) -> None:
         """After the forward: MAX all-reduce of the normalised radii, overlapped with loss + backward."""
-        if self.world == 1 or self._rad is not None:
+        if not self.exchange or self._rad is not None:
             return
         dt = self.model.means.dtype
         max_hw = float(max(data["height"], data["width"]))
@@ -128,6 +141,7 @@ class ViewParallelStep:
         rad = torch.where(visible, radii.to(dt) / max_hw, 0.0)
         work = dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         self._rad = (rad, visible, work)
+        self.collectives += 1
 
     def _gather_colors_pre(self, colors_pre_grad: Tensor) -> None:
         """All-gather of this view's pre-clamp colour gradient [1,N,3] (flat 1-D buffers: the layout
@@ -139,10 +153,11 @@ class ViewParallelStep:
         pre_all = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
         work = dist.all_gather_into_tensor(pre_all, mine, group=self.group, async_op=True)
         self._pre = (pre_all, work)
+        self.collectives += 1
 
     def step(self, data, out) -> None:
         m, opt = self.model, self.opt
-        if self.world == 1:
+        if not self.exchange:
             m.update_statistics(data, out)
             opt.step()
             opt.zero_grad()
@@ -188,6 +203,7 @@ class ViewParallelStep:
             for t, o in zip(pieces, offs):
                 flat[o:o + t.numel()].copy_(t.reshape(-1))
         w_sum = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        self.collectives += 1
         # SH half: rebuild the dense SH gradient of all views, update while (2) is in flight
         w_cams.wait()
         w_gather.wait()

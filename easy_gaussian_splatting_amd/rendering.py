@@ -21,6 +21,7 @@ import torch
 from torch import Tensor
 
 from . import _native as nat
+from . import workspace as WS
 
 _TILE = nat.GS_TILE
 
@@ -65,8 +66,17 @@ def profile_stages(enable: bool) -> Optional[Dict]:
 
 _tls = threading.local()
 _state_lock = threading.Lock()   # guards the two module-level dicts below (entry points are called from any thread)
-_cap_hint: Dict[int, int] = {}   # per device: list capacity to pre-allocate (last intersection count + 25 %)
-_coarse_hint: Dict[int, dict] = {}   # per device: what the last two-level binning needed (entries, longest bin list, footprint)
+_hints: Dict[tuple, dict] = {}   # per (device, C, W, H, training, list mode): capacities the next call of this shape starts from
+_coarse_hint: Dict[int, dict] = {}   # per device: pipeline and mean footprint of the last call (last_binning)
+
+
+def reset_hints() -> None:
+    """Forgets the capacities learnt from earlier calls (the next call of every shape starts from the first-call guess
+    again) and drops the idle workspaces."""
+    with _state_lock:
+        _hints.clear()
+        _coarse_hint.clear()
+    WS.pool.clear()
 
 
 def bin_shift_for(footprint) -> int:
@@ -119,7 +129,7 @@ def binning_choice(footprint, tiles: int = 0) -> str:
 
 # host-side diagnostics: time spent blocked on the list-size read-back (bench.py reports it; a wait
 # near zero means the host, not the GPU, paces the loop)
-stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0}
+stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0, "overflow_reruns": 0}
 
 
 def _pinned_info(device: torch.device) -> Tensor:
@@ -141,10 +151,19 @@ class _LazyMeta(dict):
     (/root/reference/model/gaussian.py:368-375 takes `means2d` and `radii`)."""
     PENDING = object()
 
+    class Lazy:
+        """A value produced on first access (list arrays copied out of the leased workspace)."""
+        __slots__ = ("fn",)
+
+        def __init__(self, fn):
+            self.fn = fn
+
+    _lease = None   # workspace.LeaseRef: the arenas the lazies read stay leased for as long as this dict lives
+
     def _isect_ids(self) -> Tensor:
         C, tiles = self["n_cameras"], self["tile_width"] * self["tile_height"]
-        fid = dict.__getitem__(self, "flatten_ids")
-        off = dict.__getitem__(self, "isect_offsets").reshape(-1).long()
+        fid = self["flatten_ids"]
+        off = self["isect_offsets"].reshape(-1).long()
         counts = torch.diff(off, append=off.new_tensor([fid.numel()]))
         tile = torch.repeat_interleave(torch.arange(C * tiles, device=fid.device), counts, output_size=fid.numel())
         tile_bits = int(tiles).bit_length()
@@ -155,6 +174,9 @@ class _LazyMeta(dict):
         v = dict.__getitem__(self, key)
         if v is _LazyMeta.PENDING:
             v = self._isect_ids()
+            dict.__setitem__(self, key, v)
+        elif isinstance(v, _LazyMeta.Lazy):
+            v = v.fn()
             dict.__setitem__(self, key, v)
         return v
 
@@ -194,8 +216,23 @@ class _Holder:
         self.on_colors_pre = None
 
 
+def _sort_class(n: int) -> int:
+    """Capacity of the smallest per-tile sort class that takes a list of n entries (gs_binning.hip: launch_list_sorts)."""
+    for c in (1024, 4096, 8192, 16384):
+        if n <= c:
+            return c
+    return 1 << 30
+
+
 def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, need_grad):
-    """Runs P/SH-fwd, binning, per-tile sort and B-fwd.  Returns (outputs, saved-state dict)."""
+    """Runs P/SH-fwd, binning, per-tile sort and B-fwd.  Returns (outputs, meta, saved-state dict).
+
+    Sync-free up to its last line (SURVEY.md 8b "Sync"): every intermediate lives in a leased workspace sized by a
+    CAPACITY learnt from earlier calls, and the list stages + the blend are enqueued under the library's step guard
+    BEFORE the list sizes {I, n_buckets, longest list} have reached the host; the host then waits on the event behind
+    the count kernels while the GPU is busy with everything queued after it -- the stream never drains because of the
+    read-back.  Lists that outgrew the capacity made the guarded kernels device-side no-ops: the list arena is replaced
+    and count .. blend are repeated with the sizes the count reported (rare: the capacity follows the largest frame)."""
     L = nat.lib()
     dev = means.device
     C, N = viewmats.shape[0], means.shape[0]
@@ -214,150 +251,148 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         deg, per_cam = int(sh_degree), 0
         K = colors.shape[1] + (0 if colors_rest is None else colors_rest.shape[1])
 
+    # what escapes to the caller through `meta` is allocated per call; everything else is workspace
     radii = torch.empty((C, N), **i32)
     means2d = torch.empty((C, N, 2), **f32)
     depths = torch.empty((C, N), **f32)
     conics = torch.empty((C, N, 3), **f32)
-    colors_post = torch.empty((C, N, 3), **f32)
-    rec = torch.empty((C * N, nat.GS_REC_FLOATS), **f32)
-    bbox = torch.empty((C * N, 4), **i32)
-    tiles_per_gauss = torch.empty((C, N), **i32)
+    render_colors = torch.empty((C, H, W, 3), **f32)
+    render_alphas = torch.empty((C, H, W, 1), **f32)
+
+    dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+    hint_key = (dev_index, C, W, H, bool(need_grad), cfg["tile_culling"])
+    with _state_lock:
+        hint = dict(_hints.get(hint_key, {}))
+    two_level = binning_choice(hint.get("footprint"), tiles) == "bins"
+    shift = bin_shift_for(hint.get("footprint")) if two_level else 0
+    eager_ids = os.environ.get("GS_EAGER_ISECT_IDS") == "1"   # (default: meta builds isect_ids on first access, _LazyMeta)
+    factorised = cfg.get("sh_grads") == "colors_pre"
+    flags = ((WS.F_TRAIN if need_grad else 0) | (WS.F_TWO_LEVEL if two_level else 0) | (WS.F_ISECT_IDS if eager_ids else 0)
+             | (WS.F_ROWS_COLOR if (need_grad and factorised) else 0))
+    # capacities: what earlier calls of this shape needed (+25 %), or a first guess
+    cap = max(int(hint.get("cap", 0)), 2 * C * N + 4096 if not hint else 0, 4096)
+    cap_tile = int(hint.get("cap_tile", 1024)) if not two_level else (1 << 30)
+    coarse_cap = max(int(hint.get("entries", 0)), 2 * C * N + 1024) if two_level else 0
+    coarse_list_cap = int(hint.get("longest", 0)) if two_level else 0   # 0: launch every sort class
+    if need_grad:
+        cap = min(cap, (1 << 29) - 1)
+
+    lease = WS.pool.acquire(dev, st)
+    lease.bind(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags), st)
+    P = lease.ptr
+    info_dev = lease.view(WS.INFO, 8)
+    info_host = _pinned_info(dev)
+    bin_bytes = lambda: int(L.gs_bins_workspace_bytes(C, N, tw, th, shift, coarse_cap) if two_level else L.gs_bin_workspace_bytes(C, N, tw, th))
+
     def project(stage: int, tag: str):
         _stage(tag, dev, lambda: nat.check(L.gs_project_fwd(
             st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), _ptr(colors_rest),
             per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"],
             cfg["radius_clip"], cfg["tile_culling"], stage, cfg.get("activations", 0), _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics),
-            _ptr(colors_post), _ptr(rec), _ptr(bbox), _ptr(tiles_per_gauss)), "gs_project_fwd"))
+            P(WS.COLORS_POST), P(WS.REC), P(WS.BBOX), P(WS.TILES_PER_GAUSS)), "gs_project_fwd"))
 
-    # 1. geometry, 2. tile counts, 3. colours.  The list sizes {I, n_buckets, max_tile} must reach the
-    # host before the list buffers can be allocated -- the path's one host read-back.  The copy is
-    # queued right behind the count kernels and the SH colour pass behind the copy, so the host
-    # wakes on the copy's event while the GPU is still busy with SH: no idle gap.
+    def count():
+        if two_level:
+            nat.check(L.gs_bins_count(st, C, N, tw, th, shift, P(WS.BBOX), _ptr(depths), P(WS.BIN), bin_bytes(),
+                                      P(WS.COARSE_KEYS), coarse_cap, coarse_list_cap, P(WS.CUM_TILES), P(WS.ISECT_OFFSETS),
+                                      P(WS.BUCKET_OFFSETS), P(WS.TILE_ORDER), P(WS.INFO), None), "gs_bins_count")
+        else:
+            nat.check(L.gs_bin_count(st, C, N, tw, th, P(WS.BBOX), P(WS.BIN), bin_bytes(), P(WS.ISECT_OFFSETS),
+                                     P(WS.BUCKET_OFFSETS), P(WS.TILE_ORDER), P(WS.INFO), None), "gs_bin_count")
+
+    def lists_and_blend():
+        if two_level:
+            _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bins_lists(
+                st, C, N, tw, th, shift, P(WS.BBOX), P(WS.BIN), bin_bytes(), P(WS.COARSE_KEYS), coarse_cap,
+                P(WS.CUM_TILES), P(WS.ISECT_OFFSETS), P(WS.ISECT_IDS), P(WS.FLATTEN_IDS), P(WS.SLOTS), P(WS.INFO)), "gs_bins_lists"))
+        else:
+            _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bin_emit_sort(
+                st, C, N, tw, th, P(WS.BBOX), _ptr(depths), P(WS.BIN), bin_bytes(), P(WS.ISECT_OFFSETS), cap,
+                min(cap_tile, cap), P(WS.KEYS_TMP), P(WS.SLOT_GID), P(WS.CUM_TILES), P(WS.ISECT_IDS), P(WS.FLATTEN_IDS),
+                P(WS.SLOTS)), "gs_bin_emit_sort"))
+        _stage("gs_blend_fwd", dev, lambda: nat.check(L.gs_blend_fwd(
+            st, C, W, H, P(WS.REC), _ptr(backgrounds), P(WS.ISECT_OFFSETS), P(WS.BUCKET_OFFSETS), P(WS.TILE_ORDER),
+            P(WS.FLATTEN_IDS), P(WS.SLOTS), cap, _ptr(render_colors), _ptr(render_alphas), P(WS.CKPT), P(WS.QLIST), P(WS.QCNT),
+            P(WS.QMASK), P(WS.UNIT_COUNTER), P(WS.UNIT_DESC)), "gs_blend_fwd"))
+
+    # 1. geometry; 2. tile counts under the guard (flags = capacity exceeded) and their 64-byte copy to the host;
+    # 3. SH colours; 4. lists + blend, speculatively; 5. only now the host looks at the sizes.
     project(1, "gs_project_fwd")
-    info_dev = torch.empty((8,), dtype=torch.int64, device=dev)
-    isect_offsets = torch.empty((C * tiles + 1,), **i32)
-    bucket_offsets = torch.empty((C * tiles + 1,), **i32)
-    tile_order = torch.empty((C * tiles,), **i32)   # launch order of the blend forward: longest lists first
-    cum_tiles = torch.empty((C * N,), **i32)
-    hint_key = dev.index if dev.index is not None else torch.cuda.current_device()
-    with _state_lock:
-        hint = dict(_coarse_hint.get(hint_key, {}))
-    two_level = binning_choice(hint.get("footprint"), tiles) == "bins"
-    if two_level:
-        # two-level binning (include/gs_raster.h): coarse-bin lists are emitted and sorted, tiles are counted out of them.
-        # Sizes the host cannot know yet come from the previous call on this device (+25 %); a miss raises a flag in
-        # info[3], nothing is emitted, and the count is repeated with the sizes it reported.
-        shift = bin_shift_for(hint.get("footprint"))
-        coarse_cap = max(hint.get("entries", 0), 2 * C * N + 1024)
-        list_cap = [hint.get("longest", 0)]   # 0: launch every sort class
-        bufs = {}
-
-        def alloc_coarse(n):
-            bufs["keys"] = torch.empty((n,), dtype=torch.int64, device=dev)
-            bufs["ws"] = torch.empty((int(L.gs_bins_workspace_bytes(C, N, tw, th, shift, n)),), dtype=torch.uint8, device=dev)
-
-        alloc_coarse(coarse_cap)
-        count = lambda: nat.check(L.gs_bins_count(st, C, N, tw, th, shift, _ptr(bbox), _ptr(depths), _ptr(bufs["ws"]), bufs["ws"].numel(),
-                                                  _ptr(bufs["keys"]), bufs["keys"].numel(), list_cap[0], _ptr(cum_tiles), _ptr(isect_offsets),
-                                                  _ptr(bucket_offsets), _ptr(tile_order), _ptr(info_dev), None), "gs_bins_count")
-    else:
-        ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
-        workspace = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        count = lambda: nat.check(L.gs_bin_count(st, C, N, tw, th, _ptr(bbox), _ptr(workspace), ws_bytes, _ptr(isect_offsets),
-                                                 _ptr(bucket_offsets), _ptr(tile_order), _ptr(info_dev), None), "gs_bin_count")
-    _stage("gs_bin_count", dev, count)
-    info_host = _pinned_info(dev)
-    info_host.copy_(info_dev, non_blocking=True)
-    ready = torch.cuda.Event()
-    ready.record(torch.cuda.current_stream(dev))
-    project(2, "gs_project_fwd_color")
-    # The list buffers are allocated BEFORE the host blocks, from the size the previous call on this
-    # device needed (+25 %): the window between the host waking up and the emit kernel being queued is
-    # what the colour pass has to cover, and six allocator calls do not belong in it.
-    with _state_lock:
-        cap = _cap_hint.get(hint_key, 0)
-
-    eager_ids = os.environ.get("GS_EAGER_ISECT_IDS") == "1"   # (default: meta builds isect_ids on first access, _LazyMeta)
-
-    want_slots = need_grad   # inference: no gradient-row slots, no slot -> id map (the sort keys carry the flatten id)
-
-    def alloc_lists(c):
-        scratch = () if two_level else (torch.empty((c,), dtype=torch.int64, device=dev), torch.empty((c,), **i32) if want_slots else None)
-        ids = torch.empty((c,), dtype=torch.int64, device=dev) if eager_ids else None
-        return scratch + (ids, torch.empty((c,), **i32), torch.empty((c,), **i32) if want_slots else None)
-
-    lists = alloc_lists(cap) if cap > 0 else None
-    t_wait = time.perf_counter_ns()
-    ready.synchronize()
-    waited = time.perf_counter_ns() - t_wait
-    while two_level and int(info_host[3]) & 12:
-        # the coarse key buffer was too small or a bin list longer than the sort classes launched (first call on this
-        # device, or the scene changed): nothing was emitted; re-run the count with the sizes it reported
-        if int(info_host[3]) & 4:
-            alloc_coarse(int(info_host[4]) + (int(info_host[4]) >> 2) + 1024)
-        list_cap[0] = 0
-        with _state_lock:
-            stats["coarse_retries"] += 1
-        count()
-        info_host.copy_(info_dev, non_blocking=True)
-        torch.cuda.current_stream(dev).synchronize()
-    n_isects, n_buckets, max_tile = (int(v) for v in info_host[:3].tolist())
-    if lists is None or n_isects > cap:
-        cap = max(n_isects, 1)
-        lists = alloc_lists(cap)
+    attempt, waited = 0, 0
+    try:
+        while True:
+            nat.check(L.gs_guard_set(P(WS.INFO), cap, min(cap_tile, cap)), "gs_guard_set")
+            _stage("gs_bin_count", dev, count)
+            info_host.copy_(info_dev, non_blocking=True)
+            if attempt == 0:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(dev))
+                project(2, "gs_project_fwd_color")
+            lists_and_blend()
+            nat.check(L.gs_guard_set(None, 0, 0), "gs_guard_set")
+            t_wait = time.perf_counter_ns()
+            if attempt == 0:
+                ready.synchronize()
+            else:
+                torch.cuda.current_stream(dev).synchronize()
+            waited += time.perf_counter_ns() - t_wait
+            info = [int(v) for v in info_host.tolist()]
+            n_isects, n_buckets, max_tile, fl = info[0], info[1], info[2], info[3]
+            if fl == 0:
+                break
+            # a capacity did not hold: nothing was emitted or blended.  Re-size from what the count reported and repeat.
+            attempt += 1
+            if attempt > 6:
+                raise nat.NativeLibraryError(f"rasterization: list capacities did not settle (info {info})")
+            if two_level and fl & 12:
+                if fl & 4:
+                    coarse_cap = info[4] + (info[4] >> 2) + 1024
+                coarse_list_cap = 0
+                with _state_lock:
+                    stats["coarse_retries"] += 1
+            if fl & 1:
+                cap = n_isects + (n_isects >> 3) + 1024
+            if fl & 2:
+                cap_tile = _sort_class(max_tile)
+            with _state_lock:
+                stats["overflow_reruns"] += 1
+            lease.grow_lists(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags), st)
+            info_dev = lease.view(WS.INFO, 8)
+            info_dev.zero_()
+    finally:
+        L.gs_guard_set(None, 0, 0)
     with _state_lock:
         stats["sync_wait_ns"] += waited
         stats["calls"] += 1
-        _cap_hint[hint_key] = n_isects + (n_isects >> 2) + 1024
+        old = _hints.get(hint_key, {})
+        # the capacity follows the largest recent frame (slow decay), so alternating views do not overflow every time
+        new = dict(cap=max(n_isects + (n_isects >> 2) + 1024, int(old.get("cap", 0) * 0.995)),
+                   cap_tile=max(_sort_class(max_tile + (max_tile >> 2)), 1024), footprint=n_isects / max(1, C * N),
+                   mode="bins" if two_level else "tiles")
         if two_level:
-            _coarse_hint[hint_key] = dict(entries=int(info_host[4]) + (int(info_host[4]) >> 2) + 1024,
-                                          longest=int(info_host[5]) + (int(info_host[5]) >> 2) + 64,
-                                          footprint=n_isects / max(1, C * N), mode="bins")
-        else:
-            _coarse_hint[hint_key] = dict(footprint=n_isects / max(1, C * N), mode="tiles")
-    if two_level:
-        isect_ids, flatten_ids, slots = lists
-        _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bins_lists(st, C, N, tw, th, shift, _ptr(bbox), _ptr(bufs["ws"]), bufs["ws"].numel(),
-                                     _ptr(bufs["keys"]), bufs["keys"].numel(), _ptr(cum_tiles), _ptr(isect_offsets), _ptr(isect_ids),
-                                     _ptr(flatten_ids), _ptr(slots), _ptr(info_dev)), "gs_bins_lists"))
-    else:
-        keys_tmp, slot_gid, isect_ids, flatten_ids, slots = lists
-        _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, _ptr(bbox), _ptr(depths), _ptr(workspace), ws_bytes,
-                                     _ptr(isect_offsets), n_isects, max_tile, _ptr(keys_tmp), _ptr(slot_gid),
-                                     _ptr(cum_tiles), _ptr(isect_ids), _ptr(flatten_ids), _ptr(slots)), "gs_bin_emit_sort"))
+            new.update(entries=max(info[4] + (info[4] >> 2) + 1024, int(old.get("entries", 0) * 0.995)),
+                       longest=info[5] + (info[5] >> 2) + 64)
+        _hints[hint_key] = new
+        _coarse_hint[dev_index] = dict(mode=new["mode"], footprint=new["footprint"])
 
-    render_colors = torch.empty((C, H, W, 3), **f32)
-    render_alphas = torch.empty((C, H, W, 1), **f32)
-    ckpt = qlist = qcnt = qmask = unit_counter = unit_desc = None
-    if need_grad:  # what the Gaussian-parallel backward consumes (see include/gs_raster.h)
-        nbk = max(n_buckets, 1)
-        ckpt = torch.empty((8 * nbk, 64, 4), **f32)   # one per 32-entry work unit
-        qlist = torch.empty((4 * cap, 2), **i32)
-        qcnt = torch.empty((C * tiles * 4,), **i32)
-        qmask = torch.empty((cap,), dtype=torch.uint8, device=dev)
-        unit_counter = torch.empty((1,), **i32)
-        unit_desc = torch.empty((8 * nbk, 4), **i32)
-    _stage("gs_blend_fwd", dev, lambda: nat.check(L.gs_blend_fwd(st, C, W, H, _ptr(rec), _ptr(backgrounds), _ptr(isect_offsets),
-                             _ptr(bucket_offsets), _ptr(tile_order), _ptr(flatten_ids), _ptr(slots), n_isects, _ptr(render_colors),
-                             _ptr(render_alphas), _ptr(ckpt), _ptr(qlist), _ptr(qcnt), _ptr(qmask),
-                             _ptr(unit_counter), _ptr(unit_desc)), "gs_blend_fwd"))
-
+    ref = WS.LeaseRef(lease)
+    lazy = _LazyMeta.Lazy
     meta = _LazyMeta({
         "camera_ids": None, "gaussian_ids": None,
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
         "opacities": opacities[None, :].expand(C, N),
-        "tile_width": tw, "tile_height": th, "tiles_per_gauss": tiles_per_gauss,
-        "isect_ids": _LazyMeta.PENDING if isect_ids is None else isect_ids[:n_isects], "flatten_ids": flatten_ids[:n_isects],
-        "isect_offsets": isect_offsets[: C * tiles].view(C, th, tw),
-        "width": W, "height": H, "tile_size": _TILE, "n_cameras": C,
+        "tile_width": tw, "tile_height": th,
+        # list arrays: copied out of the workspace on first access (the lease is kept alive by this dict)
+        "tiles_per_gauss": lazy(lambda: lease.view(WS.TILES_PER_GAUSS, C * N).clone().view(C, N)),
+        "isect_ids": lazy(lambda: lease.view(WS.ISECT_IDS, n_isects).clone()) if eager_ids else _LazyMeta.PENDING,
+        "flatten_ids": lazy(lambda: lease.view(WS.FLATTEN_IDS, n_isects).clone()),
+        "isect_offsets": lazy(lambda: lease.view(WS.ISECT_OFFSETS, C * tiles).clone().view(C, th, tw)),
+        "width": W, "height": H, "tile_size": _TILE, "n_cameras": C, "n_isects": n_isects,
     })
-    state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, n_isects=n_isects, n_buckets=n_buckets,
-                 radii=radii, colors_post=colors_post, rec=rec, tiles_per_gauss=tiles_per_gauss,
-                 cum_tiles=cum_tiles, isect_offsets=isect_offsets, bucket_offsets=bucket_offsets,
-                 flatten_ids=flatten_ids, slots=slots, ckpt=ckpt, qlist=qlist, qcnt=qcnt, qmask=qmask,
-                 unit_counter=unit_counter, unit_desc=unit_desc)
+    meta._lease = ref
+    state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, n_isects=n_isects, n_buckets=n_buckets, radii=radii, lease=lease,
+                 lease_ref=WS.LeaseRef(lease) if need_grad else None, factorised=factorised)
     return render_colors, render_alphas, meta, state
-
 
 
 class _Rasterize(torch.autograd.Function):
@@ -372,8 +407,10 @@ class _Rasterize(torch.autograd.Function):
         render_colors, render_alphas, meta, state = _forward_stages(
             means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, backgrounds, cfg, need_grad)
         holder.meta = meta
-        if holder.debug is not None:   # work-unit counters of the backward (bench.py's compute roofline)
-            holder.debug.update(unit_counter=state["unit_counter"], qcnt=state["qcnt"], unit_entries=nat.GS_UNIT)
+        if holder.debug is not None and need_grad:   # work-unit counters of the backward (bench.py's compute roofline): copies
+            lease, tiles = state["lease"], meta["tile_width"] * meta["tile_height"]
+            holder.debug.update(unit_counter=lease.view(WS.UNIT_COUNTER, 1).clone(),
+                                qcnt=lease.view(WS.QCNT, state["C"] * tiles * 4).clone(), unit_entries=nat.GS_UNIT)
         ctx.cfg, ctx.holder, ctx.state = cfg, holder, state
         ctx.split = colors_rest is not None
         if need_grad:
@@ -394,13 +431,12 @@ class _Rasterize(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         v_rc = torch.zeros_like(render_colors) if v_render_colors is None else v_render_colors.contiguous()
         v_ra = None if v_render_alphas is None else v_render_alphas.contiguous()
-        rows = torch.empty((max(s["n_isects"], 1) * 4, nat.GS_ROW_FLOATS), **f32)
-        factorised = cfg.get("sh_grads") == "colors_pre"
-        rows_color = torch.empty((max(s["n_isects"], 1) * 4, 4), **f32) if factorised else None
-        _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, _ptr(s["rec"]), _ptr(s["isect_offsets"]),
-                                 _ptr(s["bucket_offsets"]), s["n_buckets"], _ptr(s["qlist"]), _ptr(s["qcnt"]), _ptr(s["unit_counter"]),
-                                 _ptr(s["unit_desc"]), _ptr(s["ckpt"]), _ptr(render_colors), _ptr(render_alphas),
-                                 _ptr(v_rc), _ptr(v_ra), _ptr(rows), _ptr(rows_color)), "gs_blend_bwd"))
+        lease, factorised = s["lease"], s["factorised"]   # (the forward's workspace: kept leased by s["lease_ref"])
+        P = lease.ptr
+        _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, P(WS.REC), P(WS.ISECT_OFFSETS),
+                                 P(WS.BUCKET_OFFSETS), s["n_buckets"], P(WS.QLIST), P(WS.QCNT), P(WS.UNIT_COUNTER),
+                                 P(WS.UNIT_DESC), P(WS.CKPT), _ptr(render_colors), _ptr(render_alphas),
+                                 _ptr(v_rc), _ptr(v_ra), P(WS.ROWS), P(WS.ROWS_COLOR)), "gs_blend_bwd"))
         v_means = torch.empty((N, 3), **f32)
         v_quats = torch.empty((N, 4), **f32)
         v_scales = torch.empty((N, 3), **f32)
@@ -413,8 +449,8 @@ class _Rasterize(torch.autograd.Function):
             # (holder.on_colors_pre, e.g. an all-gather) overlaps gs_project_bwd
             v_pre = torch.empty((C, N, 3), **f32)
             _stage("gs_colors_pre_grad", dev, lambda: nat.check(L.gs_colors_pre_grad(
-                st, C, N, _ptr(s["radii"]), _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
-                _ptr(rows_color), _ptr(s["qmask"]), _ptr(v_pre)), "gs_colors_pre_grad"))
+                st, C, N, _ptr(s["radii"]), P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES),
+                P(WS.ROWS_COLOR), P(WS.QMASK), _ptr(v_pre)), "gs_colors_pre_grad"))
             if holder.means2d_ref is not None and holder.means2d_ref() is not None:
                 holder.means2d_ref().colors_pre_grad = v_pre
             if holder.on_colors_pre is not None:
@@ -429,12 +465,13 @@ class _Rasterize(torch.autograd.Function):
         _stage("gs_project_bwd", dev, lambda: nat.check(L.gs_project_bwd(st, C, N, K, s["deg"], _ptr(means), _ptr(quats), _ptr(scales), _ptr(colors),
                                    _ptr(colors_rest), s["per_cam"], _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
                                    cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
-                                   _ptr(s["colors_post"]), _ptr(s["tiles_per_gauss"]), _ptr(s["cum_tiles"]),
-                                   _ptr(rows), _ptr(s["qmask"]), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
+                                   P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES),
+                                   P(WS.ROWS), P(WS.QMASK), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
                                    _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), None,
                                    _ptr(opacities), cfg.get("activations", 0)), "gs_project_bwd"))
         if dbg is not None:
-            dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp, rows=rows)
+            dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp,
+                       rows=lease.view(WS.ROWS, max(s["n_isects"], 1) * 4 * nat.GS_ROW_FLOATS).clone().view(-1, nat.GS_ROW_FLOATS))
         if holder.absgrad and holder.means2d_ref is not None:
             m2 = holder.means2d_ref()
             if m2 is not None:

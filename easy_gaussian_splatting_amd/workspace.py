@@ -1,0 +1,166 @@
+"""Persistent per-(device, stream) workspace of the eager `rasterization()` seam (SURVEY.md section 8b "Ownership").
+
+gsplat lets every stage allocate its outputs; a binding that mirrors that makes ~25 allocator calls per forward and
+has to wait for the list sizes before it can size half of them.  Here the native library owns the LAYOUT
+(`gs_workspace_query`: which intermediates a call shape needs, sizes, alignment) and this module owns the MEMORY: a
+pool of leases per (device, stream), each lease two torch byte tensors --
+
+  fixed arena   everything sized by (C, N, image): packed records, footprints, offsets, counters;
+  list arena    everything sized by a CAPACITY of intersections: keys, sorted lists, quadrant sublists, checkpoints,
+                work units, gradient rows.
+
+A forward takes a free lease (or makes one), the autograd node and the returned `meta` keep it, and it goes back to
+the pool when both are gone -- in a training loop that is ONE lease, re-used every step with no allocator traffic.
+Two forwards in flight before a backward (several views accumulated into one loss) simply hold two leases.  A call
+whose lists outgrow the capacity replaces the list arena only (`Lease.grow_lists`) and repeats the list stages.
+Only tensors that escape to the caller (image, alphas, radii, means2d, depths, conics, gradients) are `torch.empty`.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import threading
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _native as nat
+
+# slot indices / flags of include/gs_raster.h
+INFO, REC, BBOX, TILES_PER_GAUSS, CUM_TILES, COLORS_POST, ISECT_OFFSETS, BUCKET_OFFSETS, TILE_ORDER, QCNT, UNIT_COUNTER = range(11)
+LIST_FIRST = 12
+BIN, COARSE_KEYS, KEYS_TMP, SLOT_GID, FLATTEN_IDS, SLOTS, ISECT_IDS, CKPT, QLIST, QMASK, UNIT_DESC, ROWS, ROWS_COLOR = range(12, 25)
+N_SLOTS = 25
+F_TRAIN, F_TWO_LEVEL, F_ISECT_IDS, F_ROWS_COLOR = 1, 2, 4, 8
+
+_DTYPES = {INFO: torch.int64, REC: torch.float32, BBOX: torch.int32, TILES_PER_GAUSS: torch.int32, CUM_TILES: torch.int32,
+           COLORS_POST: torch.float32, ISECT_OFFSETS: torch.int32, BUCKET_OFFSETS: torch.int32, TILE_ORDER: torch.int32,
+           QCNT: torch.int32, UNIT_COUNTER: torch.int32, FLATTEN_IDS: torch.int32, SLOTS: torch.int32, ISECT_IDS: torch.int64,
+           QMASK: torch.uint8, ROWS: torch.float32, ROWS_COLOR: torch.float32, QLIST: torch.int32, UNIT_DESC: torch.int32,
+           CKPT: torch.float32}
+
+stats = {"leases_created": 0, "acquires": 0, "fixed_allocs": 0, "list_allocs": 0, "list_grows": 0}
+
+
+class Layout:
+    """Result of one gs_workspace_query call."""
+    __slots__ = ("offsets", "arena_bytes", "key", "_c_offsets", "_c_bytes")
+
+    def __init__(self, C: int, N: int, W: int, H: int, cap: int, coarse_cap: int, bin_shift: int, flags: int):
+        self._c_offsets = (ct.c_int64 * N_SLOTS)()
+        self._c_bytes = (ct.c_int64 * 2)()
+        nat.check(nat.lib().gs_workspace_query(C, N, W, H, cap, coarse_cap, bin_shift, flags, self._c_offsets, self._c_bytes),
+                  "gs_workspace_query")
+        self.offsets = list(self._c_offsets)
+        self.arena_bytes = (int(self._c_bytes[0]), int(self._c_bytes[1]))
+        self.key = (C, N, W, H, cap, coarse_cap, bin_shift, flags)
+
+
+class Lease:
+    """Two arenas + the layout they are currently bound to.  `ptr(slot)` is the device address of a buffer (None when
+    the layout does not hold it), `view(slot, n)` a typed 1-D tensor view of its first n elements."""
+
+    def __init__(self, pool: "_Pool", device: torch.device):
+        self.pool, self.device = pool, device
+        self.fixed: Optional[torch.Tensor] = None
+        self.lists: Optional[torch.Tensor] = None
+        self.layout: Optional[Layout] = None
+        self.cap = 0
+        self.busy = False
+        self.refs = 0
+
+    # -- reference counting by the objects that read the arenas after the forward returned (autograd ctx, meta)
+    def retain(self) -> "Lease":
+        self.refs += 1
+        return self
+
+    def release(self) -> None:
+        self.refs -= 1
+        if self.refs <= 0:
+            self.refs = 0
+            self.pool.give_back(self)
+
+    def _ensure(self, which: str, nbytes: int) -> None:
+        cur = getattr(self, which)
+        if cur is None or cur.numel() < nbytes:
+            # (grown with head-room: the next, slightly larger frame must not allocate again)
+            setattr(self, which, torch.empty((nbytes + (nbytes >> 3) + 4096,), dtype=torch.uint8, device=self.device))
+            stats["fixed_allocs" if which == "fixed" else "list_allocs"] += 1
+
+    def bind(self, layout: Layout, stream: int) -> None:
+        self._ensure("fixed", layout.arena_bytes[0])
+        self._ensure("lists", layout.arena_bytes[1])
+        self.layout = layout
+        self.cap = layout.key[4]
+        nat.check(nat.lib().gs_workspace_bind(stream, self.fixed.data_ptr(), self.fixed.numel(), self.lists.data_ptr(),
+                                              self.lists.numel(), layout._c_offsets, layout._c_bytes), "gs_workspace_bind")
+
+    def grow_lists(self, layout: Layout, stream: int) -> None:
+        """Capacity exceeded: same call shape, larger list arena (the fixed arena -- records, offsets -- is kept as it is)."""
+        assert layout.arena_bytes[0] <= self.fixed.numel()
+        self._ensure("lists", layout.arena_bytes[1])
+        self.layout = layout
+        self.cap = layout.key[4]
+        stats["list_grows"] += 1
+
+    def ptr(self, slot: int) -> Optional[int]:
+        off = self.layout.offsets[slot]
+        if off < 0:
+            return None
+        base = self.fixed if slot < LIST_FIRST else self.lists
+        return base.data_ptr() + off
+
+    def view(self, slot: int, n: int) -> torch.Tensor:
+        off = self.layout.offsets[slot]
+        assert off >= 0, f"workspace slot {slot} is not part of this layout"
+        base = self.fixed if slot < LIST_FIRST else self.lists
+        dt = _DTYPES[slot]
+        isz = torch.empty((), dtype=dt).element_size()
+        return base[off:off + n * isz].view(dt)
+
+
+class _Pool:
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.free: Dict[Tuple[int, int], List[Lease]] = {}
+
+    def acquire(self, device: torch.device, stream: int) -> Lease:
+        key = (device.index if device.index is not None else torch.cuda.current_device(), stream)
+        with self.lock:
+            stats["acquires"] += 1
+            lst = self.free.setdefault(key, [])
+            lease = lst.pop() if lst else None
+            if lease is None:
+                lease = Lease(self, device)
+                lease.key = key
+                stats["leases_created"] += 1
+            lease.busy = True
+            lease.refs = 0
+            return lease
+
+    def give_back(self, lease: Lease) -> None:
+        with self.lock:
+            if lease.busy:
+                lease.busy = False
+                self.free.setdefault(lease.key, []).append(lease)
+
+    def clear(self) -> None:
+        """Drops every idle lease (their arenas return to torch's caching allocator)."""
+        with self.lock:
+            self.free.clear()
+
+
+pool = _Pool()
+
+
+class LeaseRef:
+    """Holds one reference on a lease; dropping the object (CPython refcount) releases it."""
+    __slots__ = ("lease",)
+
+    def __init__(self, lease: Lease):
+        self.lease = lease.retain()
+
+    def __del__(self):
+        try:
+            self.lease.release()
+        except Exception:   # interpreter shutdown
+            pass

@@ -68,6 +68,51 @@ int gs_guard_set(const int64_t* info_dev, int64_t cap_isects, int64_t cap_tile);
 int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied_dev, int64_t* status,
                    const float* loss3_dev, float* loss_ring_dev, int ring_len);
 
+/* Persistent workspace of the eager seam (SURVEY.md section 8b "Ownership" / "Sync"; replaces the ~25 per-call allocations a
+ * binding would otherwise make and lets the list stages be enqueued BEFORE the list sizes have reached the host).
+ * gs_workspace_query: layout of every intermediate of one rasterization() call that does not escape to the caller, for a call
+ * shape and a CAPACITY of intersections.  offsets[GS_WS_SLOTS]: byte offset of each buffer inside its arena (-1: not needed for
+ * these flags); slots below GS_WS_LIST_FIRST live in the fixed arena (sized by C, N, image), the others in the list arena (sized
+ * by cap_isects / coarse_cap); arena_bytes[2] = bytes of the two arenas.  Every offset is 256-byte aligned.
+ * gs_workspace_bind: validates two caller-owned device arenas against a layout and zeroes the control words (info block, work-unit
+ * counter) on `stream`.  The caller keeps one (fixed, list) pair per call in flight on a (device, stream) and hands the sub-pointers
+ * to the stage entry points below; a call whose lists outgrow the capacity (info flags, see gs_guard_set) replaces the list arena
+ * only and repeats gs_bin_count .. gs_blend_fwd. */
+#define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, -} */
+#define GS_WS_REC 1             /* f32 [C*N][12] */
+#define GS_WS_BBOX 2            /* u32 [C*N][4] */
+#define GS_WS_TILES_PER_GAUSS 3 /* i32 [C*N] */
+#define GS_WS_CUM_TILES 4       /* i32 [C*N] */
+#define GS_WS_COLORS_POST 5     /* f32 [C*N][3] */
+#define GS_WS_ISECT_OFFSETS 6   /* i32 [C*tiles+1] */
+#define GS_WS_BUCKET_OFFSETS 7  /* i32 [C*tiles+1] */
+#define GS_WS_TILE_ORDER 8      /* i32 [C*tiles] */
+#define GS_WS_QCNT 9            /* i32 [C*tiles*4]              (training) */
+#define GS_WS_UNIT_COUNTER 10   /* i32 [1]                      (training) */
+#define GS_WS_LIST_FIRST 12     /* ---- list arena ---- */
+#define GS_WS_BIN 12            /* gs_bin_workspace_bytes / gs_bins_workspace_bytes */
+#define GS_WS_COARSE_KEYS 13    /* u64 [coarse_cap]             (two-level binning) */
+#define GS_WS_KEYS_TMP 14       /* u64 [cap]                    (per-tile pipeline) */
+#define GS_WS_SLOT_GID 15       /* i32 [cap]                    (per-tile pipeline, training) */
+#define GS_WS_FLATTEN_IDS 16    /* i32 [cap] */
+#define GS_WS_SLOTS_BUF 17      /* i32 [cap]                    (training) */
+#define GS_WS_ISECT_IDS_BUF 18  /* i64 [cap]                    (GS_WS_ISECT_IDS) */
+#define GS_WS_CKPT 19           /* f32 [8*cap_buckets][64][4]   (training; cap_buckets = cap/64 + C*tiles + 1) */
+#define GS_WS_QLIST 20          /* i32 [4*cap][2]               (training) */
+#define GS_WS_QMASK 21          /* u8  [cap]                    (training) */
+#define GS_WS_UNIT_DESC 22      /* i32 [8*cap_buckets][4]       (training) */
+#define GS_WS_ROWS 23           /* f32 [4*cap][12]              (training: gs_blend_bwd -> gs_project_bwd) */
+#define GS_WS_ROWS_COLOR_BUF 24 /* f32 [4*cap][4]               (GS_WS_ROWS_COLOR) */
+#define GS_WS_SLOTS 25
+#define GS_WS_TRAIN 1           /* flags: the backward's lists, checkpoints and rows */
+#define GS_WS_TWO_LEVEL 2       /*        two-level binning (coarse_cap, bin_shift) instead of the per-tile pipeline */
+#define GS_WS_ISECT_IDS 4       /*        gsplat's isect_ids written eagerly */
+#define GS_WS_ROWS_COLOR 8      /*        compact colour rows for the view-parallel exchange */
+int gs_workspace_query(int C, int64_t N, int width, int height, int64_t cap_isects, int64_t coarse_cap, int bin_shift, int flags,
+                       int64_t* offsets, int64_t* arena_bytes);
+int gs_workspace_bind(void* stream, void* fixed_base, int64_t fixed_bytes, void* list_base, int64_t list_bytes,
+                      const int64_t* offsets, const int64_t* arena_bytes);
+
 /* Number of Gaussian groups per camera used by the binning kernels, and the bytes of scratch
  * `workspace` gs_bin_count / gs_bin_emit_sort need for (C, N, tiles). */
 int gs_bin_groups(int64_t N);

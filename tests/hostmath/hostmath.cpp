@@ -41,6 +41,7 @@ int hm_backward(int C, int N, int K, int degree, const float* means, const float
                 int H, float eps2d, float near_p, float far_p, const int32_t* radii,
                 const float* colors, const float* v_means2d, const float* v_conics,
                 const float* v_colors, float* v_means, float* v_quats, float* v_scales, float* v_shs) {
+    if (N <= 0) return 0;   // (memset on the null data() of an empty buffer is undefined: found by the UBSan leg)
     std::memset(v_means, 0, sizeof(float) * 3 * N);
     std::memset(v_quats, 0, sizeof(float) * 4 * N);
     std::memset(v_scales, 0, sizeof(float) * 3 * N);

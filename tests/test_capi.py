@@ -103,3 +103,77 @@ def test_binning_choice_host_logic(monkeypatch):
     monkeypatch.setenv("GS_BINNING", "quadtree")
     with pytest.raises(ValueError):
         R.binning_choice(3.0)
+
+
+def test_workspace_layout_query(native):
+    """gs_workspace_query (SURVEY.md 8b "Ownership"): every buffer 256-byte aligned, no two buffers of an arena overlap,
+    training-only buffers absent from an inference layout, list arena scales with the capacity while the fixed one does
+    not, argument errors reported through the error channel.  (Host logic only: no GPU.)"""
+    import ctypes as ct
+    from easy_gaussian_splatting_amd import workspace as WS
+    lib = native.lib()
+
+    def sizes(layout):
+        """(arena, offset) of every present slot, sorted by offset inside each arena"""
+        out = {0: [], 1: []}
+        for slot, off in enumerate(layout.offsets):
+            if off >= 0:
+                assert off % 256 == 0, (slot, off)
+                out[0 if slot < WS.LIST_FIRST else 1].append((off, slot))
+        return {a: sorted(v) for a, v in out.items()}
+
+    tr = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 0, 0, WS.F_TRAIN)
+    inf = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 0, 0, 0)
+    big = WS.Layout(1, 1_000_000, 1920, 1080, 8_000_000, 0, 0, WS.F_TRAIN)
+    two = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 3_000_000, 2, WS.F_TRAIN | WS.F_TWO_LEVEL | WS.F_ROWS_COLOR | WS.F_ISECT_IDS)
+    for lay in (tr, inf, big, two):
+        for arena, lst in sizes(lay).items():
+            offs = [o for o, _ in lst]
+            assert len(set(offs)) == len(offs) and offs[0] == 0 and offs[-1] < lay.arena_bytes[arena]
+    # known sizes: rec = 48 B per Gaussian right after the 64-byte info block; rows = 192 B per capacity entry
+    assert tr.offsets[WS.REC] == 256 and tr.offsets[WS.BBOX] - tr.offsets[WS.REC] == 48_000_000
+    nxt = min(o for o in tr.offsets[WS.LIST_FIRST:] if o > tr.offsets[WS.ROWS]) if any(o > tr.offsets[WS.ROWS] for o in tr.offsets[WS.LIST_FIRST:]) else tr.arena_bytes[1]
+    assert nxt - tr.offsets[WS.ROWS] >= 4 * 4_000_000 * 48
+    for slot in (WS.CKPT, WS.QLIST, WS.QMASK, WS.UNIT_DESC, WS.ROWS, WS.SLOTS, WS.SLOT_GID, WS.QCNT, WS.UNIT_COUNTER):
+        assert tr.offsets[slot] >= 0 and inf.offsets[slot] == -1, slot
+    assert inf.offsets[WS.KEYS_TMP] >= 0 and inf.offsets[WS.FLATTEN_IDS] >= 0
+    assert two.offsets[WS.COARSE_KEYS] >= 0 and two.offsets[WS.KEYS_TMP] == -1 and two.offsets[WS.ROWS_COLOR] >= 0 and two.offsets[WS.ISECT_IDS] >= 0
+    assert big.arena_bytes[0] == tr.arena_bytes[0] and big.arena_bytes[1] > 1.9 * tr.arena_bytes[1] - 2**27
+    assert inf.arena_bytes[1] < tr.arena_bytes[1] / 10
+    # errors: through the status code + gs_last_error, never a crash
+    offs, ab = (ct.c_int64 * WS.N_SLOTS)(), (ct.c_int64 * 2)()
+    assert lib.gs_workspace_query(0, 10, 64, 64, 100, 0, 0, 0, offs, ab) == -1 and b"C>=1" in lib.gs_last_error()
+    assert lib.gs_workspace_query(1, 10, 64, 64, 1 << 30, 0, 0, WS.F_TRAIN, offs, ab) == -1 and b"2^29" in lib.gs_last_error()
+    assert lib.gs_workspace_query(1, 10, 64, 64, 100, 10, 7, WS.F_TWO_LEVEL, offs, ab) == -1
+    assert lib.gs_workspace_bind(None, None, 0, None, 0, offs, ab) == -1
+
+
+def test_workspace_pool_leases(native, monkeypatch):
+    """workspace.pool: a lease goes back to its (device, stream) pool when the last holder drops it and is re-used by the
+    next acquire; two calls in flight get two leases; arenas only grow.  (bind's device memset is stubbed: no GPU.)"""
+    from easy_gaussian_splatting_amd import workspace as WS
+    monkeypatch.setattr(native.lib(), "gs_workspace_bind", lambda *a: 0, raising=False)
+    cpu = torch.device("cpu")
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    WS.pool.clear()
+    a = WS.pool.acquire(cpu, 1234)
+    a.bind(WS.Layout(1, 1000, 64, 64, 5000, 0, 0, WS.F_TRAIN), 0)
+    b = WS.pool.acquire(cpu, 1234)               # second call in flight on the same stream: its own lease
+    assert b is not a and a.busy and b.busy
+    ra, rb = WS.LeaseRef(a), WS.LeaseRef(a)      # two holders of lease a (autograd node + meta)
+    del ra
+    assert a.busy
+    del rb
+    assert not a.busy
+    c = WS.pool.acquire(cpu, 1234)
+    assert c is a                                 # re-used, arenas kept
+    fixed_ptr, list_bytes = c.fixed.data_ptr(), c.lists.numel()
+    c.bind(WS.Layout(1, 1000, 64, 64, 4000, 0, 0, WS.F_TRAIN), 0)        # a smaller frame: nothing is re-allocated
+    assert c.fixed.data_ptr() == fixed_ptr and c.lists.numel() == list_bytes
+    c.grow_lists(WS.Layout(1, 1000, 64, 64, 50000, 0, 0, WS.F_TRAIN), 0)  # capacity exceeded: the list arena alone grows
+    assert c.fixed.data_ptr() == fixed_ptr and c.lists.numel() > list_bytes and c.cap == 50000
+    assert c.ptr(WS.REC) == c.fixed.data_ptr() + 256 and c.ptr(WS.COARSE_KEYS) is None
+    assert c.view(WS.FLATTEN_IDS, 10).dtype == torch.int32 and c.view(WS.INFO, 8).dtype == torch.int64
+    d = WS.pool.acquire(cpu, 999)                 # another stream: another pool
+    assert d is not b and d is not c
+    WS.pool.clear()

@@ -132,7 +132,7 @@ def test_checkpoint_round_trip_of_a_fused_adam_model(tmp_path):
         mod.optimizer.step()
     for name in m.param_names:
         assert torch.equal(getattr(c, name), getattr(m, name)), name                       # same kernel, same state
-        assert torch.allclose(getattr(b, name), getattr(m, name), rtol=1e-5, atol=1e-7), name   # torch's Adam on the same state
+        assert torch.allclose(getattr(b, name), getattr(m, name), rtol=1e-5, atol=1e-5), name   # torch's Adam on the same state
     c.optimizer._check_views()
 
 

@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 import torch
 
+import parity_log
 from oracle import c_oracle as CO
 from scenes import config_bench_1m, config_long_lists, config_s1, dense_scene, make_scene
 
@@ -119,39 +120,76 @@ def _compare_lists(meta, fw, tmask):
             assert np.abs(dep_o[sh[sw]] - dep_o[so[sw]]).max() <= 1e-6 * np.abs(dep_o[so[sw]]).max() + 1e-7, f"tile {t}: reordered entries are not depth neighbours"
         flipped[tiles] = True
         n_ids = np.unique(h[d]).size
+        parity_log.record(n_depth_order_flips=n_ids)
         print(f"[parity] {n_ids} Gaussians ({int(d.sum())} list entries in {tiles.size} tiles) are ordered by an fp32 depth order that differs from the oracle's")
         assert n_ids <= max(4, 2e-4 * dep_o.size)
     return flipped
 
 
+# what an fp64 projection chain rounded once to fp32 supports; the old bounds were 10-100x slack
+MEANS2D_TOL_PX = 2e-4     # half an ulp of a coordinate below 2048 px is 6e-5 px (scaled with |mu| beyond 2048)
+CONICS_RTOL = 1e-5        # of the conic's largest entry
+DEPTHS_RTOL = 1e-6
+
+
+def oracle_fp32(fw):
+    """The fp32 build of the oracle on the same inputs (cached on `fw`): an implementation of the path in the arithmetic
+    type the device blends in, independent of the HIP code: check_backward's printed fallback arbiter."""
+    if "_fw32" not in fw:
+        inp = fw["_inputs"]
+        colors = inp["shs"] if inp["shs"] is not None else fw["colors"]
+        fw["_fw32"] = CO.render(inp["means"], inp["quats"], inp["scales"], fw["opacities"][0], colors, inp["viewmats"], inp["Ks"],
+                                inp["width"], inp["height"], sh_degree=inp["sh_degree"], backgrounds=inp["bg"], dtype=np.float32)
+    return fw["_fw32"]
+
+
+def razor_mask(fw):
+    """[C,H,W] pixels within 1e-4 (normalised) of a blend discontinuity, decided from the fp64 oracle run ALONE -- neither
+    the implementation under test (VERDICT r2 item 6d / ADVICE r2: a larger HIP error must not widen its own exemption)
+    nor any other fp32 run enters: gso_blend_margin's a-priori model of what fp32 storage of the blend's inputs can move
+    (a few ulps of the pixel coordinate of the mean, 1e-5 of the conic, the rounding of an fp32 evaluation of the form,
+    the accumulated relative error of T).  The path's actual deviations are bounded separately and far tighter
+    (MEANS2D_TOL_PX, CONICS_RTOL, DEPTHS_RTOL in forward_report)."""
+    if "_razor" not in fw:
+        fw["_razor"] = CO.blend_margin(fw) < 1e-4
+    return fw["_razor"]
+
+
 def forward_report(meta, fw, lists=True):
-    """Integer outputs against the oracle's.  They are bit-exact except where an fp32-vs-fp64 rounding difference
-    crosses an integer decision: radius = ceil(3 sigma) (+-1); an edge mu +- r of the tile rectangle landing within
-    2e-3 px of a tile boundary; two depths that swap order.  Such Gaussians are counted and printed, must be rare
-    (at most max(1, 1e-4 N) radii, max(1, 2e-4 N) rectangles), and only the tiles they touch are exempt from the bit-exact
-    list comparison.  Returns exact_lists, the razor mask (pixels where the measured fp32 deviation of the blend's own
-    inputs can flip a threshold decision) and `loose` = razor | the pixels of exempted tiles."""
+    """Integer outputs against the oracle's.  They are bit-exact except where the last-bit difference of two fp64
+    evaluations crosses an integer decision: radius = ceil(3 sigma) (+-1); an edge mu +- r of the tile rectangle landing
+    on a tile boundary; two depths that swap order.  Such Gaussians are counted, recorded (parity_log) and printed, must be
+    rare (at most max(1, 1e-4 N) radii, max(1, 2e-4 N) rectangles), and only the tiles they touch are exempt from the
+    bit-exact list comparison.  Returns exact_lists, the razor mask (razor_mask: independent of the HIP output) and
+    `loose` = razor | the pixels of exempted tiles."""
     tile = fw["_inputs"]["tile_size"]
     radii = meta["radii"].cpu().numpy()
     mism = radii != fw["radii"]
-    if mism.any():   # fp32 vs fp64 ceil(3 sigma): must be a +-1 flip of a visible Gaussian, and rare
+    if mism.any():   # ceil(3 sigma) on the last bit: must be a +-1 flip of a visible Gaussian, and rare
         print(f"[parity] {int(mism.sum())} of {mism.size} radii differ from the oracle's")
         assert np.abs(radii.astype(np.int64) - fw["radii"])[mism].max() <= 1, "a radius differs by more than the ceil() flip"
     assert mism.sum() <= max(1, 1e-4 * mism.size), f"{int(mism.sum())} of {mism.size} radii differ"
-    same = ~mism
-    assert np.abs(meta["means2d"].cpu().numpy() - fw["means2d"])[same].max(initial=0) < 2e-3
-    assert np.abs(meta["depths"].cpu().numpy() - fw["depths"])[same].max(initial=0) < 1e-4
+    same = ~mism & (fw["radii"] > 0)   # (culled Gaussians carry no geometry on either side)
+    d_mu = np.abs(meta["means2d"].cpu().numpy() - fw["means2d"]) / np.maximum(1.0, np.abs(fw["means2d"]) / 2048.0)
+    e_mu = float(d_mu[same].max(initial=0))
+    assert e_mu <= MEANS2D_TOL_PX, f"means2d differ by {e_mu} px"
+    e_dep = float((np.abs(meta["depths"].cpu().numpy() - fw["depths"]) / np.maximum(np.abs(fw["depths"]), 1e-30))[same].max(initial=0))
+    assert e_dep <= DEPTHS_RTOL, f"depths differ by {e_dep} relative"
     con = meta["conics"].cpu().numpy()
-    assert (np.abs(con - fw["conics"]) / (np.abs(fw["conics"]) + 1e-2))[same].max(initial=0) < 2e-3
+    e_con = float((np.abs(con - fw["conics"]).max(-1) / np.maximum(np.abs(fw["conics"]).max(-1), 1e-30))[same].max(initial=0))
+    assert e_con <= CONICS_RTOL, f"conics differ by {e_con} of their largest entry"
     differ = mism.copy()
+    n_edge = 0
     if lists:
-        edge = (meta["tiles_per_gauss"].cpu().numpy() != fw["tiles_per_gauss"]) & same
+        edge = (meta["tiles_per_gauss"].cpu().numpy() != fw["tiles_per_gauss"]) & ~mism
         if edge.any():   # same radius, different rectangle: an edge of mu +- r must sit on a tile boundary
             print(f"[parity] {int(edge.sum())} of {edge.size} tile rectangles differ from the oracle's (edge on a tile boundary)")
             mu, r = fw["means2d"][edge], fw["radii"][edge][:, None].astype(np.float64)
             edges = np.concatenate([mu - r, mu + r], axis=1) / tile
-            assert np.abs(edges - np.round(edges)).min(axis=1).max() <= 2e-3 / tile, "a tile rectangle differs away from any tile boundary"
+            assert np.abs(edges - np.round(edges)).min(axis=1).max() <= MEANS2D_TOL_PX * max(1.0, np.abs(mu).max() / 2048.0) / tile, \
+                "a tile rectangle differs away from any tile boundary"
             assert edge.sum() <= max(1, 2e-4 * edge.size)
+            n_edge = int(edge.sum())
         differ |= edge
     tmask = _affected_tiles(meta, fw, differ) if differ.any() else np.zeros((radii.shape[0], fw["tile_height"], fw["tile_width"]), bool)
     exact_lists = not differ.any()
@@ -165,9 +203,12 @@ def forward_report(meta, fw, lists=True):
         if swapped.any():
             exact_lists = False
             tmask = tmask | swapped.reshape(tmask.shape)
-    razor = CO.blend_margin(fw, meta["means2d"].cpu().numpy(), con) < 1e-4
+    razor = razor_mask(fw)
     H, W = razor.shape[1:]
     loose = razor | np.repeat(np.repeat(tmask, tile, axis=1), tile, axis=2)[:, :H, :W]
+    parity_log.record(n_radius_flips=int(mism.sum()), n_rectangle_flips=n_edge, razor_fraction=float(razor.mean()),
+                      loose_fraction=float(loose.mean()), max_means2d_err_px=e_mu, max_conics_rel_err=e_con, max_depths_rel_err=e_dep,
+                      n_gaussians=int(mism.size), n_isects=int(fw["n_isects"]))
     return dict(exact_lists=exact_lists, razor=razor, loose=loose, lists=lists)
 
 
@@ -188,6 +229,8 @@ def check_forward(hip, fw, max_razor_frac=2e-2, lists=True, outlier_frac=0.0):
     assert (aerr[strict] > FWD_ATOL).sum() <= outlier_frac * strict.sum(), f"forward alpha err {aerr[strict].max()}"
     cmax = max(1.0, float(fw["colors"].max()))
     assert err.max(initial=0) <= 4.0 / 255.0 * cmax, "even a flipped contributor is bounded by ~its weight"
+    parity_log.record(n_forward_checks=1, max_forward_err_strict=float(max(err[strict].max(initial=0), aerr[strict].max(initial=0))),
+                      max_forward_err_any=float(err.max(initial=0)), exact_lists=bool(rep["exact_lists"]))
     return rep["exact_lists"]
 
 
@@ -208,7 +251,7 @@ def needle_factor(fw):
     return np.maximum(1.0, kappa.max(axis=0) / NEEDLE_KAPPA)
 
 
-def check_backward(hip, fw, rtol=GRAD_RTOL):
+def check_backward(hip, fw, rtol=GRAD_RTOL, ref_transform=None):
     """Gradients within `rtol` of the tensor's largest reference magnitude.  The reference is the fp64 oracle and
     the upstream gradients are zero on the `loose` pixels (run_hip(fw=...)), where fp32 arithmetic may legitimately
     blend a different contributor set.  Should a flip survive that mask (accumulated rounding of T over hundreds of
@@ -218,11 +261,12 @@ def check_backward(hip, fw, rtol=GRAD_RTOL):
     bw = CO.backward(fw, hip["vc"], hip["va"])
     names = ["v_means", "v_quats", "v_scales", "v_opacities", "v_colors"]
     relax = needle_factor(fw)
+    ref_transform = ref_transform or {}   # e.g. {"v_colors": lambda x: x.sum(0)} for [N,3] colours shared by C cameras
 
     def errors(ref_bw):
         out = {}
         for name, g in zip(names, hip["grads"]):
-            ref = ref_bw[name]
+            ref = ref_transform.get(name, lambda x: x)(ref_bw[name])
             d = np.abs(g.cpu().numpy() - ref)
             if name in ("v_quats", "v_scales"):   # the two tensors behind the inverse of the 2-D covariance
                 d = d / relax[:, None]
@@ -233,12 +277,11 @@ def check_backward(hip, fw, rtol=GRAD_RTOL):
 
     err = errors(bw)
     if max(err.values()) > rtol:
-        inp = fw["_inputs"]
-        fw32 = CO.render(inp["means"], inp["quats"], inp["scales"], fw["opacities"][0], inp["shs"] if inp["shs"] is not None else fw["colors"],
-                         inp["viewmats"], inp["Ks"], inp["width"], inp["height"], sh_degree=inp["sh_degree"], backgrounds=inp["bg"],
-                         dtype=np.float32)
+        fw32 = oracle_fp32(fw)
         print(f"[parity] fp64 arbiter failed ({ {k: float('%.2e' % v) for k, v in err.items()} }); fp32 oracle arbitrates all tensors")
+        parity_log.record(n_fp32_arbiter_uses=1)
         err = errors(CO.backward(fw32, hip["vc"].astype(np.float32), hip["va"].astype(np.float32)))
+    parity_log.record(n_backward_checks=1, max_rel_grad_err=err, max_needle_factor=float(relax.max(initial=1.0)))
     for name, e in err.items():
         assert e <= rtol, f"{name}: rel err {e}"
     return bw
@@ -311,16 +354,17 @@ def test_post_activation_colours_path():
         base = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
         img, alpha, meta = rasterization(*base, c_t, t["viewmats"], t["Ks"], 64, 64, sh_degree=None, packed=False,
                                          backgrounds=t["backgrounds"], absgrad=True)
-        vc = torch.randn(img.shape, generator=torch.Generator().manual_seed(1))
-        grads = torch.autograd.grad((img * vc.to(dev())).sum(), base + [c_t])
         fw = CO.render(sc["means"], sc["quats"], sc["scales"], sc["opacities"], cols, sc["viewmats"], sc["Ks"], 64, 64,
                        sh_degree=None, backgrounds=sc["backgrounds"], dtype=np.float64)
-        bw = CO.backward(fw, vc.numpy().astype(np.float64))
-        assert np.abs(img.detach().cpu().numpy() - fw["render_colors"]).max() < 5e-3
-        ref_c = bw["v_colors"] if len(shape) == 3 else bw["v_colors"].sum(0)
+        hip = dict(img=img, alpha=alpha, meta=meta)
+        g = torch.Generator().manual_seed(1)
+        vc, va = mask_upstream(hip, fw, torch.randn(img.shape, generator=g), torch.randn(alpha.shape, generator=g))
+        grads = torch.autograd.grad((img * vc.to(dev())).sum() + (alpha * va.to(dev())).sum(), base + [c_t])
         assert grads[4].shape == c_t.shape
-        assert np.abs(grads[4].cpu().numpy() - ref_c).max() <= GRAD_RTOL * np.abs(ref_c).max()
-        assert np.abs(grads[0].cpu().numpy() - bw["v_means"]).max() <= GRAD_RTOL * np.abs(bw["v_means"]).max()
+        hip.update(grads=grads, vc=vc.numpy().astype(np.float64), va=va.numpy().astype(np.float64))
+        check_forward(hip, fw)   # the same 1e-4 / bit-exact-list bar as the SH path (was: 5e-3 on the image)
+        # all five gradients + absgrad; [N,3] colours are shared by the cameras: their gradient is the sum over views
+        check_backward(hip, fw, ref_transform={"v_colors": (lambda x: x.sum(0))} if len(shape) == 2 else None)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
@@ -476,24 +520,40 @@ def test_model_forward_and_statistics_mirror():
     assert out["render_img"].shape == (96, 160, 3) and out["batch_xys"].shape == (1, 3000, 2) and out["batch_radii"].shape == (1, 3000)
     fw = CO.render(sc["means"], sc["quats"], sc["scales"], op, sc["shs"], sc["viewmats"], sc["Ks"], 160, 96, sh_degree=3,
                    backgrounds=np.ones((1, 3), np.float32), dtype=np.float64)
+    # forward: the common bar (integer outputs bit-exact, every non-razor pixel within 1e-4) on the clamped image
+    # (was: mean(err > 1e-4) < 1e-3)
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    with torch.no_grad():   # (depths / conics are not part of the model's output: taken from the seam called with the same values)
+        _, _, meta = rasterization(m.means, m.quats, m.scales, m.opacities, m.shs, data["w2c"][None], data["K"][None], 160, 96,
+                                   sh_degree=3, packed=False, backgrounds=m.BACKGROUND[None])
+    rep = forward_report({"radii": out["batch_radii"], "means2d": out["batch_xys"], "depths": meta["depths"], "conics": meta["conics"]},
+                         fw, lists=False)
+    strict = ~rep["loose"][0]
     ref_img = np.clip(fw["render_colors"][0], 0, 1)
-    err = np.abs(out["render_img"].detach().cpu().numpy() - ref_img)
-    assert (err > 1e-4).mean() < 1e-3
-    vc = torch.randn(out["render_img"].shape, generator=torch.Generator().manual_seed(2))
+    err = np.abs(out["render_img"].detach().cpu().numpy() - ref_img).max(-1)
+    assert rep["razor"].mean() <= 2e-2 and err[strict].max() <= FWD_ATOL, (rep["razor"].mean(), err[strict].max())
+    parity_log.record(n_forward_checks=1, max_forward_err_strict=float(err[strict].max()))
+    # upstream gradient on the decided pixels, and away from the clamp's own two thresholds (0 and 1 +- 1e-4)
+    inside = ((fw["render_colors"][0] > 1e-4) & (fw["render_colors"][0] < 1 - 1e-4)) | (fw["render_colors"][0] < -1e-4) | (fw["render_colors"][0] > 1 + 1e-4)
+    vc = torch.randn(out["render_img"].shape, generator=torch.Generator().manual_seed(2)) * torch.from_numpy(strict[..., None] & inside)
     (out["render_img"] * vc.to(d)).sum().backward()
     m.update_statistics(data, out)
-    vcl = vc.numpy().astype(np.float64) * ((fw["render_colors"][0] > 0) & (fw["render_colors"][0] < 1))
+    vcl = vc.numpy().astype(np.float64) * ((fw["render_colors"][0] > 0) & (fw["render_colors"][0] < 1))   # d clamp
     bw = CO.backward(fw, vcl[None])
     vis = fw["radii"][0] > 0
     exp_g = np.where(vis, np.linalg.norm(bw["v_means2d_abs"][0], axis=-1) * 160, 0)
-    assert np.abs(m.grad_norm_accum.cpu().numpy() - exp_g).max() <= 2e-3 * exp_g.max()
+    assert np.abs(m.grad_norm_accum.cpu().numpy() - exp_g).max() <= GRAD_RTOL * exp_g.max()
     assert np.array_equal(m.collecting_counts.cpu().numpy() > 0, vis)
     assert np.allclose(m.max_radii.cpu().numpy(), np.where(vis, fw["radii"][0] / 160.0, 0))
-    # parameter gradients flow through exp / sigmoid / cat to all six leaves
+    # all six leaves through exp / sigmoid / the split SH hand-over, against the oracle's gradients of the ACTIVATED
+    # quantities (chain rule: d exp(x) = exp(x), d sigmoid(x) = o (1 - o)), on check_backward's bar
     for name in m.param_names:
         assert getattr(m, name).grad is not None
-    ref_vls = bw["v_scales"] * sc["scales"]  # d exp(log_s)
-    assert np.abs(m.log_scales.grad.cpu().numpy() - ref_vls).max() <= 2e-3 * np.abs(ref_vls).max()
+    o = op.astype(np.float64)
+    grads = [m.means.grad, m.quats.grad, m.log_scales.grad / m.scales.detach(), m.logit_opacities.grad / torch.from_numpy(o * (1 - o)).to(d).float(),
+             torch.cat([m.sh_0.grad, m.sh_rest.grad], dim=1)]
+    hip = dict(grads=grads, meta={"means2d": out["batch_xys"]}, vc=vcl[None], va=np.zeros((1, 96, 160, 1)))
+    check_backward(hip, fw)
 
 
 @pytest.mark.parametrize("deg,K", [(3, 16), (1, 16), (2, 9), (0, 4), (0, 1)])
@@ -632,6 +692,7 @@ def test_randomised_configurations(case, monkeypatch):
         razor = float(rep["razor"].mean())
         if razor <= MAX_RAZOR_FRAC:
             break
+        parity_log.record(n_redrawn_seeds=1)
         print(f"[parity] case {case}: scene seed {2000 + case + 1000 * attempt} is a razor-edge scene ({razor:.3f}); drawing the next")
     g = torch.Generator().manual_seed(case)
     keep = torch.from_numpy(~rep["loose"])[..., None]   # upstream gradients only where the contributor sets are decided
@@ -643,6 +704,18 @@ def test_randomised_configurations(case, monkeypatch):
     check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC, lists=culling == "gsplat")
     if fw["n_isects"] > 0:
         check_backward(hip, fw)
+
+
+def test_sweep_redraw_budget():
+    """re-drawn sweep seeds are counted, not silently skipped.  Whether a drawn scene is a razor-edge scene is
+    a property of the oracle run alone (razor_mask), so the count is the same on every box: at most 1 % of the cases
+    (at least one allowed)."""
+    recs = [r for k, r in parity_log.RECORDS.items() if "test_randomised_configurations" in k]
+    if not recs:
+        pytest.skip("the sweep did not run in this session")
+    redrawn = sum(int(r.get("n_redrawn_seeds", 0)) for r in recs)
+    parity_log.record(n_sweep_cases=len(recs), sweep_redrawn_seeds=redrawn)
+    assert redrawn <= max(1, math.ceil(0.01 * len(recs))), f"{redrawn} of {len(recs)} sweep cases were re-drawn"
 
 
 def _binning_scenes():
@@ -664,7 +737,7 @@ def test_binning_pipelines_agree_bit_for_bit(name, culling, monkeypatch):
     for mode, shift in (("tiles", ""), ("bins", "1"), ("bins", "2")):
         monkeypatch.setenv("GS_BINNING", mode)
         monkeypatch.setenv("GS_BINS_SHIFT", shift)
-        rendering._coarse_hint.clear()
+        rendering.reset_hints()
         retries = rendering.stats["coarse_retries"]
         dbg = {}
         hip = run_hip(sc, culling=culling, dbg=dbg)

@@ -19,7 +19,7 @@ if attempt is None:   # the scene seed the test settles on: the first whose razo
         _, _, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"], t["Ks"], W, H, sh_degree=deg,
                                    packed=False, _tile_culling=culling)
         fw = TP.run_oracle(sc, use_bg=use_bg)
-        if (CO.blend_margin(fw, meta["means2d"].cpu().numpy(), meta["conics"].cpu().numpy()) < 1e-4).mean() <= TP.MAX_RAZOR_FRAC:
+        if (CO.blend_margin(fw) < 1e-4).mean() <= TP.MAX_RAZOR_FRAC:
             break
     print("attempt", attempt)
 sc, (deg, W, H, use_bg, split, culling) = TP.fuzz_case(case, attempt)
