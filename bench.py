@@ -292,18 +292,34 @@ class DropInLoop:
         m.grad_norm_accum[visible] = m.grad_norm_accum[visible] + grads[visible]
         m.collecting_counts[visible] = m.collecting_counts[visible] + 1
 
-    def step(self, data, gt_img, mask, item_reads: bool = True):
+    def step(self, data, gt_img, mask, item_reads: bool = True, phases=None):
+        """`phases` (a dict): HIP events at the phase boundaries are appended to it (one extra pass of bench.py reports where
+        the step's time goes: event-to-event time on the stream, host-induced gaps included)."""
         torch = self.torch
+
+        def mark(name):
+            if phases is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                phases.setdefault(name, []).append(e)
+
+        mark("start")
         model_output = self.forward(data)
+        mark("forward")
         loss_dict = self.loss_dict(model_output["render_img"], gt_img, mask)
+        mark("loss")
         loss_dict["total"].backward()
+        mark("backward")
         if item_reads:
             for _name, loss in loss_dict.items():
                 loss.item()
+        mark("item_reads")
         with torch.no_grad():
             self.update_statistics(data, model_output)
+        mark("update_statistics")
         self.opt.step()
         self.opt.zero_grad()
+        mark("adam")
 
 
 # ------------------------------------------------------------------------------------------------ one rank
@@ -508,10 +524,17 @@ def run_rank(args) -> int:
                     di.forward(data)
 
             ef, _, sf, _ = timed_loop(di_fwd, nd, 3)
+            ph = {}
+            for _ in range(5):
+                di.step(data, gt_img, mask, item_reads=True, phases=ph)
+            torch.cuda.synchronize()
+            order = ["start", "forward", "loss", "backward", "item_reads", "update_statistics", "adam"]
+            phase_ms = {b: round(float(np.mean([x.elapsed_time(y) for x, y in zip(ph[a], ph[b])])), 3) for a, b in zip(order, order[1:])}
             extras["drop_in"] = {
                 "train_iters_per_s": round(nd / ed, 2), "train_ms": _percentiles(sd),
                 "forward_fps": round(nd / ef, 2), "forward_ms": _percentiles(sf),
                 "host_enqueue_ms_per_step": round(1e3 * qd / nd, 4), "blocked_on_readback_ms_per_step": round(wd, 4),
+                "phase_ms": phase_ms,
                 "without_item_reads": {"train_iters_per_s": round(nd / en, 2), "train_ms": _percentiles(sn),
                                        "host_enqueue_ms_per_step": round(1e3 * qn / nd, 4)},
                 "what": "reference loop body restated (train.py:93-157, model/gaussian.py:97-107,188-197,351-374,389-453) around "

@@ -49,7 +49,6 @@ struct BlendFwdArgs {
     int2* qlist;           // [4*I] (flatten id, row slot): per tile 4 sublists of capacity len(tile)
     int32_t* qcnt;         // [C*tiles*4]        sublist lengths
     uint8_t* qmask;        // [I] by slot        which quadrant rows of an intersection exist
-    int tail_clear;        // 1: a tile that stops early zeroes the masks of the rest of its list itself
     int32_t* unit_counter; // [1]
     int4* unit_desc;       // [8*n_buckets]      (tile*4+quadrant, entries in the unit, first qlist pair, checkpoint row)
     const int64_t* guard;  // step guard (gs_guard_set) or nullptr
@@ -58,6 +57,7 @@ struct BlendFwdArgs {
 // Work unit of the backward: kUnit consecutive entries of one quadrant sublist (half a 64-entry bucket), with a
 // checkpoint of the quadrant's 64 pixel states in front of it.
 constexpr int kUnit = 32;
+constexpr int kUnitFirst = 0x100;   // unit_desc.y flag: first unit of its sublist (no checkpoint was written for it)
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -127,12 +127,8 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
 #pragma unroll
         for (int k = 0; k < 4; ++k) qa[k] = !__all(done[k]);
         if (!(qa[0] || qa[1] || qa[2] || qa[3])) {
-            // every pixel of the tile is finished: the rest of the list contributes nothing, but its
-            // quadrant masks must still read "no rows" (this replaces a memset of the whole array)
-            // (long lists: the host has cleared the array instead -- the slots of a tile's abandoned tail are scattered, and
-            //  tens of millions of scattered byte stores cost several times the rest of the kernel)
-            if (CKPT && a.tail_clear)
-                for (int i = lo + b * GS_BUCKET + lane; i < hi; i += 64) a.qmask[a.slots[i]] = 0;
+            // every pixel of the tile is finished: the rest of the list contributes nothing (its quadrant masks already
+            // read "no rows": the mask array is cleared by one streaming memset in front of the kernel)
             break;
         }
         const int first = lo + b * GS_BUCKET;
@@ -194,9 +190,10 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
                     const bool ok = !done[k] && sigma >= 0.f && alpha >= kAlphaMin;
                     if (CKPT) {
                         if (!__any(ok)) continue;   // no pixel of the quadrant takes it: nothing to blend, nothing to list
-                        // the sublist entry that opens a new work unit saves the pixel states before it
+                        // the sublist entry that opens a new work unit saves the pixel states before it (not the first
+                        // unit of a sublist: its state is known -- T = 1 inside the image, nothing accumulated)
                         const int pos = cnt[k] + (int)__popcll(cq[k]);
-                        if ((pos & (kUnit - 1)) == 0)
+                        if ((pos & (kUnit - 1)) == 0 && pos != 0)
                             a.ckpt[((size_t)8 * bucket0 + (size_t)k * (2 * nb) + pos / kUnit) * 64 + lane] =
                                 make_float4(done[k] ? -1.f : T[k], cr[k], cg[k], cb[k]);
                         cq[k] |= 1ull << j;
@@ -215,7 +212,9 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
                 }
                 cnt[k] += __popcll(cq[k]);
             }
-            if (lane < m) a.qmask[my_slot] = (uint8_t)mybits;
+            // a scattered one-byte store leaves L2 as a 32-byte partial write (profiles/r03_traffic_calibration.json): only the
+            // entries some quadrant takes store their mask, the others keep the memset's zero
+            if (mybits) a.qmask[my_slot] = (uint8_t)mybits;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -234,8 +233,8 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
             for (int k = 0; k < 4; ++k) {
                 // everything the backward needs to start on the unit without a second round of dependent loads
                 for (int u = lane; u < nu[k]; u += 64)
-                    a.unit_desc[base + off + u] = make_int4(4 * t + k, min(kUnit, cnt[k] - u * kUnit), 4 * lo + k * len + u * kUnit,
-                                                            8 * bucket0 + k * (2 * nb) + u);
+                    a.unit_desc[base + off + u] = make_int4(4 * t + k, min(kUnit, cnt[k] - u * kUnit) | (u == 0 ? kUnitFirst : 0),
+                                                            4 * lo + k * len + u * kUnit, 8 * bucket0 + k * (2 * nb) + u);
                 off += nu[k];
             }
         }
@@ -341,7 +340,8 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
 
     int4 ud = make_int4(0, 0, 0, 0);
     if (valid) ud = a.unit_desc[unit];
-    const int tq = ud.x, n_in = ud.y;
+    const int tq = ud.x, n_in = ud.y & (kUnitFirst - 1);
+    const bool first_unit = (ud.y & kUnitFirst) != 0;   // the sublist starts here: every pixel inside the image has T = 1, no colour yet
     const int t = tq >> 2, q = tq & 3;
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
     const int tyi = tt / a.tw, txi = tt - tyi * a.tw;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
             const float va = a.v_alphas ? a.v_alphas[o] : 0.f;
             // E = T_final * v_alpha - render_colour . v_colour  (background terms cancel)
             const float E = Tf * va - (a.out_colors[3 * o] * vr + a.out_colors[3 * o + 1] * vg + a.out_colors[3 * o + 2] * vb);
-            const float4 ck = ckp[p];
+            const float4 ck = first_unit ? make_float4(1.f, 0.f, 0.f, 0.f) : ckp[p];
             pd0 = make_float4(vr, vg, vb, E);
             pck = make_float2(ck.x, ck.y * vr + ck.z * vg + ck.w * vb);
         }
@@ -464,11 +464,10 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
 #endif
     constexpr int kFwdWaves = GS_FWD_WAVES;
     const dim3 grid((n_tiles + kFwdWaves - 1) / kFwdWaves), block(64 * kFwdWaves);
-    // mean list of 1024 entries or more (opaque captures stop after a few per cent of such lists): one streaming clear of
-    // the quadrant masks instead of scattered byte stores over every abandoned tail
-    a.tail_clear = !(train && n_isects / (int64_t)n_tiles >= 1024);
     if (train) {
-        if (!a.tail_clear) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
+        // one streaming clear of the quadrant masks (I bytes): entries no quadrant takes, and the tails of lists a saturated
+        // tile abandons, then need no store at all
+        if (n_isects > 0) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
         GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves>), grid, block, 0, st, a);
     } else {

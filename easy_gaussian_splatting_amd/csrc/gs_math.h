@@ -20,7 +20,6 @@ namespace gs {
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kAlphaMax = 0.999f;
 constexpr float kTMin = 1e-4f;
-constexpr float kFovClamp = 1.3f;
 constexpr float kRadiusDiscFloor = 0.01f;
 
 // Per-camera constants, prepared once per launch on the device (see gs_kernels.hip: camera_prep).
@@ -29,8 +28,17 @@ struct Camera {
     float t[3];      // translation column
     float pos[3];    // camera centre in world space = inverse(viewmat)[:3,3]
     float fx, fy, cx, cy;
-    float limx, limy;  // 1.3 * tan(half fov)
+    float half_w, half_h;  // W/2, H/2 (exact): the FOV clamp 1.3 * tan(half fov) = 1.3 * half_w / fx is formed in the chain's own type
 };
+
+// Clamp limits of the perspective Jacobian (A.1): 1.3 * tan(half fov), in the arithmetic type of the projection chain --
+// formed in fp32 they moved the conic of every clamped (off-screen) Gaussian by ~4e-7 relative against the fp64 oracle,
+// the one deviation above half an ulp the round-3 parity bounds found (tests/test_gpu_parity.py CONICS_RTOL).
+template <typename T>
+GS_HD void fov_limits(const Camera& cam, T& limx, T& limy) {
+    limx = (T)1.3 * ((T)cam.half_w / (T)cam.fx);
+    limy = (T)1.3 * ((T)cam.half_h / (T)cam.fy);
+}
 
 struct Splat2D {
     float mx, my, depth;
@@ -134,7 +142,9 @@ GS_HD bool project_chain(const float* mean, const float* quat, const float* scal
     o.cc12 = t10 * V[6] + t11 * V[7] + t12 * V[8];
     o.cc22 = t20 * V[6] + t21 * V[7] + t22 * V[8];
 
-    const T fx = cam.fx, fy = cam.fy, limx = cam.limx, limy = cam.limy;
+    const T fx = cam.fx, fy = cam.fy;
+    T limx, limy;
+    fov_limits<T>(cam, limx, limy);
     const T rz = T(1) / o.z;
     const T rx = o.x * rz, ry = o.y * rz;
     o.clampx = rx > limx ? 1 : (rx < -limx ? -1 : 0);
@@ -325,7 +335,9 @@ GS_HD void project_vjp(const float* scale, const Camera& cam, const ProjChainT<T
                        float v_my_f, float vA_f, float vB_f, float vC_f, float v_depth_f, float* v_mean,
                        float* v_quat, float* v_scale) {
     const T v_mx = v_mx_f, v_my = v_my_f, vA = vA_f, vB = vB_f, vC = vC_f, v_depth = v_depth_f;
-    const T fx = cam.fx, fy = cam.fy, limx = cam.limx, limy = cam.limy;
+    const T fx = cam.fx, fy = cam.fy;
+    T limx, limy;
+    fov_limits<T>(cam, limx, limy);
     T V[9];
     for (int i = 0; i < 9; ++i) V[i] = (T)cam.R[i];
     // conic = inverse(cov2'); G = -X V X with V = [[vA, vB/2],[vB/2, vC]]
@@ -409,8 +421,8 @@ GS_HD void make_camera(const float* V, const float* K, int W, int H, Camera& cam
     cam.pos[1] = -(i10 * cam.t[0] + i11 * cam.t[1] + i12 * cam.t[2]);
     cam.pos[2] = -(i20 * cam.t[0] + i21 * cam.t[1] + i22 * cam.t[2]);
     cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
-    cam.limx = kFovClamp * (0.5f * (float)W / cam.fx);
-    cam.limy = kFovClamp * (0.5f * (float)H / cam.fy);
+    cam.half_w = 0.5f * (float)W;
+    cam.half_h = 0.5f * (float)H;
 }
 
 }  // namespace gs

@@ -345,15 +345,18 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
             if attempt > 6:
                 raise nat.NativeLibraryError(f"rasterization: list capacities did not settle (info {info})")
             if two_level and fl & 12:
+                # the coarse stage did not fit: the tile counts (I, longest list) were never formed -- only its own
+                # sizes {I', longest bin list} are meaningful; the tile-list capacity is checked by the repeat
                 if fl & 4:
                     coarse_cap = info[4] + (info[4] >> 2) + 1024
                 coarse_list_cap = 0
                 with _state_lock:
                     stats["coarse_retries"] += 1
-            if fl & 1:
-                cap = n_isects + (n_isects >> 3) + 1024
-            if fl & 2:
-                cap_tile = _sort_class(max_tile)
+            else:
+                if fl & 1:
+                    cap = n_isects + (n_isects >> 3) + 1024
+                if fl & 2:
+                    cap_tile = _sort_class(max_tile)
             with _state_lock:
                 stats["overflow_reruns"] += 1
             lease.grow_lists(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags), st)
@@ -367,11 +370,11 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         old = _hints.get(hint_key, {})
         # the capacity follows the largest recent frame (slow decay), so alternating views do not overflow every time
         new = dict(cap=max(n_isects + (n_isects >> 2) + 1024, int(old.get("cap", 0) * 0.995)),
-                   cap_tile=max(_sort_class(max_tile + (max_tile >> 2)), 1024), footprint=n_isects / max(1, C * N),
+                   cap_tile=max(_sort_class(max_tile + (max_tile >> 2)), int(old.get("cap_tile", 1024))), footprint=n_isects / max(1, C * N),
                    mode="bins" if two_level else "tiles")
         if two_level:
             new.update(entries=max(info[4] + (info[4] >> 2) + 1024, int(old.get("entries", 0) * 0.995)),
-                       longest=info[5] + (info[5] >> 2) + 64)
+                       longest=max(info[5] + (info[5] >> 2) + 64, int(old.get("longest", 0) * 0.995)))
         _hints[hint_key] = new
         _coarse_hint[dev_index] = dict(mode=new["mode"], footprint=new["footprint"])
 

@@ -385,9 +385,25 @@ int gso_blend_fwd(int C, int N, int W, int H, int tile, const real* means2d, con
  * perturbation of sigma is measured, not bounded: twice |sigma(other's mean, other's conic) - sigma| at this very
  * pixel, plus the rounding of an fp32 evaluation of the form (8 ulps of the magnitude of its terms). */
 #define GSO_EPS32 ((real)1.1920929e-7)
+int gso_blend_margin_tol(int C, int N, int W, int H, int tile, const real* means2d, const real* conics,
+                         const real* opac, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                         int64_t I, const real* means2d_o, const real* conics_o, real mu_tol_ulps, real conic_rtol,
+                         real* margin);
 int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, const real* conics,
                      const real* opac, const int32_t* isect_offsets, const int32_t* flatten_ids,
                      int64_t I, const real* means2d_o, const real* conics_o, real* margin) {
+    return gso_blend_margin_tol(C, N, W, H, tile, means2d, conics, opac, isect_offsets, flatten_ids, I, means2d_o, conics_o,
+                                (real)0, (real)0, margin);
+}
+
+/* The a-priori form with the storage bounds as PARAMETERS: mu_tol_ulps > 0 -- the tested path's means2d are within that many
+ * fp32 ulps (of max(|coordinate|, 32 px)) of this run's, its conics within conic_rtol of their largest entry (both are
+ * asserted by the parity tests on the path's outputs, so the exemption follows from bounds the implementation is held to and
+ * not from its measured error); <= 0: the legacy model (4 ulps of max(|coordinate|, 64), 1e-5 of the form's terms). */
+int gso_blend_margin_tol(int C, int N, int W, int H, int tile, const real* means2d, const real* conics,
+                         const real* opac, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                         int64_t I, const real* means2d_o, const real* conics_o, real mu_tol_ulps, real conic_rtol,
+                         real* margin) {
     int tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile;
     const real base = (real)1e-4;
     (void)N;
@@ -415,7 +431,13 @@ int gso_blend_margin(int C, int N, int W, int H, int tile, const real* means2d, 
                     real dxo = means2d_o[2 * g] - px, dyo = means2d_o[2 * g + 1] - py;
                     real so = (real)0.5 * (conics_o[3 * g] * dxo * dxo + conics_o[3 * g + 2] * dyo * dyo) + conics_o[3 * g + 1] * dxo * dyo;
                     es = 2 * RABS(so - sigma) + 8 * GSO_EPS32 * mag;
-                } else {   /* a-priori: mean moved by a few ulps of its coordinate, conic by 1e-5, fp32 evaluation */
+                } else if (mu_tol_ulps > 0) {   /* a-priori from the bounds the tested path is held to + fp32 evaluation of the form */
+                    real dmu = mu_tol_ulps * GSO_EPS32 * (amax > 32 ? amax : 32);
+                    real cmax = RABS(A) > RABS(Cc) ? RABS(A) : RABS(Cc);
+                    if (RABS(B) > cmax) cmax = RABS(B);
+                    real dcon = conic_rtol * cmax * ((real)0.5 * (dx * dx + dy * dy) + RABS(dx * dy));
+                    es = (RABS(A * dx + B * dy) + RABS(B * dx + Cc * dy)) * dmu + dcon + 8 * GSO_EPS32 * mag;
+                } else {   /* legacy a-priori: mean moved by a few ulps of its coordinate, conic by 1e-5, fp32 evaluation */
                     real dmu = 4 * GSO_EPS32 * (amax > 64 ? amax : 64);
                     es = (RABS(A * dx + B * dy) + RABS(B * dx + Cc * dy)) * dmu + ((real)1e-5 + 4 * GSO_EPS32) * mag;
                 }

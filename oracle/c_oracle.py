@@ -91,12 +91,15 @@ def render(means, quats, scales, opacities, colors, viewmats, Ks, width, height,
                              eps2d=eps2d, near_plane=near_plane, far_plane=far_plane))
 
 
-def blend_margin(fwd: Dict[str, np.ndarray], means2d_other=None, conics_other=None) -> np.ndarray:
+def blend_margin(fwd: Dict[str, np.ndarray], means2d_other=None, conics_other=None, mu_tol_ulps: float = 0.0,
+                 conic_rtol: float = 0.0) -> np.ndarray:
     """[C,H,W] normalised distance of every pixel to the nearest blend discontinuity (see gso_blend_margin); values
     below 1e-4 mark pixels where an fp32 evaluation may legitimately flip a contributor.  With `means2d_other` /
     `conics_other` (the implementation under test's [C,N,2] / [C,N,3] arrays) the reachable perturbation of each
     exponent is MEASURED (twice the difference between the two implementations' sigma at that pixel, plus fp32
-    evaluation rounding) instead of bounded a priori."""
+    evaluation rounding) instead of bounded a priori.  `mu_tol_ulps` > 0 (with `conic_rtol`): the a-priori form from the
+    storage bounds the tested path is HELD to (its means2d within that many fp32 ulps of max(|coordinate|, 32 px), its conics
+    within conic_rtol of their largest entry) -- independent of any measured output."""
     inp = fwd["_inputs"]
     dtype = fwd["means2d"].dtype
     L = _lib(dtype)
@@ -106,8 +109,10 @@ def blend_margin(fwd: Dict[str, np.ndarray], means2d_other=None, conics_other=No
     m_o = c_o = None
     if means2d_other is not None and conics_other is not None:
         m_o, c_o = _c(means2d_other, dtype), _c(conics_other, dtype)
-    L.gso_blend_margin(C, N, W, H, inp["tile_size"], _p(fwd["means2d"]), _p(fwd["conics"]), _p(fwd["opacities"]),
-                       _p(fwd["isect_offsets"]), _p(fwd["flatten_ids"]), ct.c_int64(fwd["n_isects"]), _p(m_o), _p(c_o), _p(out))
+    R = ct.c_double if np.dtype(dtype) == np.float64 else ct.c_float
+    L.gso_blend_margin_tol(C, N, W, H, inp["tile_size"], _p(fwd["means2d"]), _p(fwd["conics"]), _p(fwd["opacities"]),
+                           _p(fwd["isect_offsets"]), _p(fwd["flatten_ids"]), ct.c_int64(fwd["n_isects"]), _p(m_o), _p(c_o),
+                           R(mu_tol_ulps), R(conic_rtol), _p(out))
     return out
 
 

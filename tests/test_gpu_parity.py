@@ -126,10 +126,13 @@ def _compare_lists(meta, fw, tmask):
     return flipped
 
 
-# what an fp64 projection chain rounded once to fp32 supports; the old bounds were 10-100x slack
-MEANS2D_TOL_PX = 2e-4     # half an ulp of a coordinate below 2048 px is 6e-5 px (scaled with |mu| beyond 2048)
-CONICS_RTOL = 1e-5        # of the conic's largest entry
-DEPTHS_RTOL = 1e-6
+# what an fp64 projection chain rounded once to fp32 supports (the old bounds -- 2e-3 px, 2e-3, 1e-4 --
+# were 10-1000x slack): rounding once is half an ulp, the bounds are one ulp (measured on MI355X: 0.5 ulp of the
+# coordinate, 9e-8 of the conic, 6e-8 of the depth at 300 k / 2 M Gaussians, profiles/r03_parity_report.json)
+EPS32 = 1.1920929e-7
+MEANS2D_TOL_ULPS = 1.0    # of max(|coordinate|, 32 px): 1.2e-4 px at 1000 px
+CONICS_RTOL = 2.4e-7      # of the conic's largest entry
+DEPTHS_RTOL = 2.4e-7
 
 
 def oracle_fp32(fw):
@@ -146,22 +149,23 @@ def oracle_fp32(fw):
 def razor_mask(fw):
     """[C,H,W] pixels within 1e-4 (normalised) of a blend discontinuity, decided from the fp64 oracle run ALONE -- neither
     the implementation under test (VERDICT r2 item 6d / ADVICE r2: a larger HIP error must not widen its own exemption)
-    nor any other fp32 run enters: gso_blend_margin's a-priori model of what fp32 storage of the blend's inputs can move
-    (a few ulps of the pixel coordinate of the mean, 1e-5 of the conic, the rounding of an fp32 evaluation of the form,
-    the accumulated relative error of T).  The path's actual deviations are bounded separately and far tighter
-    (MEANS2D_TOL_PX, CONICS_RTOL, DEPTHS_RTOL in forward_report)."""
+    nor any other fp32 run enters.  gso_blend_margin_tol prices what an fp32 blend fed with fp32 inputs can move: the mean by
+    MEANS2D_TOL_ULPS, the conic by CONICS_RTOL -- the very bounds forward_report ASSERTS on the path's outputs, so the
+    exemption follows from limits the implementation is held to --, plus the rounding of an fp32 evaluation of the quadratic
+    form and the accumulated relative error of T."""
     if "_razor" not in fw:
-        fw["_razor"] = CO.blend_margin(fw) < 1e-4
+        fw["_razor"] = CO.blend_margin(fw, mu_tol_ulps=MEANS2D_TOL_ULPS, conic_rtol=CONICS_RTOL) < 1e-4
     return fw["_razor"]
 
 
-def forward_report(meta, fw, lists=True):
+def forward_report(meta, fw, lists=True, geom_slack=1.0):
     """Integer outputs against the oracle's.  They are bit-exact except where the last-bit difference of two fp64
     evaluations crosses an integer decision: radius = ceil(3 sigma) (+-1); an edge mu +- r of the tile rectangle landing
     on a tile boundary; two depths that swap order.  Such Gaussians are counted, recorded (parity_log) and printed, must be
     rare (at most max(1, 1e-4 N) radii, max(1, 2e-4 N) rectangles), and only the tiles they touch are exempt from the
     bit-exact list comparison.  Returns exact_lists, the razor mask (razor_mask: independent of the HIP output) and
-    `loose` = razor | the pixels of exempted tiles."""
+    `loose` = razor | the pixels of exempted tiles.  `geom_slack` multiplies the three storage bounds where the REFERENCE is
+    not the fp64 run of the very same inputs (the fp32 build of the oracle; a model whose exp / sigmoid run inside the kernel)."""
     tile = fw["_inputs"]["tile_size"]
     radii = meta["radii"].cpu().numpy()
     mism = radii != fw["radii"]
@@ -170,14 +174,14 @@ def forward_report(meta, fw, lists=True):
         assert np.abs(radii.astype(np.int64) - fw["radii"])[mism].max() <= 1, "a radius differs by more than the ceil() flip"
     assert mism.sum() <= max(1, 1e-4 * mism.size), f"{int(mism.sum())} of {mism.size} radii differ"
     same = ~mism & (fw["radii"] > 0)   # (culled Gaussians carry no geometry on either side)
-    d_mu = np.abs(meta["means2d"].cpu().numpy() - fw["means2d"]) / np.maximum(1.0, np.abs(fw["means2d"]) / 2048.0)
+    d_mu = np.abs(meta["means2d"].cpu().numpy() - fw["means2d"]).max(-1) / (EPS32 * np.maximum(np.abs(fw["means2d"]).max(-1), 32.0))
     e_mu = float(d_mu[same].max(initial=0))
-    assert e_mu <= MEANS2D_TOL_PX, f"means2d differ by {e_mu} px"
+    assert e_mu <= MEANS2D_TOL_ULPS * geom_slack, f"means2d differ by {e_mu} ulps of the coordinate"
     e_dep = float((np.abs(meta["depths"].cpu().numpy() - fw["depths"]) / np.maximum(np.abs(fw["depths"]), 1e-30))[same].max(initial=0))
-    assert e_dep <= DEPTHS_RTOL, f"depths differ by {e_dep} relative"
+    assert e_dep <= DEPTHS_RTOL * geom_slack, f"depths differ by {e_dep} relative"
     con = meta["conics"].cpu().numpy()
     e_con = float((np.abs(con - fw["conics"]).max(-1) / np.maximum(np.abs(fw["conics"]).max(-1), 1e-30))[same].max(initial=0))
-    assert e_con <= CONICS_RTOL, f"conics differ by {e_con} of their largest entry"
+    assert e_con <= CONICS_RTOL * geom_slack, f"conics differ by {e_con} of their largest entry"
     differ = mism.copy()
     n_edge = 0
     if lists:
@@ -186,7 +190,7 @@ def forward_report(meta, fw, lists=True):
             print(f"[parity] {int(edge.sum())} of {edge.size} tile rectangles differ from the oracle's (edge on a tile boundary)")
             mu, r = fw["means2d"][edge], fw["radii"][edge][:, None].astype(np.float64)
             edges = np.concatenate([mu - r, mu + r], axis=1) / tile
-            assert np.abs(edges - np.round(edges)).min(axis=1).max() <= MEANS2D_TOL_PX * max(1.0, np.abs(mu).max() / 2048.0) / tile, \
+            assert np.abs(edges - np.round(edges)).min(axis=1).max() <= MEANS2D_TOL_ULPS * EPS32 * max(32.0, np.abs(mu).max() + r.max()) / tile, \
                 "a tile rectangle differs away from any tile boundary"
             assert edge.sum() <= max(1, 2e-4 * edge.size)
             n_edge = int(edge.sum())
@@ -207,18 +211,18 @@ def forward_report(meta, fw, lists=True):
     H, W = razor.shape[1:]
     loose = razor | np.repeat(np.repeat(tmask, tile, axis=1), tile, axis=2)[:, :H, :W]
     parity_log.record(n_radius_flips=int(mism.sum()), n_rectangle_flips=n_edge, razor_fraction=float(razor.mean()),
-                      loose_fraction=float(loose.mean()), max_means2d_err_px=e_mu, max_conics_rel_err=e_con, max_depths_rel_err=e_dep,
+                      loose_fraction=float(loose.mean()), max_means2d_err_ulps=e_mu, max_conics_rel_err=e_con, max_depths_rel_err=e_dep,
                       n_gaussians=int(mism.size), n_isects=int(fw["n_isects"]))
     return dict(exact_lists=exact_lists, razor=razor, loose=loose, lists=lists)
 
 
-def check_forward(hip, fw, max_razor_frac=2e-2, lists=True, outlier_frac=0.0):
+def check_forward(hip, fw, max_razor_frac=2e-2, lists=True, outlier_frac=0.0, geom_slack=1.0):
     """Forward parity: forward_report's integer checks, then every pixel outside `loose` within 1e-4; razor pixels must
     stay rare and even they are bounded by one flipped contributor's weight."""
     assert max_razor_frac <= MAX_RAZOR_FRAC
     rep = hip.get("report")
     if rep is None or rep["lists"] != lists or rep.get("fw") is not fw:
-        rep = forward_report(hip["meta"], fw, lists)
+        rep = forward_report(hip["meta"], fw, lists, geom_slack)
     err = np.abs(hip["img"].detach().cpu().numpy() - fw["render_colors"]).max(-1)
     aerr = np.abs(hip["alpha"].detach().cpu().numpy() - fw["render_alphas"])[..., 0]
     razor, strict = rep["razor"], ~rep["loose"]
@@ -526,8 +530,9 @@ def test_model_forward_and_statistics_mirror():
     with torch.no_grad():   # (depths / conics are not part of the model's output: taken from the seam called with the same values)
         _, _, meta = rasterization(m.means, m.quats, m.scales, m.opacities, m.shs, data["w2c"][None], data["K"][None], 160, 96,
                                    sh_degree=3, packed=False, backgrounds=m.BACKGROUND[None])
+    # (the model's scales are exp(log s) evaluated by torch; the oracle was fed s itself: an ulp apart, ~1e-6 on the conic)
     rep = forward_report({"radii": out["batch_radii"], "means2d": out["batch_xys"], "depths": meta["depths"], "conics": meta["conics"]},
-                         fw, lists=False)
+                         fw, lists=False, geom_slack=16.0)
     strict = ~rep["loose"][0]
     ref_img = np.clip(fw["render_colors"][0], 0, 1)
     err = np.abs(out["render_img"].detach().cpu().numpy() - ref_img).max(-1)
@@ -935,11 +940,13 @@ def test_full_size_matches_oracle():
     fw32 = run_oracle(sc, dtype=np.float32)
     hip = run_hip(sc, fw=fw)
     check_forward(hip, fw, outlier_frac=1e-5)
-    check_forward(hip, fw32)   # (lists are compared bit for bit whenever every radius agrees)
+    # (the fp32 oracle's own geometry is tens of ulps off the fp64 truth: its storage bounds are those of an fp32 chain;
+    #  lists are compared bit for bit whenever every radius agrees)
+    check_forward(hip, fw32, geom_slack=1e3)
     check_backward(hip, fw)
     hip_t = run_hip(sc, culling="tight", upstream=(hip["vc"], hip["va"]))      # the default list mode: same image and gradients, shorter lists
     assert hip_t["meta"]["flatten_ids"].numel() < hip["meta"]["flatten_ids"].numel()
-    check_forward(hip_t, fw32, lists=False)
+    check_forward(hip_t, fw32, lists=False, geom_slack=1e3)
     for a, b in zip(hip_t["grads"], hip["grads"]):   # (tight == gsplat-mode gradients; the oracle check ran on the latter)
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
 

@@ -37,19 +37,26 @@ def test_steady_state_reuses_one_lease_and_never_reruns():
     ref = _run(t, sc, 0)
     ref_lists = {k: ref[2][k].clone() for k in ("flatten_ids", "isect_offsets", "tiles_per_gauss", "isect_ids")}
     del ref
-    _run(t, sc, 0)   # (second call: capacities now come from the first)
-    reruns, calls = rendering.stats["overflow_reruns"], rendering.stats["calls"]
-    allocs = dict(WS.stats)
-    outs = [_run(t, sc, 0) for _ in range(5)]
+    first = None
+    img = alpha = meta = grads = None
+    for it in range(8):
+        if it == 3:   # warm: capacities learnt, and the two leases a loop alternates between exist (the previous
+            #           iteration's image -- hence its autograd node and lease -- is still bound while the next forward runs)
+            reruns, calls = rendering.stats["overflow_reruns"], rendering.stats["calls"]
+            allocs = dict(WS.stats)
+        img, alpha, meta, grads = _run(t, sc, 0)
+        lists = {k: meta[k] for k in ref_lists}   # copies taken out of the workspace ...
+        del meta
+        if first is None:
+            first = (img, alpha, grads, lists)
+        assert torch.equal(img, first[0]) and torch.equal(alpha, first[1])
+        for a, b in zip(grads, first[2]):
+            assert torch.equal(a, b)
+        for k, v in ref_lists.items():   # ... stay valid after later calls re-used it
+            assert torch.equal(lists[k], v) and torch.equal(first[3][k], v), k
     assert rendering.stats["overflow_reruns"] == reruns and rendering.stats["calls"] == calls + 5
     assert WS.stats["leases_created"] == allocs["leases_created"] and WS.stats["list_allocs"] == allocs["list_allocs"] \
         and WS.stats["fixed_allocs"] == allocs["fixed_allocs"], (allocs, WS.stats)
-    for img, alpha, meta, grads in outs:
-        assert torch.equal(img, outs[0][0]) and torch.equal(alpha, outs[0][1])
-        for a, b in zip(grads, outs[0][3]):
-            assert torch.equal(a, b)
-        for k, v in ref_lists.items():   # meta's list arrays are copies: valid after later calls re-used the workspace
-            assert torch.equal(meta[k], v), k
 
 
 def test_capacity_overflow_is_repeated_transparently():
@@ -58,7 +65,7 @@ def test_capacity_overflow_is_repeated_transparently():
     a call that never speculated wrongly."""
     sc, t = _scene(n=30000)
     far = t["viewmats"].clone()
-    far[0, 2, 3] += 14.0
+    far[0, 2, 3] += 30.0
     tf = dict(t, viewmats=far)
     rendering.reset_hints()
     near_ref = _run(t, sc, 0)
@@ -66,7 +73,7 @@ def test_capacity_overflow_is_repeated_transparently():
     rendering.reset_hints()
     _run(tf, sc, 0); far_out = _run(tf, sc, 0)
     n_far = far_out[2]["flatten_ids"].numel()
-    assert n_near > 3 * n_far
+    assert n_near > 1.6 * n_far   # (the far view's capacity is n_far + 25 %)
     reruns = rendering.stats["overflow_reruns"]
     near = _run(t, sc, 0)   # same shape key as the far calls: starts from their capacity, overflows, repeats
     assert rendering.stats["overflow_reruns"] > reruns
