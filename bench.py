@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MIC
 N_SIMD = 1024            # 256 CUs x 4 SIMD-32
 VALU_CYCLES_PER_WAVE_INST = 2.0   # wave64 on a SIMD-32 (same guide, cycle-constants table)
 CLOCK_HZ = 2.4e9
-PROFILE_TAGS = ("r02", "r01")     # committed rocprofv3 summaries under profiles/, newest first
+PROFILE_TAGS = ("r03", "r02", "r01")     # committed rocprofv3 summaries under profiles/, newest first
 
 
 def parse_args(argv=None):

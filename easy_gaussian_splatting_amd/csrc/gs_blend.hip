@@ -32,6 +32,8 @@
 // set exactly (no last_ids).
 //
 // Semantics: SURVEY.md Appendix A.4 / A.5 (gsplat 1.0.0 rasterize_to_pixels fwd/bwd).
+#include <algorithm>
+
 #include "gs_common.h"
 #include "gs_math.h"
 
@@ -49,6 +51,7 @@ struct BlendFwdArgs {
     int2* qlist;           // [4*I] (flatten id, row slot): per tile 4 sublists of capacity len(tile)
     int32_t* qcnt;         // [C*tiles*4]        sublist lengths
     uint8_t* qmask;        // [I] by slot        which quadrant rows of an intersection exist
+    int tail_clear;        // (GS_FWD_QMASK_SCATTER variant) 1: a tile that stops early zeroes the masks of the rest of its list itself
     int32_t* unit_counter; // [1]
     int4* unit_desc;       // [8*n_buckets]      (tile*4+quadrant, entries in the unit, first qlist pair, checkpoint row)
     const int64_t* guard;  // step guard (gs_guard_set) or nullptr
@@ -90,6 +93,32 @@ __device__ __forceinline__ void blend_pair(const float alpha, const bool ok, con
 #define GS_FWD_TRAIN_WAVES_PER_EU 6
 #endif
 #define GS_FWD_ATTR __attribute__((amdgpu_waves_per_eu(CKPT ? GS_FWD_TRAIN_WAVES_PER_EU : 1, 8)))
+// Streaming clear of the quadrant masks (16-byte stores; `n` bytes from an arbitrarily aligned pointer) + the work-unit counter.
+__global__ __launch_bounds__(256) void qmask_clear_kernel(uint8_t* __restrict__ q, int64_t n, int32_t* __restrict__ unit_counter,
+                                                          const int64_t* __restrict__ guard) {
+    if (guard_tripped(guard)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) unit_counter[0] = 0;
+    const int64_t head = min(n, (int64_t)((16 - ((uintptr_t)q & 15)) & 15));
+    const int64_t n16 = (n - head) >> 4;
+    uint4* q16 = reinterpret_cast<uint4*>(q + head);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) q16[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+        if ((int64_t)threadIdx.x < head) q[threadIdx.x] = 0;
+        const int64_t tail0 = head + (n16 << 4);
+        if (tail0 + (int64_t)threadIdx.x < n) q[tail0 + threadIdx.x] = 0;
+    }
+}
+
+// 1: the forward does not store the checkpoint in front of a sublist's FIRST work unit (its content is known: T = 1 inside
+// the image, nothing accumulated; the backward never reads it).  Measured on MI355X (tools/tune_variants.sh, round 3): 33 MB
+// fewer writes per frame, and the kernel 0.30 -> 0.35 ms -- same registers, same spills; not understood, so the stores stay.
+#ifndef GS_FWD_SKIP_FIRST_CKPT
+#define GS_FWD_SKIP_FIRST_CKPT 0
+#endif
+#ifndef GS_FWD_QMASK_SCATTER
+#define GS_FWD_QMASK_SCATTER 0   // 1: the round-2 form (every entry stores its mask byte, tails cleared by the tile itself)
+#endif
+
 template <bool CKPT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const BlendFwdArgs a) {
     __shared__ float4 srec_all[WAVES][GS_BUCKET * 3];
@@ -128,7 +157,11 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
         for (int k = 0; k < 4; ++k) qa[k] = !__all(done[k]);
         if (!(qa[0] || qa[1] || qa[2] || qa[3])) {
             // every pixel of the tile is finished: the rest of the list contributes nothing (its quadrant masks already
-            // read "no rows": the mask array is cleared by one streaming memset in front of the kernel)
+            // read "no rows": the mask array is cleared by one streaming pass in front of the kernel)
+#if GS_FWD_QMASK_SCATTER
+            if (CKPT && a.tail_clear)
+                for (int i = lo + b * GS_BUCKET + lane; i < hi; i += 64) a.qmask[a.slots[i]] = 0;
+#endif
             break;
         }
         const int first = lo + b * GS_BUCKET;
@@ -190,10 +223,9 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
                     const bool ok = !done[k] && sigma >= 0.f && alpha >= kAlphaMin;
                     if (CKPT) {
                         if (!__any(ok)) continue;   // no pixel of the quadrant takes it: nothing to blend, nothing to list
-                        // the sublist entry that opens a new work unit saves the pixel states before it (not the first
-                        // unit of a sublist: its state is known -- T = 1 inside the image, nothing accumulated)
+                        // the sublist entry that opens a new work unit saves the pixel states before it
                         const int pos = cnt[k] + (int)__popcll(cq[k]);
-                        if ((pos & (kUnit - 1)) == 0 && pos != 0)
+                        if ((pos & (kUnit - 1)) == 0 && (pos != 0 || !GS_FWD_SKIP_FIRST_CKPT))
                             a.ckpt[((size_t)8 * bucket0 + (size_t)k * (2 * nb) + pos / kUnit) * 64 + lane] =
                                 make_float4(done[k] ? -1.f : T[k], cr[k], cg[k], cb[k]);
                         cq[k] |= 1ull << j;
@@ -214,7 +246,11 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
             }
             // a scattered one-byte store leaves L2 as a 32-byte partial write (profiles/r03_traffic_calibration.json): only the
             // entries some quadrant takes store their mask, the others keep the memset's zero
+#if GS_FWD_QMASK_SCATTER
+            if (lane < m) a.qmask[my_slot] = (uint8_t)mybits;
+#else
             if (mybits) a.qmask[my_slot] = (uint8_t)mybits;
+#endif
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -464,11 +500,22 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
 #endif
     constexpr int kFwdWaves = GS_FWD_WAVES;
     const dim3 grid((n_tiles + kFwdWaves - 1) / kFwdWaves), block(64 * kFwdWaves);
+    a.tail_clear = 1;
     if (train) {
-        // one streaming clear of the quadrant masks (I bytes): entries no quadrant takes, and the tails of lists a saturated
-        // tile abandons, then need no store at all
+#if GS_FWD_QMASK_SCATTER
+        a.tail_clear = !(n_isects / (int64_t)n_tiles >= 1024);
+        if (!a.tail_clear) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
+        GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));
+#elif defined(GS_FWD_QMASK_HIPMEMSET)
         if (n_isects > 0) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
         GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));
+#else
+        // one streaming clear of the quadrant masks (I bytes, 16-byte stores) and of the work-unit counter: entries no quadrant
+        // takes, and the tails of lists a saturated tile abandons, then need no store at all
+        const unsigned cg = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (n_isects / 16 + 255) / 256));
+        hipLaunchKernelGGL(qmask_clear_kernel, dim3(cg), dim3(256), 0, st, qmask, n_isects, unit_counter, a.guard);
+        GS_LAUNCH_CHECK("qmask_clear_kernel");
+#endif
         hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves>), grid, block, 0, st, a);
     } else {
         hipLaunchKernelGGL((blend_fwd_kernel<false, kFwdWaves>), grid, block, 0, st, a);

@@ -1,7 +1,7 @@
 #!/bin/bash
-# One GPU-box call that regenerates everything under profiles/ for a round:  tools/final_profiles.sh r02
+# One GPU-box call that regenerates everything under profiles/ for a round:  tools/final_profiles.sh r03
 # (SQ counters and HBM traffic first: bench.py quotes them in its roofline objects)
-tag=${1:-r02}
+tag=${1:-r03}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 600 bash tools/prof_sq.sh $tag > gpurun_out/${tag}_sq.log 2>&1
@@ -21,6 +21,8 @@ for m in tight gsplat; do
   grep -v "amdgpu.ids\|^W2026\|^E2026" /tmp/${tag}_longlists_$m.log > gpurun_out/${tag}_longlists_$m.txt
 done
 GS_BINNING=bins timeout 300 bash tools/prof_pmc.sh ${tag}_longlists tools/long_lists_run.py tight 3 > /dev/null 2>&1
+timeout 300 bash tools/micro/traffic_cal.sh $tag > gpurun_out/${tag}_traffic_cal.log 2>&1
+(GS_BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 50 --warmup 10 > gpurun_out/${tag}_bench_forcedist_rccl.json 2> gpurun_out/${tag}_bench_forcedist.err)
 timeout 900 python tools/config_table.py > gpurun_out/${tag}_configs.md 2> gpurun_out/${tag}_configs.err
 timeout 200 python tools/binning_sweep.py 2>/dev/null > gpurun_out/${tag}_binning_sweep.txt
 head -c 600 gpurun_out/${tag}_bench_line.json; echo; tail -3 gpurun_out/${tag}_bench.err

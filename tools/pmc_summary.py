@@ -5,10 +5,14 @@ instantiations of blend_fwd_kernel and the two stages of project_fwd_kernel stay
     python tools/pmc_summary.py traffic <dir FETCH_SIZE> <dir WRITE_SIZE>   > profiles/rNN_pmc_traffic.json
     python tools/pmc_summary.py counters <dir> [<dir> ...]                   > profiles/rNN_sq_counters.json
 
-traffic: HBM bytes per launch.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 B; per
-/opt/skills/guides/MI355X_MICROARCH.md (HBM section) FETCH_SIZE reads exactly half of the bytes of a wide
-coalesced stream on gfx950 -> doubled here; WRITE_SIZE is exact.  Collected in separate passes
-(TCC slots: FETCH_SIZE 3 + WRITE_SIZE 2 > 4).
+traffic: L2 <-> fabric bytes per launch.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in units of 1024 B, collected in
+separate passes (TCC slots: FETCH_SIZE 3 + WRITE_SIZE 2 > 4).  Calibration on gfx950 (tools/micro/traffic_cal.hip,
+profiles/r03_traffic_calibration.json): FETCH_SIZE reads exactly HALF of the bytes of a wide coalesced stream (16 B / lane;
+MI355X_MICROARCH.md, HBM section) but reads a GATHER in full at its 64-byte sector granularity (one random 16-byte record =
+64 B counted; one random 48-byte record = 80 B counted: 1.42 sectors); WRITE_SIZE is exact for streams and counts a
+scattered 1-byte store as 32 B and a scattered 48-byte row as 67 B.  A kernel's true fetch therefore lies between the raw
+figure (all gathers) and twice the raw figure (all streams): both are reported, `traffic_bytes_per_launch` keeps the x2
+figure (an upper bound for the blend kernels, exact for the streaming ones), `traffic_bytes_per_launch_lower` the raw one.
 counters: plain per-launch averages of every counter found (SQ_* passes of tools/prof_sq.sh).
 """
 import csv
@@ -51,8 +55,10 @@ def main():
             fb = 2.0 * 1024.0 * avg(f) if f else None
             wb = 1024.0 * avg(w) if w else None
             res[k] = {"launches_fetch": len(f or []), "launches_write": len(w or []),
+                      "fetch_bytes_per_launch_raw": None if fb is None else fb / 2.0,
                       "fetch_bytes_per_launch_x2_corrected": fb, "write_bytes_per_launch": wb,
-                      "traffic_bytes_per_launch": None if fb is None or wb is None else fb + wb}
+                      "traffic_bytes_per_launch": None if fb is None or wb is None else fb + wb,
+                      "traffic_bytes_per_launch_lower": None if fb is None or wb is None else fb / 2.0 + wb}
     else:
         res = defaultdict(dict)
         for d in sys.argv[2:]:

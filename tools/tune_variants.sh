@@ -19,6 +19,6 @@ else
     lib=$root/easy_gaussian_splatting_amd/libgsraster_$name.so; [ $name = base ] && lib=$root/easy_gaussian_splatting_amd/libgsraster.so
     GS_LIB_PATH=$lib timeout 200 python $root/bench.py --no-cpu-baseline --no-extras --steps 100 --warmup 20 2>/dev/null | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('$name', d['value'], d['step_ms']['median'], d['forward_fps'], {k:round(v,3) for k,v in d['stage_ms'].items() if 'blend' in k})"
+d=json.loads(sys.stdin.readline()); print('$name', d['value'], d['step_ms']['median'], d['forward_fps'], {k[3:]:round(v,3) for k,v in d['stage_ms'].items()})"
   done
 fi
