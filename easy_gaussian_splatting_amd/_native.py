@@ -50,7 +50,7 @@ SIGNATURES = {
     "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_project_bwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F,
                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
-    "gs_colors_pre_grad": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_colors_pre_grad": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _I, _P, _P]),
     "gs_sh_grad_views": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P]),
     "gs_loss_workspace_floats": (_Z, [_I, _I]),
     "gs_l1_ssim_fwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _I, _P, _P]),

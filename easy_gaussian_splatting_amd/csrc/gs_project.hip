@@ -712,7 +712,7 @@ __global__ __launch_bounds__(256) void colors_pre_grad_kernel(int64_t total, con
                                                               const float* __restrict__ colors_post,
                                                               const int32_t* __restrict__ tiles_per_gauss,
                                                               const int32_t* __restrict__ cum_tiles,
-                                                              const float4* __restrict__ rows_color,
+                                                              const float4* __restrict__ rows_color, int row_quads,
                                                               const uint8_t* __restrict__ qmask,
                                                               float* __restrict__ v_colors_pre) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -723,10 +723,12 @@ __global__ __launch_bounds__(256) void colors_pre_grad_kernel(int64_t total, con
         int bits = cnt > 0 ? (int)qmask[base] : 0;
         for (int r = 0; r < cnt; ++r) {
             const int bits_next = r + 1 < cnt ? (int)qmask[base + r + 1] : 0;
-            const float4* rp = rows_color + 4 * (int64_t)(base + r);
+            // row_quads = 1: blend_bwd's compact colour copy [I*4][4];  3: the gradient rows themselves [I*4][12], whose
+            // third quad holds the colour lanes (no second, scattered store per row in blend_bwd: 0.66 -> 0.48 ms there)
+            const float4* rp = rows_color + (int64_t)4 * row_quads * (base + r) + (row_quads - 1);
             float4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = (bits & (1 << q)) ? rp[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < 4; ++q) v[q] = (bits & (1 << q)) ? rp[q * row_quads] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { sr += v[q].x; sg += v[q].y; sb += v[q].z; }
             bits = bits_next;
@@ -744,13 +746,15 @@ using namespace gs;
 
 extern "C" int gs_colors_pre_grad(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
                                   const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows_color,
-                                  const uint8_t* qmask, float* v_colors_pre) {
+                                  int row_floats, const uint8_t* qmask, float* v_colors_pre) {
     GS_REQUIRE(C >= 1 && N >= 0, "C>=1, N>=0");
+    GS_REQUIRE(row_floats == 4 || row_floats == GS_ROW_FLOATS, "row_floats: 4 (compact colour rows) or 12 (the gradient rows)");
     if (N == 0) return GS_OK;
     GS_REQUIRE(radii && colors_post && tiles_per_gauss && cum_tiles && rows_color && qmask && v_colors_pre, "null pointer");
     const int64_t total = (int64_t)C * N;
     hipLaunchKernelGGL(colors_pre_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
-                       radii, colors_post, tiles_per_gauss, cum_tiles, reinterpret_cast<const float4*>(rows_color), qmask, v_colors_pre);
+                       radii, colors_post, tiles_per_gauss, cum_tiles, reinterpret_cast<const float4*>(rows_color), row_floats / 4, qmask,
+                       v_colors_pre);
     GS_LAUNCH_CHECK("colors_pre_grad_kernel");
     return GS_OK;
 }

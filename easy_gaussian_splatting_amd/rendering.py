@@ -64,6 +64,10 @@ def profile_stages(enable: bool) -> Optional[Dict]:
     return {k: [s.elapsed_time(e) for s, e in v] for k, v in out.items()}
 
 
+# GS_DP_ROWS_COLOR=1: gs_blend_bwd also writes the compact copy of the rows' colour lanes that gs_colors_pre_grad can read instead
+# of the rows themselves (round 2's form; measured in round 3: the second scattered store per row costs blend_bwd 0.18 ms)
+_ROWS_COLOR_COPY = os.environ.get("GS_DP_ROWS_COLOR") == "1"
+
 _tls = threading.local()
 _state_lock = threading.Lock()   # guards the two module-level dicts below (entry points are called from any thread)
 _hints: Dict[tuple, dict] = {}   # per (device, C, W, H, training, list mode): capacities the next call of this shape starts from
@@ -268,7 +272,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     eager_ids = os.environ.get("GS_EAGER_ISECT_IDS") == "1"   # (default: meta builds isect_ids on first access, _LazyMeta)
     factorised = cfg.get("sh_grads") == "colors_pre"
     flags = ((WS.F_TRAIN if need_grad else 0) | (WS.F_TWO_LEVEL if two_level else 0) | (WS.F_ISECT_IDS if eager_ids else 0)
-             | (WS.F_ROWS_COLOR if (need_grad and factorised) else 0))
+             | (WS.F_ROWS_COLOR if (need_grad and factorised and _ROWS_COLOR_COPY) else 0))
     # capacities: what earlier calls of this shape needed (+25 %), or a first guess
     cap = max(int(hint.get("cap", 0)), 2 * C * N + 4096 if not hint else 0, 4096)
     cap_tile = int(hint.get("cap_tile", 1024)) if not two_level else (1 << 30)
@@ -453,7 +457,8 @@ class _Rasterize(torch.autograd.Function):
             v_pre = torch.empty((C, N, 3), **f32)
             _stage("gs_colors_pre_grad", dev, lambda: nat.check(L.gs_colors_pre_grad(
                 st, C, N, _ptr(s["radii"]), P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES),
-                P(WS.ROWS_COLOR), P(WS.QMASK), _ptr(v_pre)), "gs_colors_pre_grad"))
+                P(WS.ROWS_COLOR) if _ROWS_COLOR_COPY else P(WS.ROWS), 4 if _ROWS_COLOR_COPY else nat.GS_ROW_FLOATS, P(WS.QMASK),
+                _ptr(v_pre)), "gs_colors_pre_grad"))
             if holder.means2d_ref is not None and holder.means2d_ref() is not None:
                 holder.means2d_ref().colors_pre_grad = v_pre
             if holder.on_colors_pre is not None:

@@ -257,12 +257,12 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    float* v_conics, float* v_colors_post, float* v_colors_pre,
                    const float* opacities, int activations);
 
-/* Row e (view sharding): v_colors_pre[C,N,3] alone, from gs_blend_bwd's optional compact output
- * rows_color[I*4][4] (the colour lanes of the gradient rows; NULL there = not written) -- identical to the
- * optional output of gs_project_bwd, but available before that (long) kernel runs, so that its
- * exchange between ranks overlaps the rest of the backward.  colors_post[C,N,3] from gs_project_fwd. */
+/* Row e (view sharding): v_colors_pre[C,N,3] alone -- identical to the optional output of gs_project_bwd, but available before
+ * that (long) kernel runs, so that its exchange between ranks overlaps the rest of the backward.  rows_color: the gradient rows
+ * of gs_blend_bwd themselves (row_floats = 12: the colour lanes are read out of each row's third quad), or that kernel's
+ * optional compact copy rows_color[I*4][4] (row_floats = 4).  colors_post[C,N,3] from gs_project_fwd. */
 int gs_colors_pre_grad(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
-                       const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows_color,
+                       const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows_color, int row_floats,
                        const uint8_t* qmask, float* v_colors_pre);
 
 /* Row e (view sharding): dense SH-parameter gradients of R views rebuilt from the per-view
