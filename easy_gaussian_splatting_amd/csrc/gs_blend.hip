@@ -386,25 +386,55 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
     // the unit's checkpoint: 64 pixel states in front of its first entry (T < 0: pixel finished or outside the image)
     const float4* ckp = a.ckpt + (size_t)ud.w * 64;
 
-    // stage the quadrant's 64 pixels: 8 per lane of the pipeline
+    // ---- prologue, three dependent memory round trips in all (unit descriptor above; everything below in two batches).
+    // Written branch-free on purpose: with the loads inside `if (inside the image)` / `if (entry exists)` blocks hipcc waits
+    // for each pixel's and each entry's loads before it issues the next ones -- 8 + 2 x 4 serialised round trips per wave in
+    // front of a main loop of comparable length, with three waves per SIMD to hide them (round 3: 0.45 -> see DESIGN.md).
+    // Out-of-range pixels / entries load from a clamped, valid address and are masked afterwards.
+    // batch 1: the sublist's (flatten id, slot) pairs and the quadrant's 64 pixels, 8 per lane of the pipeline
+    int2 gs[kPerLane];
 #pragma unroll
-    for (int i = 0; i < 64 / kPipeLanes; ++i) {
+    for (int i = 0; i < kPerLane; ++i) {
+        const int en = kPerLane * r + i;
+        gs[i] = a.qlist[(size_t)ud.z + (en < n_in ? en : 0)];
+        if (!valid) gs[i] = make_int2(0, 0);   // (pipelines past the last unit read pair 0, which nobody may have written)
+    }
+    constexpr int kPix = 64 / kPipeLanes;
+    float l_vr[kPix], l_vg[kPix], l_vb[kPix], l_oa[kPix], l_cr[kPix], l_cg[kPix], l_cb[kPix], l_va[kPix];
+    float4 l_ck[kPix];
+    const float* vap = a.v_alphas ? a.v_alphas : a.out_alphas;   // (one load either way; masked below)
+#pragma unroll
+    for (int i = 0; i < kPix; ++i) {
         const int p = r + kPipeLanes * i;
-        const int px = qx0 + (p & 7), py = qy0 + (p >> 3);
-        float4 pd0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        float2 pck = make_float2(-1.f, 0.f);
-        if (valid && px < a.W && py < a.H) {
-            const size_t o = ((size_t)cam * a.H + py) * a.W + px;
-            const float vr = a.v_colors[3 * o], vg = a.v_colors[3 * o + 1], vb = a.v_colors[3 * o + 2];
-            const float Tf = 1.f - a.out_alphas[o];
-            const float va = a.v_alphas ? a.v_alphas[o] : 0.f;
-            // E = T_final * v_alpha - render_colour . v_colour  (background terms cancel)
-            const float E = Tf * va - (a.out_colors[3 * o] * vr + a.out_colors[3 * o + 1] * vg + a.out_colors[3 * o + 2] * vb);
-            const float4 ck = first_unit ? make_float4(1.f, 0.f, 0.f, 0.f) : ckp[p];
-            pd0 = make_float4(vr, vg, vb, E);
-            pck = make_float2(ck.x, ck.y * vr + ck.z * vg + ck.w * vb);
-        }
-        sd0[p] = pd0; sck[p] = pck;
+        const int px = min(qx0 + (p & 7), a.W - 1), py = min(qy0 + (p >> 3), a.H - 1);
+        const size_t o = ((size_t)cam * a.H + py) * a.W + px;
+        l_vr[i] = a.v_colors[3 * o]; l_vg[i] = a.v_colors[3 * o + 1]; l_vb[i] = a.v_colors[3 * o + 2];
+        l_oa[i] = a.out_alphas[o];
+        l_cr[i] = a.out_colors[3 * o]; l_cg[i] = a.out_colors[3 * o + 1]; l_cb[i] = a.out_colors[3 * o + 2];
+        l_va[i] = vap[o];
+        l_ck[i] = ckp[p];
+    }
+    // batch 2: the entries' packed records (addresses from batch 1), in flight while the pixels are staged
+    float4 rq[kPerLane][3];
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) {
+        const float4* rp = a.rec + 3 * (size_t)gs[i].x;
+        rq[i][0] = rp[0]; rq[i][1] = rp[1]; rq[i][2] = rp[2];
+    }
+#pragma unroll
+    for (int i = 0; i < kPix; ++i) {
+        const int p = r + kPipeLanes * i;
+        const bool inside = valid && (qx0 + (p & 7)) < a.W && (qy0 + (p >> 3)) < a.H;
+        const float vr = l_vr[i], vg = l_vg[i], vb = l_vb[i];
+        const float Tf = 1.f - l_oa[i];
+        const float va = a.v_alphas ? l_va[i] : 0.f;
+        // E = T_final * v_alpha - render_colour . v_colour  (background terms cancel)
+        const float E = Tf * va - (l_cr[i] * vr + l_cg[i] * vg + l_cb[i] * vb);
+        // the unit's checkpoint: the pixel's state in front of its first entry (T < 0: finished or outside the image); the
+        // first unit of a sublist starts from T = 1, nothing accumulated
+        const float4 ck = first_unit ? make_float4(1.f, 0.f, 0.f, 0.f) : l_ck[i];
+        sd0[p] = inside ? make_float4(vr, vg, vb, E) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sck[p] = inside ? make_float2(ck.x, ck.y * vr + ck.z * vg + ck.w * vb) : make_float2(-1.f, 0.f);
     }
 
     EntryState e[kPerLane];
@@ -413,14 +443,9 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
     for (int i = 0; i < kPerLane; ++i) {
         const int en = kPerLane * r + i;
         e[i].has = en < n_in;
-        slot[i] = 0;
-        float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-        if (e[i].has) {
-            const int2 gs = a.qlist[(size_t)ud.z + en];
-            slot[i] = gs.y;
-            const float4* rp = a.rec + 3 * (size_t)gs.x;
-            q0 = rp[0]; q1 = rp[1]; q2 = rp[2];
-        }
+        slot[i] = e[i].has ? gs[i].y : 0;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 q0 = e[i].has ? rq[i][0] : z4, q1 = e[i].has ? rq[i][1] : z4, q2 = e[i].has ? rq[i][2] : z4;
         e[i].mx = q0.x; e[i].my = q0.y; e[i].hA = q0.z; e[i].Bc = q0.w; e[i].hC = q1.x; e[i].op = q1.y;
         e[i].colr = q2.x; e[i].colg = q2.y; e[i].colb = q2.z;
         // true conic entries for the mean gradient (the record stores them scaled by log2(e))
