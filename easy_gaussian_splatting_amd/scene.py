@@ -186,7 +186,10 @@ def load_extrinsics_binary(path: Path) -> Dict[int, Image]:
                 name += c
                 c = f.read(1)
             n2d = read_next_bytes(f, 8, "Q")[0]
-            f.seek(24 * n2d, 1)   # 2-D observations (x, y, point3D id): not needed here
+            # 2-D observations (x, y, point3D id): not needed here, skipped -- but a file that ends inside the block must
+            # fail like the reference's struct.unpack of the whole block does (/root/reference/scene/colmap_loader.py:127-128)
+            if len(f.read(24 * n2d)) != 24 * n2d:
+                raise struct.error(f"{path}: truncated observation block of image {props[0]}")
             image_map[props[0]] = Image(props[0], name.decode("utf-8"), props[8], props[1:5], props[5:8])
     return image_map
 
@@ -207,6 +210,8 @@ def load_pointcloud(path: Path) -> Pointcloud:
         rgbs[i] = buf[off + 32:off + 35]
         track = struct.unpack_from("<Q", raw, off + 43)[0]
         off += 51 + 8 * track
+        if off > len(raw):
+            raise struct.error(f"{path}: truncated track of point {i}")
     return Pointcloud(xyzs, rgbs)
 
 

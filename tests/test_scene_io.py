@@ -85,6 +85,104 @@ def test_colmap_reader_on_synthetic_model(tmp_path, model):
         S.load_pointcloud(tmp_path / "nope.bin")
 
 
+def test_colmap_reader_against_an_independent_spec_literal_writer(tmp_path):
+    """the readers were only ever fed by this repository's own writer (tools/make_synthetic_dataset.py).
+    Here a second writer, written field by field from COLMAP's documented binary layout and the field order the reference
+    consumes (/root/reference/scene/colmap_loader.py:83-160: cameras `iiQQ` + params, images `idddddddi` + a NUL-terminated
+    name + `Q` observations of `ddq`, points `QdddBBBd` + `Q` track elements of `ii`), produces what real COLMAP output has
+    and the other writer lacks: NON-EMPTY observation / track blocks of varying length that the reader must skip exactly,
+    several cameras, ids that are neither dense nor ordered, names of different lengths (with a directory part), and
+    un-normalised quaternions.  Every byte is emitted by one explicit struct.pack per field."""
+    import struct
+    rng = np.random.default_rng(7)
+    sparse = tmp_path / "sparse" / "0"
+    sparse.mkdir(parents=True)
+    # ---- cameras.bin: uint64 count; per camera int32 id, int32 model, uint64 width, uint64 height, float64 params[]
+    cams = {11: (1, 640, 480, [500.5, 510.25, 320.0, 240.0]), 3: (1, 800, 600, [700.0, 701.0, 400.5, 299.5])}
+    with open(sparse / "cameras.bin", "wb") as f:
+        f.write(struct.pack("<Q", len(cams)))
+        for cid, (model, w, h, params) in cams.items():
+            f.write(struct.pack("<i", cid)); f.write(struct.pack("<i", model))
+            f.write(struct.pack("<Q", w)); f.write(struct.pack("<Q", h))
+            for v in params:
+                f.write(struct.pack("<d", v))
+    # ---- images.bin: uint64 count; per image int32 id, float64 qw qx qy qz, float64 tx ty tz, int32 camera id,
+    #      name bytes + NUL, uint64 n observations, then per observation float64 x, float64 y, int64 point3D id
+    images = {}
+    names = ["a.png", "frames/000123.jpeg", "x" * 70 + ".png", "b.PNG", "c.png"]
+    with open(sparse / "images.bin", "wb") as f:
+        f.write(struct.pack("<Q", len(names)))
+        for k, name in enumerate(names):
+            iid = 1000 - 37 * k
+            quat = rng.standard_normal(4) * (0.3 + k)          # un-normalised on purpose
+            trans = rng.standard_normal(3) * 5
+            cid = 11 if k % 2 else 3
+            n_obs = int(rng.integers(0, 40))
+            f.write(struct.pack("<i", iid))
+            for v in quat:
+                f.write(struct.pack("<d", float(v)))
+            for v in trans:
+                f.write(struct.pack("<d", float(v)))
+            f.write(struct.pack("<i", cid))
+            f.write(name.encode("utf-8")); f.write(b"\x00")
+            f.write(struct.pack("<Q", n_obs))
+            for _ in range(n_obs):
+                f.write(struct.pack("<d", float(rng.random() * 640))); f.write(struct.pack("<d", float(rng.random() * 480)))
+                f.write(struct.pack("<q", int(rng.integers(-1, 10**6))))
+            images[iid] = (name, cid, quat, trans)
+    # ---- points3D.bin: uint64 count; per point uint64 id, float64 xyz, uint8 rgb, float64 error, uint64 track length,
+    #      then per track element int32 image id, int32 point2D index
+    n_pts = 301
+    xyz = rng.standard_normal((n_pts, 3)) * 3
+    rgb = rng.integers(0, 256, (n_pts, 3))
+    with open(sparse / "points3D.bin", "wb") as f:
+        f.write(struct.pack("<Q", n_pts))
+        for i in range(n_pts):
+            f.write(struct.pack("<Q", 5 * i + 2))
+            for v in xyz[i]:
+                f.write(struct.pack("<d", float(v)))
+            for v in rgb[i]:
+                f.write(struct.pack("<B", int(v)))
+            f.write(struct.pack("<d", float(rng.random())))
+            n_tr = int(rng.integers(0, 9))
+            f.write(struct.pack("<Q", n_tr))
+            for _ in range(n_tr):
+                f.write(struct.pack("<i", int(rng.integers(1, 1000)))); f.write(struct.pack("<i", int(rng.integers(0, 5000))))
+    got_c = S.load_intrinsics_binary(sparse / "cameras.bin")
+    assert set(got_c) == {3, 11}
+    for cid, (model, w, h, params) in cams.items():
+        c = got_c[cid]
+        assert c.model_name == "PINHOLE" and (c.width, c.height) == (w, h) and (c.fx, c.fy, c.cx, c.cy) == tuple(params)
+    got_i = S.load_extrinsics_binary(sparse / "images.bin")
+    assert set(got_i) == set(images)
+    for iid, (name, cid, quat, trans) in images.items():
+        im = got_i[iid]
+        assert im.image_file_name == name and im.camera_id == cid
+        assert tuple(im.quat) == tuple(float(v) for v in quat) and tuple(im.trans) == tuple(float(v) for v in trans)   # bit-exact doubles
+    pc = S.load_pointcloud(sparse / "points3D.bin")
+    assert pc.nbr_points == n_pts and pc.xyzs.dtype == np.float32 and pc.rgbs.dtype == np.uint8
+    assert np.array_equal(pc.xyzs, xyz.astype(np.float32)) and np.array_equal(pc.rgbs, rgb.astype(np.uint8))
+    # frames: w2c = [R(q / |q|) | t] (pyquaternion normalises, /root/reference/scene/colmap_loader.py:175-176), per-image camera
+    frames, _, train_idx, eval_idx = S.load_colmap_data(str(tmp_path), False, 0, False, 0.0, False)
+    assert [f.image_path.name for f in frames] == [Path(n).name for n in sorted(names, key=lambda n: str(tmp_path / "images" / n))]
+    by_name = {str(Path("images") / v[0]): v for v in images.values()}
+    for fr in frames:
+        name, cid, quat, trans = by_name[str(fr.image_path.relative_to(tmp_path))]
+        q = quat / np.linalg.norm(quat)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        assert np.allclose(fr.w2c[:3, :3], R, atol=1e-6) and np.allclose(fr.w2c[:3, 3], trans.astype(np.float32)) and fr.w2c[3].tolist() == [0, 0, 0, 1]
+        assert (fr.width, fr.height, fr.fx, fr.fy, fr.cx, fr.cy) == (cams[cid][1], cams[cid][2], *cams[cid][3])
+    assert sorted(train_idx) == list(range(5)) and eval_idx == []
+    # a truncated file must raise, not return garbage
+    raw = (sparse / "images.bin").read_bytes()
+    (sparse / "images.bin").write_bytes(raw[:-5])
+    with pytest.raises(Exception):
+        S.load_extrinsics_binary(sparse / "images.bin")
+
+
 def test_colmap_downscaled_images_rescale_intrinsics(tmp_path):
     truth = write_colmap(tmp_path, n_images=2, width=64, height=48, image_scale=0.5, with_masks=False)
     frames, _, _, _ = S.load_colmap_data(str(tmp_path), False, 0, False, 0.0, True)
