@@ -69,6 +69,10 @@ def test_graph_step_equals_eager_step(use_graph, with_mask, fuse_adam, binning, 
         mask = torch.zeros((208, 320), device=dev)
         mask[40:90, 100:200] = 1.0
     runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], mask, use_graph=use_graph, check_every=2, fuse_adam=fuse_adam)
+    # ROCm 7.2 on this pool: graph replays on the legacy NULL stream interleaved with other work on it ended in GPU memory
+    # faults.  The runner must therefore replay on a stream of its own; this loop IS the regression
+    # test for that -- eager steps on the caller's stream alternate with replays -- and would fault if the workaround went.
+    assert runner.stream.cuda_stream != torch.cuda.current_stream(dev).cuda_stream and runner.stream.cuda_stream != 0
     for it in range(7):
         v = it % 3
         ma.update_learning_rate(it); mb.update_learning_rate(it)
