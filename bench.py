@@ -492,20 +492,25 @@ def run_rank(args) -> int:
     if world == 1 and not args.no_extras:
         # the same two numbers with the reference's own (3-sigma) tile lists, i.e. meta's list arrays bit-exact
         ne = min(args.steps, 50)
-        model.tile_culling = "gsplat"
-        e2, q2, s2, w2 = timed_loop(train_step, ne, 10)
-        f2, _, fm2, _ = timed_loop(fwd_only, ne, 5)
-        extras["gsplat_list_mode"] = {"train_iters_per_s": round(ne / e2, 2), "train_ms": _percentiles(s2),
-                                      "forward_fps": round(ne / f2, 2), "forward_ms": _percentiles(fm2),
-                                      "host_enqueue_ms_per_step": round(1e3 * q2 / ne, 4), "blocked_on_readback_ms_per_step": round(w2, 4),
-                                      "note": "eager (not graph-replayed) steps with _tile_culling='gsplat'"}
-        if graph_step is not None:   # the same list mode under the captured step (the runner re-captures on the mode change)
-            try:
-                e3, _, s3, _ = timed_loop(graph_step.step, ne, 10, finish=graph_step.finish)
-                extras["gsplat_list_mode"]["graph"] = {"train_iters_per_s": round(ne / e3, 2), "train_ms": _percentiles(s3),
-                                                       "runner": graph_step.report()}
-            except Exception as e:
-                extras["gsplat_list_mode"]["graph"] = {"error": repr(e)[:200]}
+        # the reference's list mode.  "gsplat" (what rasterization() does by default): gsplat's exact list arrays in meta, built
+        # when read, the render walks the short lists;  "gsplat_eager": the render pipeline itself walks gsplat's lists
+        lm = {}
+        for mode in ("gsplat", "gsplat_eager"):
+            model.tile_culling = mode
+            e2, q2, s2, w2 = timed_loop(train_step, ne, 10)
+            f2, _, fm2, _ = timed_loop(fwd_only, ne, 5)
+            lm[mode] = {"train_iters_per_s": round(ne / e2, 2), "train_ms": _percentiles(s2),
+                        "forward_fps": round(ne / f2, 2), "forward_ms": _percentiles(fm2),
+                        "host_enqueue_ms_per_step": round(1e3 * q2 / ne, 4), "blocked_on_readback_ms_per_step": round(w2, 4)}
+            if graph_step is not None:   # the same list mode under the captured step (the runner re-captures on the mode change)
+                try:
+                    e3, _, s3, _ = timed_loop(graph_step.step, ne, 10, finish=graph_step.finish)
+                    lm[mode]["graph"] = {"train_iters_per_s": round(ne / e3, 2), "train_ms": _percentiles(s3), "runner": graph_step.report()}
+                except Exception as e:
+                    lm[mode]["graph"] = {"error": repr(e)[:200]}
+        extras["gsplat_list_mode"] = dict(lm["gsplat"], lists_materialised_by_the_render=lm["gsplat_eager"],
+                                          note="eager steps (+ the captured step under `graph`) with _tile_culling='gsplat': meta's list "
+                                               "arrays are gsplat's, built when read; 'lists_materialised_by_the_render' = 'gsplat_eager'")
         model.tile_culling = "tight"
         e4, q4, s4, w4 = timed_loop(train_step, ne, 10)
         extras["eager_tight"] = {"train_iters_per_s": round(ne / e4, 2), "train_ms": _percentiles(s4),

@@ -40,7 +40,7 @@ SIGNATURES = {
     "gs_bin_groups": (_I, [_L]),
     "gs_bin_workspace_bytes": (_Z, [_I, _L, _I, _I]),
     "gs_project_fwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _F, _I, _I, _I,
-                            _P, _P, _P, _P, _P, _P, _P, _P]),
+                            _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_bin_count": (_I, [_P, _I, _L, _I, _I, _P, _P, _Z, _P, _P, _P, _P, _P]),
     "gs_bin_emit_sort": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _Z, _P, _L, _L, _P, _P, _P, _P, _P, _P]),
     "gs_bins_workspace_bytes": (_Z, [_I, _L, _I, _I, _I, _L]),

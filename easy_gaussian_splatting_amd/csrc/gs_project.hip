@@ -24,6 +24,7 @@ struct ProjFwdArgs {
     float4* rec;
     uint4* bbox;
     int32_t* tiles_per_gauss;
+    uint2* rect_ref;   // optional [C*N]: the 3-sigma tile rectangle itself (x0 | x1 << 16, y0 | y1 << 16), whatever `tight` does to bbox
 };
 
 // activations != 0: `scales` / `opacities` hold the reference model's parameters (log-scales, logit
@@ -174,10 +175,12 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
             s = project_gaussian(mean, quat, scale, cam, a.W, a.H, a.eps2d, a.near_p, a.far_p, a.radius_clip, GS_TILE, a.tw, a.th);
         }
         vis = s.radius > 0;
+        if (!vis && in_range && a.rect_ref) a.rect_ref[f] = make_uint2(0u, 0u);
         int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
         float op = 0.f, ex = -1.f, ey = -1.f;
         if (vis) {
             x0 = s.x0; x1 = s.x1; y0 = s.y0; y1 = s.y1;   // from the unrounded centre (gs_math.h: preal)
+            if (a.rect_ref) a.rect_ref[f] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
             op = act_opacity(a.opacities[n], a.activations);
             alpha_extent(op, s.cxx, s.cyy, ex, ey);
             // tight mode: keep only the tiles of the 3-sigma rectangle that hold a pixel centre where
@@ -790,7 +793,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
                               float eps2d, float near_plane, float far_plane, float radius_clip,
                               int tile_culling, int stage, int activations, int32_t* radii,
                               float* means2d, float* depths, float* conics, float* colors_out, float* rec,
-                              uint32_t* bbox, int32_t* tiles_per_gauss) {
+                              uint32_t* bbox, int32_t* tiles_per_gauss, uint32_t* rect_ref) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
     GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
     GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
@@ -808,6 +811,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.viewmats = viewmats; a.Ks = Ks; a.radii = radii; a.means2d = means2d; a.depths = depths;
     a.conics = conics; a.colors_out = colors_out; a.rec = reinterpret_cast<float4*>(rec);
     a.bbox = reinterpret_cast<uint4*>(bbox); a.tiles_per_gauss = tiles_per_gauss;
+    a.rect_ref = reinterpret_cast<uint2*>(rect_ref);
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads), (unsigned)C);
     const size_t lds = proj_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;

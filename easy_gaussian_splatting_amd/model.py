@@ -74,7 +74,7 @@ class GaussianModel(nn.Module):
     # (checkpoint.load_gaussian_model) has none of them in its __dict__ and takes these.
     fuse_sh_cat = True          # hand (sh_0, sh_rest) to the rasterizer, no per-step torch.cat
     fuse_activations = True     # exp / sigmoid inside the projection kernels (GPU)
-    tile_culling = "tight"      # render-equivalent shorter lists ("gsplat": meta's list arrays bit-exact)
+    tile_culling = "tight"      # render-equivalent shorter lists ("gsplat": meta's list arrays bit-exact, built when read)
     sh_grads = "dense"
     on_colors_pre = None
     device_refine = True

@@ -220,6 +220,84 @@ class _Holder:
         self.on_colors_pre = None
 
 
+class _ReferenceLists:
+    """gsplat's list arrays for a call that rendered from the short lists (`_tile_culling="gsplat"`, the default): a function
+    of the 3-sigma tile rectangles the projection kept (`rect_ref`) and of `depths`, built -- all four at once, by the same
+    count / emit / sort kernels, in fresh buffers -- when one of them is first read.  The reference reads none of them
+    (/root/reference/model/gaussian.py:368-375 takes the image, `means2d` and `radii`), so its training loop never pays for
+    the ~40 % longer lists; a caller that does read them gets exactly what `_tile_culling="gsplat_eager"` walks."""
+
+    def __init__(self, rect_ref: Tensor, depths: Tensor, C: int, N: int, tw: int, th: int, eager_ids: bool):
+        self.rect_ref, self.depths, self.C, self.N, self.tw, self.th, self.eager_ids = rect_ref, depths, C, N, tw, th, eager_ids
+        self.out: Optional[Dict[str, Tensor]] = None
+        self.lock = threading.Lock()
+
+    def get(self, key: str) -> Tensor:
+        with self.lock:
+            if self.out is None:
+                self.out = self._build()
+        return self.out[key]
+
+    def _build(self) -> Dict[str, Tensor]:
+        L = nat.lib()
+        C, N, tw, th = self.C, self.N, self.tw, self.th
+        dev = self.depths.device
+        tiles = tw * th
+        i32 = dict(dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev), torch.no_grad():
+            st = _stream(dev)
+            # footprint records of the binning kernels: rectangle, tile bit mask (all tiles of the rectangle), tile count
+            r = self.rect_ref.long()
+            x0, x1, y0, y1 = r[:, 0] & 0xFFFF, (r[:, 0] >> 16) & 0xFFFF, r[:, 1] & 0xFFFF, (r[:, 1] >> 16) & 0xFFFF
+            cnt = (x1 - x0) * (y1 - y0)
+            mask = torch.where(cnt >= 32, torch.full_like(cnt, 0xFFFFFFFF), (torch.ones_like(cnt) << cnt.clamp(max=31)) - 1)
+            to_i32 = lambda v: torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32)   # (uint32 bit patterns)
+            bbox = torch.stack([to_i32(r[:, 0] & 0xFFFFFFFF), to_i32(r[:, 1] & 0xFFFFFFFF), to_i32(mask), cnt.to(torch.int32)], dim=1).contiguous()
+            tiles_per_gauss = cnt.to(torch.int32).view(C, N)
+            info_dev = torch.zeros((8,), dtype=torch.int64, device=dev)
+            isect_offsets = torch.empty((C * tiles + 1,), **i32)
+            bucket_offsets = torch.empty((C * tiles + 1,), **i32)
+            cum_tiles = torch.empty((C * N,), **i32)
+            footprint = float(cnt.sum().item()) / max(1, C * N)
+            two_level = binning_choice(footprint, tiles) == "bins"
+            if two_level:
+                shift = bin_shift_for(footprint) or 2
+                coarse_cap, info = 2 * C * N + 1024, None
+                while True:
+                    keys = torch.empty((coarse_cap,), dtype=torch.int64, device=dev)
+                    ws = torch.empty((int(L.gs_bins_workspace_bytes(C, N, tw, th, shift, coarse_cap)),), dtype=torch.uint8, device=dev)
+                    nat.check(L.gs_bins_count(st, C, N, tw, th, shift, _ptr(bbox), _ptr(self.depths), _ptr(ws), ws.numel(), _ptr(keys), coarse_cap,
+                                              0, _ptr(cum_tiles), _ptr(isect_offsets), _ptr(bucket_offsets), None, _ptr(info_dev), None),
+                              "gs_bins_count")
+                    info = info_dev.tolist()
+                    if not int(info[3]) & 12:
+                        break
+                    coarse_cap = int(info[4]) + (int(info[4]) >> 2) + 1024
+                    info_dev.zero_()
+                n_isects = int(info[0])
+                flatten_ids = torch.empty((max(n_isects, 1),), **i32)
+                isect_ids = torch.empty((max(n_isects, 1),), dtype=torch.int64, device=dev) if self.eager_ids else None
+                nat.check(L.gs_bins_lists(st, C, N, tw, th, shift, _ptr(bbox), _ptr(ws), ws.numel(), _ptr(keys), coarse_cap, _ptr(cum_tiles),
+                                          _ptr(isect_offsets), _ptr(isect_ids), _ptr(flatten_ids), None, _ptr(info_dev)), "gs_bins_lists")
+            else:
+                ws = torch.empty((int(L.gs_bin_workspace_bytes(C, N, tw, th)),), dtype=torch.uint8, device=dev)
+                nat.check(L.gs_bin_count(st, C, N, tw, th, _ptr(bbox), _ptr(ws), ws.numel(), _ptr(isect_offsets), _ptr(bucket_offsets), None,
+                                         _ptr(info_dev), None), "gs_bin_count")
+                info = info_dev.tolist()
+                n_isects, max_tile = int(info[0]), int(info[2])
+                flatten_ids = torch.empty((max(n_isects, 1),), **i32)
+                isect_ids = torch.empty((max(n_isects, 1),), dtype=torch.int64, device=dev) if self.eager_ids else None
+                keys_tmp = torch.empty((max(n_isects, 1),), dtype=torch.int64, device=dev)
+                nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, _ptr(bbox), _ptr(self.depths), _ptr(ws), ws.numel(), _ptr(isect_offsets), n_isects,
+                                             max_tile, _ptr(keys_tmp), None, _ptr(cum_tiles), _ptr(isect_ids), _ptr(flatten_ids), None),
+                          "gs_bin_emit_sort")
+        out = {"tiles_per_gauss": tiles_per_gauss, "flatten_ids": flatten_ids[:n_isects],
+               "isect_offsets": isect_offsets[: C * tiles].view(C, th, tw)}
+        if isect_ids is not None:
+            out["isect_ids"] = isect_ids[:n_isects]
+        return out
+
+
 def _sort_class(n: int) -> int:
     """Capacity of the smallest per-tile sort class that takes a list of n entries (gs_binning.hip: launch_list_sorts)."""
     for c in (1024, 4096, 8192, 16384):
@@ -263,6 +341,10 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     render_colors = torch.empty((C, H, W, 3), **f32)
     render_alphas = torch.empty((C, H, W, 1), **f32)
 
+    # "gsplat" lists, lazily: render from the short ("tight") lists -- image, alphas, radii, means2d bitwise the same, gradients
+    # to rounding -- and keep gsplat's 3-sigma rectangles, from which its exact list arrays are built if somebody reads them
+    lazy_ref = bool(cfg.get("lazy_ref_lists"))
+    rect_ref = torch.empty((C * N, 2), **i32) if lazy_ref else None
     dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
     hint_key = (dev_index, C, W, H, bool(need_grad), cfg["tile_culling"])
     with _state_lock:
@@ -293,7 +375,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
             st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), _ptr(colors_rest),
             per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"],
             cfg["radius_clip"], cfg["tile_culling"], stage, cfg.get("activations", 0), _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics),
-            P(WS.COLORS_POST), P(WS.REC), P(WS.BBOX), P(WS.TILES_PER_GAUSS)), "gs_project_fwd"))
+            P(WS.COLORS_POST), P(WS.REC), P(WS.BBOX), P(WS.TILES_PER_GAUSS), _ptr(rect_ref)), "gs_project_fwd"))
 
     def count():
         if two_level:
@@ -384,17 +466,25 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
 
     ref = WS.LeaseRef(lease)
     lazy = _LazyMeta.Lazy
+    if lazy_ref:
+        ref_lists = _ReferenceLists(rect_ref, depths, C, N, tw, th, eager_ids)
+        list_entries = {"tiles_per_gauss": lazy(lambda: ref_lists.get("tiles_per_gauss")),
+                        "isect_ids": lazy(lambda: ref_lists.get("isect_ids")) if eager_ids else _LazyMeta.PENDING,
+                        "flatten_ids": lazy(lambda: ref_lists.get("flatten_ids")),
+                        "isect_offsets": lazy(lambda: ref_lists.get("isect_offsets"))}
+    else:
+        list_entries = {
+            # list arrays: copied out of the workspace on first access (the lease is kept alive by this dict)
+            "tiles_per_gauss": lazy(lambda: lease.view(WS.TILES_PER_GAUSS, C * N).clone().view(C, N)),
+            "isect_ids": lazy(lambda: lease.view(WS.ISECT_IDS, n_isects).clone()) if eager_ids else _LazyMeta.PENDING,
+            "flatten_ids": lazy(lambda: lease.view(WS.FLATTEN_IDS, n_isects).clone()),
+            "isect_offsets": lazy(lambda: lease.view(WS.ISECT_OFFSETS, C * tiles).clone().view(C, th, tw))}
     meta = _LazyMeta({
         "camera_ids": None, "gaussian_ids": None,
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
         "opacities": opacities[None, :].expand(C, N),
-        "tile_width": tw, "tile_height": th,
-        # list arrays: copied out of the workspace on first access (the lease is kept alive by this dict)
-        "tiles_per_gauss": lazy(lambda: lease.view(WS.TILES_PER_GAUSS, C * N).clone().view(C, N)),
-        "isect_ids": lazy(lambda: lease.view(WS.ISECT_IDS, n_isects).clone()) if eager_ids else _LazyMeta.PENDING,
-        "flatten_ids": lazy(lambda: lease.view(WS.FLATTEN_IDS, n_isects).clone()),
-        "isect_offsets": lazy(lambda: lease.view(WS.ISECT_OFFSETS, C * tiles).clone().view(C, th, tw)),
-        "width": W, "height": H, "tile_size": _TILE, "n_cameras": C, "n_isects": n_isects,
+        "tile_width": tw, "tile_height": th, **list_entries,
+        "width": W, "height": H, "tile_size": _TILE, "n_cameras": C,
     })
     meta._lease = ref
     state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, n_isects=n_isects, n_buckets=n_buckets, radii=radii, lease=lease,
@@ -565,12 +655,14 @@ def rasterization(
     Only the configuration the reference exercises is implemented natively; anything else raises
     `NotImplementedError` instead of silently computing something different.
 
-    `_tile_culling="gsplat"` (default) reproduces the reference's lists exactly: `meta["tiles_per_gauss"]`,
-    `["isect_ids"]`, `["flatten_ids"]`, `["isect_offsets"]` are bit-for-bit gsplat's.  `"tight"` (opt-in; what
-    `model.GaussianModel` passes, since the reference model reads only `radii` and `means2d`,
-    /root/reference/model/gaussian.py:188-197, 371-372) drops, from gsplat's 3-sigma tile rectangle of each
-    Gaussian, the tiles in which no pixel can reach alpha >= 1/255; the image, alphas, radii, means2d and
-    all gradients are unaffected, only those four list arrays become a render-equivalent subset.
+    `_tile_culling="gsplat"` (default): `meta["tiles_per_gauss"]`, `["isect_ids"]`, `["flatten_ids"]`, `["isect_offsets"]` are
+    bit-for-bit gsplat's -- built when one of them is first read (`_ReferenceLists`): they are a function of the 3-sigma tile
+    rectangles and the depths, nothing in the reference reads them (/root/reference/model/gaussian.py:368-375 takes the image,
+    `means2d` and `radii`), and the render itself walks the shorter lists below (image, alphas, radii, means2d bitwise the
+    same, gradients to rounding; tested).  `"gsplat_eager"`: the render pipeline walks gsplat's own lists (rounds 1-2's
+    default; 1.4-1.7x the list entries).  `"tight"` (what `model.GaussianModel` passes): from gsplat's 3-sigma tile rectangle
+    of each Gaussian, the tiles in which no pixel can reach alpha >= 1/255 are dropped; the four list arrays in `meta` are
+    then that render-equivalent subset.
 
     `_sh_grads="colors_pre"` (SH colours only; used by `distributed.ViewParallelStep`) leaves the
     gradients of the SH coefficients to `gs_sh_grad_views`: backward returns `None` for `colors`
@@ -647,7 +739,8 @@ def rasterization(
     bg_c = None if backgrounds is None else prep(backgrounds)
     cfg = dict(width=int(width), height=int(height), near_plane=float(near_plane),
                far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d),
-               sh_degree=sh_degree, tile_culling={"gsplat": 0, "tight": 1}[_tile_culling], sh_grads=_sh_grads,
+               sh_degree=sh_degree, tile_culling={"gsplat": 1, "tight": 1, "gsplat_eager": 0}[_tile_culling],
+               lazy_ref_lists=_tile_culling == "gsplat", sh_grads=_sh_grads,
                activations={"none": 0, "exp_sigmoid": 1}[_activations], grad_enabled=torch.is_grad_enabled())
     if _sh_grads not in ("dense", "colors_pre") or (_sh_grads == "colors_pre" and sh_degree is None):
         raise ValueError("_sh_grads: 'dense', or 'colors_pre' together with sh_degree")

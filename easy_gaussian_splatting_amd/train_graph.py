@@ -256,12 +256,14 @@ class TrainStepGraph:
 
     def _project(self):
         L, b, m = nat.lib(), self.buf, self.model
-        culling = {"gsplat": 0, "tight": 1}[getattr(m, "tile_culling", "tight")]
+        # (the runner hands out no list arrays: "gsplat" -- exact arrays, built when read -- renders from the short lists
+        #  like "tight"; "gsplat_eager" walks gsplat's own lists)
+        culling = {"gsplat": 1, "tight": 1, "gsplat_eager": 0}[getattr(m, "tile_culling", "tight")]
         self._ck(L.gs_project_fwd(self._st(), 1, self.N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
                                    _p(m.logit_opacities), _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0,
                                    _p(b["viewmats"]), _p(b["Ks"]), self.W, self.H, 0.3, 0.01, 1e10, 0.0, culling, 0, 1,
                                    _p(b["radii"]), _p(b["means2d"]), _p(b["depths"]), _p(b["conics"]), _p(b["colors_post"]),
-                                   _p(b["rec"]), _p(b["bbox"]), _p(b["tiles_per_gauss"])), "gs_project_fwd")
+                                   _p(b["rec"]), _p(b["bbox"]), _p(b["tiles_per_gauss"]), None), "gs_project_fwd")
 
     def _count(self):
         L, b = nat.lib(), self.buf

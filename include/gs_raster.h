@@ -135,6 +135,9 @@ size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h);
  * rectangle intersected with the opacity-aware extent and, for footprints of <= 32 tiles, an exact
  * ellipse-vs-tile test (tiles in which no pixel can reach alpha >= 1/255 are dropped; the rendered
  * image and all gradients are unchanged).
+ * rect_ref[C*N*2] u32 (optional, may be NULL; written by stages 0 and 1): gsplat's 3-sigma tile rectangle itself (x0 | x1<<16,
+ * y0 | y1<<16; 0 for culled Gaussians) whatever tile_culling did to bbox -- with tile_culling = 1 the caller can render from
+ * the short lists and still build gsplat's exact list arrays (a function of this rectangle and `depths`) when somebody reads them.
  * stage: 0 = everything; 1 = geometry only (all outputs except colors_out and the colour quad of
  * rec); 2 = colour only, for the Gaussians a previous stage-1 call marked visible in radii.  Calling
  * 1, then the gs_bin_count kernels, then 2 lets the colour pass overlap the host read-back of I. */
@@ -145,7 +148,7 @@ int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    float near_plane, float far_plane, float radius_clip, int tile_culling, int stage, int activations,
                    int32_t* radii,
                    float* means2d, float* depths, float* conics, float* colors_out, float* rec, uint32_t* bbox,
-                   int32_t* tiles_per_gauss);
+                   int32_t* tiles_per_gauss, uint32_t* rect_ref);
 
 /* I-count (replaces the counting half of gsplat isect_tiles + its cumsum and
  * isect_offset_encode).  Writes isect_offsets[C*tiles+1] (exclusive; last = I),

@@ -52,7 +52,7 @@ def run_hip(sc, bwd=True, seed=0, use_bg=True, dbg=None, culling="gsplat", fw=No
         if upstream is not None:   # the (masked) upstream gradients of an earlier run of the same scene
             vc, va = (torch.from_numpy(x).float() for x in upstream)
         elif fw is not None:
-            vc, va = mask_upstream(out, fw, vc, va, lists=culling == "gsplat")
+            vc, va = mask_upstream(out, fw, vc, va, lists=culling != "tight")
         out["vc"], out["va"] = vc.numpy().astype(np.float64), va.numpy().astype(np.float64)
         out["grads"] = torch.autograd.grad((img * vc.to(dev())).sum() + (alpha * va.to(dev())).sum(), ins)
     torch.cuda.synchronize()
@@ -300,13 +300,13 @@ SCENES = {
 }
 
 
-@pytest.mark.parametrize("culling", ["gsplat", "tight"])
+@pytest.mark.parametrize("culling", ["gsplat", "gsplat_eager", "tight"])
 @pytest.mark.parametrize("name", list(SCENES))
 def test_forward_backward_parity_small(name, culling):
     sc = make_scene(**SCENES[name])
     fw = run_oracle(sc)
     hip = run_hip(sc, culling=culling, fw=fw)
-    check_forward(hip, fw, lists=culling == "gsplat")
+    check_forward(hip, fw, lists=culling != "tight")
     check_backward(hip, fw)
 
 
@@ -314,7 +314,14 @@ def test_tight_culling_is_render_equivalent_subset():
     """Default tight tile culling: lists are a subset of gsplat's, image and gradients identical."""
     sc = make_scene(6000, 200, 150, sh_degree=1, seed=31, k_store=4, scale_range=(0.01, 0.3), dist=4.0)
     sc["opacities"] = np.random.default_rng(5).uniform(0.002, 1.0, 6000).astype(np.float32)  # some below 1/255
-    a, b = run_hip(sc, culling="gsplat"), run_hip(sc, culling="tight")
+    a, b, e = run_hip(sc, culling="gsplat"), run_hip(sc, culling="tight"), run_hip(sc, culling="gsplat_eager")
+    # "gsplat" (the default) renders from the short lists and builds gsplat's arrays when they are read: the arrays must be
+    # those of the pipeline that walks gsplat's lists itself, bit for bit, and so must the image
+    for k in ("tiles_per_gauss", "flatten_ids", "isect_offsets", "isect_ids", "radii", "means2d"):
+        assert torch.equal(a["meta"][k], e["meta"][k]), k
+    assert torch.equal(a["img"], e["img"]) and torch.equal(a["alpha"], e["alpha"])
+    for ga, ge in zip(a["grads"], e["grads"]):
+        assert float((ga - ge).abs().max()) <= 1e-5 * float(ge.abs().max())
     ta, tb = a["meta"]["tiles_per_gauss"], b["meta"]["tiles_per_gauss"]
     assert bool((tb <= ta).all()) and int(tb.sum()) < int(ta.sum())
     assert torch.equal(a["meta"]["radii"], b["meta"]["radii"]) and torch.equal(a["meta"]["means2d"], b["meta"]["means2d"])
@@ -437,7 +444,7 @@ def test_large_tile_lists_hit_every_sort_class():
     check_backward(hip2, fw2)
 
 
-@pytest.mark.parametrize("culling", ["gsplat", "tight"])
+@pytest.mark.parametrize("culling", ["gsplat", "gsplat_eager", "tight"])
 def test_long_lists_heavy_tailed_footprints(culling):
     """Real-capture-like lists: footprints of hundreds of tiles, mean list > 2 000 entries, saturating pixels (the
     regime where emission + per-tile sort lead the forward): lists bit-exact, image and gradients within tolerance."""
@@ -446,7 +453,7 @@ def test_long_lists_heavy_tailed_footprints(culling):
     counts = np.diff(np.append(fw["isect_offsets"].reshape(-1), fw["n_isects"]))
     assert counts.mean() > 2000 and fw["tiles_per_gauss"].max() > 300
     hip = run_hip(sc, culling=culling, fw=fw)
-    check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC, lists=culling == "gsplat")
+    check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC, lists=culling != "tight")
     check_backward(hip, fw)
 
 
@@ -661,9 +668,11 @@ def fuzz_case(case, attempt=0):
     W, H = int(rng.integers(17, 260 * big)), int(rng.integers(17, 200 * big))
     smax = float(rng.choice([0.05, 0.2, 0.8]))
     dist, white = float(rng.uniform(2.5, 6.0)), bool(rng.integers(0, 2))
-    use_bg, split, culling = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)) and K > 1, str(rng.choice(["tight", "gsplat"]))
+    use_bg, split, culling = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)) and K > 1, str(rng.choice(["tight", "gsplat"]))   # (drawn before "gsplat_eager" existed: see below)
     sc = make_scene(n, W, H, sh_degree=deg, seed=2000 + case + 1000 * attempt, k_store=K, n_views=C, scale_range=(0.01, smax),
                     dist=dist, white_bg=white)
+    if culling == "gsplat" and case % 2:   # half of the reference-list cases walk gsplat's own lists in the render pipeline
+        culling = "gsplat_eager"
     return sc, (deg, W, H, use_bg, split, culling)
 
 
@@ -692,7 +701,7 @@ def test_randomised_configurations(case, monkeypatch):
                                          backgrounds=t["backgrounds"] if use_bg else None, absgrad=True, _tile_culling=culling)
         fw = run_oracle(sc, use_bg=use_bg)
         hip = dict(img=img, alpha=alpha, meta=meta)
-        rep = forward_report(meta, fw, lists=culling == "gsplat")
+        rep = forward_report(meta, fw, lists=culling != "tight")
         rep["fw"], hip["report"] = fw, rep
         razor = float(rep["razor"].mean())
         if razor <= MAX_RAZOR_FRAC:
@@ -706,7 +715,7 @@ def test_randomised_configurations(case, monkeypatch):
     if split:
         grads = list(grads[:4]) + [torch.cat([grads[4], grads[5]], dim=1)]
     hip.update(grads=grads, vc=vc.numpy().astype(np.float64), va=va.numpy().astype(np.float64))
-    check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC, lists=culling == "gsplat")
+    check_forward(hip, fw, max_razor_frac=MAX_RAZOR_FRAC, lists=culling != "tight")
     if fw["n_isects"] > 0:
         check_backward(hip, fw)
 
@@ -730,7 +739,7 @@ def _binning_scenes():
             "ragged": make_scene(1237, 333, 77, sh_degree=1, seed=3, k_store=4, scale_range=(0.02, 0.3), dist=4.0)}
 
 
-@pytest.mark.parametrize("culling", ["gsplat", "tight"])
+@pytest.mark.parametrize("culling", ["gsplat", "gsplat_eager", "tight"])
 @pytest.mark.parametrize("name", ["long_lists", "dense_3000", "two_views_big", "tiny", "ragged"])
 def test_binning_pipelines_agree_bit_for_bit(name, culling, monkeypatch):
     """The per-tile pipeline (every tile list emitted and sorted) and the two-level one (coarse bins sorted, tiles refined
@@ -799,7 +808,7 @@ def test_two_level_binning_flags_and_capacities():
     P = lambda x: x.data_ptr()
     nat.check(L.gs_project_fwd(st, C, N, 16, 3, P(t["means"]), P(t["quats"]), P(t["scales"]), P(t["opacities"]), P(t["shs"]), None, 0,
                                P(t["viewmats"]), P(t["Ks"]), W, H, 0.3, 0.01, 1e10, 0.0, 0, 1, 0, P(radii), P(m2), P(dep),
-                               P(con), P(col), P(rec), P(bbox), P(tpg)), "gs_project_fwd")
+                               P(con), P(col), P(rec), P(bbox), P(tpg), None), "gs_project_fwd")
     off = torch.empty((tiles + 1,), **i32); boff = torch.empty((tiles + 1,), **i32); order = torch.empty((tiles,), **i32)
     cum = torch.empty((C * N,), **i32)
     info = torch.zeros((8,), dtype=torch.int64, device=d)
@@ -971,7 +980,7 @@ def test_tile_launch_order_is_a_longest_first_permutation():
     P = lambda x: x.data_ptr()
     nat.check(L.gs_project_fwd(st, C, N, 1, 0, P(t["means"]), P(t["quats"]), P(t["scales"]), P(t["opacities"]), P(t["shs"]), None, 0,
                                P(t["viewmats"]), P(t["Ks"]), sc["width"], sc["height"], 0.3, 0.01, 1e10, 0.0, 1, 0, 0, P(radii), P(m2), P(dep),
-                               P(con), P(col), P(rec), P(bbox), P(tpg)), "gs_project_fwd")
+                               P(con), P(col), P(rec), P(bbox), P(tpg), None), "gs_project_fwd")
     ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=d)
     off = torch.empty((tiles + 1,), **i32); boff = torch.empty((tiles + 1,), **i32); order = torch.full((tiles,), -1, **i32)

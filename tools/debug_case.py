@@ -35,7 +35,7 @@ m2 = meta["means2d"].cpu().numpy()
 e = np.abs(m2 - fw["means2d"]).max(-1); c, i = np.unravel_index(e.argmax(), e.shape)
 print(f"means2d: worst abs err {e.max():.3e} at cam {c} gaussian {i}: hip {m2[c, i]} oracle {fw['means2d'][c, i]} depth {fw['depths'][c, i]} radius {fw['radii'][c, i]}")
 try:
-    rep = TP.forward_report(meta, fw, lists=culling == "gsplat")
+    rep = TP.forward_report(meta, fw, lists=culling != "tight")
 except AssertionError as ex:
     print("forward_report:", str(ex).splitlines()[0]); sys.exit(0)
 print("razor", rep["razor"].mean(), "loose", rep["loose"].mean(), "exact lists", rep["exact_lists"])
