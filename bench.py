@@ -253,13 +253,23 @@ class DropInLoop:
       step / zero_grad    /root/reference/train.py:152-153
     No fused loss, no in-kernel activations, no split SH hand-over, no tight lists, no HIP Adam, no hipGraph."""
 
-    def __init__(self, sc, device, lrs):
+    def __init__(self, sc, device, lrs, loss: str = "torch", adam: str = "torch"):
+        """`loss="hip"` / `adam="hip"`: the next two one-line swaps of INTEGRATION.md section 2 (this package's LossComputer /
+        build_optimizers(..., fused="hip")) on top of the import change -- the rest of the loop stays the reference's."""
         import torch
         self.torch = torch
         self.m = model_from_scene(sc, device)
         names = ["means", "log_scales", "quats", "sh_0", "sh_rest", "logit_opacities"]
-        self.opt = torch.optim.Adam([{"params": [getattr(self.m, k)], "lr": lr, "name": k} for k, lr in zip(names, lrs)])
+        if adam == "hip":
+            from easy_gaussian_splatting_amd.model import build_optimizers
+            self.opt = build_optimizers(self.m, *lrs, fused="hip")
+        else:
+            self.opt = torch.optim.Adam([{"params": [getattr(self.m, k)], "lr": lr, "name": k} for k, lr in zip(names, lrs)])
         self.lambda_ssim = 0.2
+        self.hip_loss = None
+        if loss == "hip":
+            from easy_gaussian_splatting_amd.loss import LossComputer
+            self.hip_loss = LossComputer(lambda_ssim=0.2)
 
     def forward(self, data):
         from easy_gaussian_splatting_amd.rendering import rasterization   # <- the import the maintainer changes
@@ -273,6 +283,8 @@ class DropInLoop:
         return {"render_img": render_img, "batch_xys": meta["means2d"], "batch_radii": meta["radii"]}
 
     def loss_dict(self, render_img, gt_img, mask):
+        if self.hip_loss is not None:
+            return self.hip_loss.get_loss_dict(render_img, gt_img, mask)
         import torch.nn.functional as F
         from easy_gaussian_splatting_amd.loss import ssim
         mask = mask.unsqueeze(2).repeat(1, 1, 3)
@@ -547,8 +559,17 @@ def run_rank(args) -> int:
                         ".item() per step, boolean-index update_statistics, torch.optim.Adam (six groups, foreach), eager"}
             del di
             torch.cuda.empty_cache()
+            # the next one-line swaps on top of it, the loop otherwise unchanged
+            more = {}
+            for tag, kw in (("plus_hip_loss", dict(loss="hip")), ("plus_hip_loss_and_adam", dict(loss="hip", adam="hip"))):
+                dj = DropInLoop(sc, device, lrs, **kw)
+                ej, _, sj, _ = timed_loop(lambda: dj.step(data, gt_img, mask, item_reads=True), nd, 5)
+                more[tag] = {"train_iters_per_s": round(nd / ej, 2), "train_ms": _percentiles(sj)}
+                del dj
+                torch.cuda.empty_cache()
+            extras["drop_in"].update(more)
         except Exception as e:   # a secondary timing must never cost the bench line
-            extras["drop_in"] = {"error": repr(e)[:300]}
+            extras.setdefault("drop_in", {})["error"] = repr(e)[:300]
 
         # long lists (what real captures look like to the tile lists): 200 k heavy-tailed splats, mean list ~4.6 k
         try:

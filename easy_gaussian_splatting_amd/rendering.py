@@ -486,9 +486,11 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         "tile_width": tw, "tile_height": th, **list_entries,
         "width": W, "height": H, "tile_size": _TILE, "n_cameras": C,
     })
-    meta._lease = ref
+    if not lazy_ref:
+        meta._lease = ref   # (the list lazies above read the arenas; in the "gsplat" mode nothing in meta does)
     state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, n_isects=n_isects, n_buckets=n_buckets, radii=radii, lease=lease,
                  lease_ref=WS.LeaseRef(lease) if need_grad else None, factorised=factorised)
+    del ref   # (the lease goes back to its pool here unless meta or the autograd node holds it)
     return render_colors, render_alphas, meta, state
 
 

@@ -119,17 +119,29 @@ def test_two_forwards_in_flight_hold_two_leases(culling):
 def test_inference_calls_hold_no_lease_after_meta_is_dropped():
     sc, t = _scene()
     rendering.reset_hints()
-    with torch.no_grad():
-        img, alpha, meta = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"][:1], t["Ks"][:1],
-                                         sc["width"], sc["height"], sh_degree=3, packed=False, backgrounds=t["backgrounds"][:1])
-    assert sum(len(v) for v in WS.pool.free.values()) == 0          # meta still reads the workspace
+    free = lambda: sum(len(v) for v in WS.pool.free.values())
+
+    def render(view, culling):
+        with torch.no_grad():
+            return rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"][view:view + 1],
+                                 t["Ks"][view:view + 1], sc["width"], sc["height"], sh_degree=3, packed=False,
+                                 backgrounds=t["backgrounds"][view:view + 1], _tile_culling=culling)
+
+    # "tight": meta's list arrays are read out of the workspace, so meta keeps the lease until it is dropped
+    img, alpha, meta = render(0, "tight")
+    assert free() == 0
     fid = meta["flatten_ids"]
     del meta
-    assert sum(len(v) for v in WS.pool.free.values()) == 1          # lease returned
-    with torch.no_grad():
-        img2, _, meta2 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"][1:2], t["Ks"][1:2],
-                                       sc["width"], sc["height"], sh_degree=3, packed=False, backgrounds=t["backgrounds"][1:2])
-    with torch.no_grad():
-        img3, _, meta3 = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"][:1], t["Ks"][:1],
-                                       sc["width"], sc["height"], sh_degree=3, packed=False, backgrounds=t["backgrounds"][:1])
+    assert free() == 1
+    img2, _, meta2 = render(1, "tight")
+    del meta2
+    img3, _, meta3 = render(0, "tight")
     assert torch.equal(img3, img) and torch.equal(meta3["flatten_ids"], fid) and not torch.equal(img2, img)
+    del meta3
+    # "gsplat" (default): the arrays are rebuilt from the kept rectangles when read -- the lease is free as soon as the call returns
+    img4, _, meta4 = render(0, "gsplat")
+    assert free() == 1 and torch.equal(img4, img)
+    ref_ids = meta4["flatten_ids"]
+    img5, _, meta5 = render(1, "gsplat")          # re-uses the workspace while meta4 is still alive and unread in part
+    assert torch.equal(meta4["isect_offsets"].reshape(-1)[1:] >= meta4["isect_offsets"].reshape(-1)[:-1], torch.ones_like(meta4["isect_offsets"].reshape(-1)[1:], dtype=torch.bool))
+    assert int(meta4["tiles_per_gauss"].sum()) == ref_ids.numel() and ref_ids.numel() > fid.numel()
