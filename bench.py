@@ -37,6 +37,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 N_SIMD = 1024            # 256 CUs x 4 SIMD-32
 VALU_CYCLES_PER_WAVE_INST = 2.0   # wave64 on a SIMD-32 (same guide, cycle-constants table)
+# what a SIMD actually sustains on this kernel's instruction mix, measured (tools/micro/README.md, 4 waves per SIMD, nominal
+# 2.4 GHz): fp32 fma / mul / add 2.7-3.0, v_cmp + v_cndmask 3.9 each, v_exp / v_rcp 8.4 -> ~3.2 over blend_bwd's mix
+VALU_CYCLES_PER_WAVE_INST_MEASURED = 3.2
 CLOCK_HZ = 2.4e9
 PROFILE_TAGS = ("r03", "r02", "r01")     # committed rocprofv3 summaries under profiles/, newest first
 
@@ -701,6 +704,9 @@ def run_rank(args) -> int:
             rate = sq["SQ_INSTS_VALU"] / (t_ms * 1e-3)
             rc_obj.update(valu_wave_insts_per_launch=sq["SQ_INSTS_VALU"], achieved=round(rate / 1e9, 1),
                           frac=round(rate / peak_rate, 4), counters_source=sq_src,
+                          frac_of_measured_issue_rate=round(rate / (N_SIMD * CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST_MEASURED), 4),
+                          measured_issue_note="tools/micro/README.md: this instruction mix issues at ~3.2 nominal cycles per wave64 "
+                                              "instruction, not 2; against that rate the kernel is issue-bound",
                           counters={k: sq[k] for k in sorted(sq) if k.startswith("SQ_")})
         result = {
             "metric": "train iters/sec + forward render fps, 1M Gaussians @ 1080p",
