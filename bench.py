@@ -593,7 +593,7 @@ def run_rank(args) -> int:
                 return meta
 
             out_ll = {}
-            for mode in ("gsplat", "tight"):
+            for mode in ("gsplat_eager", "tight"):   # (the render pipeline walking gsplat's own lists / the short lists)
                 meta_ll = ll_step(mode)
                 rendering.profile_stages(True)
                 e_ll, _, ms_ll, _ = timed_loop(lambda: ll_step(mode), 10, 2)
@@ -625,7 +625,7 @@ def run_rank(args) -> int:
                       "width": Wx, "height": Hx}
                 gx = smooth_target(Hx, Wx, 77, device)
                 outs = {}
-                for mode in ("gsplat", "tight"):
+                for mode in ("gsplat_eager", "tight"):   # (gsplat's own lists walked by the captured step / the short lists)
                     mx.tile_culling = mode
                     runner = TrainStepGraph(mx, ox, LossComputer(lambda_ssim=0.2, clamp_input=True), dx, gx, None)
                     ex, _, sx, _ = timed_loop(runner.step, n_steps, 5, finish=runner.finish)

@@ -16,7 +16,7 @@ for part in ("fwd", "bwd"):
 PY
 timeout 300 bash tools/prof_bench.sh ${tag}_bench > gpurun_out/${tag}_prof_bench.log 2>&1
 timeout 600 python bench.py > gpurun_out/${tag}_bench_line.json 2> gpurun_out/${tag}_bench.err
-for m in tight gsplat; do
+for m in tight gsplat_eager; do
   timeout 200 bash tools/prof_cmd.sh ${tag}_longlists_$m tools/long_lists_run.py $m 10 > /dev/null 2>&1
   grep -v "amdgpu.ids\|^W2026\|^E2026" /tmp/${tag}_longlists_$m.log > gpurun_out/${tag}_longlists_$m.txt
 done

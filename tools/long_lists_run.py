@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The bench's secondary workload (synthetic.config_long_lists: 200 k heavy-tailed splats at 1080p, mean tile list > 2 000)
-forward + backward in a loop, for kernel-level profiles: tools/prof_cmd.sh longlists tools/long_lists_run.py [gsplat|tight] [iters]"""
+forward + backward in a loop, for kernel-level profiles: tools/prof_cmd.sh longlists tools/long_lists_run.py [gsplat_eager|gsplat|tight] [iters]"""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np, torch

@@ -12,7 +12,7 @@ for name, kw in {"S3": dict(n=2_000_000, width=1920, height=1080, sh_degree=3, e
     W, H = sc["width"], sc["height"]
     ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
     sh0 = t["shs"][:, :1].contiguous().requires_grad_(True); shr = t["shs"][:, 1:].contiguous().requires_grad_(True)
-    fwd = lambda: rasterization(*ins, (sh0, shr), t["viewmats"], t["Ks"], W, H, sh_degree=3, packed=False, backgrounds=t["backgrounds"], absgrad=True, _tile_culling=os.environ.get("GS_CULL", "gsplat"))
+    fwd = lambda: rasterization(*ins, (sh0, shr), t["viewmats"], t["Ks"], W, H, sh_degree=3, packed=False, backgrounds=t["backgrounds"], absgrad=True, _tile_culling=os.environ.get("GS_CULL", "gsplat_eager"))
     img, a, meta = fwd(); vc = torch.randn_like(img) / (W * H)
     for _ in range(2):
         img, a, meta = fwd(); (img * vc).sum().backward()
