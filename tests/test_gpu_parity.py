@@ -1015,11 +1015,13 @@ def test_no_grad_takes_the_inference_path():
     with torch.no_grad():
         img_n, _, _ = rasterization(*ins, t["viewmats"], t["Ks"], 160, 112, sh_degree=2, packed=False, backgrounds=t["backgrounds"])
     assert not img_n.requires_grad and torch.equal(img_n, img_g.detach())
-    base = torch.cuda.memory_allocated()
+    # the inference call's workspace layout holds none of the backward's buffers (checkpoints, quadrant sublists, rows)
+    from easy_gaussian_splatting_amd import workspace as WS
     with torch.no_grad():
-        out = rasterization(*ins, t["viewmats"], t["Ks"], 160, 112, sh_degree=2, packed=False, backgrounds=t["backgrounds"])
-    held_inference = torch.cuda.memory_allocated() - base
-    del out
-    out = rasterization(*ins, t["viewmats"], t["Ks"], 160, 112, sh_degree=2, packed=False, backgrounds=t["backgrounds"])
-    held_training = torch.cuda.memory_allocated() - base
-    assert held_inference < held_training, (held_inference, held_training)
+        out = rasterization(*ins, t["viewmats"], t["Ks"], 160, 112, sh_degree=2, packed=False, backgrounds=t["backgrounds"], _tile_culling="tight")
+    lay_inf = out[2]._lease.lease.layout
+    out_t = rasterization(*ins, t["viewmats"], t["Ks"], 160, 112, sh_degree=2, packed=False, backgrounds=t["backgrounds"], _tile_culling="tight")
+    lay_train = out_t[0].grad_fn.state["lease"].layout
+    for slot in (WS.CKPT, WS.QLIST, WS.QMASK, WS.UNIT_DESC, WS.ROWS, WS.SLOTS):
+        assert lay_inf.offsets[slot] == -1 and lay_train.offsets[slot] >= 0, slot
+    assert lay_inf.arena_bytes[1] * 4 < lay_train.arena_bytes[1]
