@@ -73,6 +73,8 @@ class TrainStepGraph:
         # need the runtime knob.)
         self.stream = torch.cuda.Stream(self.dev)
         self.cap = 0
+        self.cap_floor = 0   # capacity carried over a rebuild: the probe sees ONE view, the steps before saw them all
+        self.seen_isects = 0  # largest intersection count the status words have shown since the last (re-)build
         self.probed = (0, 0)
         self.cap_tile = _SORT_CLASSES[0]
         self.pending: deque = deque()     # steps issued but not yet confirmed applied: (t, lrs, w2c, K, gt, mask)
@@ -147,7 +149,7 @@ class TrainStepGraph:
         if self.cap == 0 or min_cap or min_cap_tile:
             n_isects, max_tile = self._probe()
             self.probed = (n_isects, max_tile)
-            self.cap = max(int(max(n_isects, min_cap) * self.margin) + 4096, self.cap)
+            self.cap = max(int(max(n_isects, min_cap) * self.margin) + 4096, self.cap, self.cap_floor)
             need_tile = max(int(max(max_tile, min_cap_tile) * self.margin), self.cap_tile)   # (same head-room as the lists)
             self.cap_tile = next((c for c in _SORT_CLASSES if c >= need_tile), 1 << 30)
         self._alloc_binning()
@@ -437,7 +439,8 @@ class TrainStepGraph:
         W, H = (self.W, self.H) if data is None else (int(data["width"]), int(data["height"]))
         if self._state_key(W, H) != self._key:
             self.finish()
-            if (W, H) != (self.W, self.H):
+            size_changed = (W, H) != (self.W, self.H)
+            if size_changed:
                 # another frame size: the static image buffers are re-allocated, so the frame must bring its own target
                 if gt_img is None or (self.has_mask and mask is None):
                     raise ValueError("TrainStepGraph.step: a change of image size needs gt_img (and mask) of the new size")
@@ -447,6 +450,13 @@ class TrainStepGraph:
                 cur = self._last_inputs if data is None else (data["w2c"], data["K"], gt_img if gt_img is not None else self.buf["gt"],
                                                               mask if mask is not None else self.buf.get("mask"))
                 # (old static buffers named here stay alive through `cur` until the new ones have been filled from them)
+            # the largest list the status words showed since the last build, scaled to the new model size: a refinement
+            # re-captures on whichever view comes next, and a capacity learnt from that one view alone overflows on the first
+            # wider one (tools/train_soak.py: 153 of 700 steps were replayed before this).  Not the old CAPACITY scaled: that
+            # compounds margin on margin, and every kernel whose grid is sized by the capacity pays for the empty workgroups
+            n_new = self.model.means.shape[0]
+            self.cap_floor = 0 if size_changed else min(int(self.seen_isects * max(1.0, n_new / max(self.N, 1)) * self.margin), (1 << 29) - 1)
+            self.seen_isects = 0
             self.cap = 0
             self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None)
         b = self.buf
@@ -471,6 +481,7 @@ class TrainStepGraph:
         if block:
             self.stream.synchronize()
         n_isects, _, max_tile, flags, applied = (int(v) for v in self.status[:5].tolist())
+        self.seen_isects = max(self.seen_isects, n_isects)
         done = min(self.confirmed_at_build + applied - self.confirmed, len(self.pending))
         for _ in range(max(done, 0)):
             self.pending.popleft()
