@@ -37,6 +37,7 @@ def _stream(device: torch.device) -> int:
 # Optional per-stage device timing (bench.py only): when `_prof` is a dict, every native stage call
 # is bracketed by HIP events recorded on the stream the kernels are launched on.
 _prof: Optional[Dict] = None
+_prof_repeat: Dict[str, int] = {}
 
 
 def _stage(name: str, device, thunk):
@@ -44,24 +45,30 @@ def _stage(name: str, device, thunk):
         return thunk()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stream = torch.cuda.current_stream(device)
+    n = max(1, int(_prof_repeat.get(name, 1)))
     s.record(stream)
     r = thunk()
+    for _ in range(n - 1):   # (idempotent stages only: the same launch again, so that the launch gap is paid once per n)
+        thunk()
     e.record(stream)
-    _prof.setdefault(name, []).append((s, e))
+    _prof.setdefault(name, []).append((s, e, n))
     return r
 
 
-def profile_stages(enable: bool) -> Optional[Dict]:
-    """Start (True) or stop (False) stage timing; stopping returns {stage: [ms, ...]}."""
-    global _prof
+def profile_stages(enable: bool, repeat: Optional[Dict[str, int]] = None) -> Optional[Dict]:
+    """Start (True) or stop (False) stage timing; stopping returns {stage: [ms, ...]}.  `repeat={"gs_blend_bwd": 10}`: that
+    stage (it must be idempotent: the blend kernels are) is launched 10 times back to back inside its pair of events and the
+    time divided by 10 -- the kernel's duration without the launch gap a single eager launch carries (what a kernel trace
+    reports)."""
+    global _prof, _prof_repeat
     if enable:
-        _prof = {}
+        _prof, _prof_repeat = {}, dict(repeat or {})
         return None
-    out, _prof = _prof, None
+    out, _prof, _prof_repeat = _prof, None, {}
     if out is None:
         return None
     torch.cuda.synchronize()
-    return {k: [s.elapsed_time(e) for s, e in v] for k, v in out.items()}
+    return {k: [s.elapsed_time(e) / n for s, e, n in v] for k, v in out.items()}
 
 
 # GS_DP_ROWS_COLOR=1: gs_blend_bwd also writes the compact copy of the rows' colour lanes that gs_colors_pre_grad can read instead
