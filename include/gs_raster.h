@@ -210,10 +210,14 @@ int gs_bins_lists(void* stream, int C, int64_t N, int tile_w, int tile_h, int bi
  *   qcnt[C*tiles*4]     sublist lengths
  *   ckpt[8*n_buckets*64*4] f32  per GS_UNIT-entry work unit of a quadrant sublist: the quadrant's 64 pixel
  *                       states in front of it (T -- negative once saturated / outside the image -- and accumulated rgb)
- *   qmask[I] u8         by gradient-row slot: which quadrant rows of an intersection exist (fully
- *                       written: entries behind a tile's saturation point read 0)
- *   unit_counter[1], unit_desc[8*n_buckets*4] i32   work units (tile*4+quadrant, entries in the unit, index of its
- *                       first qlist pair, checkpoint row) */
+ *   qmask[I] u8         by gradient-row slot: which quadrant rows of an intersection exist.  Cleared by this call (one
+ *                       streaming pass over n_isects bytes), then only the non-zero masks are stored: a scattered one-byte
+ *                       store leaves L2 as a 32-byte partial write (profiles/r03_traffic_calibration.json)
+ *   unit_counter[1], unit_desc[8*n_buckets*4] i32   work units (tile*4+quadrant, entries in the unit | 0x100 for the first
+ *                       unit of its sublist -- its checkpoint is "T = 1 inside the image", not read --, index of its first
+ *                       qlist pair, checkpoint row)
+ * A pixel's state is one float: T > 0 live, T <= 0 finished (stop rule fired / outside the image) with |T| final; checkpoints
+ * store it as it is (gs_blend_bwd looks at the sign only). */
 int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                  const float* backgrounds, const int32_t* isect_offsets,
                  const int32_t* bucket_offsets, const int32_t* tile_order, const int32_t* flatten_ids, const int32_t* slots,
