@@ -69,21 +69,28 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // skips entries no pixel takes); straight-line, predicated.  The entry's alpha is
 // masked once (v_cndmask costs more than an fp32 multiply on gfx950, tools/micro/): a masked alpha
 // of 0 leaves T and the colour sums bit-for-bit unchanged (fma(-0, T, T) == T, fma(r, 0, c) == c).
-// A pixel's state is ONE register: T > 0 = live with transmittance T, T <= 0 = finished (the stop rule fired, or the pixel
-// lies outside the image) with final transmittance |T| -- no separate per-lane flag to test, update and keep (round 3:
-// the flag cost an and + compare + mask inversion per pair and two selects per stop).
+// A pixel's state is ONE register: T in (1e-4, 1] = live with transmittance T; T > 2^32 = finished (the stop rule fired, or
+// the pixel lies outside the image) with final transmittance T * 2^-64 -- the scaling by a power of two is exact, and it
+// makes every test a single compare: "live" is T <= 1, and the stop test Tn <= 1e-4 needs no mask, because a finished
+// pixel's Tn = fma(-0, T, T) = T is huge and a live pixel that does not take the entry keeps Tn = T > 1e-4.  (Round 3: a
+// separate per-lane flag cost an and + compare + mask inversion per pair and two selects per stop; a sign flag still needed
+// `ok && Tn <= 1e-4`, which hipcc turns into a select + compare + s_nop in front of the ballot.)
 // The stop rule (T would fall to 1e-4: the entry is NOT blended, the pixel is finished) fires a
-// handful of times per pixel at most, so it lives behind a wave-uniform branch on the ballot itself.
+// handful of times per pixel at most, so it lives behind a wave-uniform branch on the ballot of that one compare.
+constexpr float kDoneScale = 18446744073709551616.f;   // 2^64
+constexpr float kDoneInv = 5.421010862427522e-20f;      // 2^-64
+__device__ __forceinline__ bool px_live(float T) { return T <= 1.f; }
+__device__ __forceinline__ float px_final_T(float T) { return T > 2.f ? T * kDoneInv : T; }
 __device__ __forceinline__ void blend_pair(const float alpha, const bool ok, const float r,
                                            const float g, const float b, float& T, float& cr,
                                            float& cg, float& cb) {
     const float am = ok ? alpha : 0.f;
     float w = am * T;
     float Tn = fmaf(-am, T, T);   // explicit: fwd and bwd must round identically
-    const bool stop = ok && Tn <= kTMin;
+    const bool stop = Tn <= kTMin;
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(stop) != 0ull, 0)) {
         w = stop ? 0.f : w;
-        Tn = stop ? -T : Tn;
+        Tn = stop ? T * kDoneScale : Tn;
     }
     cr = fmaf(r, w, cr); cg = fmaf(g, w, cg); cb = fmaf(b, w, cb);
     T = Tn;
@@ -141,12 +148,12 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
     const int bucket0 = a.bucket_offsets[t];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    float T[4], cr[4], cg[4], cb[4];   // T > 0: live; T <= 0: finished, |T| final (blend_pair)
+    float T[4], cr[4], cg[4], cb[4];   // T <= 1: live; T > 2^32: finished, T * 2^-64 final (blend_pair)
     int cnt[4] = {0, 0, 0, 0};   // wave-uniform sublist lengths
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         cr[k] = cg[k] = cb[k] = 0.f;
-        T[k] = ((px0 + 8 * (k & 1)) < a.W && (py0 + 8 * (k >> 1)) < a.H) ? 1.f : -1.f;
+        T[k] = ((px0 + 8 * (k & 1)) < a.W && (py0 + 8 * (k >> 1)) < a.H) ? 1.f : kDoneScale;
     }
     // pixel-centre bounds of the four quadrants
     const float qxlo[2] = {(float)x0 + 0.5f, (float)x0 + 8.5f}, qxhi[2] = {(float)x0 + 7.5f, (float)x0 + 15.5f};
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
     for (int b = 0; b < nb; ++b) {
         bool qa[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) qa[k] = __builtin_amdgcn_ballot_w64(T[k] > 0.f) != 0ull;
+        for (int k = 0; k < 4; ++k) qa[k] = __builtin_amdgcn_ballot_w64(px_live(T[k])) != 0ull;
         if (!(qa[0] || qa[1] || qa[2] || qa[3])) {
             // every pixel of the tile is finished: the rest of the list contributes nothing (its quadrant masks already
             // read "no rows": the mask array is cleared by one streaming pass in front of the kernel)
@@ -221,14 +228,14 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
                     const float dx = q0.x - ((k & 1) ? fx1 : fx0), dy = q0.y - ((k >> 1) ? fy1 : fy0);
                     const float sigma = fmaf(dy, fmaf(q1.x, dy, q0.w * dx), q0.z * dx * dx);
                     const float alpha = fminf(kAlphaMax, op * fast_exp2(-sigma));
-                    const bool ok = T[k] > 0.f && sigma >= 0.f && alpha >= kAlphaMin;
+                    const bool ok = px_live(T[k]) && sigma >= 0.f && alpha >= kAlphaMin;
                     if (CKPT) {
                         if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;   // no pixel of the quadrant takes it: nothing to blend, nothing to list
                         // the sublist entry that opens a new work unit saves the pixel states before it
                         const int pos = cnt[k] + (int)__popcll(cq[k]);
                         if ((pos & (kUnit - 1)) == 0 && (pos != 0 || !GS_FWD_SKIP_FIRST_CKPT))
                             a.ckpt[((size_t)8 * bucket0 + (size_t)k * (2 * nb) + pos / kUnit) * 64 + lane] =
-                                make_float4(T[k], cr[k], cg[k], cb[k]);   // (T <= 0: finished -- all the backward looks at is the sign)
+                                make_float4(px_live(T[k]) ? T[k] : -1.f, cr[k], cg[k], cb[k]);   // (the backward's "finished" is T < 0)
                         cq[k] |= 1ull << j;
                     }
                     blend_pair(alpha, ok, r, g, bl, T[k], cr[k], cg[k], cb[k]);
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
         const int px = px0 + 8 * (k & 1), py = py0 + 8 * (k >> 1);
         if (px < a.W && py < a.H) {
             const size_t o = ((size_t)cam * a.H + py) * a.W + px;
-            const float Tf = fabsf(T[k]);
+            const float Tf = px_final_T(T[k]);
             a.out_colors[3 * o] = cr[k] + Tf * bgr;
             a.out_colors[3 * o + 1] = cg[k] + Tf * bgg;
             a.out_colors[3 * o + 2] = cb[k] + Tf * bgb;
