@@ -30,14 +30,20 @@
 
 namespace gs {
 
+#ifndef GS_BIN_PER_GROUP
+#define GS_BIN_PER_GROUP 4096     // Gaussians per binning block (histogram / emit)
+#endif
+#ifndef GS_BIN_MAX_GROUPS
+#define GS_BIN_MAX_GROUPS 256     // (bin_colscan_kernel takes up to kColChunks * 16 groups in its batched path)
+#endif
 constexpr int kBinThreads = 1024;
 constexpr int kCoopTiles = 32;  // footprints above this are spread over the whole wave
 
 BinLayout bin_layout(int C, int64_t N, int tiles) {
     BinLayout L;
-    int64_t g = (N + 4095) / 4096;
+    int64_t g = (N + GS_BIN_PER_GROUP - 1) / GS_BIN_PER_GROUP;
     if (g < 1) g = 1;
-    if (g > 256) g = 256;
+    if (g > GS_BIN_MAX_GROUPS) g = GS_BIN_MAX_GROUPS;
     L.groups = (int)g;
     L.per_group = (N + g - 1) / g;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_hist_kernel(int64_t N, int tw
 // per (camera, tile): exclusive scan over groups, in place.  One thread per (tile, chunk of kColChunk consecutive groups):
 // 64 tiles x 16 chunks per block, the chunk sums scanned across the block through LDS.  (Round 2 walked a whole column -- up
 // to 256 groups -- with one thread per tile: 8160 threads for the chip, 17 us of dependent batches; this form: 130 k threads.)
-constexpr int kColTiles = 64, kColChunks = 16;
+constexpr int kColTiles = GS_BIN_MAX_GROUPS > 256 ? 32 : 64, kColChunks = GS_BIN_MAX_GROUPS > 256 ? 32 : 16;
 __global__ __launch_bounds__(kColTiles * kColChunks) void bin_colscan_kernel(int C, int G, int tiles, uint32_t* __restrict__ hist_mat,
                                                                               uint32_t* __restrict__ tile_cnt) {
     __shared__ uint32_t part[kColChunks][kColTiles + 1];
@@ -646,9 +652,9 @@ struct BinsLayout {
 
 static BinsLayout bins_layout(int C, int64_t N, int tw, int th, int bin_shift, int64_t coarse_cap) {
     BinsLayout L;
-    int64_t g = (N + 4095) / 4096;
+    int64_t g = (N + GS_BIN_PER_GROUP - 1) / GS_BIN_PER_GROUP;
     if (g < 1) g = 1;
-    if (g > 256) g = 256;
+    if (g > GS_BIN_MAX_GROUPS) g = GS_BIN_MAX_GROUPS;
     L.groups = (int)g;
     L.per_group = (N + g - 1) / g;
     // 4x4-tile bins unless that puts more than ~2500 Gaussians per bin on average (sort classes above 4096 entries
