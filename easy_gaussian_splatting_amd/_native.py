@@ -40,7 +40,7 @@ SIGNATURES = {
     "gs_bin_groups": (_I, [_L]),
     "gs_bin_workspace_bytes": (_Z, [_I, _L, _I, _I]),
     "gs_project_fwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F, _F, _I, _I, _I,
-                            _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_bin_count": (_I, [_P, _I, _L, _I, _I, _P, _P, _Z, _P, _P, _P, _P, _P]),
     "gs_bin_emit_sort": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _Z, _P, _L, _L, _P, _P, _P, _P, _P, _P]),
     "gs_bins_workspace_bytes": (_Z, [_I, _L, _I, _I, _I, _L]),
@@ -49,7 +49,7 @@ SIGNATURES = {
     "gs_blend_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_project_bwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F,
-                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
+                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "gs_colors_pre_grad": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _I, _P, _P]),
     "gs_sh_grad_views": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P]),
     "gs_loss_workspace_floats": (_Z, [_I, _I]),
@@ -67,7 +67,7 @@ SIGNATURES = {
     "gs_refine_flags": (_I, [_P, _L, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_refine_apply": (_I, [_P, _L, _I, _I, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_project_bwd_adam": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P,
-                                  _P, _P, _P]),
+                                  _P, _P, _P, _P]),
     "gs_workspace_query": (_I, [_I, _L, _I, _I, _L, _L, _I, _I, _P, _P]),
     "gs_workspace_bind": (_I, [_P, _P, _L, _P, _L, _P, _P]),
     "gs_adam_step": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F]),

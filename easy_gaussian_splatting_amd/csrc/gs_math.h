@@ -285,6 +285,35 @@ GS_HD void sh_to_rgb(int degree, const float* sh, float ux, float uy, float uz, 
     rgb[0] = fmaxf(r + 0.5f, 0.f); rgb[1] = fmaxf(g + 0.5f, 0.f); rgb[2] = fmaxf(b + 0.5f, 0.f);
 }
 
+// g = sum_k d[k] * dY_k/du at the unit direction (x, y, z), u treated as three free variables (k >= 1; degree >= 1).
+GS_HD void sh_dir_grad(int degree, const float* d, float x, float y, float z, float& gx, float& gy, float& gz) {
+    gx = -kC1 * d[3]; gy = -kC1 * d[1]; gz = kC1 * d[2];
+    if (degree >= 2) {
+        gx += kC20 * y * d[4] - 2.f * kC21 * x * d[6] - kC20 * z * d[7] + 2.f * kC22 * x * d[8];
+        gy += kC20 * x * d[4] - kC20 * z * d[5] - 2.f * kC21 * y * d[6] - 2.f * kC22 * y * d[8];
+        gz += -kC20 * y * d[5] + 4.f * kC21 * z * d[6] - kC20 * x * d[7];
+    }
+    if (degree >= 3) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        gx += -6.f * kC30 * x * y * d[9] + kC31 * y * z * d[10] + 2.f * kC32 * x * y * d[11]
+              - 6.f * kC33 * x * z * d[12] - kC32 * (4.f * zz - 3.f * xx - yy) * d[13]
+              + 2.f * kC34 * x * z * d[14] - kC30 * (3.f * xx - 3.f * yy) * d[15];
+        gy += -kC30 * (3.f * xx - 3.f * yy) * d[9] + kC31 * x * z * d[10]
+              - kC32 * (4.f * zz - xx - 3.f * yy) * d[11] - 6.f * kC33 * y * z * d[12]
+              + 2.f * kC32 * x * y * d[13] - 2.f * kC34 * y * z * d[14] + 6.f * kC30 * x * y * d[15];
+        gz += kC31 * x * y * d[10] - 8.f * kC32 * y * z * d[11]
+              + kC33 * (6.f * zz - 3.f * xx - 3.f * yy) * d[12] - 8.f * kC32 * x * z * d[13]
+              + kC34 * (xx - yy) * d[14];
+    }
+}
+
+// v_mean += d(unit direction)/d(mean)^T g   (direction = (mean - camera centre) / dnorm)
+GS_HD void dir_grad_to_mean(float gx, float gy, float gz, float x, float y, float z, float dnorm, float* v_mean) {
+    const float ud = x * gx + y * gy + z * gz;
+    const float inv = 1.0f / dnorm;
+    v_mean[0] += (gx - x * ud) * inv; v_mean[1] += (gy - y * ud) * inv; v_mean[2] += (gz - z * ud) * inv;
+}
+
 // Appendix A.6 colour path.  In: post-activation rgb (for the clamp mask), v_rgb, SH block.
 // Out: v_sh[k][3] += Y_k v_pre  (written to `v_sh`, k < Ka), returns v_mean contribution.
 GS_HD void sh_vjp(int degree, const float* sh, const float* rgb, const float* v_rgb, float ux,
@@ -305,28 +334,40 @@ GS_HD void sh_vjp(int degree, const float* sh, const float* rgb, const float* v_
         }
     }
     if (degree < 1 || !(dnorm > 0.f)) return;
-    const float x = ux, y = uy, z = uz;
-    float gx = -kC1 * d[3], gy = -kC1 * d[1], gz = kC1 * d[2];
-    if (degree >= 2) {
-        gx += kC20 * y * d[4] - 2.f * kC21 * x * d[6] - kC20 * z * d[7] + 2.f * kC22 * x * d[8];
-        gy += kC20 * x * d[4] - kC20 * z * d[5] - 2.f * kC21 * y * d[6] - 2.f * kC22 * y * d[8];
-        gz += -kC20 * y * d[5] + 4.f * kC21 * z * d[6] - kC20 * x * d[7];
+    float gx, gy, gz;
+    sh_dir_grad(degree, d, ux, uy, uz, gx, gy, gz);
+    dir_grad_to_mean(gx, gy, gz, ux, uy, uz, dnorm, v_mean);
+}
+
+// The direction Jacobian of the pre-clamp colour, G[i][c] = d(sum_k Y_k(u) sh[k][c]) / du_i  (3 x 3, rows padded to four
+// floats): what the forward leaves for the backward so that the latter needs no SH coefficient (sh_vjp_jac).
+GS_HD void sh_dir_jacobian(int degree, const float* sh, float ux, float uy, float uz, float* G) {
+    const int Ka = (degree + 1) * (degree + 1);
+    for (int c = 0; c < 3; ++c) {
+        float d[16];
+        for (int k = 0; k < Ka; ++k) d[k] = sh[3 * k + c];
+        float gx, gy, gz;
+        sh_dir_grad(degree, d, ux, uy, uz, gx, gy, gz);
+        G[c] = gx; G[4 + c] = gy; G[8 + c] = gz;
     }
-    if (degree >= 3) {
-        const float xx = x * x, yy = y * y, zz = z * z;
-        gx += -6.f * kC30 * x * y * d[9] + kC31 * y * z * d[10] + 2.f * kC32 * x * y * d[11]
-              - 6.f * kC33 * x * z * d[12] - kC32 * (4.f * zz - 3.f * xx - yy) * d[13]
-              + 2.f * kC34 * x * z * d[14] - kC30 * (3.f * xx - 3.f * yy) * d[15];
-        gy += -kC30 * (3.f * xx - 3.f * yy) * d[9] + kC31 * x * z * d[10]
-              - kC32 * (4.f * zz - xx - 3.f * yy) * d[11] - 6.f * kC33 * y * z * d[12]
-              + 2.f * kC32 * x * y * d[13] - 2.f * kC34 * y * z * d[14] + 6.f * kC30 * x * y * d[15];
-        gz += kC31 * x * y * d[10] - 8.f * kC32 * y * z * d[11]
-              + kC33 * (6.f * zz - 3.f * xx - 3.f * yy) * d[12] - 8.f * kC32 * x * z * d[13]
-              + kC34 * (xx - yy) * d[14];
-    }
-    const float ud = x * gx + y * gy + z * gz;
-    const float inv = 1.0f / dnorm;
-    v_mean[0] += (gx - x * ud) * inv; v_mean[1] += (gy - y * ud) * inv; v_mean[2] += (gz - z * ud) * inv;
+    G[3] = G[7] = G[11] = 0.f;
+}
+
+// sh_vjp without the coefficients: v_sh[k][:] = Y_k v_pre, and the direction term of v_mean through G (degree >= 1).
+GS_HD void sh_vjp_jac(int degree, const float* G, const float* rgb, const float* v_rgb, float ux, float uy, float uz,
+                      float dnorm, float* v_sh, float* v_mean) {
+    const float vr = rgb[0] > 0.f ? v_rgb[0] : 0.f;
+    const float vg = rgb[1] > 0.f ? v_rgb[1] : 0.f;
+    const float vb = rgb[2] > 0.f ? v_rgb[2] : 0.f;
+    float Y[16];
+    sh_basis(degree, ux, uy, uz, Y);
+    const int Ka = (degree + 1) * (degree + 1);
+    for (int k = 0; k < Ka; ++k) { v_sh[3 * k] = Y[k] * vr; v_sh[3 * k + 1] = Y[k] * vg; v_sh[3 * k + 2] = Y[k] * vb; }
+    if (degree < 1 || !(dnorm > 0.f)) return;
+    const float gx = G[0] * vr + G[1] * vg + G[2] * vb;
+    const float gy = G[4] * vr + G[5] * vg + G[6] * vb;
+    const float gz = G[8] * vr + G[9] * vg + G[10] * vb;
+    dir_grad_to_mean(gx, gy, gz, ux, uy, uz, dnorm, v_mean);
 }
 
 // Appendix A.6 projection VJP for one (camera, Gaussian): adds into v_mean[3], v_quat[4], v_scale[3].

@@ -25,6 +25,7 @@ struct ProjFwdArgs {
     uint4* bbox;
     int32_t* tiles_per_gauss;
     uint2* rect_ref;   // optional [C*N]: the 3-sigma tile rectangle itself (x0 | x1 << 16, y0 | y1 << 16), whatever `tight` does to bbox
+    float4* sh_jac;    // optional, 9 floats per (camera, Gaussian): d(pre-clamp colour)/d(view direction) of the visible Gaussians, for a backward without the coefficients
 };
 
 // activations != 0: `scales` / `opacities` hold the reference model's parameters (log-scales, logit
@@ -240,6 +241,14 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
                 float ux, uy, uz;
                 view_dir(mean, cam, ux, uy, uz);
                 sh_to_rgb(DEG < 0 ? 0 : DEG, tile + threadIdx.x * (3 * a.K + 1), ux, uy, uz, rgb);
+                if (DEG >= 1 && a.sh_jac) {
+                    float G[12];
+                    sh_dir_jacobian(DEG, tile + threadIdx.x * (3 * a.K + 1), ux, uy, uz, G);
+                    // nine floats per Gaussian: eight as two aligned quads [C*N][8], the ninth in a plane of its own behind them
+                    float4* jp = a.sh_jac + 2 * f;
+                    jp[0] = make_float4(G[0], G[1], G[2], G[4]); jp[1] = make_float4(G[5], G[6], G[8], G[9]);
+                    reinterpret_cast<float*>(a.sh_jac + 2 * (int64_t)a.C * a.N)[f] = G[10];
+                }
             }
         }
     } else if (in_range) {
@@ -261,6 +270,7 @@ struct ProjBwdArgs {
     const int32_t *radii, *tiles_per_gauss, *cum_tiles;
     const float4* rows;      // [I*4][3]: one row per (intersection slot, tile quadrant)
     const uint8_t* qmask;    // [I] by slot: which of the four quadrant rows exist
+    const float4* sh_jac;    // optional, from gs_project_fwd ([C*N][8] + [C*N]): the SH rows are then not read at all
     float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_sh_rest, *v_means2d_abs, *v_means2d,
         *v_conics, *v_colors_post, *v_colors_pre;
     const float* opacities;   // raw (logit) opacities, read only when activations != 0
@@ -471,7 +481,96 @@ __device__ __forceinline__ void adam_geo_tile(const float* tile, int rows, int64
     }
 }
 
+
+// ---- gradient rows of the wave's small Gaussians, one SLOT per lane ------------------------------------------------
+// A thread that walks its own Gaussian's rows pays one HBM round trip per slot, and the wave waits for its longest
+// Gaussian (15-48 slots) while most lanes hold 1-3: the row sum was latency, 0.13 ms of the fused kernel for 250 MB.
+// Here the wave's slots -- contiguous per Gaussian, Gaussians in lane order -- are dealt out one per lane, 64 at a
+// time: masks of four such items in one round trip, the (up to four) quadrant rows of an item in one more, the next
+// item's rows in flight while this one's are added.  Each lane adds its slot's rows in quadrant order and leaves the
+// 11 sums in LDS; the owner lanes then add their slots' sums in slot order (fixed order -> reproducible sums).
+// LDS of one wave: owner lane of every slot (u8, 64 * kCoopRows) + 64 item sums of 12 floats.
+#ifndef GS_ROWSUM_PER_GAUSSIAN
+#define GS_ROWSUM_PER_GAUSSIAN 0
+#endif
+#ifndef GS_ROWSUM_DIAG
+#define GS_ROWSUM_DIAG 0
+#endif
+
 constexpr int kCoopRows = 48;  // Gaussians with more rows than this are summed by the whole wave
+constexpr int kRowOwnerFloats = 64 * kCoopRows / 4;
+constexpr int kRowWaveFloats = kRowOwnerFloats + 64 * 12;
+
+__device__ __forceinline__ void row_sum_slots(const ProjBwdArgs& a, int cs, int base, RowSum& s, float* wl) {
+    const int lane = lane_id();
+    const int incl = wave_incl_scan_add(cs);
+    const int o = incl - cs;
+    const int T = __shfl(incl, 63, 64);
+    if (T == 0) return;
+    uint8_t* own = reinterpret_cast<uint8_t*>(wl);
+    float4* item = reinterpret_cast<float4*>(wl + kRowOwnerFloats);
+    for (int r = 0; r < cs; ++r) own[o + r] = (uint8_t)lane;
+    __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in issue order)
+    const int n_items = (T + 63) >> 6;
+    auto fetch = [&](float4 (&dst)[4][3], int slot, int bits) {
+#if GS_ROWSUM_DIAG == 1   // timing only: the same loads under the same masks, but lane-contiguous addresses
+        const float4* rp = a.rows + 12 * (int64_t)__shfl(slot, 0, 64) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (bits & (1 << q)) { dst[q][0] = rp[64 * (3 * q)]; dst[q][1] = rp[64 * (3 * q + 1)]; dst[q][2] = rp[64 * (3 * q + 2)]; }
+            else { dst[q][0] = dst[q][1] = dst[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+#elif GS_ROWSUM_DIAG == 2   // timing only: no row loads
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q][0] = dst[q][1] = dst[q][2] = make_float4((float)(bits & (1 << q)), 0.f, 0.f, 0.f);
+#else
+        const float4* rp = a.rows + 12 * (int64_t)slot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (bits & (1 << q)) { dst[q][0] = rp[3 * q]; dst[q][1] = rp[3 * q + 1]; dst[q][2] = rp[3 * q + 2]; }
+            else { dst[q][0] = dst[q][1] = dst[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+#endif
+    };
+    for (int u0 = 0; u0 < n_items; u0 += 4) {
+        int sl[4], bt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = 64 * (u0 + q) + lane;
+            const bool valid = j < T;
+            const int owner = valid ? (int)own[j] : 0;
+            sl[q] = __shfl(base, owner, 64) + j - __shfl(o, owner, 64);
+            bt[q] = valid ? (int)a.qmask[sl[q]] : 0;
+        }
+        float4 buf[2][4][3];
+        fetch(buf[0], sl[0], bt[0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (u0 + q < n_items) {   // wave-uniform
+                if (q + 1 < 4 && u0 + q + 1 < n_items) fetch(buf[(q + 1) & 1], sl[(q + 1) & 3], bt[(q + 1) & 3]);
+                float4 (&d)[4][3] = buf[q & 1];
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x, z = x;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    x.x += d[k][0].x; x.y += d[k][0].y; x.z += d[k][0].z; x.w += d[k][0].w;
+                    y.x += d[k][1].x; y.y += d[k][1].y; y.z += d[k][1].z; y.w += d[k][1].w;
+                    z.x += d[k][2].x; z.y += d[k][2].y; z.z += d[k][2].z;
+                }
+                item[3 * lane] = x; item[3 * lane + 1] = y; item[3 * lane + 2] = z;
+                __builtin_amdgcn_wave_barrier();
+                const int jb = 64 * (u0 + q);
+                const int lo = max(o, jb) - jb, hi = min(o + cs, jb + 64) - jb;
+                for (int r = lo; r < hi; ++r) {
+                    const float4 ix = item[3 * r], iy = item[3 * r + 1], iz = item[3 * r + 2];
+                    s.v[0] += ix.x; s.v[1] += ix.y; s.v[2] += ix.z; s.v[3] += ix.w;
+                    s.v[4] += iy.x; s.v[5] += iy.y; s.v[6] += iy.z; s.v[7] += iy.w;
+                    s.v[8] += iz.x; s.v[9] += iz.y; s.v[10] += iz.z;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
 
 template <int DEG>
 __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwdArgs a) {
@@ -498,6 +597,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     RowSum s;
 #pragma unroll
     for (int i = 0; i < 12; ++i) s.v[i] = 0.f;
+#if GS_ROWSUM_PER_GAUSSIAN
     if (cnt <= kCoopRows) {
         // Software pipeline over the slots: the (up to four) quadrant rows of slot r+1 are requested
         // before the rows of slot r are added, and the mask byte runs two slots ahead, so a Gaussian
@@ -528,6 +628,9 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
             bits1 = bits2;
         }
     }
+#else
+    row_sum_slots(a, cnt <= kCoopRows ? cnt : 0, base, s, tile + (threadIdx.x >> 6) * kRowWaveFloats);
+#endif
     // Gaussians with many rows: the whole wave sums one of them at a time.  The quadrant masks of the NEXT one are
     // requested before the rows of the current one are read (a wave holds up to 64 such Gaussians and would otherwise
     // pay two dependent round trips for each in turn), and a Gaussian none of whose listed entries any pixel took --
@@ -597,23 +700,39 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     if (DEG >= 0) {
         const int row_f = 3 * a.K, stride = row_f + 1;
         constexpr int ka3 = 3 * (DEG + 1) * (DEG + 1);
-        vis_s[threadIdx.x] = vis ? 1 : 0;
-        __syncthreads();
-        const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
-        if (a.sh_rest) {
-            if (a.K == 16) stage_sh_rows_split<16>(a.colors_in, a.sh_rest, n0, rows, 16, ka3, vis_s, tile);
-            else stage_sh_rows_split<0>(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);
-        } else {
-            if (a.K == 16) stage_sh_rows<16>(a.colors_in, n0, rows, 16, ka3, vis_s, tile);
-            else stage_sh_rows<0>(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+        // With the forward's direction Jacobian (a.sh_jac) the backward needs no SH coefficient: v_sh = Y (x) v_pre, and the
+        // direction term of v_mean is J^T v_pre -- the block neither streams its 48 floats per Gaussian into LDS nor waits
+        // for them (0.04 ms of the fused step kernel; the forward pays 36 B per visible Gaussian and ~200 FMAs).
+        const bool use_jac = a.sh_jac != nullptr;
+        float G[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float rgb[3] = {0.f, 0.f, 0.f};
+        if (vis) {   // (requested before the barrier)
+            rgb[0] = a.colors_post[3 * f]; rgb[1] = a.colors_post[3 * f + 1]; rgb[2] = a.colors_post[3 * f + 2];
+            if (use_jac && DEG >= 1) {
+                const float4 j0 = a.sh_jac[2 * f], j1 = a.sh_jac[2 * f + 1];
+                G[10] = reinterpret_cast<const float*>(a.sh_jac + 2 * (int64_t)a.C * a.N)[f];
+                G[0] = j0.x; G[1] = j0.y; G[2] = j0.z; G[4] = j0.w; G[5] = j1.x; G[6] = j1.y; G[8] = j1.z; G[9] = j1.w;
+            }
         }
-        __syncthreads();
+        vis_s[threadIdx.x] = vis ? 1 : 0;
+        __syncthreads();   // (every wave is done with its row-sum scratch in `tile`)
+        const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
+        if (!use_jac) {
+            if (a.sh_rest) {
+                if (a.K == 16) stage_sh_rows_split<16>(a.colors_in, a.sh_rest, n0, rows, 16, ka3, vis_s, tile);
+                else stage_sh_rows_split<0>(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);
+            } else {
+                if (a.K == 16) stage_sh_rows<16>(a.colors_in, n0, rows, 16, ka3, vis_s, tile);
+                else stage_sh_rows<0>(a.colors_in, n0, rows, a.K, ka3, vis_s, tile);
+            }
+            __syncthreads();
+        }
         float* my = tile + threadIdx.x * stride;
         if (vis) {
             float ux, uy, uz;
             const float dn = view_dir(mean, cam, ux, uy, uz);
-            float rgb[3] = {a.colors_post[3 * f], a.colors_post[3 * f + 1], a.colors_post[3 * f + 2]};
-            sh_vjp(DEG < 0 ? 0 : DEG, my, rgb, v_rgb, ux, uy, uz, dn, my, v_mean, false);
+            if (use_jac) sh_vjp_jac(DEG < 0 ? 0 : DEG, G, rgb, v_rgb, ux, uy, uz, dn, my, v_mean);
+            else sh_vjp(DEG < 0 ? 0 : DEG, my, rgb, v_rgb, ux, uy, uz, dn, my, v_mean, false);
             for (int o = ka3; o < row_f; ++o) my[o] = 0.f;
             if (a.v_colors_pre) {  // gradient w.r.t. the pre-clamp colour: what gs_sh_grad_views consumes
                 float* d = a.v_colors_pre + 3 * f;
@@ -717,6 +836,14 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         adam_geo_tile(tile, (int)min((int64_t)kProjThreads, a.N - n0), n0, a);
     }
 #endif
+}
+
+static size_t proj_lds_bytes(int K, int degree);
+// backward: the tile region also holds the four waves' row-sum scratch (row_sum_slots), with or without SH
+static size_t proj_bwd_lds_bytes(int K, int degree) {
+    const size_t need = sizeof(float) * (32 + kProjThreads + (size_t)(kProjThreads / 64) * kRowWaveFloats);
+    const size_t base = proj_lds_bytes(K, degree);
+    return base > need ? base : need;
 }
 
 static size_t proj_lds_bytes(int K, int degree) {
@@ -871,7 +998,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
                               float eps2d, float near_plane, float far_plane, float radius_clip,
                               int tile_culling, int stage, int activations, int32_t* radii,
                               float* means2d, float* depths, float* conics, float* colors_out, float* rec,
-                              uint32_t* bbox, int32_t* tiles_per_gauss, uint32_t* rect_ref) {
+                              uint32_t* bbox, int32_t* tiles_per_gauss, uint32_t* rect_ref, float* sh_jac) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
     GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
     GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
@@ -890,6 +1017,7 @@ extern "C" int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.conics = conics; a.colors_out = colors_out; a.rec = reinterpret_cast<float4*>(rec);
     a.bbox = reinterpret_cast<uint4*>(bbox); a.tiles_per_gauss = tiles_per_gauss;
     a.rect_ref = reinterpret_cast<uint2*>(rect_ref);
+    a.sh_jac = sh_degree >= 1 ? reinterpret_cast<float4*>(sh_jac) : nullptr;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads), (unsigned)C);
     const size_t lds = proj_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;
@@ -920,7 +1048,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
                               const float* rows, const uint8_t* qmask, float* v_means, float* v_quats, float* v_scales,
                               float* v_opacities, float* v_colors, float* v_sh_rest, float* v_means2d_abs,
                               float* v_means2d, float* v_conics, float* v_colors_post, float* v_colors_pre,
-                              const float* opacities, int activations) {
+                              const float* opacities, int activations, const float* sh_jac) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
     GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
     GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
@@ -940,12 +1068,13 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.v_conics = v_conics; a.v_colors_post = v_colors_post; a.v_colors_pre = sh_degree >= 0 ? v_colors_pre : nullptr;
     GS_REQUIRE(!activations || opacities, "activations need the raw opacities");
     a.opacities = opacities; a.activations = activations != 0;
+    a.sh_jac = sh_degree >= 0 ? reinterpret_cast<const float4*>(sh_jac) : nullptr;
     a.guard = current_guard().info;
     a.adam = 0; a.ad_hyper = nullptr; a.ad_applied = nullptr; a.ad_b1 = a.ad_b2 = a.ad_eps = 0.f;
     a.st_max_radii = a.st_grad_norm = a.st_counts = nullptr; a.st_max_hw = 1.f;
     for (int t = 0; t < 6; ++t) a.ad_p[t] = a.ad_m[t] = a.ad_v[t] = nullptr;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
-    const size_t lds = proj_lds_bytes(K, sh_degree);
+    const size_t lds = proj_bwd_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;
     // One launch per camera: launch c accumulates onto launch c-1 (same thread owns Gaussian n in
     // every launch, stream order serialises them) -> deterministic sum over cameras, no atomics.
@@ -975,7 +1104,8 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
                                    float eps2d, float near_plane, float far_plane, const int32_t* radii, const float* colors_post,
                                    const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
                                    float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev,
-                                   int64_t* applied_dev, float* max_radii, float* grad_norm_accum, float* counts) {
+                                   int64_t* applied_dev, float* max_radii, float* grad_norm_accum, float* counts,
+                                   const float* sh_jac) {
     GS_REQUIRE(N >= 0 && width > 0 && height > 0, "N>=0, positive image size");
     GS_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16, "SH colours: 0 <= degree <= 3, (degree+1)^2 <= K <= 16");
     if (N == 0) return GS_OK;
@@ -992,6 +1122,7 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.qmask = qmask;
     a.v_means = a.v_quats = a.v_scales = a.v_opacities = a.v_colors = a.v_sh_rest = nullptr;
     a.v_means2d_abs = v_means2d_abs; a.v_means2d = a.v_conics = a.v_colors_post = a.v_colors_pre = nullptr;
+    a.sh_jac = reinterpret_cast<const float4*>(sh_jac);
     a.guard = current_guard().info;
     a.adam = 1; a.ad_hyper = hyper_dev; a.ad_applied = applied_dev; a.ad_b1 = beta1; a.ad_b2 = beta2; a.ad_eps = eps;
     GS_REQUIRE((max_radii == nullptr) == (grad_norm_accum == nullptr) && (max_radii == nullptr) == (counts == nullptr),
@@ -1001,7 +1132,7 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     for (int t = 0; t < 6; ++t) { a.ad_p[t] = params + offsets_host[t]; a.ad_m[t] = exp_avg + offsets_host[t]; a.ad_v[t] = exp_avg_sq + offsets_host[t]; }
     a.cam = 0; a.accumulate = 0;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
-    const size_t lds = proj_lds_bytes(K, sh_degree);
+    const size_t lds = proj_bwd_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;
     switch (sh_degree) {
         case 0: hipLaunchKernelGGL(project_bwd_kernel<0>, grid, dim3(kProjThreads), lds, st, a); break;

@@ -36,6 +36,7 @@ extern "C" int gs_workspace_query(int C, int64_t N, int width, int height, int64
     if (train) {
         size[GS_WS_QCNT] = CT * 4 * 4;
         size[GS_WS_UNIT_COUNTER] = 4;
+        size[GS_WS_SH_JAC] = CN * 9 * 4;
     }
     if (two_level) {
         const size_t b = gs_bins_workspace_bytes(C, N, tw, th, bin_shift, coarse_cap);

@@ -74,6 +74,8 @@ def profile_stages(enable: bool, repeat: Optional[Dict[str, int]] = None) -> Opt
 # GS_DP_ROWS_COLOR=1: gs_blend_bwd also writes the compact copy of the rows' colour lanes that gs_colors_pre_grad can read instead
 # of the rows themselves (round 2's form; measured in round 3: the second scattered store per row costs blend_bwd 0.18 ms)
 _ROWS_COLOR_COPY = os.environ.get("GS_DP_ROWS_COLOR") == "1"
+# GS_SH_JAC=0: the backward stages the SH coefficients itself instead of using the forward's direction Jacobian (A/B, tests)
+_SH_JAC = os.environ.get("GS_SH_JAC", "1") != "0"
 
 _tls = threading.local()
 _state_lock = threading.Lock()   # guards the two module-level dicts below (entry points are called from any thread)
@@ -377,12 +379,17 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     info_host = _pinned_info(dev)
     bin_bytes = lambda: int(L.gs_bins_workspace_bytes(C, N, tw, th, shift, coarse_cap) if two_level else L.gs_bin_workspace_bytes(C, N, tw, th))
 
+    # training with SH colours: the forward leaves d colour / d view direction per visible Gaussian, and the backward never
+    # reads the coefficients (include/gs_raster.h, gs_project_fwd: sh_jac)
+    use_jac = bool(need_grad and _SH_JAC and deg >= 1)
+
     def project(stage: int, tag: str):
         _stage(tag, dev, lambda: nat.check(L.gs_project_fwd(
             st, C, N, K, deg, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors), _ptr(colors_rest),
             per_cam, _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"], cfg["near_plane"], cfg["far_plane"],
             cfg["radius_clip"], cfg["tile_culling"], stage, cfg.get("activations", 0), _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics),
-            P(WS.COLORS_POST), P(WS.REC), P(WS.BBOX), P(WS.TILES_PER_GAUSS), _ptr(rect_ref)), "gs_project_fwd"))
+            P(WS.COLORS_POST), P(WS.REC), P(WS.BBOX), P(WS.TILES_PER_GAUSS), _ptr(rect_ref),
+            P(WS.SH_JAC) if use_jac else None), "gs_project_fwd"))
 
     def count():
         if two_level:
@@ -495,7 +502,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     })
     if not lazy_ref:
         meta._lease = ref   # (the list lazies above read the arenas; in the "gsplat" mode nothing in meta does)
-    state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, n_isects=n_isects, n_buckets=n_buckets, radii=radii, lease=lease,
+    state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, sh_jac=use_jac, n_isects=n_isects, n_buckets=n_buckets, radii=radii, lease=lease,
                  lease_ref=WS.LeaseRef(lease) if need_grad else None, factorised=factorised)
     del ref   # (the lease goes back to its pool here unless meta or the autograd node holds it)
     return render_colors, render_alphas, meta, state
@@ -575,7 +582,8 @@ class _Rasterize(torch.autograd.Function):
                                    P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES),
                                    P(WS.ROWS), P(WS.QMASK), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
                                    _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), None,
-                                   _ptr(opacities), cfg.get("activations", 0)), "gs_project_bwd"))
+                                   _ptr(opacities), cfg.get("activations", 0), P(WS.SH_JAC) if s.get("sh_jac") else None),
+                                                        "gs_project_bwd"))
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp,
                        rows=lease.view(WS.ROWS, max(s["n_isects"], 1) * 4 * nat.GS_ROW_FLOATS).clone().view(-1, nat.GS_ROW_FLOATS))

@@ -39,6 +39,7 @@ from torch import Tensor
 
 from . import _native as nat
 from .optim import FusedAdam
+from .rendering import _SH_JAC
 
 _TILE = nat.GS_TILE
 _SORT_CLASSES = (1024, 4096, 8192, 16384)
@@ -120,6 +121,9 @@ class TrainStepGraph:
         b["depths"] = torch.empty((1, N), **f32)
         b["conics"] = torch.empty((1, N, 3), **f32)
         b["colors_post"] = torch.empty((1, N, 3), **f32)
+        # d colour / d view direction of the visible Gaussians (gs_project_fwd -> gs_project_bwd*: no SH coefficient is read
+        # by the backward); GS_SH_JAC=0 keeps the coefficient-staging backward
+        b["sh_jac"] = torch.empty((N * 9,), **f32) if _SH_JAC else None
         b["rec"] = torch.empty((N, nat.GS_REC_FLOATS), **f32)
         b["bbox"] = torch.empty((N, 4), **i32)
         b["tiles_per_gauss"] = torch.empty((1, N), **i32)
@@ -265,7 +269,7 @@ class TrainStepGraph:
                                    _p(m.logit_opacities), _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0,
                                    _p(b["viewmats"]), _p(b["Ks"]), self.W, self.H, 0.3, 0.01, 1e10, 0.0, culling, 0, 1,
                                    _p(b["radii"]), _p(b["means2d"]), _p(b["depths"]), _p(b["conics"]), _p(b["colors_post"]),
-                                   _p(b["rec"]), _p(b["bbox"]), _p(b["tiles_per_gauss"]), None), "gs_project_fwd")
+                                   _p(b["rec"]), _p(b["bbox"]), _p(b["tiles_per_gauss"]), None, _p(b["sh_jac"])), "gs_project_fwd")
 
     def _count(self):
         L, b = nat.lib(), self.buf
@@ -357,7 +361,7 @@ class TrainStepGraph:
                                                _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]),
                                                _p(b["rows"]), _p(b["qmask"]), _p(b["v_abs"]), float(b1), float(b2),
                                                float(opt.defaults["eps"]), _p(b["hyper"]), _p(b["applied"]), _p(m.max_radii),
-                                               _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_project_bwd_adam")
+                                               _p(m.grad_norm_accum), _p(m.collecting_counts), _p(b["sh_jac"])), "gs_project_bwd_adam")
             else:
                 g = self.grads
                 self._ck(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
@@ -365,7 +369,7 @@ class TrainStepGraph:
                                           0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]),
                                           _p(b["cum_tiles"]), _p(b["rows"]), _p(b["qmask"]), _p(g["means"]), _p(g["quats"]),
                                           _p(g["log_scales"]), _p(g["logit_opacities"]), _p(g["sh_0"]), _p(g["sh_rest"]), _p(b["v_abs"]),
-                                          None, None, None, None, _p(m.logit_opacities), 1), "gs_project_bwd")
+                                          None, None, None, None, _p(m.logit_opacities), 1, _p(b["sh_jac"])), "gs_project_bwd")
                 self._ck(L.gs_update_statistics(st, N, float(max(H, W)), _p(b["radii"]), _p(b["v_abs"]), _p(m.max_radii),
                                                 _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_update_statistics")
                 ns = len(opt._plist)

@@ -89,6 +89,7 @@ int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied
 #define GS_WS_TILE_ORDER 8      /* i32 [C*tiles] */
 #define GS_WS_QCNT 9            /* i32 [C*tiles*4]              (training) */
 #define GS_WS_UNIT_COUNTER 10   /* i32 [1]                      (training) */
+#define GS_WS_SH_JAC 11         /* f32 [C*N*9]                  (training: gs_project_fwd -> gs_project_bwd) */
 #define GS_WS_LIST_FIRST 12     /* ---- list arena ---- */
 #define GS_WS_BIN 12            /* gs_bin_workspace_bytes / gs_bins_workspace_bytes */
 #define GS_WS_COARSE_KEYS 13    /* u64 [coarse_cap]             (two-level binning) */
@@ -140,7 +141,12 @@ size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h);
  * the short lists and still build gsplat's exact list arrays (a function of this rectangle and `depths`) when somebody reads them.
  * stage: 0 = everything; 1 = geometry only (all outputs except colors_out and the colour quad of
  * rec); 2 = colour only, for the Gaussians a previous stage-1 call marked visible in radii.  Calling
- * 1, then the gs_bin_count kernels, then 2 lets the colour pass overlap the host read-back of I. */
+ * 1, then the gs_bin_count kernels, then 2 lets the colour pass overlap the host read-back of I.
+ * sh_jac[C*N*9] (optional, may be NULL; written by stages 0 and 2 for visible Gaussians when sh_degree >= 1; opaque to the
+ * caller): the 3 x 3 Jacobian d(pre-clamp colour)/d(unit view direction), eight entries as [C*N][8] and the ninth as a plane
+ * [C*N] behind them.  Handed to gs_project_bwd /
+ * gs_project_bwd_adam it makes the backward independent of the SH coefficients: v_sh = Y(u) (x) v_pre, and the direction
+ * term of v_means is sh_jac^T v_pre -- the backward then never streams the 48 coefficients per Gaussian. */
 int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* opacities,
                    const float* colors_in, const float* sh_rest, int colors_per_camera,
@@ -148,7 +154,7 @@ int gs_project_fwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    float near_plane, float far_plane, float radius_clip, int tile_culling, int stage, int activations,
                    int32_t* radii,
                    float* means2d, float* depths, float* conics, float* colors_out, float* rec, uint32_t* bbox,
-                   int32_t* tiles_per_gauss, uint32_t* rect_ref);
+                   int32_t* tiles_per_gauss, uint32_t* rect_ref, float* sh_jac);
 
 /* I-count (replaces the counting half of gsplat isect_tiles + its cumsum and
  * isect_offset_encode).  Writes isect_offsets[C*tiles+1] (exclusive; last = I),
@@ -252,7 +258,9 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
  * gs_colors_pre_grad).
  * activations != 0 (both directions): `scales` / `opacities` are the reference model's log-scales and
  * logit opacities (/root/reference/model/gaussian.py:98-103); exp / sigmoid are applied inside and
- * v_scales / v_opacities are gradients w.r.t. those raw parameters.  0 = gsplat's contract. */
+ * v_scales / v_opacities are gradients w.r.t. those raw parameters.  0 = gsplat's contract.
+ * sh_jac (optional, may be NULL): gs_project_fwd's direction Jacobian of the same inputs; with it colors_in / sh_rest are not
+ * read (same gradients to rounding: the direction term of v_means is then summed as J^T v_pre instead of per coefficient). */
 int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* colors_in,
                    const float* sh_rest, int colors_per_camera, const float* viewmats,
@@ -262,7 +270,7 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities,
                    float* v_colors, float* v_sh_rest, float* v_means2d_abs, float* v_means2d,
                    float* v_conics, float* v_colors_post, float* v_colors_pre,
-                   const float* opacities, int activations);
+                   const float* opacities, int activations, const float* sh_jac);
 
 /* Row e (view sharding): v_colors_pre[C,N,3] alone -- identical to the optional output of gs_project_bwd, but available before
  * that (long) kernel runs, so that its exchange between ranks overlaps the rest of the backward.  rows_color: the gradient rows
@@ -358,13 +366,14 @@ int gs_refine_apply(void* stream, int64_t n_old, int num_splits, int K, const in
  * formed (saves writing and re-reading 59 floats per Gaussian).  params / exp_avg / exp_avg_sq and offsets_host[6]
  * (means, log_scales, quats, sh_0, sh_rest, logit_opacities; floats) describe the flat buffers of gs_adam_step.
  * Same update, bit for bit, as gs_project_bwd followed by gs_adam_step_dev.  Honours the step guard.
- * max_radii / grad_norm_accum / counts (optional, all three or none): gs_update_statistics is applied in the same pass. */
+ * max_radii / grad_norm_accum / counts (optional, all three or none): gs_update_statistics is applied in the same pass.
+ * sh_jac (optional): as in gs_project_bwd. */
 int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree, float* params, float* exp_avg, float* exp_avg_sq,
                         const int64_t* offsets_host, const float* viewmats, const float* Ks, int width, int height, float eps2d,
                         float near_plane, float far_plane, const int32_t* radii, const float* colors_post,
                         const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
                         float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev, int64_t* applied_dev,
-                        float* max_radii, float* grad_norm_accum, float* counts);
+                        float* max_radii, float* grad_norm_accum, float* counts, const float* sh_jac);
 
 /* Row e: this rank's contribution to the SUM all-reduce of the view-parallel step in one pass: the four
  * geometry gradients and this view's two additive statistics (|absgrad|_2 * max_hw, visibility count)

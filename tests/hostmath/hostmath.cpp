@@ -40,7 +40,7 @@ int hm_backward(int C, int N, int K, int degree, const float* means, const float
                 const float* scales, const float* shs, const float* viewmats, const float* Ks, int W,
                 int H, float eps2d, float near_p, float far_p, const int32_t* radii,
                 const float* colors, const float* v_means2d, const float* v_conics,
-                const float* v_colors, float* v_means, float* v_quats, float* v_scales, float* v_shs) {
+                const float* v_colors, float* v_means, float* v_quats, float* v_scales, float* v_shs, int use_jac) {
     if (N <= 0) return 0;   // (memset on the null data() of an empty buffer is undefined: found by the UBSan leg)
     std::memset(v_means, 0, sizeof(float) * 3 * N);
     std::memset(v_quats, 0, sizeof(float) * 4 * N);
@@ -56,8 +56,15 @@ int hm_backward(int C, int N, int K, int degree, const float* means, const float
             if (!gs::project_chain<gs::preal>(means + 3 * n, quats + 4 * n, scales + 3 * n, cam, eps2d, near_p, far_p, p)) continue;
             float ux, uy, uz;
             const float dn = gs::view_dir(means + 3 * n, cam, ux, uy, uz);
-            gs::sh_vjp(degree, shs + (long)n * K * 3, colors + 3 * f, v_colors + 3 * f, ux, uy, uz, dn,
-                       v_shs + (long)n * K * 3, v_means + 3 * n, true);
+            if (use_jac) {   // the coefficient-free backward: direction Jacobian from the forward (gs_project_fwd's sh_jac)
+                float G[12], row[48];
+                gs::sh_dir_jacobian(degree, shs + (long)n * K * 3, ux, uy, uz, G);
+                gs::sh_vjp_jac(degree, G, colors + 3 * f, v_colors + 3 * f, ux, uy, uz, dn, row, v_means + 3 * n);
+                for (int o = 0; o < 3 * (degree + 1) * (degree + 1); ++o) v_shs[(long)n * K * 3 + o] += row[o];
+            } else {
+                gs::sh_vjp(degree, shs + (long)n * K * 3, colors + 3 * f, v_colors + 3 * f, ux, uy, uz, dn,
+                           v_shs + (long)n * K * 3, v_means + 3 * n, true);
+            }
             gs::project_vjp<gs::preal>(scales + 3 * n, cam, p, v_means2d[2 * f], v_means2d[2 * f + 1], v_conics[3 * f],
                             v_conics[3 * f + 1], v_conics[3 * f + 2], 0.f, v_means + 3 * n, v_quats + 4 * n,
                             v_scales + 3 * n);

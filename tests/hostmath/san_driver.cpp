@@ -49,7 +49,9 @@ static double run_case(int C, int N, int W, int H, int degree, int K) {
     for (auto* v : {&v_m2, &v_cn, &v_col})
         for (auto& x : *v) x = (float)nrand();
     hm_backward(C, N, K, degree, means.data(), quats.data(), scales.data(), shs.data(), viewmats.data(), Ks.data(), W, H, 0.3f, 0.01f, 1e10f,
-                radii.data(), col.data(), v_m2.data(), v_cn.data(), v_col.data(), v_means.data(), v_quats.data(), v_scales.data(), v_shs.data());
+                radii.data(), col.data(), v_m2.data(), v_cn.data(), v_col.data(), v_means.data(), v_quats.data(), v_scales.data(), v_shs.data(), 0);
+    hm_backward(C, N, K, degree, means.data(), quats.data(), scales.data(), shs.data(), viewmats.data(), Ks.data(), W, H, 0.3f, 0.01f, 1e10f,
+                radii.data(), col.data(), v_m2.data(), v_cn.data(), v_col.data(), v_means.data(), v_quats.data(), v_scales.data(), v_shs.data(), 1);
     double sum = 0;
     for (size_t f = 0; f < CN; ++f) sum += radii[f] + tpg[f];
     for (float x : v_means) sum += std::fabs((double)x);

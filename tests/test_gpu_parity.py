@@ -330,6 +330,29 @@ def test_tight_culling_is_render_equivalent_subset():
         assert float((ga - gb).abs().max()) <= 1e-5 * float(ga.abs().max())
 
 
+@pytest.mark.parametrize("name", ["ragged_sh2_2views", "odd_n_sh1_k4", "sh3_bg"])
+def test_backward_without_the_forward_direction_jacobian(name, monkeypatch):
+    """Training with SH colours the forward leaves d colour / d view direction (gs_project_fwd: sh_jac) and the backward never
+    reads a coefficient.  The coefficient-staging backward (sh_jac = NULL: what a caller of the C ABI without that buffer gets)
+    must stay on the oracle too, and the two must agree: SH gradients bit for bit (Y (x) v_pre either way), v_means to rounding."""
+    from easy_gaussian_splatting_amd import rendering
+    cfg = SCENES.get(name) or dict(n=3000, width=160, height=96, sh_degree=3, seed=9, scale_range=(0.02, 0.3), dist=4.0)
+    sc = make_scene(**cfg)
+    fw = run_oracle(sc)
+    hip = run_hip(sc, fw=fw)
+    monkeypatch.setattr(rendering, "_SH_JAC", False)
+    ref = run_hip(sc, upstream=(hip["vc"], hip["va"]))
+    check_forward(ref, fw)
+    check_backward(ref, fw)
+    assert torch.equal(ref["img"], hip["img"])
+    g_j, g_c = hip["grads"], ref["grads"]
+    assert torch.equal(g_j[4], g_c[4])                      # v_shs
+    for i in (1, 2, 3):                                     # quats, scales, opacities: untouched by the colour path
+        assert torch.equal(g_j[i], g_c[i])
+    scale = float(g_c[0].abs().max())
+    assert float((g_j[0] - g_c[0]).abs().max()) <= 2e-5 * scale
+
+
 def test_config_s1_parity():
     """BASELINE.json configs[0]: 10k random Gaussians, 256x256, SH degree 0."""
     sc = config_s1()
@@ -808,7 +831,7 @@ def test_two_level_binning_flags_and_capacities():
     P = lambda x: x.data_ptr()
     nat.check(L.gs_project_fwd(st, C, N, 16, 3, P(t["means"]), P(t["quats"]), P(t["scales"]), P(t["opacities"]), P(t["shs"]), None, 0,
                                P(t["viewmats"]), P(t["Ks"]), W, H, 0.3, 0.01, 1e10, 0.0, 0, 1, 0, P(radii), P(m2), P(dep),
-                               P(con), P(col), P(rec), P(bbox), P(tpg), None), "gs_project_fwd")
+                               P(con), P(col), P(rec), P(bbox), P(tpg), None, None), "gs_project_fwd")
     off = torch.empty((tiles + 1,), **i32); boff = torch.empty((tiles + 1,), **i32); order = torch.empty((tiles,), **i32)
     cum = torch.empty((C * N,), **i32)
     info = torch.zeros((8,), dtype=torch.int64, device=d)
@@ -980,7 +1003,7 @@ def test_tile_launch_order_is_a_longest_first_permutation():
     P = lambda x: x.data_ptr()
     nat.check(L.gs_project_fwd(st, C, N, 1, 0, P(t["means"]), P(t["quats"]), P(t["scales"]), P(t["opacities"]), P(t["shs"]), None, 0,
                                P(t["viewmats"]), P(t["Ks"]), sc["width"], sc["height"], 0.3, 0.01, 1e10, 0.0, 1, 0, 0, P(radii), P(m2), P(dep),
-                               P(con), P(col), P(rec), P(bbox), P(tpg), None), "gs_project_fwd")
+                               P(con), P(col), P(rec), P(bbox), P(tpg), None, None), "gs_project_fwd")
     ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=d)
     off = torch.empty((tiles + 1,), **i32); boff = torch.empty((tiles + 1,), **i32); order = torch.full((tiles,), -1, **i32)

@@ -24,8 +24,9 @@ def _p(a):
     return a.ctypes.data_as(ct.c_void_p)
 
 
+@pytest.mark.parametrize("use_jac", [0, 1])   # 1: the coefficient-free SH backward (direction Jacobian from the forward)
 @pytest.mark.parametrize("deg,C,K", [(0, 1, 1), (1, 1, 4), (2, 2, 16), (3, 2, 16)])
-def test_projection_sh_forward_and_vjp(hm, deg, C, K):
+def test_projection_sh_forward_and_vjp(hm, deg, C, K, use_jac):
     N, W, H = 1500, 96, 64
     sc = make_scene(N, W, H, sh_degree=deg, n_views=C, seed=11 + deg, k_store=K, scale_range=(0.02, 0.4), dist=3.0)
     fw = CO.render(sc["means"], sc["quats"], sc["scales"], sc["opacities"], sc["shs"], sc["viewmats"], sc["Ks"], W, H,
@@ -62,7 +63,7 @@ def test_projection_sh_forward_and_vjp(hm, deg, C, K):
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
     hm.hm_backward(C, N, K, deg, _p(sc["means"]), _p(sc["quats"]), _p(sc["scales"]), _p(sc["shs"]), _p(sc["viewmats"]),
                    _p(sc["Ks"]), W, H, F(0.3), F(0.01), F(1e10), _p(rad_use), _p(f32(fw["colors"])), _p(f32(vm)), _p(f32(vcn)),
-                   _p(f32(vc)), _p(h_means), _p(h_quats), _p(h_scales), _p(h_shs))
+                   _p(f32(vc)), _p(h_means), _p(h_quats), _p(h_scales), _p(h_shs), use_jac)
     for name, a, b in (("means", h_means, v_means), ("quats", h_quats, v_quats), ("scales", h_scales, v_scales), ("shs", h_shs, v_shs)):
         assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max(), name  # north_star: grads within 1e-3 rel
 
