@@ -142,6 +142,61 @@ __device__ __forceinline__ void stage_sh_rows_split(const float* __restrict__ sh
     }
 }
 
+// The same staging in two halves, for the one-launch forward (STAGE 0) with the reference's full SH3 rows in the split
+// layout: `sh_rows_issue` requests a block's whole slice (every thread its 12 quads of sh_rest and <= 3 floats of sh_0) at
+// the top of the kernel, `sh_rows_commit` moves it into the LDS tile once the visibility flags exist -- the 192 bytes
+// per Gaussian then arrive while the fp64 projection chain runs instead of after it (the block used to stream them in
+// a phase of its own, between two barriers, with nothing else to do).
+struct ShPrefetch {
+    float4 v[12];
+    float s0[3];
+};
+
+__device__ __forceinline__ void sh_rows_issue(const float* __restrict__ sh0, const float* __restrict__ shr, int64_t n0,
+                                              int rows, ShPrefetch& pf) {
+    constexpr int rest_f = 45;
+    const float4* src4 = reinterpret_cast<const float4*>(shr + n0 * rest_f);
+    const int total4 = (rows * rest_f) >> 2;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const int e4 = threadIdx.x + q * kProjThreads;
+        pf.v[q] = e4 < total4 ? nt_load4(src4 + e4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e = threadIdx.x + q * kProjThreads;
+        pf.s0[q] = e < rows * 3 ? sh0[n0 * 3 + e] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void sh_rows_commit(const ShPrefetch& pf, const float* __restrict__ shr, int64_t n0, int rows,
+                                               const int* vis, float* tile) {
+    constexpr int rest_f = 45, stride = 49;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e = threadIdx.x + q * kProjThreads;
+        if (e < rows * 3) { const int g = e / 3; if (vis[g]) tile[g * stride + (e - 3 * g)] = pf.s0[q]; }
+    }
+    const int total = rows * rest_f, total4 = total >> 2;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const int e4 = threadIdx.x + q * kProjThreads;
+        if (e4 < total4) {
+            const float vv[4] = {pf.v[q].x, pf.v[q].y, pf.v[q].z, pf.v[q].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = (e4 << 2) + i, g = e / rest_f, o = e - g * rest_f;
+                if (vis[g]) tile[g * stride + 3 + o] = vv[i];
+            }
+        }
+    }
+    const float* src = shr + n0 * rest_f;
+    for (int e = (total & ~3) + threadIdx.x; e < total; e += blockDim.x) {   // (the last block's 0-3 trailing floats)
+        const int g = e / rest_f, o = e - g * rest_f;
+        if (vis[g]) tile[g * stride + 3 + o] = src[e];
+    }
+}
+
 // STAGE 0: geometry + colour in one launch.  STAGE 1: geometry only (radii, means2d, depths,
 // conics, footprint, record quads 0-1).  STAGE 2: colour only (SH evaluation -> colors_out and
 // record quad 2) for the Gaussians stage 1 found visible.  The split lets the host enqueue the
@@ -162,17 +217,32 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
     Camera cam;
     load_camera(a.viewmats, a.Ks, c, a.W, a.H, lds_cam, cam);
 
+    // one-launch forward, full SH3 rows in the split layout (what the reference model trains with): the block's SH slice is
+    // requested now and consumed after the projection chain (sh_rows_issue)
+    const bool prefetch_sh = STAGE == 0 && DEG == 3 && a.sh_rest != nullptr && a.K == 16 && (((uintptr_t)a.sh_rest & 15) == 0);
+    // (vector memory loads return in issue order: the geometry inputs are requested FIRST, so that the chain below waits
+    //  for them only and runs while the SH slice is still in flight)
     float mean[3] = {0.f, 0.f, 0.f};
     if (in_range) { mean[0] = a.means[3 * n]; mean[1] = a.means[3 * n + 1]; mean[2] = a.means[3 * n + 2]; }
+    float4 q4 = make_float4(1.f, 0.f, 0.f, 0.f);
+    float sc_raw[3] = {0.f, 0.f, 0.f}, op_raw = 0.f;
+    if (STAGE != 2 && in_range) {
+        q4 = reinterpret_cast<const float4*>(a.quats)[n];
+        sc_raw[0] = a.scales[3 * n]; sc_raw[1] = a.scales[3 * n + 1]; sc_raw[2] = a.scales[3 * n + 2];
+        op_raw = a.opacities[n];
+    }
+    ShPrefetch pf;
+    if (STAGE == 0 && DEG == 3 && prefetch_sh)
+        sh_rows_issue(a.colors_in, a.sh_rest, n0, (int)min((int64_t)kProjThreads, a.N - n0), pf);
+
     bool vis = false;
     if (STAGE != 2) {
         Splat2D s;
         s.radius = 0; s.mx = s.my = s.depth = s.A = s.B = s.C = s.cxx = s.cyy = 0.f; s.x0 = s.x1 = s.y0 = s.y1 = 0;
         if (in_range) {
-            const float4 q4 = reinterpret_cast<const float4*>(a.quats)[n];
             const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-            const float scale[3] = {act_scale(a.scales[3 * n], a.activations), act_scale(a.scales[3 * n + 1], a.activations),
-                                    act_scale(a.scales[3 * n + 2], a.activations)};
+            const float scale[3] = {act_scale(sc_raw[0], a.activations), act_scale(sc_raw[1], a.activations),
+                                    act_scale(sc_raw[2], a.activations)};
             s = project_gaussian(mean, quat, scale, cam, a.W, a.H, a.eps2d, a.near_p, a.far_p, a.radius_clip, GS_TILE, a.tw, a.th);
         }
         vis = s.radius > 0;
@@ -182,7 +252,7 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
         if (vis) {
             x0 = s.x0; x1 = s.x1; y0 = s.y0; y1 = s.y1;   // from the unrounded centre (gs_math.h: preal)
             if (a.rect_ref) a.rect_ref[f] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
-            op = act_opacity(a.opacities[n], a.activations);
+            op = act_opacity(op_raw, a.activations);
             alpha_extent(op, s.cxx, s.cyy, ex, ey);
             // tight mode: keep only the tiles of the 3-sigma rectangle that hold a pixel centre where
             // alpha can reach 1/255 (the blend skips every other pixel anyway: identical image)
@@ -229,7 +299,9 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
         if (any_vis) {
             const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
             constexpr int ka3 = 3 * (DEG + 1) * (DEG + 1);
-            if (a.sh_rest) {
+            if (STAGE == 0 && DEG == 3 && prefetch_sh) {
+                sh_rows_commit(pf, a.sh_rest, n0, rows, vis_s, tile);
+            } else if (a.sh_rest) {
                 if (a.K == 16) stage_sh_rows_split<16>(a.colors_in, a.sh_rest, n0, rows, 16, ka3, vis_s, tile);
                 else stage_sh_rows_split<0>(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);
             } else {
@@ -311,11 +383,13 @@ __device__ __forceinline__ void row_add(RowSum& s, const float4* __restrict__ ro
 
 // Dense, coalesced write-out of one block's SH-gradient tile (LDS rows of 3K floats, row stride
 // 3K+1) to v_shs[n0 : n0+rows]: unsplit [N,K,3] or split v_sh_0[N,1,3] + v_sh_rest[N,K-1,3].
-__device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K, int64_t n0, float* v_colors,
-                                              float* v_sh_rest, bool accumulate) {
+template <int KC>   // KC > 0: K at compile time (divisions by 45 / 48 / 12 as multiply-shifts), see stage_sh_rows
+__device__ __forceinline__ void write_sh_tile_k(const float* tile, int rows, int Krt, int64_t n0, float* v_colors,
+                                                float* v_sh_rest, bool accumulate) {
+    const int K = KC > 0 ? KC : Krt;
     const int row_f = 3 * K, stride = row_f + 1;
         if (v_sh_rest) {  // split layout: v_sh_0[N,1,3] and v_sh_rest[N,K-1,3]
-            const int rest_f = K == 16 ? 45 : row_f - 3, total = rows * rest_f;
+            const int rest_f = row_f - 3, total = rows * rest_f;
             float* d0 = v_colors + n0 * 3;
             for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
                 const int g = e / 3;
@@ -365,6 +439,12 @@ __device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K
         }
 }
 
+__device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K, int64_t n0, float* v_colors,
+                                              float* v_sh_rest, bool accumulate) {
+    if (K == 16) write_sh_tile_k<16>(tile, rows, 16, n0, v_colors, v_sh_rest, accumulate);
+    else write_sh_tile_k<0>(tile, rows, K, n0, v_colors, v_sh_rest, accumulate);
+}
+
 #ifndef GS_ADAM_BATCH
 #define GS_ADAM_BATCH 3
 #endif
@@ -372,7 +452,11 @@ __device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K
 // and their moments: the 48 SH gradients per Gaussian (81 % of all gradient bytes at SH3) are never written to HBM
 // nor read back by a separate optimizer pass.  (The block staged its own SH rows into LDS before the barrier in
 // front of this call, and no other block touches them, so updating in place is race-free.)
-__device__ __forceinline__ void adam_sh_tile(const float* tile, int rows, int K, int64_t n0, const ProjBwdArgs& a) {
+// KC > 0 fixes K at compile time (K = 16: the reference's SH3 layout): the per-element Gaussian / offset divisions by 45
+// become multiply-shifts (four run-time integer divisions per 16 bytes otherwise).
+template <int KC>
+__device__ __forceinline__ void adam_sh_tile(const float* tile, int rows, int Krt, int64_t n0, const ProjBwdArgs& a) {
+    const int K = KC > 0 ? KC : Krt;
     const int row_f = 3 * K, stride = row_f + 1;
     const float isbc2 = a.ad_hyper[0], ss0 = a.ad_hyper[1 + 3], ssr = a.ad_hyper[1 + 4];
     {
@@ -572,11 +656,13 @@ __device__ __forceinline__ void row_sum_slots(const ProjBwdArgs& a, int cs, int 
     }
 }
 
-template <int DEG>
+// ADAM: the fused step kernel (gs_project_bwd_adam) -- a separate instantiation, so that neither form carries the other's code
+// and registers, and the two show up under their own names in a kernel trace.
+template <int DEG, bool ADAM>
 __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (guard_tripped(a.guard)) return;
-    if (a.adam && a.ad_applied != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.ad_applied[0] += 1;
+    if (ADAM && a.ad_applied != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.ad_applied[0] += 1;
     float* lds_cam = smem;
     int* vis_s = reinterpret_cast<int*>(smem + 32);
     float* tile = smem + 32 + kProjThreads;
@@ -742,9 +828,10 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
             for (int o = 0; o < row_f; ++o) my[o] = 0.f;
             if (a.v_colors_pre) { float* d = a.v_colors_pre + 3 * f; d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; }
         }
-        if (a.adam) {
+        if (ADAM) {
             __syncthreads();
-            adam_sh_tile(tile, rows, a.K, n0, a);
+            if (a.K == 16) adam_sh_tile<16>(tile, rows, 16, n0, a);
+            else adam_sh_tile<0>(tile, rows, a.K, n0, a);
         } else if (a.v_colors) {  // NULL: the caller rebuilds the SH gradients from v_colors_pre (gs_sh_grad_views)
             __syncthreads();
             write_sh_tile(tile, rows, a.K, n0, a.v_colors, a.v_sh_rest, a.accumulate);
@@ -768,9 +855,12 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         const float scale[3] = {act_scale(a.scales[3 * n], a.activations), act_scale(a.scales[3 * n + 1], a.activations),
                                 act_scale(a.scales[3 * n + 2], a.activations)};
         if (a.activations) { sc_fac[0] = scale[0]; sc_fac[1] = scale[1]; sc_fac[2] = scale[2]; }
-        ProjChain p;
-        if (project_chain<preal>(mean, quat, scale, cam, a.eps2d, a.near_p, a.far_p, p))
-            project_vjp<preal>(scale, cam, p, s.v[0], s.v[1], s.v[4], s.v[5], s.v[6], 0.f, v_mean, v_quat, v_scale);
+#ifndef GS_BWD_REAL   // (diagnostic builds: -DGS_BWD_REAL=float prices the fp64 chain of the backward)
+#define GS_BWD_REAL preal
+#endif
+        ProjChainT<GS_BWD_REAL> p;
+        if (project_chain<GS_BWD_REAL>(mean, quat, scale, cam, a.eps2d, a.near_p, a.far_p, p))
+            project_vjp<GS_BWD_REAL>(scale, cam, p, s.v[0], s.v[1], s.v[4], s.v[5], s.v[6], 0.f, v_mean, v_quat, v_scale);
     }
     float geo_op = 0.f;
     if (in_range) {
@@ -778,7 +868,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         v_scale[0] *= sc_fac[0]; v_scale[1] *= sc_fac[1]; v_scale[2] *= sc_fac[2];
         const float v_op = s.v[7] * op_fac;
         float* vm = a.v_means + 3 * n; float* vq = a.v_quats + 4 * n; float* vs = a.v_scales + 3 * n;
-        if (a.adam) {
+        if (ADAM) {
 #if GS_GEO_ADAM_SCALAR
             const float isbc2 = a.ad_hyper[0];
             auto upd = [&](int t, int64_t idx, float g) {
@@ -816,7 +906,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         if (a.v_colors_post) { a.v_colors_post[3 * f] = v_rgb[0]; a.v_colors_post[3 * f + 1] = v_rgb[1]; a.v_colors_post[3 * f + 2] = v_rgb[2]; }
     }
 #if !GS_GEO_ADAM_SCALAR
-    if (DEG >= 0 && a.adam) {
+    if (DEG >= 0 && ADAM) {
         // Geometry Adam, block-wide: the 11 gradients of every Gaussian of the block go through LDS into element order, and
         // means / log-scales / quaternions / logit-opacities (+ their moments) are updated with 16-byte accesses, every load
         // of a thread issued before its first store.  One gradient per thread and launch-order scalar accesses (33 dependent
@@ -1081,11 +1171,11 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     for (int c = 0; c < C; ++c) {
         a.cam = c; a.accumulate = c > 0;
         switch (sh_degree) {
-            case 0: hipLaunchKernelGGL(project_bwd_kernel<0>, grid, dim3(kProjThreads), lds, st, a); break;
-            case 1: hipLaunchKernelGGL(project_bwd_kernel<1>, grid, dim3(kProjThreads), lds, st, a); break;
-            case 2: hipLaunchKernelGGL(project_bwd_kernel<2>, grid, dim3(kProjThreads), lds, st, a); break;
-            case 3: hipLaunchKernelGGL(project_bwd_kernel<3>, grid, dim3(kProjThreads), lds, st, a); break;
-            default: hipLaunchKernelGGL(project_bwd_kernel<-1>, grid, dim3(kProjThreads), lds, st, a); break;
+            case 0: hipLaunchKernelGGL((project_bwd_kernel<0, false>), grid, dim3(kProjThreads), lds, st, a); break;
+            case 1: hipLaunchKernelGGL((project_bwd_kernel<1, false>), grid, dim3(kProjThreads), lds, st, a); break;
+            case 2: hipLaunchKernelGGL((project_bwd_kernel<2, false>), grid, dim3(kProjThreads), lds, st, a); break;
+            case 3: hipLaunchKernelGGL((project_bwd_kernel<3, false>), grid, dim3(kProjThreads), lds, st, a); break;
+            default: hipLaunchKernelGGL((project_bwd_kernel<-1, false>), grid, dim3(kProjThreads), lds, st, a); break;
         }
         GS_LAUNCH_CHECK("project_bwd_kernel");
     }
@@ -1135,10 +1225,10 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     const size_t lds = proj_bwd_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;
     switch (sh_degree) {
-        case 0: hipLaunchKernelGGL(project_bwd_kernel<0>, grid, dim3(kProjThreads), lds, st, a); break;
-        case 1: hipLaunchKernelGGL(project_bwd_kernel<1>, grid, dim3(kProjThreads), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(project_bwd_kernel<2>, grid, dim3(kProjThreads), lds, st, a); break;
-        default: hipLaunchKernelGGL(project_bwd_kernel<3>, grid, dim3(kProjThreads), lds, st, a); break;
+        case 0: hipLaunchKernelGGL((project_bwd_kernel<0, true>), grid, dim3(kProjThreads), lds, st, a); break;
+        case 1: hipLaunchKernelGGL((project_bwd_kernel<1, true>), grid, dim3(kProjThreads), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((project_bwd_kernel<2, true>), grid, dim3(kProjThreads), lds, st, a); break;
+        default: hipLaunchKernelGGL((project_bwd_kernel<3, true>), grid, dim3(kProjThreads), lds, st, a); break;
     }
     GS_LAUNCH_CHECK("project_bwd_kernel (fused Adam)");
     return GS_OK;
