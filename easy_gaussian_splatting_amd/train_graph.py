@@ -41,6 +41,7 @@ from . import _native as nat
 from .optim import FusedAdam
 from .rendering import _SH_JAC
 
+
 _TILE = nat.GS_TILE
 _SORT_CLASSES = (1024, 4096, 8192, 16384)
 
@@ -228,13 +229,15 @@ class TrainStepGraph:
         """`with runner._on_stream():` -- everything inside is enqueued on the runner's stream, ordered after the
         caller's current stream on entry and before it on exit."""
 
-        def __init__(self, runner):
+        def __init__(self, runner, wait_outer: bool = True):
             self.r = runner
+            self.wait_outer = wait_outer
 
         def __enter__(self):
             r = self.r
             self.outer = torch.cuda.current_stream(r.dev)
-            r.stream.wait_stream(self.outer)
+            if self.wait_outer:
+                r.stream.wait_stream(self.outer)
             self.ctx = torch.cuda.stream(r.stream)
             self.ctx.__enter__()
 
@@ -243,8 +246,8 @@ class TrainStepGraph:
             self.outer.wait_stream(self.r.stream)
             return False
 
-    def _on_stream(self):
-        return TrainStepGraph._OnStepStream(self)
+    def _on_stream(self, wait_outer: bool = True):
+        return TrainStepGraph._OnStepStream(self, wait_outer)
 
     stop_after = int(__import__('os').environ.get('GS_TG_STOP_AFTER', '0'))
     debug_sync = False   # set True to synchronise after every stage (locates a faulting kernel; never under capture)
@@ -426,8 +429,15 @@ class TrainStepGraph:
 
     # ------------------------------------------------------------------------------------------ stepping
     def _issue(self, entry):
-        t, lrs, w2c, K, gt, mask = entry
-        with torch.cuda.device(self.dev), self._on_stream():
+        t, lrs, w2c, K, gt, mask, ready = entry
+        # A step that takes nothing from the caller (every input IS the runner's static buffer: "same as last step") need not
+        # wait for the caller's stream.  That wait is not free: the event it waits for sits behind the previous step's
+        # hand-back on the caller's stream, so step i+1 would start two cross-queue signal hops after step i ended (39 us of
+        # idle GPU per step in the kernel trace of the bench loop) instead of right behind it in stream order.
+        b = self.buf
+        own = (w2c.data_ptr() == b["viewmats"].data_ptr() and K.data_ptr() == b["Ks"].data_ptr() and gt.data_ptr() == b["gt"].data_ptr()
+               and (not self.has_mask or (mask is not None and mask.data_ptr() == b["mask"].data_ptr())))
+        with torch.cuda.device(self.dev), self._on_stream(wait_outer=not (own or ready)):
             self._set_inputs(w2c, K, gt, mask)
             self._hyper(t, lrs)
             if self.graph is not None:
@@ -437,9 +447,12 @@ class TrainStepGraph:
         self.pending.append(entry)
         self.issued += 1
 
-    def step(self, data: Optional[Dict[str, Any]] = None, gt_img: Optional[Tensor] = None, mask: Optional[Tensor] = None):
+    def step(self, data: Optional[Dict[str, Any]] = None, gt_img: Optional[Tensor] = None, mask: Optional[Tensor] = None,
+             inputs_ready: bool = False):
         """One training iteration.  `data` / `gt_img` / `mask` default to the previous step's (static buffers are
-        re-used as they are).  Returns the runner's static output tensors (valid until the next step)."""
+        re-used as they are).  Returns the runner's static output tensors (valid until the next step).
+        `inputs_ready=True` is the caller's promise that no work still pending on its stream writes the tensors handed in
+        (a dataset uploaded before the loop started): the step then does not wait for the caller's stream (see `_issue`)."""
         W, H = (self.W, self.H) if data is None else (int(data["width"]), int(data["height"]))
         if self._state_key(W, H) != self._key:
             self.finish()
@@ -475,7 +488,7 @@ class TrainStepGraph:
         # into a camera / target / mask tensor it has handed in before `finish()` (or `check_every` further steps).  Entries
         # that alias the runner's OWN static buffers (data=None / gt_img=None steps) are snapshotted right before a later
         # step overwrites those buffers (`_protect_pending`), so a skipped step is always replayed with its own inputs.
-        self._issue([opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk])
+        self._issue([opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk, bool(inputs_ready)])
         if self.issued % self.check_every == 0:
             self._poll(block=False)
         return {"render_img": b["render_colors"][0], "loss3": b["loss3"], "batch_radii": b["radii"], "absgrad": b["v_abs"]}
