@@ -76,6 +76,9 @@ def profile_stages(enable: bool, repeat: Optional[Dict[str, int]] = None) -> Opt
 _ROWS_COLOR_COPY = os.environ.get("GS_DP_ROWS_COLOR") == "1"
 # GS_SH_JAC=0: the backward stages the SH coefficients itself instead of using the forward's direction Jacobian (A/B, tests)
 _SH_JAC = os.environ.get("GS_SH_JAC", "1") != "0"
+# GS_FWD_SPLIT=1: projection and SH colour as two launches around the tile count (the form that hid the size read-back before
+# the list stages became speculative)
+_SPLIT_PROJECT = os.environ.get("GS_FWD_SPLIT") == "1"
 
 _tls = threading.local()
 _state_lock = threading.Lock()   # guards the two module-level dicts below (entry points are called from any thread)
@@ -417,7 +420,9 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
 
     # 1. geometry; 2. tile counts under the guard (flags = capacity exceeded) and their 64-byte copy to the host;
     # 3. SH colours; 4. lists + blend, speculatively; 5. only now the host looks at the sizes.
-    project(1, "gs_project_fwd")
+    # (one launch for geometry + colour: since the list stages no longer wait for the host, a colour pass of its own behind
+    #  the tile count hides nothing, and the fused launch is 25 us shorter than the two -- GS_FWD_SPLIT=1 keeps the split)
+    project(1 if _SPLIT_PROJECT else 0, "gs_project_fwd")
     attempt, waited = 0, 0
     try:
         while True:
@@ -427,7 +432,8 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
             if attempt == 0:
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream(dev))
-                project(2, "gs_project_fwd_color")
+                if _SPLIT_PROJECT:
+                    project(2, "gs_project_fwd_color")
             lists_and_blend()
             nat.check(L.gs_guard_set(None, 0, 0), "gs_guard_set")
             t_wait = time.perf_counter_ns()

@@ -31,6 +31,7 @@ from __future__ import annotations
 
 import ctypes as ct
 import math
+import time
 from collections import deque
 from typing import Any, Dict, Optional
 
@@ -104,6 +105,7 @@ class TrainStepGraph:
         of the list sizes if needed, warms every kernel up eagerly and captures the step."""
         m, dev = self.model, self.dev
         L = nat.lib()
+        t_build = time.perf_counter()
         self.N = N = m.means.shape[0]
         self.K = 1 + m.sh_rest.shape[1]
         W, H = self.W, self.H
@@ -161,8 +163,12 @@ class TrainStepGraph:
         self._alloc_lists()
         self._key = self._state_key()
         # eager warm-up of the guarded pipeline (raises every kernel attribute; also a functional check before capture)
+        t_cap = time.perf_counter()
         self._capture()
         self.stats["rebuilds"] += 1
+        now = time.perf_counter()
+        self.stats["build_ms"] = round(self.stats.get("build_ms", 0.0) + 1e3 * (now - t_build), 2)        # whole (re-)builds, wall clock
+        self.stats["capture_ms"] = round(self.stats.get("capture_ms", 0.0) + 1e3 * (now - t_cap), 2)    # ... of which warm-up + capture
 
     def _alloc_binning(self):
         """Workspace of the binning pipeline the probe chose (rendering.binning_mode): per-tile lists sorted one by one
