@@ -1006,6 +1006,54 @@ __global__ __launch_bounds__(kProjThreads) void sh_grad_views_kernel(const ShGra
 // colour lanes of Gaussian f's gradient rows (read from blend_bwd's compact rows_color copy) -- the only part of project_bwd's output other ranks
 // need.  Running it as its own light kernel right after blend_bwd lets the all-gather of
 // v_colors_pre overlap the (much longer) project_bwd.  Same row order as project_bwd -> same sums.
+// (lane-per-slot sum of the colour lanes, as row_sum_slots does for whole rows: a wave's small Gaussians pay a handful of
+//  round trips instead of one per slot of its longest Gaussian)
+__device__ __forceinline__ void color_sum_slots(const float4* __restrict__ rows_color, int row_quads, const uint8_t* __restrict__ qmask,
+                                                int cs, int base, float& sr, float& sg, float& sb, float* wl) {
+    const int lane = lane_id();
+    const int incl = wave_incl_scan_add(cs);
+    const int o = incl - cs;
+    const int T = __shfl(incl, 63, 64);
+    if (T == 0) return;
+    uint8_t* own = reinterpret_cast<uint8_t*>(wl);
+    float4* item = reinterpret_cast<float4*>(wl + kRowOwnerFloats);
+    for (int r = 0; r < cs; ++r) own[o + r] = (uint8_t)lane;
+    __builtin_amdgcn_wave_barrier();
+    const int n_items = (T + 63) >> 6;
+    for (int u0 = 0; u0 < n_items; u0 += 4) {
+        int sl[4], bt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = 64 * (u0 + q) + lane;
+            const bool valid = j < T;
+            const int owner = valid ? (int)own[j] : 0;
+            sl[q] = __shfl(base, owner, 64) + j - __shfl(o, owner, 64);
+            bt[q] = valid ? (int)qmask[sl[q]] : 0;
+        }
+        float4 d[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // the colour quads of four items: every load issued before the first use
+            const float4* rp = rows_color + (int64_t)4 * row_quads * sl[q] + (row_quads - 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[q][k] = (bt[q] & (1 << k)) ? rp[k * row_quads] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (u0 + q < n_items) {   // wave-uniform
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x.x += d[q][k].x; x.y += d[q][k].y; x.z += d[q][k].z; }
+                item[lane] = x;
+                __builtin_amdgcn_wave_barrier();
+                const int jb = 64 * (u0 + q);
+                const int lo = max(o, jb) - jb, hi = min(o + cs, jb + 64) - jb;
+                for (int r = lo; r < hi; ++r) { const float4 ix = item[r]; sr += ix.x; sg += ix.y; sb += ix.z; }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void colors_pre_grad_kernel(int64_t total, const int32_t* __restrict__ radii,
                                                               const float* __restrict__ colors_post,
                                                               const int32_t* __restrict__ tiles_per_gauss,
@@ -1013,12 +1061,15 @@ __global__ __launch_bounds__(256) void colors_pre_grad_kernel(int64_t total, con
                                                               const float4* __restrict__ rows_color, int row_quads,
                                                               const uint8_t* __restrict__ qmask,
                                                               float* __restrict__ v_colors_pre) {
+    __shared__ __attribute__((aligned(16))) float wl_all[4][kRowOwnerFloats + 64 * 4];
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= total) return;
+    const bool in_range = f < total;
+    const bool vis = in_range && radii[f] > 0;
+    const int cnt = vis ? tiles_per_gauss[f] : 0, base = vis ? cum_tiles[f] : 0;
     float sr = 0.f, sg = 0.f, sb = 0.f;
-    if (radii[f] > 0) {
-        const int cnt = tiles_per_gauss[f], base = cum_tiles[f];
-        int bits = cnt > 0 ? (int)qmask[base] : 0;
+    color_sum_slots(rows_color, row_quads, qmask, cnt <= kCoopRows ? cnt : 0, base, sr, sg, sb, wl_all[threadIdx.x >> 6]);
+    if (cnt > kCoopRows) {   // the few Gaussians with many slots: their own lane walks them (mask one slot ahead)
+        int bits = (int)qmask[base];
         for (int r = 0; r < cnt; ++r) {
             const int bits_next = r + 1 < cnt ? (int)qmask[base + r + 1] : 0;
             // row_quads = 1: blend_bwd's compact colour copy [I*4][4];  3: the gradient rows themselves [I*4][12], whose
@@ -1031,6 +1082,9 @@ __global__ __launch_bounds__(256) void colors_pre_grad_kernel(int64_t total, con
             for (int q = 0; q < 4; ++q) { sr += v[q].x; sg += v[q].y; sb += v[q].z; }
             bits = bits_next;
         }
+    }
+    if (!in_range) return;
+    if (vis) {
         sr = colors_post[3 * f] > 0.f ? sr : 0.f;
         sg = colors_post[3 * f + 1] > 0.f ? sg : 0.f;
         sb = colors_post[3 * f + 2] > 0.f ? sb : 0.f;
