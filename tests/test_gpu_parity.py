@@ -353,6 +353,43 @@ def test_backward_without_the_forward_direction_jacobian(name, monkeypatch):
     assert float((g_j[0] - g_c[0]).abs().max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("name", ["ragged_sh2_2views", "sh3_split"])
+def test_one_launch_projection_equals_the_two_stage_form(name, monkeypatch):
+    """The eager forward runs geometry + SH colour as ONE launch (stage 0; with the reference's split SH3 layout the SH slice is
+    requested ahead of the projection chain); `GS_FWD_SPLIT=1` keeps the two launches around the tile count.  Same results,
+    bit for bit, gradients included."""
+    from easy_gaussian_splatting_amd import rendering
+    if name == "sh3_split":
+        sc = make_scene(3001, 150, 90, sh_degree=3, seed=23, k_store=16, scale_range=(0.02, 0.2), dist=4.0)
+    else:
+        sc = make_scene(**SCENES[name])
+    t = to_dev(sc)
+    W, H = int(sc["width"]), int(sc["height"])
+
+    def run():
+        base = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
+        if name == "sh3_split":
+            cols = (t["shs"][:, :1].clone().contiguous().requires_grad_(True), t["shs"][:, 1:].clone().contiguous().requires_grad_(True))
+            leaves = base + list(cols)
+        else:
+            cols = t["shs"].clone().requires_grad_(True)
+            leaves = base + [cols]
+        img, alpha, meta = rendering.rasterization(*base, cols, t["viewmats"], t["Ks"], W, H, sh_degree=int(sc["sh_degree"]), packed=False,
+                                                   backgrounds=t["backgrounds"], absgrad=True)
+        vc = torch.randn(img.shape, generator=torch.Generator().manual_seed(3)).to(dev())
+        grads = torch.autograd.grad((img * vc).sum() + alpha.sum(), leaves)
+        return img, alpha, meta, grads
+
+    one = run()
+    monkeypatch.setattr(rendering, "_SPLIT_PROJECT", True)
+    two = run()
+    assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1])
+    for k in ("radii", "means2d", "depths", "conics", "tiles_per_gauss", "flatten_ids", "isect_offsets"):
+        assert torch.equal(one[2][k], two[2][k]), k
+    for a, b in zip(one[3], two[3]):
+        assert torch.equal(a, b)
+
+
 def test_config_s1_parity():
     """BASELINE.json configs[0]: 10k random Gaussians, 256x256, SH degree 0."""
     sc = config_s1()
