@@ -1,9 +1,11 @@
 // gs_project.hip -- per-Gaussian stages for gfx950:
-//   project_fwd_kernel : P-fwd + SH-fwd fused (one pass over means/quats/scales/shs)
-//   project_bwd_kernel : gradient-row reduction + SH-bwd + P-bwd fused (no atomics)
-// Both are HBM-streaming kernels.  The [N,K,3] SH block (192 B per Gaussian at SH3) is moved
-// through LDS with coalesced 16-byte accesses and read per thread at an odd row stride
-// (3K+1 dwords) so the per-thread walk over its own row is bank-conflict free.
+//   project_fwd_kernel : P-fwd + SH-fwd fused (one pass over means/quats/scales/shs); when training with SH colours it
+//                        also leaves d colour / d view direction (sh_jac), so that the backward reads no coefficient
+//   project_bwd_kernel : gradient-row reduction (a lane per slot: row_sum_slots) + SH-bwd + P-bwd fused, no atomics;
+//                        <DEG, true>: Adam and update_statistics applied in the same pass (gs_project_bwd_adam)
+// The [N,K,3] SH block (192 B per Gaussian at SH3) is moved through LDS with coalesced 16-byte accesses and read per
+// thread at an odd row stride (3K+1 dwords) so the per-thread walk over its own row is bank-conflict free.  The
+// geometry half of the forward is VALU-bound (the fp64 chain), the rest HBM streams and gathers.
 #include "gs_common.h"
 #include "gs_math.h"
 
