@@ -790,14 +790,17 @@ __global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total
     }
     unsigned long long carry = 0, ccarry = 0;
     uint32_t max_cnt = 0;
-    const int chunk = kBinThreads * kScanItems;
+    // (8 bins per thread, not kScanItems = 16: with the chunk-descriptor loop in the second pass 16 spilled to scratch, and a
+    //  kernel that needs scratch can stall its queue for milliseconds, see gs_blend.hip)
+    constexpr int kItems = 8;
+    const int chunk = kBinThreads * kItems;
     for (int base = 0; base < n_bins_total; base += chunk) {
-        const int first = base + threadIdx.x * kScanItems;
-        uint32_t v[kScanItems];
+        const int first = base + threadIdx.x * kItems;
+        uint32_t v[kItems];
         unsigned long long si = 0, sc = 0;
         const uint32_t cmask = (1u << chunk_shift) - 1u;
 #pragma unroll
-        for (int k = 0; k < kScanItems; ++k) {
+        for (int k = 0; k < kItems; ++k) {
             v[k] = (first + k < n_bins_total) ? bin_cnt[first + k] : 0u;
             si += v[k];
             sc += (v[k] + cmask) >> chunk_shift;
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total
         const unsigned long long ex = block_excl_scan_add(si | (sc << 36), scratch, &total);
         unsigned long long run = carry + (ex & ((1ull << 36) - 1)), crun = ccarry + (ex >> 36);
 #pragma unroll
-        for (int k = 0; k < kScanItems; ++k) {
+        for (int k = 0; k < kItems; ++k) {
             const uint32_t nch = (v[k] + cmask) >> chunk_shift;
             if (first + k < n_bins_total) {
                 coff[first + k] = (int32_t)min(run, (unsigned long long)0x7fffffff);

@@ -96,10 +96,14 @@ __device__ __forceinline__ void blend_pair(const float alpha, const bool ok, con
     T = Tn;
 }
 
-// The training instantiation needs 96 VGPRs left to itself (5 waves / SIMD: the 8160 tile-waves of a 1080p frame then run
-// in 1.6 rounds); held to 80 (11 spilled) it keeps 6 resident and is 3 % faster.  The inference one fits 8 waves / SIMD.
+// The training instantiation needs 90 VGPRs left to itself (5 waves / SIMD: the 8160 tile-waves of a 1080p frame then run
+// in 1.6 rounds); held to 80 (5 spilled to scratch) it keeps 6 resident and is 2-3 % faster back to back -- but a kernel
+// that needs SCRATCH makes the runtime (re-)provision scratch memory for the queue it is launched on: once another
+// stream of the process had run the captured step, every eager launch of this kernel on the caller's stream stalled 0.5-2 ms
+// behind that (bench.py's eager stage profile read 0.76-2.4 ms for a 0.28 ms kernel on some boxes).
+// No kernel of the library uses scratch (tests/test_capi.py checks the compiler's resource report).  Inference: 8 waves.
 #ifndef GS_FWD_TRAIN_WAVES_PER_EU
-#define GS_FWD_TRAIN_WAVES_PER_EU 6
+#define GS_FWD_TRAIN_WAVES_PER_EU 5
 #endif
 #define GS_FWD_ATTR __attribute__((amdgpu_waves_per_eu(CKPT ? GS_FWD_TRAIN_WAVES_PER_EU : 1, 8)))
 // Streaming clear of the quadrant masks (16-byte stores; `n` bytes from an arbitrarily aligned pointer) + the work-unit counter.
@@ -316,6 +320,9 @@ struct BlendBwdArgs {
 #ifndef GS_BWD_WAVES
 #define GS_BWD_WAVES 4
 #endif
+#ifndef GS_BWD_PXY_TABLE
+#define GS_BWD_PXY_TABLE 0
+#endif
 constexpr int kBwdWaves = GS_BWD_WAVES;
 constexpr int kPipeLanes = 8;                       // lanes per systolic pipeline (two pipelines share a 16-lane DPP row)
 constexpr int kPerLane = kUnit / kPipeLanes;        // 4 entries per lane
@@ -373,6 +380,11 @@ __device__ __forceinline__ void bwd_pair(EntryState& e, const float4 d0, const f
 __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(const BlendBwdArgs a) {
     __shared__ float4 sd0_all[kBwdWaves][kUnitsPerWave][64];   // 8 KB per wave: v_r, v_g, v_b, E of the unit's 64 pixels
     __shared__ float2 sck_all[kBwdWaves][kUnitsPerWave][64];   // 4 KB per wave: checkpoint T, P = checkpoint colour . v
+#if GS_BWD_PXY_TABLE
+    __shared__ float2 pxy[64];   // (p & 7, p >> 3) as floats: one LDS read instead of and / shift / two conversions per step
+    if (threadIdx.x < 64) pxy[threadIdx.x] = make_float2((float)(threadIdx.x & 7), (float)(threadIdx.x >> 3));
+    __syncthreads();
+#endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pipe = lane / kPipeLanes, r = lane & (kPipeLanes - 1);
     if (guard_tripped(a.guard)) return;
@@ -475,7 +487,12 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
         const int pc = min(max(p, 0), 63);
         const float4 d0 = sd0[pc];
         const float2 ck = sck[pc];
+#if GS_BWD_PXY_TABLE
+        const float2 rel = pxy[pc];
+        const float2 d1 = make_float2(fx0 + rel.x, fy0 + rel.y);   // pixel centre
+#else
         const float2 d1 = make_float2(fx0 + (float)(pc & 7), fy0 + (float)(pc >> 3));   // pixel centre
+#endif
         if (r == 0) { T = ck.x; P = ck.y; }   // head of the pipeline: fed from the checkpoint, not from the lane below
         T = act ? T : -1.f;   // pipeline fill / drain: nothing contributes
 #pragma unroll

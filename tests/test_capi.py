@@ -28,6 +28,29 @@ def test_header_symbols_all_exported(native):
     assert names == set(native.SIGNATURES), "ctypes signature table out of sync with the header"
 
 
+def test_no_kernel_needs_scratch_memory(native):
+    """A kernel with register spills (or a dynamically indexed local array) makes the HIP runtime provision scratch memory for
+    the queue it is launched on; with two streams of one process taking turns (the captured step on the runner's stream, eager
+    calls on the caller's) every eager launch of such a kernel stalled 0.5-2 ms behind that.  The
+    Makefile keeps the compiler's resource report of every object (csrc/*.res): all kernels must report ScratchSize 0."""
+    import glob
+    import subprocess
+    csrc = native.CSRC_DIR
+    hips = sorted(glob.glob(os.path.join(csrc, "*.hip")))
+    if any(not os.path.exists(h[:-4] + ".res") for h in hips):   # objects of an older build: make them again with the report
+        subprocess.run(["make", "-C", csrc, "-B", "-j4"], check=True, capture_output=True)
+    n_kernels = 0
+    for h in hips:
+        rep = open(h[:-4] + ".res").read()
+        names = re.findall(r"Function Name: (\S+)", rep)
+        sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", rep)]
+        assert len(names) == len(sizes)
+        n_kernels += len(names)
+        for nme, sz in zip(names, sizes):
+            assert sz == 0, f"{os.path.basename(h)}: kernel {nme} uses {sz} bytes of scratch per lane"
+    assert n_kernels >= 60
+
+
 def test_identity_and_layout_queries(native):
     lib = native.lib()
     assert lib.gs_version() >= 100
