@@ -35,7 +35,7 @@ extern "C" int gs_workspace_query(int C, int64_t N, int width, int height, int64
     size[GS_WS_TILE_ORDER] = CT * 4;
     if (train) {
         size[GS_WS_QCNT] = CT * 4 * 4;
-        size[GS_WS_UNIT_COUNTER] = 4;
+        size[GS_WS_UNIT_COUNTER] = 0;   // (lives in the last, otherwise unused word of the info block: one memset per call)
         size[GS_WS_SH_JAC] = CN * 9 * 4;
     }
     if (two_level) {
@@ -66,6 +66,7 @@ extern "C" int gs_workspace_query(int C, int64_t N, int width, int height, int64
         offsets[i] = off[arena];
         off[arena] = gs::align256(off[arena] + size[i]);
     }
+    offsets[GS_WS_UNIT_COUNTER] = train ? offsets[GS_WS_INFO] + 7 * (int64_t)sizeof(int64_t) : -1;
     arena_bytes[0] = off[0] > 0 ? off[0] : 256;
     arena_bytes[1] = off[1] > 0 ? off[1] : 256;
     return GS_OK;
@@ -78,8 +79,7 @@ extern "C" int gs_workspace_bind(void* stream, void* fixed_base, int64_t fixed_b
     GS_REQUIRE(fixed_bytes >= arena_bytes[0] && list_bytes >= arena_bytes[1], "arena smaller than gs_workspace_query reported");
     GS_REQUIRE(offsets[GS_WS_INFO] >= 0, "layout without an info block");
     hipStream_t st = (hipStream_t)stream;
-    // the control words a call expects at zero: the info block (flags are sticky ORs) and the work-unit counter
+    // the control words a call expects at zero: the info block (flags are sticky ORs), whose last word is the work-unit counter
     GS_HIP_CHECK(hipMemsetAsync((char*)fixed_base + offsets[GS_WS_INFO], 0, 8 * sizeof(int64_t), st));
-    if (offsets[GS_WS_UNIT_COUNTER] >= 0) GS_HIP_CHECK(hipMemsetAsync((char*)fixed_base + offsets[GS_WS_UNIT_COUNTER], 0, 4, st));
     return GS_OK;
 }

@@ -78,7 +78,7 @@ int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied
  * counter) on `stream`.  The caller keeps one (fixed, list) pair per call in flight on a (device, stream) and hands the sub-pointers
  * to the stage entry points below; a call whose lists outgrow the capacity (info flags, see gs_guard_set) replaces the list arena
  * only and repeats gs_bin_count .. gs_blend_fwd. */
-#define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, -} */
+#define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, work-unit counter} */
 #define GS_WS_REC 1             /* f32 [C*N][12] */
 #define GS_WS_BBOX 2            /* u32 [C*N][4] */
 #define GS_WS_TILES_PER_GAUSS 3 /* i32 [C*N] */
@@ -88,7 +88,7 @@ int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied
 #define GS_WS_BUCKET_OFFSETS 7  /* i32 [C*tiles+1] */
 #define GS_WS_TILE_ORDER 8      /* i32 [C*tiles] */
 #define GS_WS_QCNT 9            /* i32 [C*tiles*4]              (training) */
-#define GS_WS_UNIT_COUNTER 10   /* i32 [1]                      (training) */
+#define GS_WS_UNIT_COUNTER 10   /* i32 [1]                      (training; the last word of the info block) */
 #define GS_WS_SH_JAC 11         /* f32 [C*N*9]                  (training: gs_project_fwd -> gs_project_bwd) */
 #define GS_WS_LIST_FIRST 12     /* ---- list arena ---- */
 #define GS_WS_BIN 12            /* gs_bin_workspace_bytes / gs_bins_workspace_bytes */
