@@ -59,6 +59,8 @@ SIGNATURES = {
     "gs_pack_view_step": (_I, [_P, _L, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_update_statistics": (_I, [_P, _L, _F, _P, _P, _P, _P, _P]),
     "gs_guard_set": (_I, [_P, _L, _L]),
+    "gs_guard_set_call": (_I, [_P, _L, _L]),
+    "gs_info_mirror_set": (_I, [_P]),
     "gs_step_status": (_I, [_P, _P, _P, _P, _P, _P, _I]),
     "gs_adam_hyper": (_I, [_P, _I, _P, _F, _F, _L, _P]),
     "gs_adam_step_dev": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P, _P]),

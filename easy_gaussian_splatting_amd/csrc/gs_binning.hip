@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
     const uint32_t* __restrict__ grp_tot, int32_t* __restrict__ isect_offsets,
     int32_t* __restrict__ bucket_offsets, uint32_t* __restrict__ grp_base,
     int64_t* __restrict__ info, int32_t* __restrict__ tile_order, int64_t cap_isects, int64_t cap_tile,
-    int64_t keep_mask, int32_t* __restrict__ sort_counts) {
+    int64_t keep_mask, int32_t* __restrict__ sort_counts, int64_t* __restrict__ info_mirror, int per_call) {
     __shared__ unsigned long long scratch[17];
     const int chunk = kBinThreads * kScanItems;
     if (blockIdx.x == 2) {   // group bases (few thousand values at most): serial chunks of kBinThreads
@@ -274,9 +274,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
             // guarded step (gs_guard_set): flags are sticky -- once a step does not fit, this and every later
             // step is a no-op until the host has re-sized the buffers and cleared the word
             const int64_t f = ((int64_t)carry_i > cap_isects ? 1 : 0) | ((int64_t)mm > cap_tile ? 2 : 0);
-            if (f) info[3] |= f;
+            if (per_call) info[3] = (info[3] & keep_mask) | f;   // (gs_guard_set_call: whatever an earlier call left is overwritten)
+            else if (f) info[3] |= f;
         } else {
             info[3] = keep_mask ? (info[3] & keep_mask) : 0;   // (two-level binning: the coarse stage's overflow bit survives)
+        }
+        if (info_mirror) {   // page-locked host memory (gs_info_mirror_set): the sizes reach the host without a copy on the stream
+#pragma unroll
+            for (int i = 0; i < 8; ++i) info_mirror[i] = info[i];
+            __threadfence_system();
         }
     }
 }
@@ -1229,7 +1235,7 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
     GS_REQUIRE(gd.info == nullptr || gd.info == info_dev, "the guard set by gs_guard_set must be this call's info_dev");
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(3), dim3(kBinThreads), 0, st, (int)ct, C * L.groups, tile_cnt,
                        grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev, tile_order, gd.cap_isects, gd.cap_tile,
-                       (int64_t)0, (int32_t*)(ws + L.items_off));
+                       (int64_t)0, (int32_t*)(ws + L.items_off), current_info_mirror(), gd.per_call);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
     if (info_host) {
         GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -1350,7 +1356,7 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     hipLaunchKernelGGL(bins_scan_kernel, dim3(2), dim3(kBinThreads), 0, st, (int)cb, C * L.groups, bin_cnt, grp_tot, coff,
                        (int32_t*)(ws + L.choff_off), (int4*)(ws + L.chunk_bin_off), L.max_chunks, L.chunk_shift, grp_base,
                        info_dev, coarse_cap, list_cap,
-                       gd.info != nullptr ? 1 : 0, (int32_t*)(ws + L.items_off));
+                       (gd.info != nullptr && !gd.per_call) ? 1 : 0, (int32_t*)(ws + L.items_off));   // (per-call guard: overwrite)
     GS_LAUNCH_CHECK("bins_scan_kernel");
     if (N > 0) {
         if (int rc = ensure_lds((const void*)bins_emit_kernel, lds)) return rc;
@@ -1379,7 +1385,7 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     }
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(2), dim3(kBinThreads), 0, st, C * tiles, 0, tile_cnt, (const uint32_t*)nullptr,
                        isect_offsets, bucket_offsets, (uint32_t*)nullptr, info_dev, tile_order, gd.cap_isects,
-                       (int64_t)0x7fffffffffffffffll, (int64_t)12, (int32_t*)nullptr);
+                       (int64_t)0x7fffffffffffffffll, (int64_t)12, (int32_t*)nullptr, current_info_mirror(), gd.per_call);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
     if (info_host) {
         GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));

@@ -12,9 +12,16 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-static thread_local Guard g_guard = {nullptr, 0, 0};
+static thread_local Guard g_guard = {nullptr, 0, 0, 0};
 Guard current_guard() { return g_guard; }
+static thread_local int64_t* g_info_mirror = nullptr;
+int64_t* current_info_mirror() { return g_info_mirror; }
 }  // namespace gs
+
+extern "C" int gs_info_mirror_set(int64_t* info_host_mapped) {
+    gs::g_info_mirror = info_host_mapped;
+    return GS_OK;
+}
 
 extern "C" int gs_guard_set(const int64_t* info_dev, int64_t cap_isects, int64_t cap_tile) {
     if (info_dev != nullptr && (cap_isects <= 0 || cap_tile <= 0)) {
@@ -24,6 +31,13 @@ extern "C" int gs_guard_set(const int64_t* info_dev, int64_t cap_isects, int64_t
     gs::g_guard.info = info_dev;
     gs::g_guard.cap_isects = info_dev ? cap_isects : 0;
     gs::g_guard.cap_tile = info_dev ? cap_tile : 0;
+    gs::g_guard.per_call = 0;
+    return GS_OK;
+}
+
+extern "C" int gs_guard_set_call(const int64_t* info_dev, int64_t cap_isects, int64_t cap_tile) {
+    if (int rc = gs_guard_set(info_dev, cap_isects, cap_tile)) return rc;
+    gs::g_guard.per_call = info_dev != nullptr;
     return GS_OK;
 }
 

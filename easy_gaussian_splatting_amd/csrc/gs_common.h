@@ -48,8 +48,12 @@ struct Guard {
     const int64_t* info;   // device pointer, nullptr = unguarded
     int64_t cap_isects;    // capacity of the intersection-indexed buffers
     int64_t cap_tile;      // longest tile list the sort classes launched can take
+    int per_call;          // gs_guard_set_call: the flags belong to ONE call -- its first flag writer overwrites info[3]
 };
 Guard current_guard();
+// Host mirror of the info block (gs_info_mirror_set): page-locked, device-visible host memory the tile scan writes the
+// eight info words into directly -- the eager seam learns the list sizes without a device-to-host copy on the stream.
+int64_t* current_info_mirror();
 __device__ __forceinline__ bool guard_tripped(const int64_t* info) { return info != nullptr && info[3] != 0; }
 
 // Workspace layout of the binning stage (all offsets in bytes, 256-B aligned).

@@ -148,6 +148,11 @@ def binning_choice(footprint, tiles: int = 0) -> str:
 stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0, "overflow_reruns": 0}
 
 
+def _quantize_up(x: int) -> int:
+    g = 1 << max(12, int(x).bit_length() - 5)
+    return (int(x) + g - 1) // g * g
+
+
 def _pinned_info(device: torch.device) -> Tensor:
     """Page-locked 8 x int64 landing buffer for the list sizes, one per (host thread, device)."""
     cache = getattr(_tls, "pinned", None)
@@ -372,6 +377,9 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     cap_tile = int(hint.get("cap_tile", 1024)) if not two_level else (1 << 30)
     coarse_cap = max(int(hint.get("entries", 0)), 2 * C * N + 1024) if two_level else 0
     coarse_list_cap = int(hint.get("longest", 0)) if two_level else 0   # 0: launch every sort class
+    # (capacities in steps of ~3 %: the hint drifts a little with every frame, the LAYOUT should not -- a lease whose arenas
+    #  and layout are those of the last call is not re-bound: no validation, no memset on the stream)
+    cap, coarse_cap = _quantize_up(cap), (_quantize_up(coarse_cap) if two_level else 0)
     if need_grad:
         cap = min(cap, (1 << 29) - 1)
 
@@ -426,9 +434,11 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     attempt, waited = 0, 0
     try:
         while True:
-            nat.check(L.gs_guard_set(P(WS.INFO), cap, min(cap_tile, cap)), "gs_guard_set")
+            nat.check(L.gs_guard_set_call(P(WS.INFO), cap, min(cap_tile, cap)), "gs_guard_set_call")
+            # (the tile scan writes the eight info words straight into the page-locked landing buffer: no copy on the stream)
+            nat.check(L.gs_info_mirror_set(info_host.data_ptr()), "gs_info_mirror_set")
             _stage("gs_bin_count", dev, count)
-            info_host.copy_(info_dev, non_blocking=True)
+            nat.check(L.gs_info_mirror_set(None), "gs_info_mirror_set")
             if attempt == 0:
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream(dev))
@@ -470,6 +480,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
             info_dev.zero_()
     finally:
         L.gs_guard_set(None, 0, 0)
+        L.gs_info_mirror_set(None)
     with _state_lock:
         stats["sync_wait_ns"] += waited
         stats["calls"] += 1

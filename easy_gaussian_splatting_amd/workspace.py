@@ -38,7 +38,7 @@ _DTYPES = {INFO: torch.int64, REC: torch.float32, BBOX: torch.int32, TILES_PER_G
            QMASK: torch.uint8, ROWS: torch.float32, ROWS_COLOR: torch.float32, QLIST: torch.int32, UNIT_DESC: torch.int32,
            CKPT: torch.float32}
 
-stats = {"leases_created": 0, "acquires": 0, "fixed_allocs": 0, "list_allocs": 0, "list_grows": 0}
+stats = {"leases_created": 0, "acquires": 0, "fixed_allocs": 0, "list_allocs": 0, "list_grows": 0, "binds": 0}
 
 
 class Layout:
@@ -67,6 +67,7 @@ class Lease:
         self.cap = 0
         self.busy = False
         self.refs = 0
+        self._bound = None
 
     # -- reference counting by the objects that read the arenas after the forward returned (autograd ctx, meta)
     def retain(self) -> "Lease":
@@ -89,10 +90,17 @@ class Lease:
     def bind(self, layout: Layout, stream: int) -> None:
         self._ensure("fixed", layout.arena_bytes[0])
         self._ensure("lists", layout.arena_bytes[1])
+        bound = (self.fixed.data_ptr(), self.lists.data_ptr(), layout.key)
         self.layout = layout
         self.cap = layout.key[4]
+        if bound == self._bound:
+            # same arenas, same layout as the last call: nothing to validate, and nothing to zero -- the call runs under
+            # gs_guard_set_call (its first flag writer overwrites the flags word) and the blend clears its own counter
+            return
         nat.check(nat.lib().gs_workspace_bind(stream, self.fixed.data_ptr(), self.fixed.numel(), self.lists.data_ptr(),
                                               self.lists.numel(), layout._c_offsets, layout._c_bytes), "gs_workspace_bind")
+        self._bound = bound
+        stats["binds"] += 1
 
     def grow_lists(self, layout: Layout, stream: int) -> None:
         """Capacity exceeded: same call shape, larger list arena (the fixed arena -- records, offsets -- is kept as it is)."""
@@ -100,6 +108,7 @@ class Lease:
         self._ensure("lists", layout.arena_bytes[1])
         self.layout = layout
         self.cap = layout.key[4]
+        self._bound = (self.fixed.data_ptr(), self.lists.data_ptr(), layout.key)   # (the caller zeroes the info block itself)
         stats["list_grows"] += 1
 
     def ptr(self, slot: int) -> Optional[int]:

@@ -58,6 +58,17 @@ const char* gs_arch(void); /* "gfx950" */
  * step enqueued behind it -- is a no-op the host can detect later (read info_dev), re-size for, clear and replay.
  * n_isects / n_buckets / max_tile_count arguments of those entry points may then be the capacities. */
 int gs_guard_set(const int64_t* info_dev, int64_t cap_isects, int64_t cap_tile);
+/* The same guard for ONE call (the eager seam: every rasterization() enqueues its list stages and blend speculatively under it):
+ * the flags are not sticky across calls -- the call's first flag writer (gs_bins_count's bin scan, else gs_bin_count's tile scan)
+ * OVERWRITES info_dev[3], so the info block need not be zeroed between calls. */
+int gs_guard_set_call(const int64_t* info_dev, int64_t cap_isects, int64_t cap_tile);
+
+/* Host mirror of the info block (per host thread; NULL clears it): page-locked host memory the device can address
+ * (hipHostMalloc / torch pin_memory), int64[8].  While set, gs_bin_count / gs_bins_count have their last kernel write the eight
+ * info words there as well, followed by a system-scope fence: a caller that records an event behind the call and waits for it
+ * reads the list sizes and flags from plain memory -- no device-to-host copy (a 4 us transfer kernel and the idle gap behind
+ * it) on the stream.  The blocking `info_host` argument of those calls is independent of this. */
+int gs_info_mirror_set(int64_t* info_host_mapped);
 
 /* Publishes a guarded step's outcome without a copy or an event: one tiny launch writes
  * status[0..3] = info_dev[0..3] ({I, n_buckets, max tile, flags}) and status[4] = applied_dev[0] (may be NULL).
@@ -75,7 +86,8 @@ int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied
  * these flags); slots below GS_WS_LIST_FIRST live in the fixed arena (sized by C, N, image), the others in the list arena (sized
  * by cap_isects / coarse_cap); arena_bytes[2] = bytes of the two arenas.  Every offset is 256-byte aligned.
  * gs_workspace_bind: validates two caller-owned device arenas against a layout and zeroes the control words (info block, work-unit
- * counter) on `stream`.  The caller keeps one (fixed, list) pair per call in flight on a (device, stream) and hands the sub-pointers
+ * counter) on `stream`; needed once per (arena pair, layout) -- calls made under gs_guard_set_call leave nothing behind that the
+ * next call could trip over.  The caller keeps one (fixed, list) pair per call in flight on a (device, stream) and hands the sub-pointers
  * to the stage entry points below; a call whose lists outgrow the capacity (info flags, see gs_guard_set) replaces the list arena
  * only and repeats gs_bin_count .. gs_blend_fwd. */
 #define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, work-unit counter} */
