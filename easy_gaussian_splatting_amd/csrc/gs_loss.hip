@@ -24,7 +24,7 @@ constexpr int kHalo = 5;
 constexpr int kLR = kLT + 2 * kHalo;  // 42 staged rows / cols
 constexpr int kLRP = kLR + 1;         // padded row stride of the staged tiles
 constexpr int kHP = kLT + 1;          // row stride of the horizontal-pass buffers
-static_assert(kLT * (kLT / 4) == 256 && kLR * (kLT / 8) <= 256, "thread mapping of the separable passes");
+static_assert(kLT * (kLT / 4) == 256 && kLR * (kLT / 8) <= 256 && kLR * 6 <= 256, "thread mapping of the separable passes");
 static_assert(kLR % 2 == 0 && kLR * 3 <= 128, "staging: two 128-thread halves, one staged row each");
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
@@ -33,6 +33,9 @@ __device__ __constant__ float kWin[11] = {1.0283800845e-03f, 7.5987581352e-03f, 
                                           2.1300553771e-01f, 1.0936068951e-01f, 3.6000772128e-02f,
                                           7.5987581352e-03f, 1.0283800845e-03f};
 
+#ifndef GS_SSIM_HPASS_6
+#define GS_SSIM_HPASS_6 1
+#endif
 struct LossArgs {
     int H, W;
     int clamp_input;                   // render is the un-clamped image: clamp to [0,1] on load, mask the gradient
@@ -105,17 +108,26 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
         // horizontal 11-tap pass with a register sliding window: one thread = one staged row x 8
         // output columns (18 + 18 LDS reads feed 8 x 5 outputs); lanes run down the rows, so the
         // odd row strides keep the reads and the writes conflict-free
+#if GS_SSIM_HPASS_6
+        // 42 rows x 6 column groups of 6 outputs (the last group starts at column 26 and recomputes two): 252 of the 256
+        // threads work, 330 instead of 440 FMAs on the longest path (42 x 4 groups of 8 left a third of the block idle)
+        if (tid < kLR * 6) {
+            constexpr int kOut = 6, kWinN = kOut + 10;
+            const int g = tid / kLR, row = tid - g * kLR, c0 = min(kOut * g, kLT - kOut);
+#else
         if (tid < kLR * (kLT / 8)) {
+            constexpr int kOut = 8, kWinN = kOut + 10;
             const int g = tid / kLR, row = tid - g * kLR, c0 = 8 * g;
-            float xv[18], yv[18], xx[18], yy[18], xy[18];
+#endif
+            float xv[kWinN], yv[kWinN], xx[kWinN], yy[kWinN], xy[kWinN];
 #pragma unroll
-            for (int i = 0; i < 18; ++i) {
+            for (int i = 0; i < kWinN; ++i) {
                 xv[i] = X[row * kLRP + c0 + i]; yv[i] = Y[row * kLRP + c0 + i];
                 xx[i] = xv[i] * xv[i]; yy[i] = yv[i] * yv[i]; xy[i] = xv[i] * yv[i];
             }
             float* h = hp + row * kHP + c0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < kOut; ++j) {
                 float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 11; ++k) {
@@ -241,15 +253,22 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
 #endif
         if (GS_LOSS_BWD_PREFETCH && ch < 2) fetch(ch + 1);
         __syncthreads();
+#if GS_SSIM_HPASS_6
+        if (tid < kLR * 6) {   // horizontal pass, sliding window: one row x 6 columns per thread (see the forward kernel)
+            constexpr int kOut = 6, kWinN = kOut + 10;
+            const int g = tid / kLR, row = tid - g * kLR, c0 = min(kOut * g, kLT - kOut);
+#else
         if (tid < kLR * (kLT / 8)) {   // horizontal pass, sliding window: one row x 8 columns per thread
+            constexpr int kOut = 8, kWinN = kOut + 10;
             const int g = tid / kLR, row = tid - g * kLR, c0 = 8 * g;
+#endif
 #pragma unroll
             for (int mi = 0; mi < 3; ++mi) {
-                float w[18];
+                float w[kWinN];
 #pragma unroll
-                for (int i = 0; i < 18; ++i) w[i] = sm[(mi * kLR + row) * kLRP + c0 + i];
+                for (int i = 0; i < kWinN; ++i) w[i] = sm[(mi * kLR + row) * kLRP + c0 + i];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < kOut; ++j) {
                     float acc = 0.f;
 #pragma unroll
                     for (int k = 0; k < 11; ++k) acc = fmaf(kWin[k], w[j + k], acc);
