@@ -456,6 +456,9 @@ __global__ void tile_sort_kernel(const SortArgs a) {
 // Equal depths must come out in slot order (the stable-sort contract of the reference, A.3) but
 // arrive in arbitrary order: a tile in which an equal-depth pair is out of order -- practically
 // never -- is re-sorted on the full 64-bit key by the bitonic network.
+#ifndef GS_SORT_MATCH_SELECT
+#define GS_SORT_MATCH_SELECT 0
+#endif
 template <int T>
 __device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vblock) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
@@ -529,6 +532,7 @@ __device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vbl
                 const bool valid = i < w_hi;
                 const unsigned long long k = valid ? src[i] : 0ull;
                 const int d = (int)((k >> shift) & 255ull);
+#if GS_SORT_MATCH_SELECT
                 unsigned long long peers = __ballot(valid);
 #pragma unroll
                 for (int b = 0; b < 8; ++b) {
@@ -536,6 +540,19 @@ __device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vbl
                     const unsigned long long bm = __ballot(bit);
                     peers &= bit ? bm : ~bm;
                 }
+#else
+                // lanes whose digit differs from this lane's in bit b: ballot ^ (-bit) -- one sign-extending bit-field
+                // extract, one compare, two xor and two or per bit (the select form costs two cndmask + two and + a not more)
+                uint32_t mlo = 0u, mhi = 0u;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int e = __builtin_amdgcn_sbfe(d, b, 1);   // 0 or -1
+                    const unsigned long long bm = __ballot(e != 0);
+                    mlo |= (uint32_t)bm ^ (uint32_t)e;
+                    mhi |= (uint32_t)(bm >> 32) ^ (uint32_t)e;
+                }
+                const unsigned long long peers = __ballot(valid) & ~(((unsigned long long)mhi << 32) | (unsigned long long)mlo);
+#endif
                 if (valid) {
                     const int rank = __popcll(peers & lt_mask);
                     const uint32_t off = cnt[wave * 256 + d];
