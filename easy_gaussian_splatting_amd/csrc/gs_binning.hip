@@ -82,10 +82,11 @@ __global__ __launch_bounds__(kBinThreads) void bin_hist_kernel(int64_t N, int tw
         uint4 fp = make_uint4(0u, 0u, 0u, 0u);
         if (n < g1) { fp = bbox[(int64_t)c * N + n]; unpack_bbox(fp, x0, x1, y0, y1); }
         const int w = x1 - x0, rect = w * (y1 - y0), cnt = (int)fp.w;
+        const float inv_w = 1.0f / (float)max(w, 1);
         local += cnt;
         if (rect <= kCoopTiles)   // small footprints: one bit per tile of the rectangle
             for (uint32_t mb = fp.z; mb; mb &= mb - 1) {
-                const int i = __ffs((int)mb) - 1, yy = i / w;
+                const int i = __ffs((int)mb) - 1, yy = div_by_width(i, inv_w);
                 atomicAdd(&hist[(y0 + yy) * tw + x0 + (i - yy * w)], 1u);
             }
         unsigned long long big = __ballot(rect > kCoopTiles);
@@ -94,8 +95,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_hist_kernel(int64_t N, int tw
             big &= big - 1;
             const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w, src, 64),
                       bcnt = __shfl(cnt, src, 64);
+            const float binv = __shfl(inv_w, src, 64);
             for (int i = lane_id(); i < bcnt; i += 64) {
-                const int yy = i / bw;
+                const int yy = div_by_width(i, binv);
                 atomicAdd(&hist[(by0 + yy) * tw + bx0 + (i - yy * bw)], 1u);
             }
         }
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
         const float dcur = d_next;
         if (n < g1) unpack_bbox(fp, x0, x1, y0, y1);
         const int w = x1 - x0, rect = w * (y1 - y0), cnt = (int)fp.w;
+        const float inv_w = 1.0f / (float)max(w, 1);
         uint32_t total;
         const uint32_t slot0 = running + block_excl_scan_add((uint32_t)cnt, scratch, &total);
         running += total;
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
         if (rect <= kCoopTiles) {
             uint32_t k = 0;
             for (uint32_t mb = fp.z; mb; mb &= mb - 1, ++k) {
-                const int i = __ffs((int)mb) - 1, yy = i / w;
+                const int i = __ffs((int)mb) - 1, yy = div_by_width(i, inv_w);
                 const uint32_t pos = atomicAdd(&cursor[(y0 + yy) * tw + x0 + (i - yy * w)], 1u);
                 keys[pos] = ((unsigned long long)dbits << 32) | (slot_gid ? slot0 + k : (uint32_t)f);
                 if (slot_gid) slot_gid[slot0 + k] = (int32_t)f;
@@ -355,8 +358,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
                       bcnt = __shfl(cnt, src, 64);
             const uint32_t bslot = __shfl((int)slot0, src, 64), bd = __shfl((int)dbits, src, 64);
             const int32_t bf = (int32_t)(c * N + base) + (src + (threadIdx.x & ~63));
+            const float binv = __shfl(inv_w, src, 64);
             for (int i = lane_id(); i < bcnt; i += 64) {
-                const int yy = i / bw;
+                const int yy = div_by_width(i, binv);
                 const uint32_t pos = atomicAdd(&cursor[(by0 + yy) * tw + bx0 + (i - yy * bw)], 1u);
                 keys[pos] = ((unsigned long long)bd << 32) | (slot_gid ? bslot + i : (uint32_t)bf);
                 if (slot_gid) slot_gid[bslot + i] = bf;

@@ -69,6 +69,11 @@ struct BinLayout {
 };
 BinLayout bin_layout(int C, int64_t N, int tiles);
 
+// i / w for the small non-negative integers of a tile footprint (i < 2^20, w <= 2^12), w's reciprocal formed once per
+// footprint: exact ((i + 0.5) / w is at least 0.5 / w away from an integer, far beyond fp32 rounding), and 3 instructions
+// instead of the ~35 of a run-time integer division -- which was 20 % of the projection kernel's instruction count.
+__device__ __forceinline__ int div_by_width(int i, float inv_w) { return (int)(((float)i + 0.5f) * inv_w); }
+
 // ---- wavefront helpers (wave = 64 lanes on gfx950) ----
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -268,8 +268,9 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
             const float tau = __log2f(255.f * op) + 0.02f, lim = tau + 1e-4f * fabsf(tau);
             const float qa = 0.5f * kLog2e * s.A, qb = kLog2e * s.B, qc = 0.5f * kLog2e * s.C;
             tmask = 0u;
+            const float inv_rw = 1.0f / (float)rw;
             for (int i = 0; i < rect_tiles; ++i) {
-                const int ty = y0 + i / rw, tx = x0 + (i - (i / rw) * rw);
+                const int row = div_by_width(i, inv_rw), ty = y0 + row, tx = x0 + (i - row * rw);
                 const float dx0 = (float)(tx * GS_TILE) + 0.5f - s.mx, dy0 = (float)(ty * GS_TILE) + 0.5f - s.my;
                 if (quad_min_on_rect(qa, qb, qc, dx0, dx0 + (float)(GS_TILE - 1), dy0, dy0 + (float)(GS_TILE - 1)) <= lim) tmask |= 1u << i;
             }
