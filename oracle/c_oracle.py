@@ -48,7 +48,11 @@ def _c(a, dt):
 def render(means, quats, scales, opacities, colors, viewmats, Ks, width, height, sh_degree=None,
            backgrounds=None, near_plane=0.01, far_plane=1e10, radius_clip=0.0, eps2d=0.3,
            tile_size=16, dtype=np.float32) -> Dict[str, np.ndarray]:
-    """Full forward; returns dict with render_colors/alphas and all meta arrays."""
+    """Full forward; returns dict with render_colors/alphas and all meta arrays.
+    The scalar parameters are rounded to float32 first: that is how they arrive at the boundary (gsplat's kernels and the
+    C ABI here take `float eps2d` ...), and the fp64 build must restate the SAME inputs -- 0.3 as a double differs from
+    0.3f by 1.2e-8, enough to flip one `ceil(3 sqrt(lambda))` in 36 M Gaussians (found by a 3000-configuration sweep)."""
+    eps2d, near_plane, far_plane, radius_clip = (float(np.float32(v)) for v in (eps2d, near_plane, far_plane, radius_clip))
     L = _lib(dtype)
     R = ct.c_double if np.dtype(dtype) == np.float64 else ct.c_float
     means, quats, scales = _c(means, dtype), _c(quats, dtype), _c(scales, dtype)

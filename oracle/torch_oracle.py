@@ -62,7 +62,10 @@ def project(means: Tensor, quats: Tensor, scales: Tensor, viewmats: Tensor, Ks: 
             far_plane: float = 1e10, radius_clip: float = 0.0
             ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     """Appendix A.1.  Returns radii[C,N] int32, means2d[C,N,2], depths[C,N], conics[C,N,3].
-    Culled entries are exactly zero (and carry zero gradient)."""
+    Culled entries are exactly zero (and carry zero gradient).  The scalar parameters are taken as the float32 values that
+    reach the boundary (see oracle/c_oracle.py: render)."""
+    import numpy as _np
+    eps2d, near_plane, far_plane, radius_clip = (float(_np.float32(v)) for v in (eps2d, near_plane, far_plane, radius_clip))
     C = viewmats.shape[0]
     Rq = quat_to_rotmat(quats)                                   # [N,3,3]
     M = Rq * scales[:, None, :]                                  # Rq @ diag(s)
