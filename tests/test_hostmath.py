@@ -57,7 +57,7 @@ def test_projection_sh_forward_and_vjp(hm, deg, C, K, use_jac):
     Lo.gso_sh_bwd(C, N, K, deg, _p(a64["means"]), _p(a64["viewmats"]), _p(a64["shs"]), _p(rad_use), _p(fw["colors"]),
                   _p(vc), _p(v_shs), _p(v_means))
     Lo.gso_project_bwd(C, N, _p(a64["means"]), _p(a64["quats"]), _p(a64["scales"]), _p(a64["viewmats"]), _p(a64["Ks"]),
-                       W, H, D(0.3), D(0.01), D(1e10), _p(rad_use), _p(vm), None, _p(vcn), _p(v_means), _p(v_quats), _p(v_scales))
+                       W, H, D(float(np.float32(0.3))), D(float(np.float32(0.01))), D(1e10), _p(rad_use), _p(vm), None, _p(vcn), _p(v_means), _p(v_quats), _p(v_scales))
     h_means = np.zeros((N, 3), np.float32); h_quats = np.zeros((N, 4), np.float32)
     h_scales = np.zeros((N, 3), np.float32); h_shs = np.zeros((N, K, 3), np.float32)
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
