@@ -21,6 +21,7 @@ constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kAlphaMax = 0.999f;
 constexpr float kTMin = 1e-4f;
 constexpr float kRadiusDiscFloor = 0.01f;
+constexpr float kFovClamp = 1.3f;   // (the float32 value widened into the chain's type, like eps2d and the discriminant floor)
 
 // Per-camera constants, prepared once per launch on the device (see gs_kernels.hip: camera_prep).
 struct Camera {
@@ -36,8 +37,8 @@ struct Camera {
 // the one deviation above half an ulp the round-3 parity bounds found (tests/test_gpu_parity.py CONICS_RTOL).
 template <typename T>
 GS_HD void fov_limits(const Camera& cam, T& limx, T& limy) {
-    limx = (T)1.3 * ((T)cam.half_w / (T)cam.fx);
-    limy = (T)1.3 * ((T)cam.half_h / (T)cam.fy);
+    limx = (T)kFovClamp * ((T)cam.half_w / (T)cam.fx);
+    limy = (T)kFovClamp * ((T)cam.half_h / (T)cam.fy);
 }
 
 struct Splat2D {

@@ -45,8 +45,10 @@ typedef float real;
 #define ALPHA_MIN ((real)(1.0 / 255.0))
 #define ALPHA_MAX ((real)0.999)
 #define T_MIN ((real)1e-4)
-#define FOV_CLAMP ((real)1.3)
-#define RADIUS_DISC_FLOOR ((real)0.01)
+/* (as float32 values, like every scalar of the path: gsplat writes 1.3f and 0.01f, and the device chain widens the same floats --
+ *  0.01 as a double differs from 0.01f by 2e-10, enough to move a ceil(3 sqrt(lambda)) once in ~1e9 near-isotropic Gaussians) */
+#define FOV_CLAMP ((real)1.3f)
+#define RADIUS_DISC_FLOOR ((real)0.01f)
 
 static const real SH_C0 = (real)0.2820947917738781;
 static const real SH_C1 = (real)0.4886025119029199;

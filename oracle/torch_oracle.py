@@ -32,9 +32,9 @@ from torch import Tensor
 ALPHA_MIN = 1.0 / 255.0
 ALPHA_MAX = 0.999
 T_MIN = 1e-4
-FOV_CLAMP = 1.3
+FOV_CLAMP = 1.2999999523162842        # 1.3f: the float32 value, as in gsplat and in the device chain (oracle/c/gs_oracle.c)
 RADIUS_SIGMA = 3.0
-RADIUS_DISC_FLOOR = 0.01
+RADIUS_DISC_FLOOR = 0.009999999776482582   # 0.01f
 
 SH_C0 = 0.2820947917738781
 SH_C1 = 0.4886025119029199
