@@ -240,6 +240,101 @@ def smooth_target(H: int, W: int, seed: int, device):
                                            align_corners=False)[0].permute(1, 2, 0).contiguous()
 
 
+class ViewSchedule:
+    """`shuffle=True` of the reference's DataLoader (/root/reference/train.py:36-43): a fresh seeded permutation of the
+    views per epoch; rank r of `world` takes draws r, r + world, ... of the common stream (one view per GPU per step)."""
+
+    def __init__(self, n_views: int, world: int = 1, rank: int = 0, seed: int = 0):
+        import numpy as np
+        self.n, self.world, self.rank = n_views, world, rank
+        self.rng = np.random.RandomState(seed)
+        self.queue = []
+        self.step = 0          # 1-based iteration count after the first next(): what update_learning_rate receives
+
+    def next(self) -> int:
+        self.step += 1
+        picks = []
+        for _ in range(self.world):
+            if not self.queue:
+                self.queue = list(self.rng.permutation(self.n))
+            picks.append(int(self.queue.pop(0)))
+        return picks[self.rank]
+
+
+def real_loop(sc, device, lrs, datas, targets, mask, steps: int, refine_every: int, reset_at: int, captured: bool,
+              max_growth: float = 3.0):
+    """The reference's loop END TO END on the bench workload (/root/reference/train.py:93-157): a shuffled view every step,
+    update_statistics every step, `densify_and_prune` every `refine_every` steps (train.py:129-135; the reference's
+    refine_every is 200), ONE `reset_opacities` (at step `reset_at`) instead of the densification of that step, the
+    means-LR schedule every step -- wall clock from the first step to the last, re-builds / re-captures / overflow replays
+    of the captured step INCLUDED.  `captured`: train_graph.TrainStepGraph, else the eager model step.  A fresh model from the
+    same seed either way, so the two trajectories are comparable."""
+    import numpy as np
+    import torch
+    from easy_gaussian_splatting_amd.loss import LossComputer
+    from easy_gaussian_splatting_amd.model import build_optimizers
+    model = model_from_scene(sc, device)
+    opt = build_optimizers(model, *lrs, fused="hip")
+    lc = LossComputer(lambda_ssim=0.2, clamp_input=True)
+    sched = ViewSchedule(len(datas), seed=1)
+    gen = torch.Generator(device=device).manual_seed(7)   # split noise: the same stream in both modes
+    n0 = model.nbr_gaussians
+    runner = None
+    if captured:
+        from easy_gaussian_splatting_amd.train_graph import TrainStepGraph
+        runner = TrainStepGraph(model, opt, lc, datas[0], targets[0], mask, handback="lazy")
+    one = torch.ones((), device=device)
+    losses, traj, refine_s, drain_s = [], [n0], 0.0, 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, steps + 1):
+        v = sched.next()
+        if runner is not None:
+            runner.step(datas[v], targets[v], mask)
+        else:
+            out = model(datas[v], clamp=False)
+            loss3 = lc.get_loss_dict(out["render_img"], targets[v], mask)
+            loss3["total"].backward(gradient=one)
+            model.update_statistics(datas[v], out)
+            opt.step()
+            opt.zero_grad()
+            losses.append(loss3["total"].detach())
+        model.update_learning_rate(it)
+        if it % refine_every == 0 and it < steps:
+            td = time.perf_counter()
+            if runner is not None:
+                runner.finish()
+            torch.cuda.synchronize()   # (the refinement's one host read would drain the queue anyway: counted apart)
+            tr = time.perf_counter()
+            drain_s += tr - td
+            if it == reset_at:
+                model.reset_opacities()
+            elif model.nbr_gaussians <= max_growth * n0:
+                model.densify_and_prune(generator=gen)
+            traj.append(model.nbr_gaussians)
+            torch.cuda.synchronize()
+            refine_s += time.perf_counter() - tr
+    if runner is not None:
+        runner.finish()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if runner is not None:
+        tail = runner.loss_history(50)[:, 2]
+    else:
+        tail = torch.stack(losses[-50:])
+    out = {"train_iters_per_s": round(steps / wall, 2), "wall_s": round(wall, 3), "steps": steps,
+           "refine_every": refine_every, "reset_opacities_at": reset_at, "n_gaussians": traj,
+           "refine_wall_s": round(refine_s, 4), "queue_drain_wait_s": round(drain_s, 3), "loss_mean_last_50": round(float(tail.mean().item()), 6),
+           "finite": bool(torch.isfinite(tail).all().item())}
+    if runner is not None:
+        rep = runner.report()
+        out.update(captures=rep["captures"], overflows=rep["overflows"], replayed_steps=rep["replayed_steps"], rebuilds=rep["rebuilds"],
+                   build_ms=rep.get("build_ms"), capture_ms=rep.get("capture_ms"))
+    del runner, model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ the reference's loop, restated
 class DropInLoop:
     """What a maintainer of the reference gets from the ONE-LINE import change of INTEGRATION.md section 2 and nothing
@@ -390,11 +485,17 @@ def run_rank(args) -> int:
     n_views = max(8, world)
     sc, model = build_workload(args.gaussians, n_views, device)
     W, H = sc["width"], sc["height"]
+    # The reference's loop shape (/root/reference/train.py:36-43, 93-98): a DataLoader with shuffle=True hands the step a
+    # DIFFERENT view every iteration -- camera, target image and mask change, and with them the visible set and every list
+    # length.  The "dataset" is the 8 views of SURVEY.md 8d's generator, uploaded before the loop (the DataLoader itself
+    # is outside the metric, 8d); rank r of an N-rank job takes every N-th draw of the same seeded permutation stream.
+    datas = [{"w2c": torch.from_numpy(sc["viewmats"][v]).to(device), "K": torch.from_numpy(sc["Ks"][v]).to(device),
+              "width": W, "height": H} for v in range(n_views)]
+    targets = [smooth_target(H, W, 1234 + v, device) for v in range(n_views)]
     view = rank % n_views
-    data = {"w2c": torch.from_numpy(sc["viewmats"][view]).to(device), "K": torch.from_numpy(sc["Ks"][view]).to(device),
-            "width": W, "height": H}
-    gt_img = smooth_target(H, W, 1234 + view, device)
+    data, gt_img = datas[view], targets[view]      # the static-camera figures (`static_view`, forward fps, stage profile)
     mask = torch.zeros((H, W), device=device)
+    sched = ViewSchedule(n_views, world, rank, seed=0)
     lrs = (1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2)   # /root/reference/configs/tandt_db.yaml
     if args.torch_adam:
         optimizer = build_optimizers(model, *lrs, fused=True)
@@ -412,7 +513,7 @@ def run_rank(args) -> int:
 
     one = torch.ones((), device=device)   # root gradient, allocated once (backward() would fill a new one per step)
 
-    def train_step():
+    def train_step(data=data, gt_img=gt_img):
         if vp is not None:
             vp.begin_step(data)
         out = model(data, clamp=False)
@@ -441,19 +542,35 @@ def run_rank(args) -> int:
     if world == 1 and not force_dist and not args.no_graph and not args.torch_adam:
         try:
             from easy_gaussian_splatting_amd.train_graph import TrainStepGraph
-            graph_step = TrainStepGraph(model, optimizer, loss_computer, data, gt_img, mask, margin=float(os.environ.get('GS_TG_MARGIN', '1.3')))
+            # handback="lazy": this loop reads nothing between steps (the reference's three .item() reads per step feed
+            # TensorBoard: outside the metric), so the caller's stream stays idle and the wait every step
+            # performs on it is free; `inputs_ready` stays off
+            graph_step = TrainStepGraph(model, optimizer, loss_computer, data, gt_img, mask, margin=float(os.environ.get('GS_TG_MARGIN', '1.3')),
+                                        handback=os.environ.get("GS_TG_HANDBACK", "lazy"))
         except ImportError:
             graph_step = None
-    step_fn = graph_step.step if graph_step is not None else train_step
+
+    def loop_step():
+        """One iteration of the reference's loop: the next shuffled view (camera + target), the step, the means-LR
+        schedule (/root/reference/train.py:93-98, 140, 152-153)."""
+        v = sched.next()
+        if graph_step is not None:
+            graph_step.step(datas[v], targets[v], mask)
+        else:
+            train_step(datas[v], targets[v])
+        model.update_learning_rate(sched.step)
+
+    step_fn = loop_step
 
     def barrier():
         if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_loop(fn, steps, warmup, finish=None):
+    def timed_loop(fn, steps, warmup, finish=None, ev_stream=None):
         """EXACTLY `steps` calls of fn between barrier+synchronize brackets (wall clock, the contract's number),
-        with one HIP event per step boundary on the launch stream for the per-step distribution.  `finish` (the graph
+        with one HIP event per step boundary on the launch stream for the per-step distribution (`ev_stream`: the graph
+        runner's own stream -- with a lazy hand-back the caller's stream carries nothing).  `finish` (the graph
         runner's deferred overflow check + replay of skipped steps) runs INSIDE the timed bracket."""
         for _ in range(warmup):
             fn()
@@ -461,7 +578,7 @@ def run_rank(args) -> int:
             finish()
         barrier()
         rendering.stats["sync_wait_ns"] = 0
-        stream = torch.cuda.current_stream(device)
+        stream = ev_stream if ev_stream is not None else torch.cuda.current_stream(device)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
         evs[0].record(stream)
@@ -483,10 +600,20 @@ def run_rank(args) -> int:
 
     trace("setup done")
     # ---- train iterations (the timed region)
+    g_stream = None if graph_step is None else graph_step.stream
     elapsed, t_enqueued, step_ms, host_wait_ms = timed_loop(step_fn, args.steps, args.warmup,
-                                                            finish=None if graph_step is None else graph_step.finish)
+                                                            finish=None if graph_step is None else graph_step.finish, ev_stream=g_stream)
     trace("timed loop done")
     graph_report = None if graph_step is None else graph_step.report()   # (of the headline run: the extras re-capture the runner)
+    # the round-1..3 headline, kept for comparison: ONE static camera, no input copies, no LR change
+    static_view = None
+    if world == 1 and not force_dist:
+        if graph_step is not None:
+            graph_step.step(data, gt_img, mask)   # (the static buffers now hold view `view`; argument-less steps re-use them)
+        sfn = (lambda: graph_step.step()) if graph_step is not None else train_step
+        e_s, _, s_s, _ = timed_loop(sfn, args.steps, 10, finish=None if graph_step is None else graph_step.finish, ev_stream=g_stream)
+        static_view = {"train_iters_per_s": round(args.steps / e_s, 2), "train_ms": _percentiles(s_s),
+                       "note": "the same step replayed on one static camera and target (rounds 1-3's headline)"}
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -519,18 +646,37 @@ def run_rank(args) -> int:
                         "host_enqueue_ms_per_step": round(1e3 * q2 / ne, 4), "blocked_on_readback_ms_per_step": round(w2, 4)}
             if graph_step is not None:   # the same list mode under the captured step (the runner re-captures on the mode change)
                 try:
-                    e3, _, s3, _ = timed_loop(graph_step.step, ne, 10, finish=graph_step.finish)
+                    e3, _, s3, _ = timed_loop(graph_step.step, ne, 10, finish=graph_step.finish, ev_stream=g_stream)
                     lm[mode]["graph"] = {"train_iters_per_s": round(ne / e3, 2), "train_ms": _percentiles(s3), "runner": graph_step.report()}
                 except Exception as e:
                     lm[mode]["graph"] = {"error": repr(e)[:200]}
         extras["gsplat_list_mode"] = dict(lm["gsplat"], lists_materialised_by_the_render=lm["gsplat_eager"],
-                                          note="eager steps (+ the captured step under `graph`) with _tile_culling='gsplat': meta's list "
+                                          note="static view; eager steps (+ the captured step under `graph`) with _tile_culling='gsplat': meta's list "
                                                "arrays are gsplat's, built when read; 'lists_materialised_by_the_render' = 'gsplat_eager'")
         model.tile_culling = "tight"
-        e4, q4, s4, w4 = timed_loop(train_step, ne, 10)
+
+        def eager_loop_step():
+            v = sched.next()
+            train_step(datas[v], targets[v])
+            model.update_learning_rate(sched.step)
+
+        e4, q4, s4, w4 = timed_loop(eager_loop_step, ne, 10)
         extras["eager_tight"] = {"train_iters_per_s": round(ne / e4, 2), "train_ms": _percentiles(s4),
                                  "host_enqueue_ms_per_step": round(1e3 * q4 / ne, 4), "blocked_on_readback_ms_per_step": round(w4, 4),
-                                 "note": "the headline configuration enqueued step by step from Python (no hipGraph)"}
+                                 "note": "the headline loop (shuffled views, per-step means-LR) enqueued step by step from Python (no hipGraph)"}
+
+        # ---- real_loop: the reference's loop end to end (shuffled views, LR schedule, densify / reset), captured and eager
+        try:
+            n_rl = int(os.environ.get("GS_BENCH_REAL_LOOP_STEPS", "600"))
+            rl = {}
+            for tag, cap in (("captured", True), ("eager", False)):
+                rl[tag] = real_loop(sc, device, lrs, datas, targets, mask, steps=n_rl, refine_every=100, reset_at=400, captured=cap)
+            rl["what"] = ("reference loop shape end to end at the bench workload: shuffled views, update_statistics + means-LR every "
+                          "step, densify_and_prune every 100 steps (one reset_opacities at 400), wall clock INCLUDING re-captures, "
+                          "refinement and overflow replays; same seeds in both modes")
+            extras["real_loop"] = rl
+        except Exception as e:   # a secondary timing must never cost the bench line
+            extras["real_loop"] = {"error": repr(e)[:300]}
 
         # ---- drop_in: the reference's own loop body behind the one-line import change (DropInLoop above)
         try:
@@ -628,7 +774,7 @@ def run_rank(args) -> int:
                 for mode in ("gsplat_eager", "tight"):   # (gsplat's own lists walked by the captured step / the short lists)
                     mx.tile_culling = mode
                     runner = TrainStepGraph(mx, ox, LossComputer(lambda_ssim=0.2, clamp_input=True), dx, gx, None)
-                    ex, _, sx, _ = timed_loop(runner.step, n_steps, 5, finish=runner.finish)
+                    ex, _, sx, _ = timed_loop(runner.step, n_steps, 5, finish=runner.finish, ev_stream=runner.stream)
                     rep = runner.report()
                     outs[mode] = {"train_iters_per_s": round(n_steps / ex, 2), "train_ms": _percentiles(sx),
                                   "n_isects": rep["probed_isects"], "longest_list": rep["probed_longest_list"], "binning": rep["binning"],
@@ -731,6 +877,9 @@ def run_rank(args) -> int:
             "forward_step_ms": _percentiles(fwd_ms),
             "config": {"workload": f"{args.gaussians} Gaussians, {W}x{H}, SH degree {sc['sh_degree']}, "
                                    "1 view per GPU per step, full train step (fwd + L1/SSIM + bwd + stats + Adam)",
+                       "view_schedule": f"{n_views} views (camera + target image), a fresh seeded permutation per epoch "
+                                        "(DataLoader shuffle=True, /root/reference/train.py:36-43), a different view every "
+                                        "step, means-LR schedule updated every step (train.py:140); inputs_ready off",
                        "n_visible": n_vis, "n_isects": n_isects, "n_isects_gsplat_lists": n_isects_ref,
                        "list_mode": "tight (model default; image, radii, means2d and gradients identical to the gsplat-list mode)",
                        "parallelism": f"view-dp{world}", "exchange": exchange,
@@ -750,6 +899,8 @@ def run_rank(args) -> int:
             "roofline": roofline,
             "roofline_compute": rc_obj,
         }
+        if static_view is not None:
+            result["static_view"] = static_view
         if graph_report is not None:
             result["host"]["graph"] = graph_report
             if graph_report["overflows"]:

@@ -54,7 +54,18 @@ def _p(t: Optional[Tensor]):
 class TrainStepGraph:
     def __init__(self, model, optimizer: FusedAdam, loss_computer, data: Dict[str, Any], gt_img: Tensor,
                  mask: Optional[Tensor] = None, margin: float = 1.3, use_graph: bool = True, check_every: int = 16,
-                 fuse_adam: bool = True):
+                 fuse_adam: bool = True, handback: str = "eager"):
+        """`handback`: when the caller's stream is ordered behind a step.
+        "eager" (default): on return from every `step()` -- whatever the caller enqueues next (a read of the outputs, an eval
+        render that reads the parameters, `densify_and_prune`) sees the finished step, no thought required.
+        "lazy": only when the caller touches the returned outputs (`out["loss3"]`, ...), calls `fence()` or `finish()`.
+        A loop that looks at nothing between steps then leaves its own stream idle, and the wait every step performs on
+        entry (below) costs nothing; with the eager form that wait sits behind the previous step's hand-back on the caller's
+        stream -- two cross-queue signal hops, 24 us of idle GPU per step in the kernel trace of the bench loop.  Parameters
+        and statistics are NOT intercepted: a lazy caller that reads them between steps calls `fence()` first."""
+        if handback not in ("eager", "lazy"):
+            raise ValueError("handback: 'eager' or 'lazy'")
+        self.handback = handback
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("TrainStepGraph drives optim.FusedAdam (flat parameter / moment buffers)")
         if not getattr(loss_computer, "clamp_input", False) or not getattr(loss_computer, "fused", True):
@@ -78,6 +89,8 @@ class TrainStepGraph:
         self.cap = 0
         self.cap_floor = 0   # capacity carried over a rebuild: the probe sees ONE view, the steps before saw them all
         self.seen_isects = 0  # largest intersection count the status words have shown since the last (re-)build
+        self.seen_tile = 0    # ... and the longest tile list
+        self.binning = None
         self.probed = (0, 0)
         self.cap_tile = _SORT_CLASSES[0]
         self.pending: deque = deque()     # steps issued but not yet confirmed applied: (t, lrs, w2c, K, gt, mask)
@@ -100,9 +113,12 @@ class TrainStepGraph:
                 m.collecting_counts.data_ptr(), m.active_sh_degree, getattr(m, "tile_culling", "tight"),
                 self.W if W is None else int(W), self.H if H is None else int(H))
 
-    def _build(self, data, gt_img, mask, min_cap: int = 0, min_cap_tile: int = 0):
+    def _build(self, data, gt_img, mask, min_cap: int = 0, min_cap_tile: int = 0, projected=None):
         """(Re-)allocates the workspace for the model as it is now, learns the capacities from one blocking probe
-        of the list sizes if needed, warms every kernel up eagerly and captures the step."""
+        of the list sizes if needed, warms every kernel up eagerly and captures the step.
+        `projected` = (I, longest tile list) carried over from the steps before a refinement (`step()`): no probe, no
+        warm-up step -- the re-build is allocation + capture and never touches the device's queue.  (A projection that
+        does not hold trips the step guard like any overflow; `_recover` then probes.)"""
         m, dev = self.model, self.dev
         L = nat.lib()
         t_build = time.perf_counter()
@@ -153,7 +169,13 @@ class TrainStepGraph:
             "logit_opacities": torch.empty((N,), **f32)}
         b["hyper"] = torch.zeros((16,), **f32)
         self._set_inputs(data["w2c"], data["K"], gt_img, mask)
-        if self.cap == 0 or min_cap or min_cap_tile:
+        if projected is not None:
+            n_isects, max_tile = projected
+            self.cap = int(n_isects * self.margin) + 4096
+            need_tile = int(max_tile * self.margin)
+            self.cap_tile = next((c for c in _SORT_CLASSES if c >= need_tile), 1 << 30)
+            self.stats["projected_rebuilds"] = self.stats.get("projected_rebuilds", 0) + 1
+        elif self.cap == 0 or min_cap or min_cap_tile:
             n_isects, max_tile = self._probe()
             self.probed = (n_isects, max_tile)
             self.cap = max(int(max(n_isects, min_cap) * self.margin) + 4096, self.cap, self.cap_floor)
@@ -164,7 +186,7 @@ class TrainStepGraph:
         self._key = self._state_key()
         # eager warm-up of the guarded pipeline (raises every kernel attribute; also a functional check before capture)
         t_cap = time.perf_counter()
-        self._capture()
+        self._capture(warm_up=projected is None)
         self.stats["rebuilds"] += 1
         now = time.perf_counter()
         self.stats["build_ms"] = round(self.stats.get("build_ms", 0.0) + 1e3 * (now - t_build), 2)        # whole (re-)builds, wall clock
@@ -233,11 +255,12 @@ class TrainStepGraph:
 
     class _OnStepStream:
         """`with runner._on_stream():` -- everything inside is enqueued on the runner's stream, ordered after the
-        caller's current stream on entry and before it on exit."""
+        caller's current stream on entry and (`hand_back`) before it on exit."""
 
-        def __init__(self, runner, wait_outer: bool = True):
+        def __init__(self, runner, wait_outer: bool = True, hand_back: bool = True):
             self.r = runner
             self.wait_outer = wait_outer
+            self.hand_back = hand_back
 
         def __enter__(self):
             r = self.r
@@ -249,13 +272,49 @@ class TrainStepGraph:
 
         def __exit__(self, *exc):
             self.ctx.__exit__(*exc)
-            self.outer.wait_stream(self.r.stream)
+            if self.hand_back:
+                self.outer.wait_stream(self.r.stream)
             return False
 
-    def _on_stream(self, wait_outer: bool = True):
-        return TrainStepGraph._OnStepStream(self, wait_outer)
+    def _on_stream(self, wait_outer: bool = True, hand_back: bool = True):
+        return TrainStepGraph._OnStepStream(self, wait_outer, hand_back)
+
+    def fence(self):
+        """Orders the caller's current stream behind every step issued so far (what `handback="eager"` does on return from
+        each `step()`): call it before reading parameters / statistics / outputs on the caller's stream in "lazy" mode."""
+        torch.cuda.current_stream(self.dev).wait_stream(self.stream)
+
+    class _StepOutputs(dict):
+        """The runner's static output tensors; in `handback="lazy"` mode the first access orders the caller's current
+        stream behind the step that produced them."""
+
+        def __init__(self, runner, items, lazy: bool):
+            super().__init__(items)
+            self._runner, self._pending = runner, lazy
+
+        def _touch(self):
+            if self._pending:
+                self._pending = False
+                self._runner.fence()
+
+        def __getitem__(self, k):
+            self._touch()
+            return super().__getitem__(k)
+
+        def get(self, k, default=None):
+            self._touch()
+            return super().get(k, default)
+
+        def values(self):
+            self._touch()
+            return super().values()
+
+        def items(self):
+            self._touch()
+            return super().items()
 
     stop_after = int(__import__('os').environ.get('GS_TG_STOP_AFTER', '0'))
+    project_rebuilds = __import__('os').environ.get('GS_TG_PROJECT_REBUILDS', '1') != '0'   # 0: every re-build probes and warms up
     debug_sync = False   # set True to synchronise after every stage (locates a faulting kernel; never under capture)
 
     class _Stop(Exception):
@@ -402,26 +461,28 @@ class TrainStepGraph:
         nat.check(L.gs_adam_hyper(self._st(), ns, (ct.c_float * ns)(*lrs), float(b1), float(b2), int(t), _p(self.buf["hyper"])),
                   "gs_adam_hyper")
 
-    def _capture(self):
+    def _capture(self, warm_up: bool = True):
         """Warm-up outside capture is NOT possible without applying a step, so the first launch of every kernel
         happens on a throw-away copy of the optimizer state: parameters, moments and statistics are saved, one eager
-        guarded step runs (raising kernel attributes, validating capacities), and the state is restored."""
+        guarded step runs (raising kernel attributes, validating capacities), and the state is restored.
+        `warm_up=False` (a re-build on projected capacities: every kernel has run before in this process): capture only."""
         opt, m = self.opt, self.model
         names = ("max_radii", "grad_norm_accum", "collecting_counts")
         with torch.cuda.device(self.dev), self._on_stream():
-            saved = [opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()] + [getattr(m, n).clone() for n in names]
-            self._hyper(max(opt._step, 0) + 1, [float(grp["lr"]) for grp, _ in opt._plist])
-            self._enqueue_step()
-            self.stream.synchronize()
-            info = self.buf["info"].tolist()
-            with torch.no_grad():
-                opt.flat_param.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
-                for n, s in zip(names, saved[3:]):
-                    getattr(m, n).copy_(s)
-            self.buf["applied"].zero_()
-            if info[3] != 0:   # the capacities learnt from the probe do not hold (cannot happen unless inputs changed in between)
-                self.buf["info"].zero_()
-                raise RuntimeError(f"TrainStepGraph: warm-up step overflowed its own capacities {info}")
+            if warm_up:
+                saved = [opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()] + [getattr(m, n).clone() for n in names]
+                self._hyper(max(opt._step, 0) + 1, [float(grp["lr"]) for grp, _ in opt._plist])
+                self._enqueue_step()
+                self.stream.synchronize()
+                info = self.buf["info"].tolist()
+                with torch.no_grad():
+                    opt.flat_param.copy_(saved[0]); opt.exp_avg.copy_(saved[1]); opt.exp_avg_sq.copy_(saved[2])
+                    for n, s in zip(names, saved[3:]):
+                        getattr(m, n).copy_(s)
+                self.buf["applied"].zero_()
+                if info[3] != 0:   # the capacities learnt from the probe do not hold (cannot happen unless inputs changed in between)
+                    self.buf["info"].zero_()
+                    raise RuntimeError(f"TrainStepGraph: warm-up step overflowed its own capacities {info}")
             self.graph = None
             if self.use_graph:
                 g = torch.cuda.CUDAGraph()
@@ -429,21 +490,22 @@ class TrainStepGraph:
                     self._enqueue_step()
                 self.graph = g
                 self.stats["captures"] += 1
-            self.stream.synchronize()
+            if warm_up:
+                self.stream.synchronize()
         self.status.zero_()   # (nothing is in flight: the warm-up step's status words are stale)
         self.confirmed_at_build = self.confirmed
 
     # ------------------------------------------------------------------------------------------ stepping
     def _issue(self, entry):
         t, lrs, w2c, K, gt, mask, ready = entry
-        # A step that takes nothing from the caller (every input IS the runner's static buffer: "same as last step") need not
-        # wait for the caller's stream.  That wait is not free: the event it waits for sits behind the previous step's
-        # hand-back on the caller's stream, so step i+1 would start two cross-queue signal hops after step i ended (39 us of
-        # idle GPU per step in the kernel trace of the bench loop) instead of right behind it in stream order.
-        b = self.buf
-        own = (w2c.data_ptr() == b["viewmats"].data_ptr() and K.data_ptr() == b["Ks"].data_ptr() and gt.data_ptr() == b["gt"].data_ptr()
-               and (not self.has_mask or (mask is not None and mask.data_ptr() == b["mask"].data_ptr())))
-        with torch.cuda.device(self.dev), self._on_stream(wait_outer=not (own or ready)):
+        # The step waits for the caller's stream on entry: that orders it behind pending WRITERS of the inputs handed in and
+        # behind pending READERS of what the replay overwrites -- the static outputs the previous `step()` returned, the
+        # parameters and moments (fused Adam), the statistics.  (Round 3 skipped the wait for steps that take no input from
+        # the caller; a loss accumulation, a PSNR kernel or an eval render queued on the caller's stream after step i could
+        # then run concurrently with replay i+1: ADVICE r3.)  Only `inputs_ready=True` -- the caller's promise that its
+        # stream holds neither -- skips it.  The wait is free when the caller's stream is idle, i.e. with handback="lazy" in a
+        # loop that reads nothing between steps; behind an eager hand-back it costs two cross-queue signal hops.
+        with torch.cuda.device(self.dev), self._on_stream(wait_outer=not ready, hand_back=self.handback == "eager"):
             self._set_inputs(w2c, K, gt, mask)
             self._hyper(t, lrs)
             if self.graph is not None:
@@ -456,9 +518,11 @@ class TrainStepGraph:
     def step(self, data: Optional[Dict[str, Any]] = None, gt_img: Optional[Tensor] = None, mask: Optional[Tensor] = None,
              inputs_ready: bool = False):
         """One training iteration.  `data` / `gt_img` / `mask` default to the previous step's (static buffers are
-        re-used as they are).  Returns the runner's static output tensors (valid until the next step).
-        `inputs_ready=True` is the caller's promise that no work still pending on its stream writes the tensors handed in
-        (a dataset uploaded before the loop started): the step then does not wait for the caller's stream (see `_issue`)."""
+        re-used as they are).  Returns the runner's static output tensors (valid until the next `step()` is CALLED: reads
+        enqueued on the caller's stream before that call are ordered in front of the replay that overwrites them).
+        `inputs_ready=True` is the caller's promise that no work still pending on its stream (a) writes the tensors handed
+        in, (b) reads the outputs of an earlier step, the model's parameters or its statistics: the step then does not wait
+        for the caller's stream (see `_issue`).  Without the promise every step does."""
         W, H = (self.W, self.H) if data is None else (int(data["width"]), int(data["height"]))
         if self._state_key(W, H) != self._key:
             self.finish()
@@ -478,10 +542,19 @@ class TrainStepGraph:
             # wider one (tools/train_soak.py: 153 of 700 steps were replayed before this).  Not the old CAPACITY scaled: that
             # compounds margin on margin, and every kernel whose grid is sized by the capacity pays for the empty workgroups
             n_new = self.model.means.shape[0]
-            self.cap_floor = 0 if size_changed else min(int(self.seen_isects * max(1.0, n_new / max(self.N, 1)) * self.margin), (1 << 29) - 1)
-            self.seen_isects = 0
+            growth = max(1.0, n_new / max(self.N, 1))
+            self.cap_floor = 0 if size_changed else min(int(self.seen_isects * growth * self.margin), (1 << 29) - 1)
+            # ... and when that history exists (same frame size, per-tile binning, a model that grew by less than 2 x) the
+            # re-build needs no probe at all: the host never reads the device between the refinement and the next replay
+            # (bench.py `real_loop`: a probing re-build cost 5.5 ms + a throw-away warm-up step per refinement, more than the
+            # 100 captured steps in between had saved against the eager loop)
+            projected = None
+            if (not size_changed and self.binning == "tiles" and self.seen_isects > 0 and growth <= 2.0 and self.project_rebuilds
+                    and self._key is not None and self._state_key(W, H)[5:] == self._key[5:]):
+                projected = (min(int(self.seen_isects * growth), (1 << 29) // 2), max(int(self.seen_tile * min(growth, 1.25)), 64))
+            self.seen_isects = self.seen_tile = 0
             self.cap = 0
-            self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None)
+            self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None, projected=projected)
         b = self.buf
         w2c = b["viewmats"][0] if data is None else data["w2c"]
         K = b["Ks"][0] if data is None else data["K"]
@@ -497,7 +570,8 @@ class TrainStepGraph:
         self._issue([opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk, bool(inputs_ready)])
         if self.issued % self.check_every == 0:
             self._poll(block=False)
-        return {"render_img": b["render_colors"][0], "loss3": b["loss3"], "batch_radii": b["radii"], "absgrad": b["v_abs"]}
+        return TrainStepGraph._StepOutputs(self, {"render_img": b["render_colors"][0], "loss3": b["loss3"], "batch_radii": b["radii"],
+                                                  "absgrad": b["v_abs"]}, lazy=self.handback == "lazy")
 
     def _poll(self, block: bool):
         """Reads the device-written status words (plain host memory) and retires the steps known to be applied."""
@@ -505,6 +579,7 @@ class TrainStepGraph:
             self.stream.synchronize()
         n_isects, _, max_tile, flags, applied = (int(v) for v in self.status[:5].tolist())
         self.seen_isects = max(self.seen_isects, n_isects)
+        self.seen_tile = max(self.seen_tile, max_tile)
         done = min(self.confirmed_at_build + applied - self.confirmed, len(self.pending))
         for _ in range(max(done, 0)):
             self.pending.popleft()

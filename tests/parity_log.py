@@ -17,7 +17,9 @@ def record(**fields) -> None:
     """Merges `fields` into the running test's record; numeric fields that repeat keep their maximum, `n_*` counters add."""
     rec = RECORDS.setdefault(_test_id(), OrderedDict(checks=0))
     for k, v in fields.items():
-        if isinstance(v, dict):
+        if isinstance(v, dict) and not all(isinstance(vv, (int, float)) and not isinstance(vv, bool) for vv in v.values()):
+            rec[k] = v   # a structured note (lists, nested reports): stored as it is
+        elif isinstance(v, dict):
             cur = rec.setdefault(k, {})
             for kk, vv in v.items():
                 cur[kk] = max(cur.get(kk, 0.0), float(vv))
@@ -43,7 +45,17 @@ def dump(path: str) -> None:
         for k, v in r.get("max_rel_grad_err", {}).items():
             worst[k] = max(worst.get(k, 0.0), v)
     tot["max_rel_grad_err"] = worst
+    for key in ("max_rel_l2_grad_err", "max_row_bad_frac", "unmasked_vs_fp32_max", "unmasked_vs_fp32_l2", "unmasked_vs_fp32_rows_beyond_1e3"):
+        w = {}
+        for r in RECORDS.values():
+            for k, v in r.get(key, {}).items():
+                w[k] = max(w.get(k, 0.0), v)
+        tot[key] = w
+    tot["n_needles_relaxed"] = sum(int(r.get("n_needles_relaxed", 0)) for r in RECORDS.values())
+    tot["n_visible_gaussians_checked"] = sum(int(r.get("n_visible_gaussians", 0)) for r in RECORDS.values())
+    tot["n_unmasked_backward_checks"] = sum(int(r.get("n_unmasked_backward_checks", 0)) for r in RECORDS.values())
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
-        json.dump({"summary": tot, "tolerances": {"forward_abs": 1e-4, "grad_rel": 1e-3, "means2d_ulps": 1.0, "conics_rel": 2.4e-7,
+        json.dump({"summary": tot, "tolerances": {"forward_abs": 1e-4, "grad_rel": 1e-3, "grad_rel_l2": 1e-4, "row_bad_frac": 2e-3,
+                                                  "unmasked_l2": 5e-4, "unmasked_max": 1e-2, "means2d_ulps": 1.0, "conics_rel": 2.4e-7,
                                                   "depths_rel": 2.4e-7}, "tests": RECORDS}, f, indent=1)

@@ -233,3 +233,109 @@ def test_graph_step_equals_eager_step_at_bench_size():
     _assert_same(ma, oa, mb, ob, "bench size")
     rep = runner.report()
     assert rep["graph"] and rep["steps"] == 3 and rep["probed_isects"] > 2_000_000
+
+
+@pytest.mark.parametrize("handback", ["eager", "lazy"])
+def test_pending_readers_on_the_callers_stream_are_ordered_before_the_next_replay(handback):
+    """the replay of step i+1 overwrites the static outputs step i returned and (fused Adam) the parameters.
+    Work the caller queued on ITS stream after step i -- here a copy of the image and of a parameter, parked behind a long
+    sleep kernel -- must still see step i's values, whether the next step takes inputs from the caller or not."""
+    dev, make, datas, gts = _setup()
+    (ma, oa), (mb, ob) = make(), make()
+    lc = LossComputer(0.2, clamp_input=True)
+    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], None, handback=handback)
+    kept_img, kept_means, ref_img, ref_means = [], [], [], []
+    for it in range(4):
+        # reference: the eager step, read back synchronously
+        out_ref = ma(datas[0], clamp=False)
+        loss = lc.get_loss_dict(out_ref["render_img"], gts[0], None)
+        loss["total"].backward()
+        ma.update_statistics(datas[0], out_ref)
+        oa.step(); oa.zero_grad()
+        ref_img.append(out_ref["render_img"].detach().clone())
+        ref_means.append(ma.means.detach().clone())
+        # runner: argument-less steps from the second on ("takes nothing from the caller")
+        out = runner.step(datas[0], gts[0]) if it == 0 else runner.step()
+        img = out["render_img"]                # (lazy mode: this access is the hand-back)
+        torch.cuda._sleep(40_000_000)          # ~20 ms on the caller's stream: the readers below are still pending ...
+        kept_img.append(img.clone())
+        kept_means.append(mb.means.detach().clone())
+        # ... when the next step is issued (no finish(), no synchronize in between)
+    runner.finish()
+    torch.cuda.synchronize()
+    for it in range(4):
+        assert torch.equal(kept_img[it], ref_img[it]), ("image torn by the next replay", it)
+        assert torch.equal(kept_means[it], ref_means[it]), ("parameters torn by the next replay", it)
+
+
+def test_soak_reference_loop_shape_captured_equals_eager():
+    """The reference's loop shape END TO END (/root/reference/train.py:93-157): a different view every step, the means-LR
+    schedule every step, densify_and_prune every 100 steps with one reset_opacities, 700 steps at 150 k Gaussians / 800x800:
+    the captured runner (re-captures after every refinement, lazy hand-back) must follow the eager loop's loss to four digits,
+    stay finite, and need no overflow replay after the first refinement (the capacity carried over a re-build, scaled with N)."""
+    dev = torch.device("cuda:0")
+    N, W, H, V = 150_000, 800, 800, 6
+    sc = make_scene(N, W, H, sh_degree=3, n_views=V, seed=3, scale_range=(0.01, 0.06), dist=5.0)
+    T = torch.from_numpy
+
+    def model_from(noise, seed):
+        g = torch.Generator().manual_seed(seed)
+        op = np.clip(sc["opacities"], 1e-3, 1 - 1e-3)
+        shs = T(sc["shs"])
+        m = GaussianModel(means=T(sc["means"]) + noise * 0.02 * torch.randn(sc["means"].shape, generator=g),
+                          log_scales=torch.log(T(sc["scales"])) + noise * 0.2 * torch.randn(sc["scales"].shape, generator=g),
+                          quats=T(sc["quats"]), sh_0=(shs[:, :1] + noise * 0.3 * torch.randn(shs[:, :1].shape, generator=g)).contiguous(),
+                          sh_rest=(shs[:, 1:] * (1 - noise)).contiguous(), logit_opacities=T(np.log(op / (1 - op)).astype(np.float32)),
+                          sh_degree=3, white_background=True).to(dev)
+        return m, build_optimizers(m, *LRS, fused="hip")
+
+    datas = [{"w2c": T(sc["viewmats"][v]).to(dev), "K": T(sc["Ks"][v]).to(dev), "width": W, "height": H} for v in range(V)]
+    with torch.no_grad():
+        ref, _ = model_from(0.0, 0)
+        targets = [ref(d)["render_img"].clone() for d in datas]
+    del ref
+    order = np.random.RandomState(5).randint(0, V, size=701)   # the DataLoader's shuffle: no fixed period
+
+    def run(captured):
+        model, opt = model_from(1.0, 1)
+        lc = LossComputer(0.2, clamp_input=True)
+        gen = torch.Generator(device=dev).manual_seed(9)
+        runner = TrainStepGraph(model, opt, lc, datas[0], targets[0], None, handback="lazy") if captured else None
+        means, ns, losses = [], [N], []
+        overflows_after_first_refinement = 0
+        for it in range(1, 701):
+            v = int(order[it])
+            if runner is not None:
+                runner.step(datas[v], targets[v])
+            else:
+                losses.append(_eager_step(model, opt, lc, datas[v], targets[v])[2])
+            model.update_learning_rate(it)
+            if it % 100 == 0:
+                if runner is not None:
+                    runner.finish()
+                    means.append(float(runner.loss_history(50)[:, 2].mean().item()))
+                    if it == 100:
+                        ov0 = runner.report()["overflows"]
+                else:
+                    means.append(float(torch.stack(losses[-50:]).mean().item()))
+                if it == 400:
+                    model.reset_opacities()
+                elif it < 700:
+                    model.densify_and_prune(generator=gen)
+                ns.append(model.nbr_gaussians)
+        rep = None
+        if runner is not None:
+            rep = runner.report()
+            overflows_after_first_refinement = rep["overflows"] - ov0
+        return means, ns, rep, overflows_after_first_refinement
+
+    m_e, n_e, _, _ = run(False)
+    m_g, n_g, rep, late_overflows = run(True)
+    assert n_e == n_g, (n_e, n_g)                       # the same refinement decisions
+    assert all(np.isfinite(m_g)) and m_g[-1] < m_g[0]    # finite, decreasing
+    np.testing.assert_allclose(m_g, m_e, rtol=1e-4)
+    assert late_overflows == 0, rep
+    assert rep["captures"] >= 7 and rep["steps"] == 700
+    import parity_log
+    parity_log.record(soak={"steps": 700, "n_gaussians": n_g, "loss_mean_last_50_per_100_captured": m_g,
+                            "loss_mean_last_50_per_100_eager": m_e, "runner": rep})
