@@ -62,6 +62,26 @@ struct BlendFwdArgs {
 constexpr int kUnit = 32;
 constexpr int kUnitFirst = 0x100;   // unit_desc.y flag: first unit of its sublist (no checkpoint was written for it)
 
+// -DGS_CLOCK_PROBE (tools/clock_probe.sh; never in the product build): every wave of the two blend kernels adds the shader-clock
+// cycles (s_memtime) and the constant-rate ticks (s_memrealtime) between its first and last instruction to two device
+// words -- their ratio is the shader clock the kernel actually ran at (profiles/r04_clock.json).
+#ifdef GS_CLOCK_PROBE
+__device__ unsigned long long gs_clk_acc[4];   // {fwd cycles, fwd ticks, bwd cycles, bwd ticks}
+struct ClockProbe {
+    long long c0, w0; int slot;
+    __device__ ClockProbe(int s) : c0(clock64()), w0(wall_clock64()), slot(s) {}
+    __device__ ~ClockProbe() {
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&gs_clk_acc[slot], (unsigned long long)(clock64() - c0));
+            atomicAdd(&gs_clk_acc[slot + 1], (unsigned long long)(wall_clock64() - w0));
+        }
+    }
+};
+#define GS_CLOCK_PROBE_SCOPE(slot) ClockProbe clock_probe_(slot)
+#else
+#define GS_CLOCK_PROBE_SCOPE(slot)
+#endif
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
@@ -128,6 +148,9 @@ __global__ __launch_bounds__(256) void qmask_clear_kernel(uint8_t* __restrict__ 
 #ifndef GS_FWD_SKIP_FIRST_CKPT
 #define GS_FWD_SKIP_FIRST_CKPT 0
 #endif
+#ifndef GS_EXP_CKPT_EVERY
+#define GS_EXP_CKPT_EVERY 1   // (timing experiment only: > 1 breaks the backward)
+#endif
 #ifndef GS_FWD_QMASK_SCATTER
 #define GS_FWD_QMASK_SCATTER 0   // 1: the round-2 form (every entry stores its mask byte, tails cleared by the tile itself)
 #endif
@@ -139,6 +162,7 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
     const int ti = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
     if (ti >= a.C * a.tiles) return;   // wave-uniform
     if (guard_tripped(a.guard)) return;
+    GS_CLOCK_PROBE_SCOPE(0);
     const int t = a.tile_order ? a.tile_order[ti] : ti;   // launch slot -> tile (longest lists first)
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
     const int tyi = tt / a.tw, txi = tt - tyi * a.tw;
@@ -237,7 +261,7 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
                         if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;   // no pixel of the quadrant takes it: nothing to blend, nothing to list
                         // the sublist entry that opens a new work unit saves the pixel states before it
                         const int pos = cnt[k] + (int)__popcll(cq[k]);
-                        if ((pos & (kUnit - 1)) == 0 && (pos != 0 || !GS_FWD_SKIP_FIRST_CKPT))
+                        if ((pos & (kUnit * GS_EXP_CKPT_EVERY - 1)) == 0 && (pos != 0 || !GS_FWD_SKIP_FIRST_CKPT))
                             a.ckpt[((size_t)8 * bucket0 + (size_t)k * (2 * nb) + pos / kUnit) * 64 + lane] =
                                 make_float4(px_live(T[k]) ? T[k] : -1.f, cr[k], cg[k], cb[k]);   // (the backward's "finished" is T < 0)
                         cq[k] |= 1ull << j;
@@ -391,6 +415,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
     const int n_units = a.unit_counter[0];
     const int unit = ((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave + pipe;
     if (((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave >= n_units) return;   // wave-uniform
+    GS_CLOCK_PROBE_SCOPE(2);
     const bool valid = unit < n_units;
     float4* sd0 = sd0_all[wave][pipe];
     float2* sck = sck_all[wave][pipe];
@@ -517,6 +542,15 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
 }  // namespace gs
 
 using namespace gs;
+
+#ifdef GS_CLOCK_PROBE
+extern "C" int gs_debug_clock_probe(int64_t* out4, int reset) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (out4) { GS_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(gs_clk_acc), sizeof(h))); for (int i = 0; i < 4; ++i) out4[i] = (int64_t)h[i]; }
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; GS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(gs_clk_acc), z, sizeof(z))); }
+    return GS_OK;
+}
+#endif
 
 extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                             const float* backgrounds, const int32_t* isect_offsets,

@@ -391,17 +391,23 @@ def test_config_s5_4k_against_oracle():
     fw = run_oracle(sc)
     fw32 = run_oracle(sc, dtype=np.float32)
     t_or = time.time() - t0
-    hip = run_hip(sc, fw=fw)
-    exact = check_forward(hip, fw, outlier_frac=1e-5)
-    check_forward(hip, fw32, geom_slack=1e3)
+    hip = run_hip(sc, fw=fw, max_flip_tile_frac=0.05)
+    # (razor pixels grow with the contributors per pixel: 0.3 % at S2, 1.5 % at 1 M, 1.7 % at 2 M, 2.2 % here; the suite's
+    #  hard limit is 5 %)
+    exact = check_forward(hip, fw, outlier_frac=1e-5, max_razor_frac=0.03, max_flip_tile_frac=0.05)
+    # (the fp32 build's own geometry is tens of ulps off the fp64 truth: 80 of its 5 M radii / rectangles differ from the
+    #  path's, and the tiles those touch are exempt; against the fp64 oracle above: 0 flips, lists identical)
+    check_forward(hip, fw32, geom_slack=1e3, max_razor_frac=0.03, max_flip_tile_frac=0.05)
     assert int(hip["meta"]["flatten_ids"].numel()) == fw["n_isects"] or not exact
     t0 = time.time()
     check_backward(hip, fw)
     parity_log.record(oracle_forward_s=round(t_or, 1), oracle_backward_s=round(time.time() - t0, 1), n_isects_gsplat=int(fw["n_isects"]))
     hip_t = run_hip(sc, culling="tight", upstream=(hip["vc"], hip["va"]))
     assert hip_t["meta"]["flatten_ids"].numel() < hip["meta"]["flatten_ids"].numel()
-    check_forward(hip_t, fw32, lists=False, geom_slack=1e3)
-    for a, b in zip(hip_t["grads"], hip["grads"]):
+    # the short lists render the SAME image bit for bit (so every forward check above holds for them) ...
+    assert torch.equal(hip_t["img"], hip["img"]) and torch.equal(hip_t["alpha"], hip["alpha"])
+    assert torch.equal(hip_t["meta"]["radii"], hip["meta"]["radii"]) and torch.equal(hip_t["meta"]["means2d"], hip["meta"]["means2d"])
+    for a, b in zip(hip_t["grads"], hip["grads"]):   # ... and the same gradients to rounding
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
 
 

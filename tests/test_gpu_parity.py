@@ -34,7 +34,7 @@ def to_dev(sc):
     return {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev()) for k, v in sc.items() if isinstance(v, np.ndarray) and v.dtype.kind == "f"}
 
 
-def run_hip(sc, bwd=True, seed=0, use_bg=True, dbg=None, culling="gsplat", fw=None, upstream=None):
+def run_hip(sc, bwd=True, seed=0, use_bg=True, dbg=None, culling="gsplat", fw=None, upstream=None, max_flip_tile_frac=0.02):
     """With `fw` (the oracle's forward of the same scene) the random upstream gradients are zeroed on the pixels
     where the contributor set itself is undecided between fp32 and fp64 (loose_pixels), so that check_backward
     compares like with like: the gradient of the pixels on which both sides blend the same list."""
@@ -52,15 +52,15 @@ def run_hip(sc, bwd=True, seed=0, use_bg=True, dbg=None, culling="gsplat", fw=No
         if upstream is not None:   # the (masked) upstream gradients of an earlier run of the same scene
             vc, va = (torch.from_numpy(x).float() for x in upstream)
         elif fw is not None:
-            vc, va = mask_upstream(out, fw, vc, va, lists=culling != "tight")
+            vc, va = mask_upstream(out, fw, vc, va, lists=culling != "tight", max_flip_tile_frac=max_flip_tile_frac)
         out["vc"], out["va"] = vc.numpy().astype(np.float64), va.numpy().astype(np.float64)
         out["grads"] = torch.autograd.grad((img * vc.to(dev())).sum() + (alpha * va.to(dev())).sum(), ins)
     torch.cuda.synchronize()
     return out
 
 
-def mask_upstream(hip, fw, vc, va, lists=True):
-    rep = hip["report"] = forward_report(hip["meta"], fw, lists)
+def mask_upstream(hip, fw, vc, va, lists=True, max_flip_tile_frac=0.02):
+    rep = hip["report"] = forward_report(hip["meta"], fw, lists, max_flip_tile_frac=max_flip_tile_frac)
     rep["fw"] = fw
     keep = torch.from_numpy(~rep["loose"])
     return vc * keep[..., None], va * keep[..., None]
@@ -158,7 +158,7 @@ def razor_mask(fw):
     return fw["_razor"]
 
 
-def forward_report(meta, fw, lists=True, geom_slack=1.0):
+def forward_report(meta, fw, lists=True, geom_slack=1.0, max_flip_tile_frac=0.02):
     """Integer outputs against the oracle's.  They are bit-exact except where the last-bit difference of two fp64
     evaluations crosses an integer decision: radius = ceil(3 sigma) (+-1); an edge mu +- r of the tile rectangle landing
     on a tile boundary; two depths that swap order.  Such Gaussians are counted, recorded (parity_log) and printed, must be
@@ -195,6 +195,19 @@ def forward_report(meta, fw, lists=True, geom_slack=1.0):
             assert edge.sum() <= max(1, 2e-4 * edge.size)
             n_edge = int(edge.sum())
         differ |= edge
+    if geom_slack > 1.0:
+        # the reference is NOT the fp64 run of the same inputs (the fp32 build of the oracle, whose own geometry is tens of
+        # ulps off): a rectangle can also differ with the same tile count, or -- in the short-list mode -- without being
+        # compared at all.  Each side's 3-sigma rectangle from its own (means2d, radius); Gaussians whose rectangles differ
+        # exempt the tiles they touch, and must be as rare as the flips above.
+        def rects(m2, r):
+            lo = np.clip(np.floor((m2 - r[..., None]) / tile), 0, [fw["tile_width"], fw["tile_height"]])
+            hi = np.clip(np.ceil((m2 + r[..., None]) / tile), 0, [fw["tile_width"], fw["tile_height"]])
+            return np.concatenate([lo, hi], axis=-1)
+        shifted = (rects(meta["means2d"].cpu().numpy().astype(np.float64), radii.astype(np.float64))
+                   != rects(fw["means2d"].astype(np.float64), fw["radii"].astype(np.float64))).any(-1) & same
+        assert shifted.sum() <= max(1, 2e-4 * shifted.size), f"{int(shifted.sum())} rectangles differ from the fp32 reference's"
+        differ |= shifted
     tmask = _affected_tiles(meta, fw, differ) if differ.any() else np.zeros((radii.shape[0], fw["tile_height"], fw["tile_width"]), bool)
     exact_lists = not differ.any()
     if lists:  # integer / index work is bit-exact wherever no rounding flip reaches
@@ -202,7 +215,9 @@ def forward_report(meta, fw, lists=True, geom_slack=1.0):
             assert np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), fw["tiles_per_gauss"])
             assert np.array_equal(meta["isect_offsets"].cpu().numpy(), fw["isect_offsets"])
         else:
-            assert tmask.mean() <= 0.02 or tmask.sum() <= 16, f"{tmask.mean()} of the tiles touched by rounding flips"
+            # (the flipped Gaussians themselves are bounded above -- 1e-4 N radii, 2e-4 N rectangles; this bounds the TILES they
+            #  exempt: 2 % by default; 5 M Gaussians at 4K put 80 flips (1.6e-5 N) on 2.8 % of the tiles and pass 0.05)
+            assert tmask.mean() <= max_flip_tile_frac or tmask.sum() <= 16, f"{tmask.mean()} of the tiles touched by rounding flips"
         swapped = _compare_lists(meta, fw, tmask)
         if swapped.any():
             exact_lists = False
@@ -216,13 +231,13 @@ def forward_report(meta, fw, lists=True, geom_slack=1.0):
     return dict(exact_lists=exact_lists, razor=razor, loose=loose, lists=lists)
 
 
-def check_forward(hip, fw, max_razor_frac=2e-2, lists=True, outlier_frac=0.0, geom_slack=1.0):
+def check_forward(hip, fw, max_razor_frac=2e-2, lists=True, outlier_frac=0.0, geom_slack=1.0, max_flip_tile_frac=0.02):
     """Forward parity: forward_report's integer checks, then every pixel outside `loose` within 1e-4; razor pixels must
     stay rare and even they are bounded by one flipped contributor's weight."""
     assert max_razor_frac <= MAX_RAZOR_FRAC
     rep = hip.get("report")
     if rep is None or rep["lists"] != lists or rep.get("fw") is not fw:
-        rep = forward_report(hip["meta"], fw, lists, geom_slack)
+        rep = forward_report(hip["meta"], fw, lists, geom_slack, max_flip_tile_frac)
     err = np.abs(hip["img"].detach().cpu().numpy() - fw["render_colors"]).max(-1)
     aerr = np.abs(hip["alpha"].detach().cpu().numpy() - fw["render_alphas"])[..., 0]
     razor, strict = rep["razor"], ~rep["loose"]
@@ -257,7 +272,7 @@ def needle_factor(fw):
 
 GRAD_L2_RTOL = 1e-4        # ||hip - ref||_2 / ||ref||_2 per tensor
 ROW_FLOOR = 1e-3           # per-Gaussian criterion: |delta| <= rtol * max(|ref row|_max, ROW_FLOOR * tensor max)
-ROW_BAD_MAX = 2e-3         # fraction of Gaussians (rows) allowed beyond the per-Gaussian criterion (0.2 %: bounded below)
+ROW_BAD_MAX = 1e-3         # fraction of Gaussians (rows) allowed beyond the per-Gaussian criterion (measured: <= 5.5e-4, v_opacities)
 UNMASKED_L2_RTOL = 5e-4    # unmasked upstream gradient against the fp32 oracle: isolated threshold flips, bounded
 UNMASKED_MAX_RTOL = 1e-2
 
