@@ -37,11 +37,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 N_SIMD = 1024            # 256 CUs x 4 SIMD-32
 VALU_CYCLES_PER_WAVE_INST = 2.0   # wave64 on a SIMD-32 (same guide, cycle-constants table)
-# what a SIMD actually sustains on this kernel's instruction mix, measured (tools/micro/README.md, 4 waves per SIMD, nominal
-# 2.4 GHz): fp32 fma / mul / add 2.7-3.0, v_cmp + v_cndmask 3.9 each, v_exp / v_rcp 8.4 -> ~3.2 over blend_bwd's mix
-VALU_CYCLES_PER_WAVE_INST_MEASURED = 3.2
-CLOCK_HZ = 2.4e9
-PROFILE_TAGS = ("r03", "r02", "r01")     # committed rocprofv3 summaries under profiles/, newest first
+CLOCK_HZ_NOMINAL = 2.4e9
+# blend_bwd's main loop, one systolic step of four (pixel, entry) pairs per lane, counted in the ISA hipcc emits
+# (hipcc -S of csrc/gs_blend.hip, loop .LBB1_24): 208 VALU = 160 fma / mul / add / sub / min / DPP moves, 21 v_cmp, 19 v_cndmask,
+# 8 transcendentals (4 v_exp_f32 + 4 v_rcp_f32); 24 SALU and 2 LDS reads ride along
+BWD_LOOP_MIX = {"simple": 160, "cmp_cndmask": 40, "transcendental": 8}
+PROFILE_TAGS = ("r04", "r03", "r02", "r01")     # committed rocprofv3 summaries under profiles/, newest first
 
 
 def parse_args(argv=None):
@@ -669,6 +670,16 @@ def run_rank(args) -> int:
         try:
             n_rl = int(os.environ.get("GS_BENCH_REAL_LOOP_STEPS", "600"))
             rl = {}
+            # (first use of the refinement kernels in this process -- code-object load, first allocations: 13 ms once -- on a
+            #  throw-away model, so that neither mode pays it inside its bracket: tools/refine_in_loop.py)
+            from easy_gaussian_splatting_amd.synthetic import make_scene
+            wm = model_from_scene(make_scene(4096, 64, 64, sh_degree=sc["sh_degree"], seed=1), device)
+            build_optimizers(wm, *lrs, fused="hip")
+            wm.grad_norm_accum += 1.0
+            wm.collecting_counts += 1.0
+            wm.densify_and_prune()
+            wm.reset_opacities()
+            del wm
             for tag, cap in (("captured", True), ("eager", False)):
                 rl[tag] = real_loop(sc, device, lrs, datas, targets, mask, steps=n_rl, refine_every=100, reset_at=400, captured=cap)
             rl["what"] = ("reference loop shape end to end at the bench workload: shuffled views, update_statistics + means-LR every "
@@ -853,17 +864,39 @@ def run_rank(args) -> int:
                           pairs_evaluated=n_units * ue * 64, pairs_listed=listed * 64,
                           pairs_evaluated_per_s=None if not t_ms or t_ms != t_ms else round(n_units * ue * 64 / (t_ms * 1e-3), 0))
         sq, sq_src = sq_counters(kname[dom])
-        peak_rate = N_SIMD * CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST
-        rc_obj.update(peak=round(peak_rate / 1e9, 1), unit="G wave-instr/s",
-                      peak_note="1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction (nominal clock; sustained clocks are lower)")
+        # The shader clock the kernel ACTUALLY ran at (tools/clock_probe.py: every wave's d(s_memtime) / d(s_memrealtime), measured
+        # inside blend_bwd itself) and the issue cost of each instruction class at that clock (tools/micro/clock_probe.hip, four
+        # waves per SIMD) -- VERDICT r3 item 5: the round-3 line priced the kernel against a self-measured "3.2 nominal cycles".
+        clk, clk_src = _profile_json("clock.json")
+        clock_mhz, cls_cost = None, {}
+        if clk:
+            kk = clk.get("kernels", {}).get("blend_bwd_kernel" if dom == "gs_blend_bwd" else "blend_fwd_kernel<train>", {})
+            clock_mhz = kk.get("clock_MHz")
+            for m in clk.get("micro", []):
+                if m.get("waves_per_simd") == 4 and "cycles_per_wave_instr_at_measured_clock" in m:
+                    cls_cost[m["kernel"]] = m["cycles_per_wave_instr_at_measured_clock"]
+        clock_hz = 1e6 * clock_mhz if clock_mhz else CLOCK_HZ_NOMINAL
+        peak_rate = N_SIMD * clock_hz / VALU_CYCLES_PER_WAVE_INST
+        rc_obj.update(peak=round(peak_rate / 1e9, 1), unit="G wave-instr/s", clock_mhz=clock_mhz, clock_source=clk_src,
+                      peak_note="1024 SIMD-32 x the shader clock measured inside the kernel / 2 cycles per wave64 instruction (the guide's rate)")
         if sq and sq.get("SQ_INSTS_VALU") and t_ms == t_ms and t_ms > 0:
             rate = sq["SQ_INSTS_VALU"] / (t_ms * 1e-3)
             rc_obj.update(valu_wave_insts_per_launch=sq["SQ_INSTS_VALU"], achieved=round(rate / 1e9, 1),
                           frac=round(rate / peak_rate, 4), counters_source=sq_src,
-                          frac_of_measured_issue_rate=round(rate / (N_SIMD * CLOCK_HZ / VALU_CYCLES_PER_WAVE_INST_MEASURED), 4),
-                          measured_issue_note="tools/micro/README.md: this instruction mix issues at ~3.2 nominal cycles per wave64 "
-                                              "instruction, not 2; against that rate the kernel is issue-bound",
                           counters={k: sq[k] for k in sorted(sq) if k.startswith("SQ_")})
+            if dom == "gs_blend_bwd" and {"v_fma_f32", "v_cmp+v_cndmask", "v_exp_f32"} <= set(cls_cost):
+                # what this instruction MIX can issue at, from the measured class costs: not a hardware peak, a model of the
+                # stream as compiled -- reported so that "how far from the guide's 2 cycles" and "why" are separate numbers
+                n_mix = sum(BWD_LOOP_MIX.values())
+                cyc = (BWD_LOOP_MIX["simple"] * cls_cost["v_fma_f32"] + BWD_LOOP_MIX["cmp_cndmask"] * cls_cost["v_cmp+v_cndmask"]
+                       + BWD_LOOP_MIX["transcendental"] * cls_cost["v_exp_f32"]) / n_mix
+                rc_obj["issue_model"] = {
+                    "loop_mix_valu_per_step": BWD_LOOP_MIX, "class_cycles_measured": {k: cls_cost[k] for k in ("v_fma_f32", "v_cmp+v_cndmask", "v_exp_f32")},
+                    "modelled_cycles_per_wave_instr": round(cyc, 3),
+                    "frac_of_modelled_issue_rate": round(rate / (N_SIMD * clock_hz / cyc), 4),
+                    "note": "class costs at 4 waves per SIMD (the kernel runs 3: plain fma measured 5.5 / 2.8 / 2.55 / 2.3 cycles at 1 / 2 / 4 / 8 "
+                            "waves per SIMD -- a wave cannot issue VALU back to back, the guide's 2 cycles need >= 8 waves); a fraction above 1 "
+                            "means hipcc's schedule hides part of the v_cmp -> v_cndmask dependency the micro-kernel exposes"}
         result = {
             "metric": "train iters/sec + forward render fps, 1M Gaussians @ 1080p",
             "value": round(world * args.steps / elapsed, 3), "unit": "iters/s",

@@ -21,7 +21,7 @@ GS_TILE = 16
 GS_BUCKET = 64
 GS_UNIT = 32
 GS_REC_FLOATS = 12
-GS_ROW_FLOATS = 12
+GS_ROW_FLOATS = int(os.environ.get("GS_ROW_FLOATS", "12"))   # (env: tuning variants built with -DGS_ROW_FLOATS=...)
 
 _lib: Optional[ct.CDLL] = None
 _lock = threading.Lock()

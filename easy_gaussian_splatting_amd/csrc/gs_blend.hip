@@ -528,7 +528,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
         if (e[i].has) {
-            float4* rp = a.rows + 3 * ((size_t)slot[i] * 4 + q);
+            float4* rp = a.rows + (GS_ROW_FLOATS / 4) * ((size_t)slot[i] * 4 + q);
             // v_opacity = sum vis * v_alpha = -sum(vs) / opacity   (vs = -opacity*vis*v_alpha)
             const float v_op = e[i].op > 0.f ? -e[i].s_vs / e[i].op : 0.f;
             rp[0] = make_float4(e[i].s_mx, e[i].s_my, e[i].s_ax, e[i].s_ay);

@@ -368,6 +368,7 @@ struct ProjBwdArgs {
 struct RowSum {
     float v[12];
 };
+constexpr int kRow4 = GS_ROW_FLOATS / 4;   // float4 per gradient row (include/gs_raster.h)
 
 // adds the existing quadrant rows of one intersection slot (fixed order -> reproducible sums)
 __device__ __forceinline__ void row_add(RowSum& s, const float4* __restrict__ rows, const uint8_t* __restrict__ qmask, int64_t slot) {
@@ -375,7 +376,7 @@ __device__ __forceinline__ void row_add(RowSum& s, const float4* __restrict__ ro
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (bits & (1 << q)) {
-            const float4* r = rows + 3 * (slot * 4 + q);
+            const float4* r = rows + kRow4 * (slot * 4 + q);
             const float4 a = r[0], b = r[1], c = r[2];
             s.v[0] += a.x; s.v[1] += a.y; s.v[2] += a.z; s.v[3] += a.w;
             s.v[4] += b.x; s.v[5] += b.y; s.v[6] += b.z; s.v[7] += b.w;
@@ -611,10 +612,10 @@ __device__ __forceinline__ void row_sum_slots(const ProjBwdArgs& a, int cs, int 
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q][0] = dst[q][1] = dst[q][2] = make_float4((float)(bits & (1 << q)), 0.f, 0.f, 0.f);
 #else
-        const float4* rp = a.rows + 12 * (int64_t)slot;
+        const float4* rp = a.rows + 4 * kRow4 * (int64_t)slot;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (bits & (1 << q)) { dst[q][0] = rp[3 * q]; dst[q][1] = rp[3 * q + 1]; dst[q][2] = rp[3 * q + 2]; }
+            if (bits & (1 << q)) { dst[q][0] = rp[kRow4 * q]; dst[q][1] = rp[kRow4 * q + 1]; dst[q][2] = rp[kRow4 * q + 2]; }
             else { dst[q][0] = dst[q][1] = dst[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
         }
 #endif
@@ -694,10 +695,10 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         // exact zeros (fixed order -> reproducible sums).
         float4 cur[4][3], nxt[4][3];
         auto fetch = [&](float4 (&dst)[4][3], int r, int bits) {
-            const float4* rp = a.rows + 12 * (int64_t)(base + r);
+            const float4* rp = a.rows + 4 * kRow4 * (int64_t)(base + r);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (bits & (1 << q)) { dst[q][0] = rp[3 * q]; dst[q][1] = rp[3 * q + 1]; dst[q][2] = rp[3 * q + 2]; }
+                if (bits & (1 << q)) { dst[q][0] = rp[kRow4 * q]; dst[q][1] = rp[kRow4 * q + 1]; dst[q][2] = rp[kRow4 * q + 2]; }
                 else { dst[q][0] = dst[q][1] = dst[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
             }
         };
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (bits & (1 << q)) {
-                const float4* r = a.rows + 3 * (slot * 4 + q);
+                const float4* r = a.rows + kRow4 * (slot * 4 + q);
                 const float4 x = r[0], y = r[1], z = r[2];
                 p.v[0] += x.x; p.v[1] += x.y; p.v[2] += x.z; p.v[3] += x.w;
                 p.v[4] += y.x; p.v[5] += y.y; p.v[6] += y.z; p.v[7] += y.w;
@@ -1036,7 +1037,7 @@ __device__ __forceinline__ void color_sum_slots(const float4* __restrict__ rows_
         float4 d[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {   // the colour quads of four items: every load issued before the first use
-            const float4* rp = rows_color + (int64_t)4 * row_quads * sl[q] + (row_quads - 1);
+            const float4* rp = rows_color + (int64_t)4 * row_quads * sl[q] + (row_quads > 1 ? 2 : 0);   // (colour lanes: third quad of a gradient row)
 #pragma unroll
             for (int k = 0; k < 4; ++k) d[q][k] = (bt[q] & (1 << k)) ? rp[k * row_quads] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -1077,7 +1078,7 @@ __global__ __launch_bounds__(256) void colors_pre_grad_kernel(int64_t total, con
             const int bits_next = r + 1 < cnt ? (int)qmask[base + r + 1] : 0;
             // row_quads = 1: blend_bwd's compact colour copy [I*4][4];  3: the gradient rows themselves [I*4][12], whose
             // third quad holds the colour lanes (no second, scattered store per row in blend_bwd: 0.66 -> 0.48 ms there)
-            const float4* rp = rows_color + (int64_t)4 * row_quads * (base + r) + (row_quads - 1);
+            const float4* rp = rows_color + (int64_t)4 * row_quads * (base + r) + (row_quads > 1 ? 2 : 0);
             float4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = (bits & (1 << q)) ? rp[q * row_quads] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1103,7 +1104,7 @@ extern "C" int gs_colors_pre_grad(void* stream, int C, int64_t N, const int32_t*
                                   const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows_color,
                                   int row_floats, const uint8_t* qmask, float* v_colors_pre) {
     GS_REQUIRE(C >= 1 && N >= 0, "C>=1, N>=0");
-    GS_REQUIRE(row_floats == 4 || row_floats == GS_ROW_FLOATS, "row_floats: 4 (compact colour rows) or 12 (the gradient rows)");
+    GS_REQUIRE(row_floats == 4 || row_floats == GS_ROW_FLOATS, "row_floats: 4 (compact colour rows) or GS_ROW_FLOATS (the gradient rows)");
     if (N == 0) return GS_OK;
     GS_REQUIRE(radii && colors_post && tiles_per_gauss && cum_tiles && rows_color && qmask && v_colors_pre, "null pointer");
     const int64_t total = (int64_t)C * N;

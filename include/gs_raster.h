@@ -35,7 +35,9 @@ extern "C" {
 #define GS_BUCKET 64         /* entries per bucket = one wavefront */
 #define GS_UNIT 32           /* quadrant-sublist entries per work unit of gs_blend_bwd (one checkpoint each) */
 #define GS_REC_FLOATS 12     /* packed per-(camera,Gaussian) blend record */
+#ifndef GS_ROW_FLOATS
 #define GS_ROW_FLOATS 12     /* per-intersection gradient row written by gs_blend_bwd */
+#endif
 
 #define GS_OK 0
 #define GS_ERR_ARG (-1)
