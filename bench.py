@@ -352,7 +352,7 @@ class DropInLoop:
       step / zero_grad    /root/reference/train.py:152-153
     No fused loss, no in-kernel activations, no split SH hand-over, no tight lists, no HIP Adam, no hipGraph."""
 
-    def __init__(self, sc, device, lrs, loss: str = "torch", adam: str = "torch"):
+    def __init__(self, sc, device, lrs, loss: str = "torch", adam: str = "torch", size_check: str = "immediate"):
         """`loss="hip"` / `adam="hip"`: the next two one-line swaps of INTEGRATION.md section 2 (this package's LossComputer /
         build_optimizers(..., fused="hip")) on top of the import change -- the rest of the loop stays the reference's."""
         import torch
@@ -365,6 +365,7 @@ class DropInLoop:
         else:
             self.opt = torch.optim.Adam([{"params": [getattr(self.m, k)], "lr": lr, "name": k} for k, lr in zip(names, lrs)])
         self.lambda_ssim = 0.2
+        self.size_check = size_check   # "deferred": rasterization(..., _size_check="deferred") -- the opt-in sync-free seam
         self.hip_loss = None
         if loss == "hip":
             from easy_gaussian_splatting_amd.loss import LossComputer
@@ -377,7 +378,8 @@ class DropInLoop:
         batch_render_imgs, _, meta = rasterization(
             means=m.means, quats=m.quats, scales=torch.exp(m.log_scales), opacities=torch.sigmoid(m.logit_opacities),
             colors=torch.cat([m.sh_0, m.sh_rest], dim=1), sh_degree=m.active_sh_degree, viewmats=w2c[None], Ks=data["K"][None],
-            width=data["width"], height=data["height"], backgrounds=m.BACKGROUND[None], absgrad=True, packed=False)
+            width=data["width"], height=data["height"], backgrounds=m.BACKGROUND[None], absgrad=True, packed=False,
+            **({} if self.size_check == "immediate" else {"_size_check": self.size_check}))
         render_img = torch.clamp(batch_render_imgs[0], min=0.0, max=1.0)
         return {"render_img": render_img, "batch_xys": meta["means2d"], "batch_radii": meta["radii"]}
 
@@ -728,6 +730,25 @@ def run_rank(args) -> int:
                 del dj
                 torch.cuda.empty_cache()
             extras["drop_in"].update(more)
+            # the opt-in sync-free seam (`_size_check="deferred"`, SURVEY.md 8b "Sync"): the same loop, the size record read by the
+            # call's own backward / the next forward instead of before the forward returns
+            dk = DropInLoop(sc, device, lrs, size_check="deferred")
+            ek, qk, sk, wk = timed_loop(lambda: dk.step(data, gt_img, mask, item_reads=True), nd, 5)
+
+            def dk_fwd():
+                with torch.no_grad():
+                    dk.forward(data)
+
+            efk, _, sfk, wfk = timed_loop(dk_fwd, nd, 3)
+            rendering.flush_size_checks()
+            extras["drop_in"]["deferred_size_check"] = {
+                "train_iters_per_s": round(nd / ek, 2), "train_ms": _percentiles(sk), "blocked_on_readback_ms_per_step": round(wk, 4),
+                "forward_fps": round(nd / efk, 2), "forward_ms": _percentiles(sfk), "forward_blocked_on_readback_ms": round(wfk, 4),
+                "late_overflows": rendering.stats["late_overflows"],
+                "note": "opt-in: an overflow found late is repaired in place, but consumers queued in between saw unwritten memory "
+                        "(backward refuses) -- hence not the default"}
+            del dk
+            torch.cuda.empty_cache()
         except Exception as e:   # a secondary timing must never cost the bench line
             extras.setdefault("drop_in", {})["error"] = repr(e)[:300]
 

@@ -145,7 +145,7 @@ def binning_choice(footprint, tiles: int = 0) -> str:
 
 # host-side diagnostics: time spent blocked on the list-size read-back (bench.py reports it; a wait
 # near zero means the host, not the GPU, paces the loop)
-stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0, "overflow_reruns": 0}
+stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0, "overflow_reruns": 0, "deferred_calls": 0, "late_overflows": 0}
 
 
 def _quantize_up(x: int) -> int:
@@ -153,16 +153,58 @@ def _quantize_up(x: int) -> int:
     return (int(x) + g - 1) // g * g
 
 
+_INFO_RING = 8   # size records in flight per (host thread, device) with the deferred size check
+
+
 def _pinned_info(device: torch.device) -> Tensor:
-    """Page-locked 8 x int64 landing buffer for the list sizes, one per (host thread, device)."""
+    """Page-locked 8 x int64 landing buffer for the list sizes: the next of a ring of `_INFO_RING` per (host thread, device).
+    (With the immediate size check a call has read its record before it returns; with the deferred one -- `_size_check=
+    "deferred"` -- up to `_INFO_RING - 1` later calls may be issued before it is looked at, `_pending_checks`.)"""
     cache = getattr(_tls, "pinned", None)
     if cache is None:
         cache = _tls.pinned = {}
     key = device.index if device.index is not None else torch.cuda.current_device()
-    buf = cache.get(key)
-    if buf is None:
-        buf = cache[key] = torch.empty((8,), dtype=torch.int64, pin_memory=True)
-    return buf
+    ring = cache.get(key)
+    if ring is None:
+        ring = cache[key] = [torch.empty((_INFO_RING, 8), dtype=torch.int64, pin_memory=True), 0]
+    ring[1] = (ring[1] + 1) % _INFO_RING
+    return ring[0][ring[1]]
+
+
+def _pending_checks() -> list:
+    q = getattr(_tls, "pending_checks", None)
+    if q is None:
+        q = _tls.pending_checks = []
+    return q
+
+
+def flush_size_checks() -> int:
+    """Resolves every deferred size check of this host thread (`_size_check="deferred"`): waits for the size records, repairs
+    -- in place, into the very tensors that were handed out -- any forward whose list capacities did not hold.  Returns the
+    number of repaired calls.  Called implicitly by the next `rasterization()` on the thread, by `backward()` of the call
+    itself and by the first read of one of `meta`'s list arrays."""
+    q = _pending_checks()
+    late = 0
+    while q:
+        late += int(q.pop(0).resolve())
+    return late
+
+
+class _PendingCheck:
+    """A forward whose size record {I, buckets, longest list, flags} has not been looked at yet."""
+
+    def __init__(self, resolve_fn):
+        self._fn, self.done, self.late = resolve_fn, False, False
+        self._lock = threading.Lock()   # (backward() runs on the autograd engine's thread, the next forward on the caller's)
+
+    def resolve(self) -> bool:
+        with self._lock:
+            if not self.done:
+                self.late = bool(self._fn())
+                self.done = True
+                self._fn = None
+                self.lease_ref = None
+        return self.late
 
 
 class _LazyMeta(dict):
@@ -431,69 +473,129 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     # (one launch for geometry + colour: since the list stages no longer wait for the host, a colour pass of its own behind
     #  the tile count hides nothing, and the fused launch is 25 us shorter than the two -- GS_FWD_SPLIT=1 keeps the split)
     project(1 if _SPLIT_PROJECT else 0, "gs_project_fwd")
-    attempt, waited = 0, 0
-    try:
-        while True:
-            nat.check(L.gs_guard_set_call(P(WS.INFO), cap, min(cap_tile, cap)), "gs_guard_set_call")
-            # (the tile scan writes the eight info words straight into the page-locked landing buffer: no copy on the stream)
-            nat.check(L.gs_info_mirror_set(info_host.data_ptr()), "gs_info_mirror_set")
+    sizes = {"attempt": 0, "waited": 0, "info": None}   # (mutable: the deferred check finishes this call after it returned)
+    tstream = torch.cuda.current_stream(dev)            # (the stream `st` belongs to: a late repair runs on it, whoever calls)
+
+    def enqueue_attempt():
+        """Tile counts under the guard (flags = capacity exceeded), their 64-byte record straight into page-locked memory,
+        then lists + blend, speculatively."""
+        nat.check(L.gs_guard_set_call(P(WS.INFO), cap, min(cap_tile, cap)), "gs_guard_set_call")
+        # (the tile scan writes the eight info words straight into the page-locked landing buffer: no copy on the stream)
+        nat.check(L.gs_info_mirror_set(info_host.data_ptr()), "gs_info_mirror_set")
+        try:
             _stage("gs_bin_count", dev, count)
             nat.check(L.gs_info_mirror_set(None), "gs_info_mirror_set")
-            if attempt == 0:
-                ready = torch.cuda.Event()
-                ready.record(torch.cuda.current_stream(dev))
-                if _SPLIT_PROJECT:
-                    project(2, "gs_project_fwd_color")
+            ev = torch.cuda.Event()
+            ev.record(tstream)
+            if sizes["attempt"] == 0 and _SPLIT_PROJECT:
+                project(2, "gs_project_fwd_color")
             lists_and_blend()
-            nat.check(L.gs_guard_set(None, 0, 0), "gs_guard_set")
-            t_wait = time.perf_counter_ns()
-            if attempt == 0:
-                ready.synchronize()
-            else:
-                torch.cuda.current_stream(dev).synchronize()
-            waited += time.perf_counter_ns() - t_wait
-            info = [int(v) for v in info_host.tolist()]
-            n_isects, n_buckets, max_tile, fl = info[0], info[1], info[2], info[3]
-            if fl == 0:
-                break
-            # a capacity did not hold: nothing was emitted or blended.  Re-size from what the count reported and repeat.
-            attempt += 1
-            if attempt > 6:
-                raise nat.NativeLibraryError(f"rasterization: list capacities did not settle (info {info})")
-            if two_level and fl & 12:
-                # the coarse stage did not fit: the tile counts (I, longest list) were never formed -- only its own
-                # sizes {I', longest bin list} are meaningful; the tile-list capacity is checked by the repeat
-                if fl & 4:
-                    coarse_cap = info[4] + (info[4] >> 2) + 1024
-                coarse_list_cap = 0
-                with _state_lock:
-                    stats["coarse_retries"] += 1
-            else:
-                if fl & 1:
-                    cap = n_isects + (n_isects >> 3) + 1024
-                if fl & 2:
-                    cap_tile = _sort_class(max_tile)
+        finally:
+            L.gs_guard_set(None, 0, 0)
+            L.gs_info_mirror_set(None)
+        return ev
+
+    def settle(ev, whole_stream: bool) -> bool:
+        """Waits for the size record; True when the capacities held.  Otherwise nothing was emitted or blended: re-sizes from
+        what the count reported (the caller repeats the attempt)."""
+        nonlocal cap, cap_tile, coarse_cap, coarse_list_cap, info_dev
+        t_wait = time.perf_counter_ns()
+        if whole_stream:
+            tstream.synchronize()
+        else:
+            ev.synchronize()
+        sizes["waited"] += time.perf_counter_ns() - t_wait
+        info = sizes["info"] = [int(v) for v in info_host.tolist()]
+        n_isects, max_tile, fl = info[0], info[2], info[3]
+        if fl == 0:
+            return True
+        sizes["attempt"] += 1
+        if sizes["attempt"] > 6:
+            raise nat.NativeLibraryError(f"rasterization: list capacities did not settle (info {info})")
+        if two_level and fl & 12:
+            # the coarse stage did not fit: the tile counts (I, longest list) were never formed -- only its own
+            # sizes {I', longest bin list} are meaningful; the tile-list capacity is checked by the repeat
+            if fl & 4:
+                coarse_cap = info[4] + (info[4] >> 2) + 1024
+            coarse_list_cap = 0
             with _state_lock:
-                stats["overflow_reruns"] += 1
-            lease.grow_lists(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags), st)
-            info_dev = lease.view(WS.INFO, 8)
-            info_dev.zero_()
-    finally:
-        L.gs_guard_set(None, 0, 0)
-        L.gs_info_mirror_set(None)
-    with _state_lock:
-        stats["sync_wait_ns"] += waited
-        stats["calls"] += 1
-        old = _hints.get(hint_key, {})
-        # the capacity follows the largest recent frame (slow decay), so alternating views do not overflow every time
-        new = dict(cap=max(n_isects + (n_isects >> 2) + 1024, int(old.get("cap", 0) * 0.995)),
-                   cap_tile=max(_sort_class(max_tile + (max_tile >> 2)), int(old.get("cap_tile", 1024))), footprint=n_isects / max(1, C * N),
-                   mode="bins" if two_level else "tiles")
-        if two_level:
-            new.update(entries=max(info[4] + (info[4] >> 2) + 1024, int(old.get("entries", 0) * 0.995)),
-                       longest=max(info[5] + (info[5] >> 2) + 64, int(old.get("longest", 0) * 0.995)))
-        _hints[hint_key] = new
-        _coarse_hint[dev_index] = dict(mode=new["mode"], footprint=new["footprint"])
+                stats["coarse_retries"] += 1
+        else:
+            if fl & 1:
+                cap = n_isects + (n_isects >> 3) + 1024
+            if fl & 2:
+                cap_tile = _sort_class(max_tile)
+        with _state_lock:
+            stats["overflow_reruns"] += 1
+        lease.grow_lists(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags), st)
+        info_dev = lease.view(WS.INFO, 8)
+        info_dev.zero_()
+        return False
+
+    def learn():
+        """The capacity hints follow what this call needed."""
+        info = sizes["info"]
+        n_isects, max_tile = info[0], info[2]
+        with _state_lock:
+            stats["sync_wait_ns"] += sizes["waited"]
+            stats["calls"] += 1
+            old = _hints.get(hint_key, {})
+            # the capacity follows the largest recent frame (slow decay), so alternating views do not overflow every time
+            new = dict(cap=max(n_isects + (n_isects >> 2) + 1024, int(old.get("cap", 0) * 0.995)),
+                       cap_tile=max(_sort_class(max_tile + (max_tile >> 2)), int(old.get("cap_tile", 1024))), footprint=n_isects / max(1, C * N),
+                       mode="bins" if two_level else "tiles", n=N)
+            if two_level:
+                new.update(entries=max(info[4] + (info[4] >> 2) + 1024, int(old.get("entries", 0) * 0.995)),
+                           longest=max(info[5] + (info[5] >> 2) + 64, int(old.get("longest", 0) * 0.995)))
+            _hints[hint_key] = new
+            _coarse_hint[dev_index] = dict(mode=new["mode"], footprint=new["footprint"])
+
+    # SURVEY.md 8b "Sync".  Immediate (default): the host reads the size record before the call returns -- it never drains the
+    # stream (everything above is queued behind the count already), but it cannot run ahead of the count either.  Deferred
+    # (`_size_check="deferred"`, opt-in): with capacities learnt from earlier calls of this shape the call returns at once; the
+    # record is looked at by the next call on this thread, by this call's own backward or by the first read of a list array
+    # (`flush_size_checks`).  An overflow found then is repaired IN PLACE -- count .. blend repeated into the very tensors
+    # that were handed out, bit-identical to what the immediate check produces -- but whatever the caller enqueued in
+    # between has consumed unwritten memory: inference loops see the repaired frame, `backward()` refuses (its upstream
+    # gradient came from that memory).  That is why it is not the default.
+    deferred = bool(cfg.get("defer_size_check")) and bool(hint) and int(hint.get("n", N)) == N
+    ev0 = enqueue_attempt()
+    state_late = {}
+    if deferred:
+        n_buckets_bound = cap // nat.GS_BUCKET + C * tiles + 1
+
+        def resolve_late() -> bool:
+            late = False
+            ev, whole = ev0, False
+            with torch.cuda.device(dev):
+                while not settle(ev, whole):
+                    late = True
+                    ev, whole = enqueue_attempt(), True
+            learn()
+            state_late["n_isects"], state_late["n_buckets"] = sizes["info"][0], sizes["info"][1]
+            if late:
+                with _state_lock:
+                    stats["late_overflows"] += 1
+            return late
+
+        pending = _PendingCheck(resolve_late)
+        _pending_checks().append(pending)
+        with _state_lock:
+            stats["deferred_calls"] += 1
+        n_isects, n_buckets, max_tile = None, n_buckets_bound, None
+    else:
+        pending = None
+        ev, whole = ev0, False
+        while not settle(ev, whole):
+            ev, whole = enqueue_attempt(), True
+        learn()
+        n_isects, n_buckets, max_tile = sizes["info"][0], sizes["info"][1], sizes["info"][2]
+
+    def isects() -> int:
+        if pending is not None:
+            pending.resolve()
+            return state_late["n_isects"]
+        return n_isects
 
     ref = WS.LeaseRef(lease)
     lazy = _LazyMeta.Lazy
@@ -506,10 +608,10 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     else:
         list_entries = {
             # list arrays: copied out of the workspace on first access (the lease is kept alive by this dict)
-            "tiles_per_gauss": lazy(lambda: lease.view(WS.TILES_PER_GAUSS, C * N).clone().view(C, N)),
-            "isect_ids": lazy(lambda: lease.view(WS.ISECT_IDS, n_isects).clone()) if eager_ids else _LazyMeta.PENDING,
-            "flatten_ids": lazy(lambda: lease.view(WS.FLATTEN_IDS, n_isects).clone()),
-            "isect_offsets": lazy(lambda: lease.view(WS.ISECT_OFFSETS, C * tiles).clone().view(C, th, tw))}
+            "tiles_per_gauss": lazy(lambda: (isects(), lease.view(WS.TILES_PER_GAUSS, C * N).clone().view(C, N))[1]),
+            "isect_ids": lazy(lambda: lease.view(WS.ISECT_IDS, isects()).clone()) if eager_ids else _LazyMeta.PENDING,
+            "flatten_ids": lazy(lambda: lease.view(WS.FLATTEN_IDS, isects()).clone()),
+            "isect_offsets": lazy(lambda: (isects(), lease.view(WS.ISECT_OFFSETS, C * tiles).clone().view(C, th, tw))[1])}
     meta = _LazyMeta({
         "camera_ids": None, "gaussian_ids": None,
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics,
@@ -520,7 +622,10 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     if not lazy_ref:
         meta._lease = ref   # (the list lazies above read the arenas; in the "gsplat" mode nothing in meta does)
     state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, sh_jac=use_jac, n_isects=n_isects, n_buckets=n_buckets, radii=radii, lease=lease,
-                 lease_ref=WS.LeaseRef(lease) if need_grad else None, factorised=factorised)
+                 lease_ref=WS.LeaseRef(lease) if (need_grad or pending is not None) else None, factorised=factorised, pending=pending,
+                 late=state_late)
+    if pending is not None:
+        pending.lease_ref = state["lease_ref"]   # (a repair needs the arenas: leased until the check has run)
     del ref   # (the lease goes back to its pool here unless meta or the autograd node holds it)
     return render_colors, render_alphas, meta, state
 
@@ -562,6 +667,13 @@ class _Rasterize(torch.autograd.Function):
         v_rc = torch.zeros_like(render_colors) if v_render_colors is None else v_render_colors.contiguous()
         v_ra = None if v_render_alphas is None else v_render_alphas.contiguous()
         lease, factorised = s["lease"], s["factorised"]   # (the forward's workspace: kept leased by s["lease_ref"])
+        if s.get("pending") is not None:
+            # deferred size check: this call's own record (backward may run on the autograd engine's thread)
+            if s["pending"].resolve():
+                raise RuntimeError("rasterization(_size_check='deferred'): the forward of this call outgrew its list capacities and was "
+                                   "repaired only now -- the loss and the upstream gradient of this backward were computed from unwritten "
+                                   "memory.  Re-run the step (the capacities have been raised), or use the default immediate size check.")
+            s["n_isects"], s["n_buckets"] = s["late"]["n_isects"], s["late"]["n_buckets"]
         P = lease.ptr
         _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, P(WS.REC), P(WS.ISECT_OFFSETS),
                                  P(WS.BUCKET_OFFSETS), s["n_buckets"], P(WS.QLIST), P(WS.QCNT), P(WS.UNIT_COUNTER),
@@ -678,6 +790,7 @@ def rasterization(
     _sh_grads: str = "dense",
     _on_colors_pre=None,
     _activations: str = "none",
+    _size_check: Optional[str] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize 3D Gaussians to images; same tensor signature and return value as
     `gsplat.rendering.rasterization` (gsplat 1.0.0).
@@ -709,6 +822,12 @@ def rasterization(
     (log-scales, logit opacities, /root/reference/model/gaussian.py:98-103); exp and sigmoid are applied
     inside the projection kernels and the returned gradients are w.r.t. the raw parameters, which
     removes the model's four activation kernels per step.  `meta["opacities"]` then holds the logits.
+
+    `_size_check` ("immediate" | "deferred"; default: env GS_SIZE_CHECK or "immediate"): when the host looks at the list sizes
+    the count kernels reported.  "immediate": before the call returns (one host wait per forward, never a stream drain).
+    "deferred": at the next call on this host thread / in this call's backward / at the first read of a list array in `meta`
+    (`flush_size_checks()`); the forward then returns without blocking once a call of the same shape has primed the
+    capacities.  See `_forward_stages` for what a late-discovered overflow means -- opt-in for that reason.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -759,6 +878,10 @@ def rasterization(
         raise RuntimeError("rasterization() runs on the GPU only: tensors must live on a HIP device "
                            "(there is no CPU fallback in this package)")
     nat.lib()  # fail loudly here if the extension is missing
+    size_check = _size_check or os.environ.get("GS_SIZE_CHECK", "immediate")
+    if size_check not in ("immediate", "deferred"):
+        raise ValueError("_size_check: 'immediate' or 'deferred'")
+    flush_size_checks()   # (size records of earlier deferred calls on this thread: looked at -- and repaired -- in order)
 
     def prep(t: Tensor) -> Tensor:
         if t.dtype != torch.float32:
@@ -775,7 +898,8 @@ def rasterization(
                far_plane=float(far_plane), radius_clip=float(radius_clip), eps2d=float(eps2d),
                sh_degree=sh_degree, tile_culling={"gsplat": 1, "tight": 1, "gsplat_eager": 0}[_tile_culling],
                lazy_ref_lists=_tile_culling == "gsplat", sh_grads=_sh_grads,
-               activations={"none": 0, "exp_sigmoid": 1}[_activations], grad_enabled=torch.is_grad_enabled())
+               activations={"none": 0, "exp_sigmoid": 1}[_activations], grad_enabled=torch.is_grad_enabled(),
+               defer_size_check=size_check == "deferred")
     if _sh_grads not in ("dense", "colors_pre") or (_sh_grads == "colors_pre" and sh_degree is None):
         raise ValueError("_sh_grads: 'dense', or 'colors_pre' together with sh_degree")
     holder = _Holder(absgrad)

@@ -145,3 +145,79 @@ def test_inference_calls_hold_no_lease_after_meta_is_dropped():
     img5, _, meta5 = render(1, "gsplat")          # re-uses the workspace while meta4 is still alive and unread in part
     assert torch.equal(meta4["isect_offsets"].reshape(-1)[1:] >= meta4["isect_offsets"].reshape(-1)[:-1], torch.ones_like(meta4["isect_offsets"].reshape(-1)[1:], dtype=torch.bool))
     assert int(meta4["tiles_per_gauss"].sum()) == ref_ids.numel() and ref_ids.numel() > fid.numel()
+
+
+def _render_nograd(t, sc, view, size_check, culling="tight"):
+    with torch.no_grad():
+        return rasterization(t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"][view:view + 1],
+                             t["Ks"][view:view + 1], sc["width"], sc["height"], sh_degree=3, packed=False,
+                             backgrounds=t["backgrounds"][view:view + 1], _tile_culling=culling, _size_check=size_check)
+
+
+def test_deferred_size_check_steady_state_never_blocks_and_matches():
+    """`_size_check="deferred"` (opt-in, SURVEY.md 8b "Sync"): once a call of the shape has primed the capacities, forwards
+    return without the host ever waiting on the size record; results are bit-identical to the immediate check, in training
+    too (the record is looked at by the call's own backward)."""
+    sc, t = _scene()
+    rendering.reset_hints()
+    ref = [_render_nograd(t, sc, v, "immediate") for v in range(3)]
+    ref_ids = [r[2]["flatten_ids"].clone() for r in ref]
+    d0, w0 = rendering.stats["deferred_calls"], rendering.stats["sync_wait_ns"]
+    outs = [_render_nograd(t, sc, v % 3, "deferred") for v in range(9)]
+    assert rendering.stats["deferred_calls"] == d0 + 9 and rendering.stats["late_overflows"] == 0
+    assert rendering.flush_size_checks() == 0
+    for i, o in enumerate(outs):
+        assert torch.equal(o[0], ref[i % 3][0]) and torch.equal(o[1], ref[i % 3][1])
+        assert torch.equal(o[2]["flatten_ids"], ref_ids[i % 3])
+    # training: same gradients, the check happens inside backward()
+    g_ref = _run(t, sc, 1)[3]
+    ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+    for _ in range(3):
+        img, _, meta = rasterization(*ins, t["viewmats"][1:2], t["Ks"][1:2], sc["width"], sc["height"], sh_degree=3, packed=False,
+                                     backgrounds=t["backgrounds"][1:2], absgrad=True, _size_check="deferred")
+        grads = torch.autograd.grad((img * torch.ones_like(img)).sum(), ins)
+    for a, b in zip(grads, g_ref):
+        assert torch.equal(a, b)
+    assert rendering.stats["late_overflows"] == 0
+
+
+def test_deferred_size_check_overflow_discovered_one_call_late_is_repaired_in_place():
+    """Capacities primed by a far-away camera, then a close-up with several times the intersections under the deferred
+    check: the call returns at once with its guarded kernels having been device-side no-ops; the NEXT call on the thread
+    finds the flag in the size record and repeats count .. blend into the very tensors the first call handed out -- bit-identical
+    to a call that checked immediately.  A training call in the same situation refuses in backward()."""
+    sc, t = _scene(n=30000)
+    far = t["viewmats"].clone()
+    far[0, 2, 3] += 30.0
+    tf = dict(t, viewmats=far)
+    rendering.reset_hints()
+    near_ref = _render_nograd(t, sc, 0, "immediate")
+    near_ids = near_ref[2]["flatten_ids"].clone()
+    rendering.reset_hints()
+    _render_nograd(tf, sc, 0, "immediate"); far_ref = _render_nograd(tf, sc, 0, "immediate")
+    assert near_ids.numel() > 1.6 * far_ref[2]["flatten_ids"].numel()
+    late0 = rendering.stats["late_overflows"]
+    img, alpha, meta = _render_nograd(t, sc, 0, "deferred")        # overflows the far view's capacities: nothing blended yet
+    assert rendering.stats["late_overflows"] == late0              # ... and nobody has looked
+    img_far, _, _ = _render_nograd(tf, sc, 0, "deferred")          # the next call on the thread discovers and repairs it first
+    assert rendering.stats["late_overflows"] == late0 + 1
+    assert torch.equal(img, near_ref[0]) and torch.equal(alpha, near_ref[1])      # the SAME tensor objects, now written
+    assert torch.equal(meta["flatten_ids"], near_ids) and torch.equal(meta["radii"], near_ref[2]["radii"])
+    assert torch.equal(img_far, far_ref[0])
+    assert rendering.flush_size_checks() == 0
+    # a training forward in that situation: backward() finds the overflow and refuses (its upstream gradient is from unwritten memory)
+    rendering.reset_hints()
+    _render_nograd(tf, sc, 0, "immediate")
+    ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+    insf = [tf[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+    kw = dict(sh_degree=3, packed=False, absgrad=True, _tile_culling="tight")
+    rasterization(*insf, tf["viewmats"][0:1], tf["Ks"][0:1], sc["width"], sc["height"], backgrounds=tf["backgrounds"][0:1], **kw)
+    imgt, _, _ = rasterization(*ins, t["viewmats"][0:1], t["Ks"][0:1], sc["width"], sc["height"], backgrounds=t["backgrounds"][0:1],
+                               _size_check="deferred", **kw)
+    with pytest.raises(RuntimeError, match="deferred"):
+        imgt.sum().backward()
+    # ... and the capacities have been raised: the re-run of the step goes through
+    imgt, _, _ = rasterization(*ins, t["viewmats"][0:1], t["Ks"][0:1], sc["width"], sc["height"], backgrounds=t["backgrounds"][0:1],
+                               _size_check="deferred", **kw)
+    imgt.sum().backward()
+    assert torch.isfinite(ins[0].grad).all()
