@@ -140,10 +140,16 @@ def load_gaussian_model(path: Path, iterations: Optional[int] = None, device: Op
     opt = gaussian_model.__dict__.get("optimizer")
     opt_state = None if opt is None else opt.state_dict()   # (before .to(): FusedAdam reads its flat CPU buffers here)
     gaussian_model = gaussian_model.to(device)
-    for name in ("grad_norm_accum", "collecting_counts", "max_radii", "MAX_SCALE_RATIO"):   # plain attributes in the reference's pickles
+    for name in ("grad_norm_accum", "collecting_counts", "max_radii"):   # plain attributes in the reference's pickles
         t = gaussian_model.__dict__.get(name)
         if isinstance(t, torch.Tensor):
             gaussian_model.__dict__[name] = t.to(device)
+    # MAX_SCALE_RATIO is a 0-d tensor in files the reference wrote (or `reference_compatible=True` here): a Python float from
+    # now on -- read ONCE, on the CPU copy -- so that get_regularization_dict() never costs a device-to-host sync per
+    # training step; save_gaussian_model(reference_compatible=True) re-tensorises it at save time
+    ratio = gaussian_model.__dict__.get("MAX_SCALE_RATIO")
+    if isinstance(ratio, torch.Tensor):
+        gaussian_model.__dict__["MAX_SCALE_RATIO"] = float(ratio.detach().cpu())
     if opt is not None:
         from .optim import FusedAdam
         groups = [{"params": list(g["params"]), "lr": g["lr"], "name": g.get("name")} for g in opt.param_groups]

@@ -191,10 +191,12 @@ __global__ __launch_bounds__(256) void pack_view_step_kernel(int64_t n, float ma
                                                              int64_t o_scales, int64_t o_quats, int64_t o_opac, int64_t o_gn, int64_t o_cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    flat[3 * i] = v_means[3 * i]; flat[3 * i + 1] = v_means[3 * i + 1]; flat[3 * i + 2] = v_means[3 * i + 2];
-    flat[o_scales + 3 * i] = v_scales[3 * i]; flat[o_scales + 3 * i + 1] = v_scales[3 * i + 1]; flat[o_scales + 3 * i + 2] = v_scales[3 * i + 2];
-    reinterpret_cast<float4*>(flat + o_quats)[i] = reinterpret_cast<const float4*>(v_quats)[i];
-    flat[o_opac + i] = v_opac[i];
+    if (v_means) {   // (NULL: the projection backward wrote its gradients into `flat` itself -- only the statistics are left)
+        flat[3 * i] = v_means[3 * i]; flat[3 * i + 1] = v_means[3 * i + 1]; flat[3 * i + 2] = v_means[3 * i + 2];
+        flat[o_scales + 3 * i] = v_scales[3 * i]; flat[o_scales + 3 * i + 1] = v_scales[3 * i + 1]; flat[o_scales + 3 * i + 2] = v_scales[3 * i + 2];
+        reinterpret_cast<float4*>(flat + o_quats)[i] = reinterpret_cast<const float4*>(v_quats)[i];
+        flat[o_opac + i] = v_opac[i];
+    }
     const bool vis = radii[i] > 0;
     const float2 g = absgrad[i];
     flat[o_gn + i] = vis ? sqrtf(g.x * g.x + g.y * g.y) * max_hw : 0.f;
@@ -207,7 +209,9 @@ extern "C" int gs_pack_view_step(void* stream, int64_t n, float max_hw, const fl
                                  float* flat) {
     GS_REQUIRE(n >= 0 && max_hw > 0.f, "n >= 0 and positive image extent");
     if (n == 0) return GS_OK;
-    GS_REQUIRE(v_means && v_scales && v_quats && v_opacities && radii && absgrad && flat, "null pointer");
+    GS_REQUIRE(radii && absgrad && flat, "null pointer");
+    GS_REQUIRE((v_means && v_scales && v_quats && v_opacities) || (!v_means && !v_scales && !v_quats && !v_opacities),
+               "the four gradients: all (packed here) or none (already in place in flat)");
     GS_REQUIRE((((uintptr_t)v_quats | (uintptr_t)flat) & 15) == 0, "v_quats and flat must be 16-byte aligned");
     auto pad4 = [](int64_t x) { return (x + 3) / 4 * 4; };
     const int64_t o_scales = pad4(3 * n), o_quats = o_scales + pad4(3 * n), o_opac = o_quats + 4 * n, o_gn = o_opac + pad4(n),

@@ -114,9 +114,37 @@ class ViewParallelStep:
         self.sh_grad_fn = sh_grad_fn
         self._cams = self._rad = self._pre = None
         self.collectives = 0   # collectives issued so far (diagnostics / tests)
+        self._flat = self._offs = None
         if self.exchange:   # started from inside backward(), as soon as the colour gradient exists
             model.on_colors_pre = self._gather_colors_pre
+            if model.means.is_cuda and model.means.dtype == torch.float32:
+                # the projection backward writes the four geometry gradients straight into the all-reduce bucket
+                model.grad_out = self._grad_views
         model.sh_grads = "colors_pre" if self.exchange else "dense"
+
+    def _layout(self):
+        """Segments of the SUM all-reduce bucket [means 3N | log_scales 3N | quats 4N | logit_opacities N | grad_norm N | count N],
+        each padded to 16 bytes (the layout gs_pack_view_step fills)."""
+        m = self.model
+        N = m.means.shape[0]
+        sizes = [3 * N, 3 * N, 4 * N, N, N, N]
+        offs, off = [], 0
+        for n_el in sizes:
+            offs.append(off)
+            off = (off + n_el + 3) // 4 * 4
+        return N, offs, off
+
+    def _grad_views(self):
+        """Called by the model's forward: the bucket's gradient segments as the rasterizer's `_grad_out` tensors (re-made
+        when N changed: densify_and_prune)."""
+        m = self.model
+        N, offs, total = self._layout()
+        if self._flat is None or self._flat.numel() != total or self._flat.device != m.means.device:
+            self._flat = torch.zeros(total, dtype=torch.float32, device=m.means.device)   # (pads stay zero for good)
+            self._offs = offs
+        f = self._flat
+        return {"means": f[offs[0]:offs[0] + 3 * N].view(N, 3), "scales": f[offs[1]:offs[1] + 3 * N].view(N, 3),
+                "quats": f[offs[2]:offs[2] + 4 * N].view(N, 4), "opacities": f[offs[3]:offs[3] + N]}
 
     # Optional hooks that move the two small collectives off the end of the step (every rank must make
     # the same calls in the same order; `step` issues whatever was not issued before).
@@ -180,20 +208,21 @@ class ViewParallelStep:
         # (2) all-reduce SUM: geometry gradients + the two additive statistics of this view
         #     (/root/reference/model/gaussian.py:188-197), segments padded to 16 bytes
         geo = [getattr(m, name) for name in self.GEOMETRY]
-        sizes = [p.numel() for p in geo] + [N, N]
-        offs, off = [], 0
-        for n_el in sizes:
-            offs.append(off)
-            off = (off + n_el + 3) // 4 * 4
+        _, offs, off = self._layout()
         if dt == torch.float32 and m.means.is_cuda:
-            # one HIP pass packs the four gradients and derives the two statistics (gs_pack_view_step)
             from . import _native as nat
-            flat = torch.empty(off, **f32)
-            g = [p.grad.contiguous() for p in geo]
+            in_place = self._flat is not None and self._flat.numel() == off and all(p.grad is None for p in geo)
+            if in_place:
+                # the projection backward wrote the four gradients into the bucket itself (`_grad_out`): one small pass
+                # derives the two statistics segments
+                flat, g = self._flat, [None] * 4
+            else:   # (a model whose forward did not take the bucket: pack the gradients autograd holds)
+                flat = torch.empty(off, **f32)
+                g = [p.grad.contiguous() for p in geo]
             with torch.cuda.device(m.means.device):
                 nat.check(nat.lib().gs_pack_view_step(
-                    torch.cuda.current_stream(m.means.device).cuda_stream, N, max_hw, g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(),
-                    g[3].data_ptr(), out["batch_radii"][0].contiguous().data_ptr(), xys.absgrad[0].contiguous().data_ptr(),
+                    torch.cuda.current_stream(m.means.device).cuda_stream, N, max_hw, *[None if t is None else t.data_ptr() for t in g],
+                    out["batch_radii"][0].contiguous().data_ptr(), xys.absgrad[0].contiguous().data_ptr(),
                     flat.data_ptr()), "gs_pack_view_step")
         else:   # the CPU tests drive this class with float64 tensors
             pieces = [p.grad for p in geo]
@@ -216,8 +245,11 @@ class ViewParallelStep:
         for p, o in zip(geo, offs):
             p.grad = flat[o:o + p.numel()].view_as(p)
         opt.step(only=self.GEOMETRY, grad_scale=1.0 / world, advance=False)
-        m.grad_norm_accum.add_(flat[offs[4]:offs[4] + N])
-        m.collecting_counts.add_(flat[offs[5]:offs[5] + N].to(m.collecting_counts.dtype))
+        if m.collecting_counts.dtype == dt:   # (one launch for both additive statistics)
+            torch._foreach_add_([m.grad_norm_accum, m.collecting_counts], [flat[offs[4]:offs[4] + N], flat[offs[5]:offs[5] + N]])
+        else:
+            m.grad_norm_accum.add_(flat[offs[4]:offs[4] + N])
+            m.collecting_counts.add_(flat[offs[5]:offs[5] + N].to(m.collecting_counts.dtype))
         w_max.wait()
         torch.maximum(m.max_radii, rad, out=m.max_radii)
         opt.zero_grad()

@@ -77,6 +77,7 @@ class GaussianModel(nn.Module):
     tile_culling = "tight"      # render-equivalent shorter lists ("gsplat": meta's list arrays bit-exact, built when read)
     sh_grads = "dense"
     on_colors_pre = None
+    grad_out = None             # callable -> {name: tensor}: caller-owned geometry-gradient tensors (distributed.ViewParallelStep)
     device_refine = True
 
     def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, sh_0: Tensor, sh_rest: Tensor,
@@ -176,7 +177,9 @@ class GaussianModel(nn.Module):
         if self.USE_SCALE_REGULARIZATION:
             scales = self.scales
             ratio = scales.amax(dim=1) / scales.amin(dim=1)
-            max_ratio = float(self.MAX_SCALE_RATIO)   # (a 0-d tensor in files the reference wrote)
+            max_ratio = self.MAX_SCALE_RATIO   # (a Python float: checkpoint.load_gaussian_model converts the reference's 0-d tensor once)
+            if isinstance(max_ratio, Tensor):   # (an object unpickled by hand: convert once, not per step)
+                max_ratio = self.MAX_SCALE_RATIO = float(max_ratio.detach().cpu())
             reg["scale_reg"] = torch.mean(torch.clamp(ratio, min=max_ratio) - max_ratio)
         return reg
 
@@ -390,6 +393,7 @@ class GaussianModel(nn.Module):
             _sh_grads=getattr(self, "sh_grads", "dense"),
             _activations="exp_sigmoid" if raw else "none",
             _on_colors_pre=getattr(self, "on_colors_pre", None),
+            _grad_out=self.grad_out() if callable(getattr(self, "grad_out", None)) else None,
         )
         render_img = batch_render_imgs.squeeze(0)   # (a view both ways: `[0]` would cost a zero-fill + copy in backward)
         if clamp:

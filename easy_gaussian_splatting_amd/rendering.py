@@ -269,7 +269,7 @@ class _Holder:
     the node own its own output (the weak reference lets backward attach `.absgrad` to the very
     tensor object that was handed out in `meta`)."""
 
-    __slots__ = ("meta", "means2d_ref", "absgrad", "debug", "on_colors_pre")
+    __slots__ = ("meta", "means2d_ref", "absgrad", "debug", "on_colors_pre", "grad_out", "lease_ref")
 
     def __init__(self, absgrad: bool):
         self.meta: Dict = {}
@@ -277,6 +277,8 @@ class _Holder:
         self.absgrad = absgrad
         self.debug: Optional[Dict] = None
         self.on_colors_pre = None
+        self.grad_out = None
+        self.lease_ref = None
 
 
 class _ReferenceLists:
@@ -290,6 +292,10 @@ class _ReferenceLists:
         self.rect_ref, self.depths, self.C, self.N, self.tw, self.th, self.eager_ids = rect_ref, depths, C, N, tw, th, eager_ids
         self.out: Optional[Dict[str, Tensor]] = None
         self.lock = threading.Lock()
+        # the lists are built on whatever stream is current when they are first READ: ordered behind the projection that
+        # produced `rect_ref` / `depths` by this event (a reader on another stream raced the producer)
+        self.produced = torch.cuda.Event()
+        self.produced.record(torch.cuda.current_stream(depths.device))
 
     def get(self, key: str) -> Tensor:
         with self.lock:
@@ -303,7 +309,11 @@ class _ReferenceLists:
         dev = self.depths.device
         tiles = tw * th
         i32 = dict(dtype=torch.int32, device=dev)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("meta's list arrays of a `_tile_culling='gsplat'` call are built on first access with host read-backs: "
+                               "read them before the capture starts, or render with _tile_culling='gsplat_eager' / 'tight'")
         with torch.cuda.device(dev), torch.no_grad():
+            torch.cuda.current_stream(dev).wait_event(self.produced)
             st = _stream(dev)
             # footprint records of the binning kernels: rectangle, tile bit mask (all tiles of the rectangle), tile count
             r = self.rect_ref.long()
@@ -622,10 +632,9 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     if not lazy_ref:
         meta._lease = ref   # (the list lazies above read the arenas; in the "gsplat" mode nothing in meta does)
     state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, sh_jac=use_jac, n_isects=n_isects, n_buckets=n_buckets, radii=radii, lease=lease,
-                 lease_ref=WS.LeaseRef(lease) if (need_grad or pending is not None) else None, factorised=factorised, pending=pending,
-                 late=state_late)
+                 lease_ref=WS.LeaseRef(lease) if need_grad else None, factorised=factorised, pending=pending, late=state_late)
     if pending is not None:
-        pending.lease_ref = state["lease_ref"]   # (a repair needs the arenas: leased until the check has run)
+        pending.lease_ref = WS.LeaseRef(lease)   # (a repair needs the arenas: leased until the check has run)
     del ref   # (the lease goes back to its pool here unless meta or the autograd node holds it)
     return render_colors, render_alphas, meta, state
 
@@ -646,6 +655,11 @@ class _Rasterize(torch.autograd.Function):
             lease, tiles = state["lease"], meta["tile_width"] * meta["tile_height"]
             holder.debug.update(unit_counter=lease.view(WS.UNIT_COUNTER, 1).clone(),
                                 qcnt=lease.view(WS.QCNT, state["C"] * tiles * 4).clone(), unit_entries=nat.GS_UNIT)
+        # The backward reads the forward's workspace (lists, checkpoints, records).  Its lease is NOT held by this ctx -- that
+        # would keep it until the OUTPUT tensors die, and a loop that holds the previous image while the next forward runs
+        # would pin two full workspaces -- but by the saved tensors (`rasterization()` installs a pack hook that
+        # attaches it): the engine drops those when a backward without retain_graph has finished, or when the graph dies.
+        holder.lease_ref = state.pop("lease_ref")
         ctx.cfg, ctx.holder, ctx.state = cfg, holder, state
         ctx.split = colors_rest is not None
         if need_grad:
@@ -666,7 +680,7 @@ class _Rasterize(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         v_rc = torch.zeros_like(render_colors) if v_render_colors is None else v_render_colors.contiguous()
         v_ra = None if v_render_alphas is None else v_render_alphas.contiguous()
-        lease, factorised = s["lease"], s["factorised"]   # (the forward's workspace: kept leased by s["lease_ref"])
+        lease, factorised = s["lease"], s["factorised"]   # (the forward's workspace: kept leased by the saved tensors, see forward)
         if s.get("pending") is not None:
             # deferred size check: this call's own record (backward may run on the autograd engine's thread)
             if s["pending"].resolve():
@@ -679,10 +693,14 @@ class _Rasterize(torch.autograd.Function):
                                  P(WS.BUCKET_OFFSETS), s["n_buckets"], P(WS.QLIST), P(WS.QCNT), P(WS.UNIT_COUNTER),
                                  P(WS.UNIT_DESC), P(WS.CKPT), _ptr(render_colors), _ptr(render_alphas),
                                  _ptr(v_rc), _ptr(v_ra), P(WS.ROWS), P(WS.ROWS_COLOR)), "gs_blend_bwd"))
-        v_means = torch.empty((N, 3), **f32)
-        v_quats = torch.empty((N, 4), **f32)
-        v_scales = torch.empty((N, 3), **f32)
-        v_opac = torch.empty((N,), **f32)
+        go = holder.grad_out or {}   # (`_grad_out`: caller-owned gradient tensors; autograd then receives None for those inputs)
+        for k_, shp in (("means", (N, 3)), ("quats", (N, 4)), ("scales", (N, 3)), ("opacities", (N,))):
+            if k_ in go and not (go[k_].shape == shp and go[k_].is_contiguous() and go[k_].dtype == torch.float32 and go[k_].device == dev):
+                raise ValueError(f"_grad_out['{k_}'] must be a contiguous float32 tensor of shape {shp} on {dev}")
+        v_means = go["means"] if "means" in go else torch.empty((N, 3), **f32)
+        v_quats = go["quats"] if "quats" in go else torch.empty((N, 4), **f32)
+        v_scales = go["scales"] if "scales" in go else torch.empty((N, 3), **f32)
+        v_opac = go["opacities"] if "opacities" in go else torch.empty((N,), **f32)
         v_colors = None if factorised else torch.empty(colors.shape, **f32)
         v_rest = torch.empty(colors_rest.shape, **f32) if (ctx.split and not factorised) else None
         v_pre = None
@@ -721,8 +739,9 @@ class _Rasterize(torch.autograd.Function):
             if m2 is not None:
                 m2.absgrad = v_abs
         ni = ctx.needs_input_grad
-        return (v_means if ni[0] else None, v_quats if ni[1] else None, v_scales if ni[2] else None,
-                v_opac if ni[3] else None, v_colors if (ni[4] and not factorised) else None,
+        return (v_means if (ni[0] and "means" not in go) else None, v_quats if (ni[1] and "quats" not in go) else None,
+                v_scales if (ni[2] and "scales" not in go) else None,
+                v_opac if (ni[3] and "opacities" not in go) else None, v_colors if (ni[4] and not factorised) else None,
                 v_rest if (ctx.split and ni[5] and not factorised) else None,
                 None, None, None, None, None)
 
@@ -791,6 +810,7 @@ def rasterization(
     _on_colors_pre=None,
     _activations: str = "none",
     _size_check: Optional[str] = None,
+    _grad_out: Optional[Dict[str, Tensor]] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize 3D Gaussians to images; same tensor signature and return value as
     `gsplat.rendering.rasterization` (gsplat 1.0.0).
@@ -822,6 +842,10 @@ def rasterization(
     (log-scales, logit opacities, /root/reference/model/gaussian.py:98-103); exp and sigmoid are applied
     inside the projection kernels and the returned gradients are w.r.t. the raw parameters, which
     removes the model's four activation kernels per step.  `meta["opacities"]` then holds the logits.
+
+    `_grad_out` (used by `distributed.ViewParallelStep`): {"means" | "quats" | "scales" | "opacities": tensor} -- gradient tensors
+    the caller owns (e.g. segments of its all-reduce bucket); backward writes those gradients there and hands autograd `None`
+    for the corresponding inputs (their `.grad` stays untouched), so no pack / copy pass stands between backward and exchange.
 
     `_size_check` ("immediate" | "deferred"; default: env GS_SIZE_CHECK or "immediate"): when the host looks at the list sizes
     the count kernels reported.  "immediate": before the call returns (one host wait per forward, never a stream drain).
@@ -905,9 +929,12 @@ def rasterization(
     holder = _Holder(absgrad)
     holder.debug = _debug
     holder.on_colors_pre = _on_colors_pre
-    with torch.cuda.device(means.device):
+    holder.grad_out = _grad_out
+    # (pack hook: every tensor the node saves for backward carries the workspace lease -- see _Rasterize.forward)
+    with torch.cuda.device(means.device), torch.autograd.graph.saved_tensors_hooks(lambda t: (t, holder.lease_ref), lambda p: p[0]):
         render_colors, render_alphas = _Rasterize.apply(means_c, quats_c, scales_c, opac_c, colors_c, rest_c,
                                                         viewmats_c, Ks_c, bg_c, cfg, holder)
+    holder.lease_ref = None   # (held by the saved tensors now, if anything was saved)
     meta = holder.meta
     holder.meta = {}
     holder.means2d_ref = weakref.ref(meta["means2d"])

@@ -69,16 +69,20 @@ class Lease:
         self.refs = 0
         self._bound = None
 
-    # -- reference counting by the objects that read the arenas after the forward returned (autograd ctx, meta)
+    # -- reference counting by the objects that read the arenas after the forward returned (autograd ctx, meta).
+    # Under the pool's (re-entrant) lock: meta is dropped on the caller's thread, the autograd ctx on the engine's -- an
+    # unsynchronised `refs -= 1` could lose an update and strand the lease.
     def retain(self) -> "Lease":
-        self.refs += 1
+        with self.pool.lock:
+            self.refs += 1
         return self
 
     def release(self) -> None:
-        self.refs -= 1
-        if self.refs <= 0:
-            self.refs = 0
-            self.pool.give_back(self)
+        with self.pool.lock:
+            self.refs -= 1
+            if self.refs <= 0:
+                self.refs = 0
+                self.pool.give_back(self)
 
     def _ensure(self, which: str, nbytes: int) -> None:
         cur = getattr(self, which)
@@ -129,7 +133,9 @@ class Lease:
 
 class _Pool:
     def __init__(self):
-        self.lock = threading.Lock()
+        # re-entrant: LeaseRef.__del__ -> release() -> give_back() can run on the very thread that holds the lock, when a
+        # cyclic-GC pass triggered by an allocation inside acquire() / give_back() finalises a meta dict or an autograd ctx
+        self.lock = threading.RLock()
         self.free: Dict[Tuple[int, int], List[Lease]] = {}
 
     def acquire(self, device: torch.device, stream: int) -> Lease:

@@ -392,7 +392,9 @@ int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree, float* pa
 /* Row e: this rank's contribution to the SUM all-reduce of the view-parallel step in one pass: the four
  * geometry gradients and this view's two additive statistics (|absgrad|_2 * max_hw, visibility count)
  * packed into flat = [means 3N | log_scales 3N | quats 4N | logit_opacities N | grad_norm N | count N],
- * every segment padded to a multiple of 4 floats (flat holds 4*ceil(3N/4)*2 + 4N + 3*4*ceil(N/4) floats). */
+ * every segment padded to a multiple of 4 floats (flat holds 4*ceil(3N/4)*2 + 4N + 3*4*ceil(N/4) floats).
+ * v_means = v_scales = v_quats = v_opacities = NULL: gs_project_bwd has written its four gradients into those segments of
+ * `flat` itself (they are plain output pointers there); only the two statistics segments are filled in. */
 int gs_pack_view_step(void* stream, int64_t n, float max_hw, const float* v_means, const float* v_scales,
                       const float* v_quats, const float* v_opacities, const int32_t* radii, const float* absgrad,
                       float* flat);

@@ -221,3 +221,26 @@ def test_deferred_size_check_overflow_discovered_one_call_late_is_repaired_in_pl
                                _size_check="deferred", **kw)
     imgt.sum().backward()
     assert torch.isfinite(ins[0].grad).all()
+
+
+def test_lease_returns_when_backward_is_done_not_when_the_outputs_die():
+    """the forward's workspace is held by the node's SAVED TENSORS, which the engine drops at the end of a backward
+    without retain_graph -- the image may live on (a loop keeping the previous frame pinned two workspaces before).  A
+    retained graph keeps the lease, and its second backward reads the same lists."""
+    sc, t = _scene()
+    rendering.reset_hints()
+    free = lambda: sum(len(v) for v in WS.pool.free.values())
+    ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+    kw = dict(sh_degree=3, packed=False, backgrounds=t["backgrounds"][0:1], absgrad=True, _tile_culling="tight")
+    img, _, meta = rasterization(*ins, t["viewmats"][0:1], t["Ks"][0:1], sc["width"], sc["height"], **kw)
+    del meta                                     # ("tight": meta holds the lease for its list arrays)
+    assert free() == 0
+    g1 = torch.autograd.grad(img.sum(), ins, retain_graph=True)
+    assert free() == 0                           # retained: a second backward must find the forward's lists
+    g2 = torch.autograd.grad(img.sum(), ins)
+    assert free() == 1 and img is not None       # done: the lease is back although `img` is alive
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    img2, _, meta2 = rasterization(*ins, t["viewmats"][0:1], t["Ks"][0:1], sc["width"], sc["height"], **kw)   # re-uses it
+    del meta2
+    assert free() == 0 and torch.equal(img2, img)
