@@ -126,7 +126,11 @@ def pmc_traffic(kernel_prefix: str):
         return None, None
     for k, v in data.items():
         if k.startswith(kernel_prefix) and v.get("traffic_bytes_per_launch") is not None:
-            return v["traffic_bytes_per_launch"], src
+            # [lower, upper]: FETCH_SIZE raw + writes (what a gather-dominated kernel moves: gathers are counted in full at their
+            # 64-byte sector) and 2 x FETCH_SIZE + writes (the guide's correction, exact for coalesced streams) --
+            # profiles/r03_traffic_calibration.json; the blend kernels' reads are record gathers: near the lower end
+            lo = v.get("traffic_bytes_per_launch_lower")
+            return ([lo, v["traffic_bytes_per_launch"]] if lo is not None else v["traffic_bytes_per_launch"]), src
     return None, src
 
 
@@ -867,6 +871,8 @@ def run_rank(args) -> int:
                     "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "traffic_source": traffic_src,
+                    "traffic_note": "[lower, upper] bytes per launch: FETCH_SIZE raw / x2, + WRITE_SIZE (counter calibration per access shape: "
+                                    "profiles/r03_traffic_calibration.json); this kernel's reads are 48-byte record gathers: near the lower bound",
                     "algorithmic_bytes": alg[dom], "n_isects_processed": n_isects,
                     "algorithmic_bytes_gsplat_lists": (40 + (88 if dom == "gs_blend_bwd" else 0)) * n_isects_ref + (24 if dom == "gs_blend_bwd" else 20) * H * W,
                     "avg_launch_ms": None if t_ms != t_ms else round(t_ms, 4),

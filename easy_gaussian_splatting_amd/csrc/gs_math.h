@@ -1,5 +1,5 @@
 // gs_math.h -- per-Gaussian arithmetic of the splat rasterizer (projection, SH colour and their
-// VJPs), written once and used by the gfx950 kernels in gs_kernels.hip.  The functions are plain
+// VJPs), written once and used by the gfx950 kernels in gs_project.hip (projection forward / backward) and gs_blend.hip.  The functions are plain
 // scalar fp32 code behind GS_HD so that a host build (tests/hostmath) can exercise exactly the
 // same source on the CPU against the oracle without a GPU.
 //
@@ -23,7 +23,7 @@ constexpr float kTMin = 1e-4f;
 constexpr float kRadiusDiscFloor = 0.01f;
 constexpr float kFovClamp = 1.3f;   // (the float32 value widened into the chain's type, like eps2d and the discriminant floor)
 
-// Per-camera constants, prepared once per launch on the device (see gs_kernels.hip: camera_prep).
+// Per-camera constants, prepared once per launch on the device (see gs_project.hip: make_camera).
 struct Camera {
     float R[9];      // world->camera rotation block of viewmat (row-major)
     float t[3];      // translation column

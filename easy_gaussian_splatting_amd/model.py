@@ -9,7 +9,14 @@ step drives); names and argument meaning follow /root/reference/model/gaussian.p
   GaussianModel.densify_and_prune / reset_opacities  <- :130-146, 259-349  ("next" row f-3: same
       decisions, but one gather per tensor and three host reads instead of ~20 boolean-index
       copies and 8 host syncs; works on torch.optim.Adam and on optim.FusedAdam state)
-Checkpoint IO, loaders and the viewer are out of scope.
+Checkpoint IO and loaders live in checkpoint.py / scene.py; the viewer is out of scope.
+
+Lines that mirror the reference verbatim, and why: the accessors `nbr_gaussians / scales / opacities / shs / param_names`,
+`register_optimizer`, `up_sh_degree`, `update_learning_rate` (error strings included) and the six-group parameter list of
+`build_optimizers` follow /root/reference/model/gaussian.py:97-128, 389-412 line for line -- rows a-1 / a-2 of SURVEY.md 8
+require the same names, call site and optimizer group order (checkpoints are pickled under the reference's class paths and
+must load into either class), so there is no second way to write them.  Everything else in this file (device-side
+refinement, fused statistics, in-kernel activations, the split SH hand-over) is this package's own.
 """
 from __future__ import annotations
 

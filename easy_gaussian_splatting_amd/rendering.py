@@ -719,8 +719,10 @@ class _Rasterize(torch.autograd.Function):
         v_abs = torch.empty((C, N, 2), **f32)
         dbg = holder.debug
         v_m2 = v_cn = v_cp = None
+        m2_out = holder.means2d_ref() if holder.means2d_ref is not None else None
+        if dbg is not None or (m2_out is not None and m2_out.requires_grad):
+            v_m2 = torch.empty((C, N, 2), **f32)   # dL/d means2d: gsplat's `meta["means2d"].grad` (8 B per Gaussian)
         if dbg is not None:
-            v_m2 = torch.empty((C, N, 2), **f32)
             v_cn = torch.empty((C, N, 3), **f32)
             v_cp = torch.empty((C, N, 3), **f32)
         _stage("gs_project_bwd", dev, lambda: nat.check(L.gs_project_bwd(st, C, N, K, s["deg"], _ptr(means), _ptr(quats), _ptr(scales), _ptr(colors),
@@ -734,10 +736,14 @@ class _Rasterize(torch.autograd.Function):
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp,
                        rows=lease.view(WS.ROWS, max(s["n_isects"], 1) * 4 * nat.GS_ROW_FLOATS).clone().view(-1, nat.GS_ROW_FLOATS))
-        if holder.absgrad and holder.means2d_ref is not None:
-            m2 = holder.means2d_ref()
-            if m2 is not None:
-                m2.absgrad = v_abs
+        if m2_out is not None:
+            if holder.absgrad:
+                m2_out.absgrad = v_abs
+            if m2_out.requires_grad and v_m2 is not None:
+                # gsplat hands `means2d` out as a graph tensor: after `meta["means2d"].retain_grad()` its `.grad` holds
+                # dL/d means2d.  Here the projection and the blend are ONE autograd node, so the tensor is a leaf that
+                # requires grad (retain_grad() is then a no-op) and the node deposits the same quantity itself.
+                m2_out.grad = v_m2 if m2_out.grad is None else m2_out.grad + v_m2
         ni = ctx.needs_input_grad
         return (v_means if (ni[0] and "means" not in go) else None, v_quats if (ni[1] and "quats" not in go) else None,
                 v_scales if (ni[2] and "scales" not in go) else None,
@@ -816,7 +822,8 @@ def rasterization(
     `gsplat.rendering.rasterization` (gsplat 1.0.0).
 
     Returns `(render_colors [C,H,W,3], render_alphas [C,H,W,1], meta)`.  `meta["means2d"]`
-    receives the attribute `.absgrad` ([C,N,2]) during backward when `absgrad=True`;
+    receives the attribute `.absgrad` ([C,N,2]) during backward when `absgrad=True`, and -- a leaf that requires grad whenever
+    the render does -- `.grad` = dL/d means2d ([C,N,2]; gsplat: after `meta["means2d"].retain_grad()`, a no-op here);
     `meta["radii"]` is int32 [C,N] with `> 0` marking visible Gaussians.
 
     Only the configuration the reference exercises is implemented natively; anything else raises
@@ -937,5 +944,7 @@ def rasterization(
     holder.lease_ref = None   # (held by the saved tensors now, if anything was saved)
     meta = holder.meta
     holder.meta = {}
+    if render_colors.requires_grad:
+        meta["means2d"].requires_grad_(True)   # (gsplat's graph tensor: `.retain_grad()` / `.grad` work, see backward)
     holder.means2d_ref = weakref.ref(meta["means2d"])
     return render_colors, render_alphas, meta

@@ -236,8 +236,10 @@ int gs_bins_lists(void* stream, int C, int64_t N, int tile_w, int tile_h, int bi
  *   unit_counter[1], unit_desc[8*n_buckets*4] i32   work units (tile*4+quadrant, entries in the unit | 0x100 for the first
  *                       unit of its sublist -- its checkpoint is "T = 1 inside the image", not read --, index of its first
  *                       qlist pair, checkpoint row)
- * A pixel's state is one float: T > 0 live, T <= 0 finished (stop rule fired / outside the image) with |T| final; checkpoints
- * store it as it is (gs_blend_bwd looks at the sign only). */
+ * Inside the forward a pixel's state is one float: T in (1e-4, 1] = live; a finished pixel (stop rule fired / outside the image)
+ * carries its final transmittance scaled by 2^64 (exact in fp32; "live" is T <= 1).  Checkpoints do NOT store that form: a live
+ * pixel's checkpoint holds T, a finished one holds -1 (gs_blend_bwd looks at the sign only; the final T of a finished pixel comes
+ * from render_alphas). */
 int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
                  const float* backgrounds, const int32_t* isect_offsets,
                  const int32_t* bucket_offsets, const int32_t* tile_order, const int32_t* flatten_ids, const int32_t* slots,

@@ -174,7 +174,7 @@ def forward_report(meta, fw, lists=True, geom_slack=1.0, max_flip_tile_frac=0.02
         assert np.abs(radii.astype(np.int64) - fw["radii"])[mism].max() <= 1, "a radius differs by more than the ceil() flip"
     assert mism.sum() <= max(1, 1e-4 * mism.size), f"{int(mism.sum())} of {mism.size} radii differ"
     same = ~mism & (fw["radii"] > 0)   # (culled Gaussians carry no geometry on either side)
-    d_mu = np.abs(meta["means2d"].cpu().numpy() - fw["means2d"]).max(-1) / (EPS32 * np.maximum(np.abs(fw["means2d"]).max(-1), 32.0))
+    d_mu = np.abs(meta["means2d"].detach().cpu().numpy() - fw["means2d"]).max(-1) / (EPS32 * np.maximum(np.abs(fw["means2d"]).max(-1), 32.0))
     e_mu = float(d_mu[same].max(initial=0))
     assert e_mu <= MEANS2D_TOL_ULPS * geom_slack, f"means2d differ by {e_mu} ulps of the coordinate"
     e_dep = float((np.abs(meta["depths"].cpu().numpy() - fw["depths"]) / np.maximum(np.abs(fw["depths"]), 1e-30))[same].max(initial=0))
@@ -204,7 +204,7 @@ def forward_report(meta, fw, lists=True, geom_slack=1.0, max_flip_tile_frac=0.02
             lo = np.clip(np.floor((m2 - r[..., None]) / tile), 0, [fw["tile_width"], fw["tile_height"]])
             hi = np.clip(np.ceil((m2 + r[..., None]) / tile), 0, [fw["tile_width"], fw["tile_height"]])
             return np.concatenate([lo, hi], axis=-1)
-        shifted = (rects(meta["means2d"].cpu().numpy().astype(np.float64), radii.astype(np.float64))
+        shifted = (rects(meta["means2d"].detach().cpu().numpy().astype(np.float64), radii.astype(np.float64))
                    != rects(fw["means2d"].astype(np.float64), fw["radii"].astype(np.float64))).any(-1) & same
         assert shifted.sum() <= max(1, 2e-4 * shifted.size), f"{int(shifted.sum())} rectangles differ from the fp32 reference's"
         differ |= shifted
@@ -383,6 +383,33 @@ def test_forward_backward_parity_small(name, culling):
     check_backward(hip, fw)
     if culling == "gsplat":
         check_backward_unmasked(sc, fw, culling)
+
+
+def test_means2d_is_a_graph_tensor_with_grad_like_gsplat():
+    """gsplat hands `meta["means2d"]` out as a tensor of the autograd graph: `retain_grad()` before backward, `.grad` (dL/d means2d)
+    and `.absgrad` after it.  Same calls here; `.grad` against the oracle's v_means2d; not there under no_grad."""
+    from easy_gaussian_splatting_amd.rendering import rasterization
+    sc = make_scene(**SCENES["ragged_sh2_2views"])
+    fw = run_oracle(sc)
+    t = to_dev(sc)
+    ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+    img, alpha, meta = rasterization(*ins, t["viewmats"], t["Ks"], int(sc["width"]), int(sc["height"]), sh_degree=int(sc["sh_degree"]),
+                                     packed=False, backgrounds=t["backgrounds"], absgrad=True)
+    assert meta["means2d"].requires_grad
+    meta["means2d"].retain_grad()   # (what gsplat's strategies call; harmless here)
+    g = torch.Generator().manual_seed(5)
+    vc, va = torch.randn(img.shape, generator=g), torch.randn(alpha.shape, generator=g)
+    hip = dict(img=img, alpha=alpha, meta=meta, ins=ins)
+    vc, va = mask_upstream(hip, fw, vc, va)
+    ((img * vc.to(dev())).sum() + (alpha * va.to(dev())).sum()).backward()
+    bw = CO.backward(fw, vc.numpy().astype(np.float64), va.numpy().astype(np.float64))
+    got, ref = meta["means2d"].grad.cpu().numpy(), bw["v_means2d"]
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= GRAD_RTOL * np.abs(ref).max()
+    assert np.abs(meta["means2d"].absgrad.cpu().numpy() - bw["v_means2d_abs"]).max() <= GRAD_RTOL * np.abs(bw["v_means2d_abs"]).max()
+    with torch.no_grad():
+        _, _, meta2 = rasterization(*ins, t["viewmats"], t["Ks"], int(sc["width"]), int(sc["height"]), sh_degree=int(sc["sh_degree"]),
+                                    packed=False, backgrounds=t["backgrounds"])
+    assert not meta2["means2d"].requires_grad and torch.equal(meta2["means2d"], meta["means2d"].detach())
 
 
 def test_tight_culling_is_render_equivalent_subset():

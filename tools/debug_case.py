@@ -31,7 +31,7 @@ dbg = {}
 img, alpha, meta = rasterization(*base, t["viewmats"], t["Ks"], W, H, sh_degree=deg, packed=False,
                                  backgrounds=t["backgrounds"] if use_bg else None, absgrad=True, _tile_culling=culling, _debug=dbg)
 fw = TP.run_oracle(sc, use_bg=use_bg)
-m2 = meta["means2d"].cpu().numpy()
+m2 = meta["means2d"].detach().cpu().numpy()
 e = np.abs(m2 - fw["means2d"]).max(-1); c, i = np.unravel_index(e.argmax(), e.shape)
 print(f"means2d: worst abs err {e.max():.3e} at cam {c} gaussian {i}: hip {m2[c, i]} oracle {fw['means2d'][c, i]} depth {fw['depths'][c, i]} radius {fw['radii'][c, i]}")
 try:
