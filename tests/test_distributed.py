@@ -23,10 +23,10 @@ def _free_port():
     return p
 
 
-def _scene():
+def _scene(n_views=2):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     from scenes import make_scene
-    return make_scene(80, 36, 28, sh_degree=1, n_views=2, seed=21, scale_range=(0.05, 0.4), dist=4.0)
+    return make_scene(80, 36, 28, sh_degree=1, n_views=n_views, seed=21, scale_range=(0.05, 0.4), dist=4.0)
 
 
 def _params(sc):
@@ -194,12 +194,13 @@ def _vp_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from easy_gaussian_splatting_amd.distributed import ViewParallelStep
-    sc = _scene()
+    torch.set_num_threads(1)   # (eight ranks share this box's cores)
+    sc = _scene(world)
     model = _Model(sc)
     opt = _SGD(model)
     vp = ViewParallelStep(model, opt, sh_grad_fn=_torch_sh_grad_views)
-    assert model.sh_grads == "colors_pre"
-    target = torch.rand((2, sc["height"], sc["width"], 3), generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    assert model.sh_grads == "colors_pre" and vp.world == world
+    target = torch.rand((world, sc["height"], sc["width"], 3), generator=torch.Generator().manual_seed(5), dtype=torch.float64)
     data = {"w2c": torch.tensor(sc["viewmats"][rank], dtype=torch.float64), "height": sc["height"], "width": sc["width"]}
     for it in range(2):   # first step with the two early-collective hooks, second without
         if it == 0:
@@ -215,29 +216,34 @@ def _vp_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_view_parallel_step_equals_two_view_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_view_parallel_step_equals_two_view_batch(tmp_path, world):
+    """world = 8: BASELINE.json configs[3]'s rank count -- the 8-way all_gather_into_tensor layout, the rank-order sum over eight
+    views, 1/8 folded into the optimizer step -- on gloo (the GPU twin is
+    tests/test_gpu_configs.py::test_config_s4_eight_ranks_equal_single_process)."""
     from oracle import torch_oracle as TO
     port = _free_port()
-    mp.spawn(_vp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = (np.load(os.path.join(tmp_path, f"vp{r}.npz")) for r in range(2))
-    for k in r0.files:
-        np.testing.assert_array_equal(r0[k], r1[k], err_msg=f"replicas diverged in {k}")
-    # single-process reference: mean loss over both views through the ordinary SH path, plain SGD
-    sc = _scene()
+    mp.spawn(_vp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, *others = (np.load(os.path.join(tmp_path, f"vp{r}.npz")) for r in range(world))
+    for r1 in others:
+        for k in r0.files:
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=f"replicas diverged in {k}")
+    # single-process reference: mean loss over all views through the ordinary SH path, plain SGD
+    sc = _scene(world)
     model = _Model(sc)
     dt = torch.float64
-    target = torch.rand((2, sc["height"], sc["width"], 3), generator=torch.Generator().manual_seed(5), dtype=dt)
-    V = torch.tensor(sc["viewmats"][:2], dtype=dt); K = torch.tensor(sc["Ks"][:2], dtype=dt)
-    bg = torch.tensor(sc["backgrounds"][:2], dtype=dt)
+    target = torch.rand((world, sc["height"], sc["width"], 3), generator=torch.Generator().manual_seed(5), dtype=dt)
+    V = torch.tensor(sc["viewmats"][:world], dtype=dt); K = torch.tensor(sc["Ks"][:world], dtype=dt)
+    bg = torch.tensor(sc["backgrounds"][:world], dtype=dt)
     max_hw = max(sc["width"], sc["height"])
     for _ in range(2):
         means, quats, scales, opac = model.inputs()
         img, _, meta = TO.rasterization(means, quats, scales, opac, torch.cat([model.sh_0, model.sh_rest], dim=1), V, K,
                                         sc["width"], sc["height"], sh_degree=1, packed=False, backgrounds=bg, absgrad=True)
-        (((img - target) ** 2).mean(dim=(1, 2, 3)).sum() / 2).backward()
+        (((img - target) ** 2).mean(dim=(1, 2, 3)).sum() / world).backward()
         vis = meta["radii"] > 0
-        # each rank back-propagated its own un-divided view loss -> absgrad is twice the batch's
-        model.grad_norm_accum += (torch.where(vis, 2.0 * meta["means2d"].absgrad.norm(dim=-1) * max_hw, 0.0)).sum(0)
+        # each rank back-propagated its own un-divided view loss -> absgrad is `world` times the batch's
+        model.grad_norm_accum += (torch.where(vis, float(world) * meta["means2d"].absgrad.norm(dim=-1) * max_hw, 0.0)).sum(0)
         model.collecting_counts += vis.double().sum(0)
         model.max_radii = torch.maximum(model.max_radii, torch.where(vis, meta["radii"].double() / max_hw, 0.0).max(0).values)
         with torch.no_grad():
