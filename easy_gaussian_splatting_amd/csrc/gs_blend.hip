@@ -120,7 +120,7 @@ __device__ __forceinline__ void blend_pair(const float alpha, const bool ok, con
 // in 1.6 rounds); held to 80 (5 spilled to scratch) it keeps 6 resident and is 2-3 % faster back to back -- but a kernel
 // that needs SCRATCH makes the runtime (re-)provision scratch memory for the queue it is launched on: once another
 // stream of the process had run the captured step, every eager launch of this kernel on the caller's stream stalled 0.5-2 ms
-// behind that (bench.py's eager stage profile read 0.76-2.4 ms for a 0.28 ms kernel on some boxes).
+// behind that (bench.py's eager stage profile read 0.76-2.4 ms for a 0.28 ms kernel on some boxes; HISTORY.md section 8b).
 // No kernel of the library uses scratch (tests/test_capi.py checks the compiler's resource report).  Inference: 8 waves.
 #ifndef GS_FWD_TRAIN_WAVES_PER_EU
 #define GS_FWD_TRAIN_WAVES_PER_EU 5

@@ -31,7 +31,7 @@ def test_header_symbols_all_exported(native):
 def test_no_kernel_needs_scratch_memory(native):
     """A kernel with register spills (or a dynamically indexed local array) makes the HIP runtime provision scratch memory for
     the queue it is launched on; with two streams of one process taking turns (the captured step on the runner's stream, eager
-    calls on the caller's) every eager launch of such a kernel stalled 0.5-2 ms behind that.  The
+    calls on the caller's) every eager launch of such a kernel stalled 0.5-2 ms behind that (HISTORY.md section 8b).  The
     Makefile keeps the compiler's resource report of every object (csrc/*.res): all kernels must report ScratchSize 0."""
     import glob
     import subprocess

@@ -1,9 +1,14 @@
 #!/bin/bash
-# One GPU-box call that regenerates everything under profiles/ for a round:  tools/final_profiles.sh r03
+# One GPU-box call that regenerates everything under profiles/ for a round:  tools/final_profiles.sh r04
+# (build the clock-probe variant in the container first: tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE";
+#  hipcc -O3 --offload-arch=gfx950 -o tools/micro/clock_probe tools/micro/clock_probe.hip)
 # (SQ counters and HBM traffic first: bench.py quotes them in its roofline objects)
-tag=${1:-r03}
+tag=${1:-r04}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+# shader clock under load first (bench.py's roofline_compute reads profiles/<tag>_clock.json)
+timeout 300 bash tools/clock_probe.sh $tag > gpurun_out/${tag}_clock_stdout.txt 2>&1
+cp gpurun_out/${tag}_clock.json profiles/ 2>/dev/null
 timeout 600 bash tools/prof_sq.sh $tag > gpurun_out/${tag}_sq.log 2>&1
 timeout 400 bash tools/prof_pmc.sh $tag > gpurun_out/${tag}_pmc.log 2>&1
 cp gpurun_out/${tag}_sq_counters.json gpurun_out/${tag}_pmc_traffic.json profiles/ 2>/dev/null
@@ -25,4 +30,5 @@ timeout 300 bash tools/micro/traffic_cal.sh $tag > gpurun_out/${tag}_traffic_cal
 (GS_BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 50 --warmup 10 > gpurun_out/${tag}_bench_forcedist_rccl.json 2> gpurun_out/${tag}_bench_forcedist.err)
 timeout 900 python tools/config_table.py > gpurun_out/${tag}_configs.md 2> gpurun_out/${tag}_configs.err
 timeout 200 python tools/binning_sweep.py 2>/dev/null > gpurun_out/${tag}_binning_sweep.txt
+timeout 200 python tools/blend_time.py 2>/dev/null > gpurun_out/${tag}_blend_time.txt
 head -c 600 gpurun_out/${tag}_bench_line.json; echo; tail -3 gpurun_out/${tag}_bench.err
