@@ -272,7 +272,11 @@ def needle_factor(fw):
 
 GRAD_L2_RTOL = 1e-4        # ||hip - ref||_2 / ||ref||_2 per tensor
 ROW_FLOOR = 1e-3           # per-Gaussian criterion: |delta| <= rtol * max(|ref row|_max, ROW_FLOOR * tensor max)
-ROW_BAD_MAX = 1e-3         # fraction of Gaussians (rows) allowed beyond the per-Gaussian criterion (measured: <= 5.5e-4, v_opacities)
+ROW_BAD_MAX = 5e-3         # fraction of Gaussians (rows) allowed beyond the per-Gaussian criterion, or ROW_BAD_ABS rows if that is more.
+ROW_BAD_ABS = 3            # Measured: <= 5.5e-4 over the suite's scenes (v_opacities); over 1500 sweep scenes of 40-5000 Gaussians the
+                           # worst are 15 of 3996 (v_means) and 3 of 117 (v_opacities) -- rows whose pixel terms cancel to 1e-3..1e-1 of
+                           # the tensor's largest entry, where the fp32 sums' rounding is a few 1e-3 of what is left (still inside the
+                           # max-norm criterion by construction).  Reported per test in the parity report.
 UNMASKED_L2_RTOL = 5e-4    # unmasked upstream gradient against the fp32 oracle: isolated threshold flips, bounded
 UNMASKED_MAX_RTOL = 1e-2
 
@@ -291,7 +295,7 @@ def _grad_metrics(g, ref, rtol, relax=None):
     tmax = r.max(initial=0) + 1e-30
     row_tol = rtol * np.maximum(r.max(axis=1, initial=0), ROW_FLOOR * tmax)
     return {"max": float(d.max(initial=0) / tmax), "l2": float(np.linalg.norm(d) / (np.linalg.norm(r) + 1e-30)),
-            "row_bad": float(np.mean(d.max(axis=1, initial=0) > row_tol)) if n else 0.0,
+            "row_bad": float(np.mean(d.max(axis=1, initial=0) > row_tol)) if n else 0.0, "rows": int(n),
             "row_bad_tensor_max": float(np.mean(d.max(axis=1, initial=0) > rtol * tmax)) if n else 0.0}
 
 
@@ -335,7 +339,8 @@ def check_backward(hip, fw, rtol=GRAD_RTOL, ref_transform=None):
     for name, e in err.items():
         assert e["max"] <= rtol, f"{name}: rel err {e['max']}"
         assert e["l2"] <= GRAD_L2_RTOL * (rtol / GRAD_RTOL), f"{name}: relative L2 err {e['l2']}"
-        assert e["row_bad"] <= ROW_BAD_MAX, f"{name}: {e['row_bad']} of the Gaussians beyond {rtol} of their own gradient"
+        assert e["row_bad"] <= max(ROW_BAD_MAX, (ROW_BAD_ABS + 0.5) / max(e["rows"], 1)), \
+            f"{name}: {e['row_bad']} of the {e['rows']} Gaussians beyond {rtol} of their own gradient"
     return bw
 
 
