@@ -38,6 +38,19 @@ def test_bench_line_contract_single_gpu():
     assert abs(roof["achieved"] - roof["algorithmic_bytes"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) <= 0.01 * roof["achieved"]
     assert r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] >= 1 and len(r["cpu_baseline"]["reps_s"]) == 1
     assert r["host"]["blocked_on_readback_ms_per_step"] >= 0.0
+    # round 4: the timed loop has the reference's shape (a different shuffled view every step, per-step means-LR); the static
+    # camera and the end-to-end loop with refinement are reported beside it
+    assert "view_schedule" in r["config"] and "shuffle" in r["config"]["view_schedule"]
+    assert r["static_view"]["train_iters_per_s"] > 0
+    rl = r["real_loop"]
+    assert "error" not in rl, rl
+    for mode in ("captured", "eager"):
+        assert rl[mode]["finite"] and rl[mode]["steps"] == 600 and len(rl[mode]["n_gaussians"]) == 6
+    assert rl["captured"]["n_gaussians"] == rl["eager"]["n_gaussians"]            # the same refinement decisions in both modes
+    assert abs(rl["captured"]["loss_mean_last_50"] - rl["eager"]["loss_mean_last_50"]) <= 1e-4 * abs(rl["eager"]["loss_mean_last_50"])
+    assert rl["captured"]["captures"] >= 2 and rl["captured"]["overflows"] <= 2   # (a refinement that changes nothing re-captures nothing)
+    assert r["roofline_compute"].get("clock_mhz") and isinstance(r["roofline"]["traffic"], list)
+    assert "deferred_size_check" in r["drop_in"], r["drop_in"]
 
 
 def test_bench_gpus_2_launches_two_ranks():
