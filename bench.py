@@ -881,6 +881,20 @@ def run_rank(args) -> int:
                     "back_to_back_launch_ms": None if dom not in kernel_ms else round(kernel_ms[dom], 4),
                     # priced against HBM as the contract asks; the kernel's actual limiter is VALU issue (roofline_compute)
                     "limiter": "valu-issue"}
+        # the whole step against the same peak: SURVEY.md 8d's algorithmic bytes per frame for the realised N, N_vis, I (per-tile LDS sort:
+        # 16 I), plus the loss (24 HW + 72 HW of maps) and Adam (28 x 59 N) rows of DESIGN.md section 2
+        Ng, K_act = args.gaussians, (sc["sh_degree"] + 1) ** 2
+        step_bytes = {"project_fwd": 68 * Ng + 20 * Ng, "sh_fwd": (12 * K_act + 12) * n_vis + 12 * Ng, "emit": 20 * Ng + 12 * n_isects,
+                      "sort": 16 * n_isects, "offsets": 8 * n_isects + 4 * (W // 16 + 1) * (H // 16 + 1), "blend_fwd": alg["gs_blend_fwd"],
+                      "l1_ssim": 2 * (24 + 72) * H * W, "blend_bwd": alg["gs_blend_bwd"],
+                      "sh_bwd_project_bwd": (24 + 12 * K_act) * n_vis + 132 * Ng, "adam": 28 * 59 * Ng}
+        step_total = sum(step_bytes.values())
+        ms_step = 1e3 * elapsed / args.steps
+        roofline_step = {"bound": "hbm", "algorithmic_bytes": step_total, "by_stage": step_bytes, "ms_per_step": round(ms_step, 4),
+                         "achieved": round(step_total / (ms_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(step_total / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "all stages of one train step (SURVEY.md 8d per-unit figures, SH gradients never materialised: fused Adam) "
+                                 "over the timed step; the two blend kernels are issue-bound (roofline_compute), the rest streams"}
         # compute view of the same kernel: (pixel, Gaussian) pairs and VALU wave-instructions against the issue rate
         rc_obj = {"bound": "valu-issue", "kernel": kname[dom]}
         if dom == "gs_blend_bwd" and dbg.get("unit_counter") is not None:
@@ -958,6 +972,7 @@ def run_rank(args) -> int:
                      "blocked_on_readback_ms_per_step": round(host_wait_ms, 4)},
             "roofline": roofline,
             "roofline_compute": rc_obj,
+            "roofline_step": roofline_step,
         }
         if static_view is not None:
             result["static_view"] = static_view
