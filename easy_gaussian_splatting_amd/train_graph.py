@@ -99,6 +99,7 @@ class TrainStepGraph:
         self.confirmed = 0                # steps known to be applied
         self.issued = 0
         self.stats = {"captures": 0, "overflows": 0, "replayed_steps": 0, "rebuilds": 0}
+        self._pool: Dict[str, Tensor] = {}
         self._key = None
         self.confirmed_at_build = 0
         self._last_inputs = (data["w2c"], data["K"], gt_img, mask)
@@ -135,18 +136,18 @@ class TrainStepGraph:
         b["gt"] = torch.empty((H, W, 3), **f32)
         b["mask"] = torch.empty((H, W), **f32) if self.has_mask else None
         b["bg"] = m.BACKGROUND.detach().reshape(1, 3).to(dev, torch.float32).contiguous().clone()
-        b["radii"] = torch.empty((1, N), **i32)
-        b["means2d"] = torch.empty((1, N, 2), **f32)
-        b["depths"] = torch.empty((1, N), **f32)
-        b["conics"] = torch.empty((1, N, 3), **f32)
-        b["colors_post"] = torch.empty((1, N, 3), **f32)
+        b["radii"] = self._take("radii", (1, N), torch.int32)
+        b["means2d"] = self._take("means2d", (1, N, 2), torch.float32)
+        b["depths"] = self._take("depths", (1, N), torch.float32)
+        b["conics"] = self._take("conics", (1, N, 3), torch.float32)
+        b["colors_post"] = self._take("colors_post", (1, N, 3), torch.float32)
         # d colour / d view direction of the visible Gaussians (gs_project_fwd -> gs_project_bwd*: no SH coefficient is read
         # by the backward); GS_SH_JAC=0 keeps the coefficient-staging backward
-        b["sh_jac"] = torch.empty((N * 9,), **f32) if _SH_JAC else None
-        b["rec"] = torch.empty((N, nat.GS_REC_FLOATS), **f32)
-        b["bbox"] = torch.empty((N, 4), **i32)
-        b["tiles_per_gauss"] = torch.empty((1, N), **i32)
-        b["cum_tiles"] = torch.empty((N,), **i32)
+        b["sh_jac"] = self._take("sh_jac", (N * 9,), torch.float32) if _SH_JAC else None
+        b["rec"] = self._take("rec", (N, nat.GS_REC_FLOATS), torch.float32)
+        b["bbox"] = self._take("bbox", (N, 4), torch.int32)
+        b["tiles_per_gauss"] = self._take("tiles_per_gauss", (1, N), torch.int32)
+        b["cum_tiles"] = self._take("cum_tiles", (N,), torch.int32)
         b["isect_offsets"] = torch.empty((tiles + 1,), **i32)
         b["bucket_offsets"] = torch.empty((tiles + 1,), **i32)
         b["tile_order"] = torch.empty((tiles,), **i32)
@@ -161,7 +162,7 @@ class TrainStepGraph:
         b["v_render"] = torch.empty((H, W, 3), **f32)
         b["qcnt"] = torch.empty((tiles * 4,), **i32)
         b["unit_counter"] = torch.zeros((1,), **i32)
-        b["v_abs"] = torch.empty((1, N, 2), **f32)
+        b["v_abs"] = self._take("v_abs", (1, N, 2), torch.float32)
         self.grads = None if self.fuse_adam else {
             "means": torch.empty((N, 3), **f32), "log_scales": torch.empty((N, 3), **f32),
             "quats": torch.empty((N, 4), **f32), "sh_0": torch.empty((N, 1, 3), **f32),
@@ -192,6 +193,22 @@ class TrainStepGraph:
         self.stats["build_ms"] = round(self.stats.get("build_ms", 0.0) + 1e3 * (now - t_build), 2)        # whole (re-)builds, wall clock
         self.stats["capture_ms"] = round(self.stats.get("capture_ms", 0.0) + 1e3 * (now - t_cap), 2)    # ... of which warm-up + capture
 
+    def _take(self, name: str, shape, dtype) -> Tensor:
+        """A buffer of the workspace from the runner's pool: re-used across re-builds while it fits, re-allocated with head-room
+        when it does not (a model that has been refined once will be refined again: `densify_and_prune` grows N by 20-30 % per
+        call, and a re-build that has to `hipMalloc` twenty-five new buffers cost 16 ms per refinement on some boxes of the
+        pool against 1.3 ms of capture -- bench.py `real_loop`).  First build: exact sizes."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        t = self._pool.get(name)
+        if t is None or t.dtype != dtype or t.numel() < n:
+            slack = 1.0 if self.stats["rebuilds"] == 0 else 1.6
+            t = torch.empty((int(n * slack) + 16,), dtype=dtype, device=self.dev)
+            self._pool[name] = t
+            self.stats["pool_allocs"] = self.stats.get("pool_allocs", 0) + 1
+        return t[:n].view(*shape)
+
     def _alloc_binning(self):
         """Workspace of the binning pipeline the probe chose (rendering.binning_mode): per-tile lists sorted one by one
         ("tiles") or coarse-bin lists sorted and refined ("bins"; capacities for the coarse entries and the longest bin
@@ -199,13 +216,13 @@ class TrainStepGraph:
         L, b, dev = nat.lib(), self.buf, self.dev
         if self.binning == "bins":
             ws = int(L.gs_bins_workspace_bytes(1, self.N, self.tw, self.th, self.bin_shift, self.cap_coarse))
-            b["coarse_keys"] = torch.empty((self.cap_coarse,), dtype=torch.int64, device=dev)
+            b["coarse_keys"] = self._take("coarse_keys", (self.cap_coarse,), torch.int64)
         else:
             ws = int(L.gs_bin_workspace_bytes(1, self.N, self.tw, self.th))
-            b["keys_tmp"] = torch.empty((self.cap,), dtype=torch.int64, device=dev)
-            b["slot_gid"] = torch.empty((self.cap,), dtype=torch.int32, device=dev)
+            b["keys_tmp"] = self._take("keys_tmp", (self.cap,), torch.int64)
+            b["slot_gid"] = self._take("slot_gid", (self.cap,), torch.int32)
         self.ws_bytes = ws
-        b["ws"] = torch.empty((ws,), dtype=torch.uint8, device=dev)
+        b["ws"] = self._take("ws", (ws,), torch.uint8)
 
     def _alloc_lists(self):
         b, dev, cap = self.buf, self.dev, self.cap
@@ -213,13 +230,13 @@ class TrainStepGraph:
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.cap_buckets = cap // nat.GS_BUCKET + tiles + 1
-        b["flatten_ids"] = torch.empty((cap,), **i32)
-        b["slots"] = torch.empty((cap,), **i32)
-        b["ckpt"] = torch.empty((8 * self.cap_buckets, 64, 4), **f32)
-        b["qlist"] = torch.empty((4 * cap, 2), **i32)
-        b["qmask"] = torch.empty((cap,), dtype=torch.uint8, device=dev)
-        b["unit_desc"] = torch.empty((8 * self.cap_buckets, 4), **i32)
-        b["rows"] = torch.empty((4 * cap, nat.GS_ROW_FLOATS), **f32)
+        b["flatten_ids"] = self._take("flatten_ids", (cap,), torch.int32)
+        b["slots"] = self._take("slots", (cap,), torch.int32)
+        b["ckpt"] = self._take("ckpt", (8 * self.cap_buckets, 64, 4), torch.float32)
+        b["qlist"] = self._take("qlist", (4 * cap, 2), torch.int32)
+        b["qmask"] = self._take("qmask", (cap,), torch.uint8)
+        b["unit_desc"] = self._take("unit_desc", (8 * self.cap_buckets, 4), torch.int32)
+        b["rows"] = self._take("rows", (4 * cap, nat.GS_ROW_FLOATS), torch.float32)
 
     def _protect_pending(self, static: Tensor):
         """`static` (one of the runner's input buffers) is about to be overwritten: steps still pending that were issued
