@@ -47,10 +47,11 @@ SIGNATURES = {
     "gs_bins_count": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _P, _Z, _P, _L, _L, _P, _P, _P, _P, _P, _P]),
     "gs_bins_lists": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _Z, _P, _L, _P, _P, _P, _P, _P, _P]),
     "gs_blend_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_project_bwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F,
-                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "gs_colors_pre_grad": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _I, _P, _P]),
+                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "gs_row_sums": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "gs_sh_adam_views": (_I, [_P, _I, _L, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _L, _F, _P]),
     "gs_sh_grad_views": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P]),
     "gs_loss_workspace_floats": (_Z, [_I, _I]),
     "gs_l1_ssim_fwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _I, _P, _P]),

@@ -337,7 +337,6 @@ struct BlendBwdArgs {
     const float4* ckpt;
     const float *out_colors, *out_alphas, *v_colors, *v_alphas;
     float4* rows;   // [I*4][3]
-    float4* rows_color;   // optional [I*4]: a compact copy of the rows' colour lanes (view-parallel exchange)
     const int64_t* guard;
 };
 
@@ -534,7 +533,6 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
             rp[0] = make_float4(e[i].s_mx, e[i].s_my, e[i].s_ax, e[i].s_ay);
             rp[1] = make_float4(0.5f * e[i].s_A, e[i].s_B, 0.5f * e[i].s_C, v_op);
             rp[2] = make_float4(e[i].s_r, e[i].s_g, e[i].s_b, 0.f);
-            if (a.rows_color) a.rows_color[(size_t)slot[i] * 4 + q] = rp[2];
         }
     }
 }
@@ -615,7 +613,7 @@ extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const fl
                             const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_counter,
                             const int32_t* unit_desc, const float* ckpt, const float* render_colors,
                             const float* render_alphas, const float* v_render_colors,
-                            const float* v_render_alphas, float* rows, float* rows_color) {
+                            const float* v_render_alphas, float* rows) {
     GS_REQUIRE(C >= 1 && width > 0 && height > 0 && n_buckets >= 0, "C>=1, positive image size, n_buckets>=0");
     if (n_buckets == 0) return GS_OK;
     GS_REQUIRE(rec && isect_offsets && bucket_offsets && qlist && qcnt && unit_counter && unit_desc && ckpt, "null list pointer");
@@ -629,7 +627,7 @@ extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const fl
     a.unit_desc = reinterpret_cast<const int4*>(unit_desc);
     a.ckpt = reinterpret_cast<const float4*>(ckpt); a.out_colors = render_colors;
     a.out_alphas = render_alphas; a.v_colors = v_render_colors; a.v_alphas = v_render_alphas;
-    a.rows = reinterpret_cast<float4*>(rows); a.rows_color = reinterpret_cast<float4*>(rows_color);
+    a.rows = reinterpret_cast<float4*>(rows);
     a.guard = current_guard().info;
     // upper bound on work units: 4 quadrant sublists per tile, each at most as long as the tile list
     const int64_t max_units = 8 * n_buckets;

@@ -363,7 +363,15 @@ struct ProjBwdArgs {
     // the absgrad this thread holds anyway (optional: NULL = not fused)
     float *st_max_radii, *st_grad_norm, *st_counts;
     float st_max_hw;
+    // View-parallel step (distributed.ViewParallelStep): the row sums come from gs_row_sums (formed early, for the colour
+    // exchange), and this view's two additive statistics are WRITTEN (not accumulated) into the all-reduce bucket:
+    // |absgrad|_2 * max_hw and the visibility flag, 0 for culled Gaussians (st_max_hw as above)
+    const float* row_sums;            // optional [C*N][12]
+    float *st_gn_out, *st_cnt_out;    // optional [N] each (single camera)
 };
+
+__device__ __forceinline__ float sh_adam_isbc2(const ProjBwdArgs& a) { return a.ad_hyper[0]; }
+__device__ __forceinline__ float sh_adam_ss(const ProjBwdArgs& a, int t) { return a.ad_hyper[1 + t]; }
 
 struct RowSum {
     float v[12];
@@ -458,11 +466,16 @@ __device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K
 // front of this call, and no other block touches them, so updating in place is race-free.)
 // KC > 0 fixes K at compile time (K = 16: the reference's SH3 layout): the per-element Gaussian / offset divisions by 45
 // become multiply-shifts (four run-time integer divisions per 16 bytes otherwise).
-template <int KC>
-__device__ __forceinline__ void adam_sh_tile(const float* tile, int rows, int Krt, int64_t n0, const ProjBwdArgs& a) {
+// (templated on the argument block: project_bwd_kernel reads the bias corrections from the device array gs_adam_hyper wrote,
+//  sh_grad_views_kernel<.., ADAM> carries them as kernel arguments; both expose ad_p / ad_m / ad_v [3], [4] and the betas)
+struct ProjBwdArgs;
+__device__ __forceinline__ float sh_adam_isbc2(const ProjBwdArgs& a);
+__device__ __forceinline__ float sh_adam_ss(const ProjBwdArgs& a, int t);
+template <int KC, class A>
+__device__ __forceinline__ void adam_sh_tile(const float* tile, int rows, int Krt, int64_t n0, const A& a) {
     const int K = KC > 0 ? KC : Krt;
     const int row_f = 3 * K, stride = row_f + 1;
-    const float isbc2 = a.ad_hyper[0], ss0 = a.ad_hyper[1 + 3], ssr = a.ad_hyper[1 + 4];
+    const float isbc2 = sh_adam_isbc2(a), ss0 = sh_adam_ss(a, 3), ssr = sh_adam_ss(a, 4);
     {
         float *p0 = a.ad_p[3] + n0 * 3, *m0 = a.ad_m[3] + n0 * 3, *v0 = a.ad_v[3] + n0 * 3;
         for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
@@ -589,7 +602,8 @@ constexpr int kCoopRows = 48;  // Gaussians with more rows than this are summed 
 constexpr int kRowOwnerFloats = 64 * kCoopRows / 4;
 constexpr int kRowWaveFloats = kRowOwnerFloats + 64 * 12;
 
-__device__ __forceinline__ void row_sum_slots(const ProjBwdArgs& a, int cs, int base, RowSum& s, float* wl) {
+template <class A>
+__device__ __forceinline__ void row_sum_slots(const A& a, int cs, int base, RowSum& s, float* wl) {
     const int lane = lane_id();
     const int incl = wave_incl_scan_add(cs);
     const int o = incl - cs;
@@ -660,9 +674,9 @@ __device__ __forceinline__ void row_sum_slots(const ProjBwdArgs& a, int cs, int 
     }
 }
 
-// ADAM: the fused step kernel (gs_project_bwd_adam) -- a separate instantiation, so that neither form carries the other's code
-// and registers, and the two show up under their own names in a kernel trace.
-template <int DEG, bool ADAM>
+// SUMS: the row sums come from gs_row_sums (a.row_sums) -- an instantiation of its own, so that the row-walking form keeps the
+// registers it had (a run-time branch cost it its third wave per SIMD and put the fused form into scratch).
+template <int DEG, bool ADAM, bool SUMS = false>
 __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (guard_tripped(a.guard)) return;
@@ -683,103 +697,18 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     const int cnt = vis ? a.tiles_per_gauss[f] : 0;
     const int base = vis ? a.cum_tiles[f] : 0;
 
-    // ---- 1. sum this Gaussian's gradient rows (contiguous, written once each by blend_bwd)
+    // ---- 1. sum this Gaussian's gradient rows (contiguous, written once each by blend_bwd) -- or take the sums gs_row_sums
+    //         left (a.row_sums: the view-parallel step forms them early, for the colour-gradient exchange)
     RowSum s;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) s.v[i] = 0.f;
-#if GS_ROWSUM_PER_GAUSSIAN
-    if (cnt <= kCoopRows) {
-        // Software pipeline over the slots: the (up to four) quadrant rows of slot r+1 are requested
-        // before the rows of slot r are added, and the mask byte runs two slots ahead, so a Gaussian
-        // with k rows pays ~one HBM round trip instead of k.  Missing quadrants load nothing and add
-        // exact zeros (fixed order -> reproducible sums).
-        float4 cur[4][3], nxt[4][3];
-        auto fetch = [&](float4 (&dst)[4][3], int r, int bits) {
-            const float4* rp = a.rows + 4 * kRow4 * (int64_t)(base + r);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (bits & (1 << q)) { dst[q][0] = rp[kRow4 * q]; dst[q][1] = rp[kRow4 * q + 1]; dst[q][2] = rp[kRow4 * q + 2]; }
-                else { dst[q][0] = dst[q][1] = dst[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
-            }
-        };
-        int bits1 = cnt > 1 ? (int)a.qmask[base + 1] : 0;
-        if (cnt > 0) fetch(cur, 0, (int)a.qmask[base]);
-        for (int r = 0; r < cnt; ++r) {
-            const int bits2 = r + 2 < cnt ? (int)a.qmask[base + r + 2] : 0;
-            if (r + 1 < cnt) fetch(nxt, r + 1, bits1);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s.v[0] += cur[q][0].x; s.v[1] += cur[q][0].y; s.v[2] += cur[q][0].z; s.v[3] += cur[q][0].w;
-                s.v[4] += cur[q][1].x; s.v[5] += cur[q][1].y; s.v[6] += cur[q][1].z; s.v[7] += cur[q][1].w;
-                s.v[8] += cur[q][2].x; s.v[9] += cur[q][2].y; s.v[10] += cur[q][2].z;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { cur[q][0] = nxt[q][0]; cur[q][1] = nxt[q][1]; cur[q][2] = nxt[q][2]; }
-            bits1 = bits2;
-        }
-    }
-#else
-    row_sum_slots(a, cnt <= kCoopRows ? cnt : 0, base, s, tile + (threadIdx.x >> 6) * kRowWaveFloats);
-#endif
-    // Gaussians with many rows: the whole wave sums one of them at a time.  The quadrant masks of the NEXT one are
-    // requested before the rows of the current one are read (a wave holds up to 64 such Gaussians and would otherwise
-    // pay two dependent round trips for each in turn), and a Gaussian none of whose listed entries any pixel took --
-    // most of them behind an opaque surface -- costs no reduction at all.  Per lane the rows are still added in slot
-    // order (fixed order -> reproducible sums).
-    constexpr int kPre = 4;   // 256 slots' masks ahead
-    auto fetch_masks = [&](int bbase, int bcnt, int (&mk)[kPre]) {
-#pragma unroll
-        for (int k = 0; k < kPre; ++k) { const int r = lane_id() + 64 * k; mk[k] = r < bcnt ? (int)a.qmask[bbase + r] : 0; }
-    };
-    auto add_bits = [&](RowSum& p, int64_t slot, int bits) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (bits & (1 << q)) {
-                const float4* r = a.rows + kRow4 * (slot * 4 + q);
-                const float4 x = r[0], y = r[1], z = r[2];
-                p.v[0] += x.x; p.v[1] += x.y; p.v[2] += x.z; p.v[3] += x.w;
-                p.v[4] += y.x; p.v[5] += y.y; p.v[6] += y.z; p.v[7] += y.w;
-                p.v[8] += z.x; p.v[9] += z.y; p.v[10] += z.z;
-            }
-        }
-    };
-    unsigned long long big = __ballot(cnt > kCoopRows);
-    int cur = -1, ccnt = 0, cbase = 0, cmk[kPre], nmk[kPre];
-    if (big) {
-        cur = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        ccnt = __shfl(cnt, cur, 64); cbase = __shfl(base, cur, 64);
-        fetch_masks(cbase, ccnt, cmk);
-    }
-    while (cur >= 0) {
-        int nxt = -1, ncnt = 0, nbase = 0;
-        if (big) {
-            nxt = __ffsll((long long)big) - 1;
-            big &= big - 1;
-            ncnt = __shfl(cnt, nxt, 64); nbase = __shfl(base, nxt, 64);
-            fetch_masks(nbase, ncnt, nmk);
-        }
-        RowSum p;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) p.v[i] = 0.f;
-        bool any_rows = false;
-#pragma unroll
-        for (int k = 0; k < kPre; ++k)
-            if (cmk[k]) { add_bits(p, (int64_t)(cbase + lane_id() + 64 * k), cmk[k]); any_rows = true; }
-        for (int r = lane_id() + 64 * kPre; r < ccnt; r += 64) {
-            const int bits = a.qmask[cbase + r];
-            if (bits) { add_bits(p, (int64_t)(cbase + r), bits); any_rows = true; }
-        }
-        if (__any(any_rows)) {
-#pragma unroll
-            for (int i = 0; i < 11; ++i) {
-                const float t = wave_reduce_add(p.v[i]);
-                if (lane_id() == cur) s.v[i] = t;
-            }
-        }
-        cur = nxt; ccnt = ncnt; cbase = nbase;
-#pragma unroll
-        for (int k = 0; k < kPre; ++k) cmk[k] = nmk[k];
+    if (SUMS) {
+        const float4* rs = reinterpret_cast<const float4*>(a.row_sums) + 3 * f;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x, z = x;
+        if (vis) { x = rs[0]; y = rs[1]; z = rs[2]; }
+        s.v[0] = x.x; s.v[1] = x.y; s.v[2] = x.z; s.v[3] = x.w; s.v[4] = y.x; s.v[5] = y.y; s.v[6] = y.z; s.v[7] = y.w;
+        s.v[8] = z.x; s.v[9] = z.y; s.v[10] = z.z; s.v[11] = 0.f;
+    } else {
+        float* row_wl = tile + (threadIdx.x >> 6) * kRowWaveFloats;
+#include "gs_rowsum_body.inc"
     }
 
     // ---- 2. colour path
@@ -905,6 +834,10 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
             a.v_opacities[n] = v_op;
         }
         reinterpret_cast<float2*>(a.v_means2d_abs)[f] = make_float2(s.v[2], s.v[3]);
+        if (SUMS && a.st_gn_out) {   // (only with row_sums: the view-parallel step; the row-walking form keeps HEAD's registers)
+            a.st_gn_out[n] = vis ? sqrtf(s.v[2] * s.v[2] + s.v[3] * s.v[3]) * a.st_max_hw : 0.f;   // (update_statistics_kernel's arithmetic)
+            a.st_cnt_out[n] = vis ? 1.f : 0.f;
+        }
         if (a.v_means2d) reinterpret_cast<float2*>(a.v_means2d)[f] = make_float2(s.v[0], s.v[1]);
         if (a.v_conics) { a.v_conics[3 * f] = s.v[4]; a.v_conics[3 * f + 1] = s.v[5]; a.v_conics[3 * f + 2] = s.v[6]; }
         if (a.v_colors_post) { a.v_colors_post[3 * f] = v_rgb[0]; a.v_colors_post[3 * f + 1] = v_rgb[1]; a.v_colors_post[3 * f + 2] = v_rgb[2]; }
@@ -957,21 +890,35 @@ struct ShGradArgs {
     int R, K;
     int64_t N;
     const float *means, *viewmats, *v_colors_pre;
+    int64_t view_stride;   // floats between view r and view r+1 of v_colors_pre (3N for a dense [R,N,3]; the payload stride of
+    int64_t cam_stride;    // gs_sh_adam_views) and of viewmats (16 for a dense [R,4,4])
     float *v_colors, *v_sh_rest;
+    // gs_sh_adam_views: no gradient is written -- sh_0 / sh_rest and their moments are updated in place (ShAdam), gradients
+    // scaled by grad_scale first (1/world), and max_radii[n] = max(max_radii[n], max_r radii_norm[r][n])
+    float *ad_p[6], *ad_m[6], *ad_v[6];                       // (only [3] = sh_0 and [4] = sh_rest are set: param_names order)
+    float ad_b1, ad_b2, ad_eps, ad_isbc2, ad_ss0, ad_ssr;     // betas, eps, 1/sqrt(1-beta2^t), lr/(1-beta1^t) of the two groups
+    float grad_scale;
+    const float* radii_norm;   // optional: view r's normalised radii at radii_norm + r * view_stride
+    float* max_radii;
+    const int64_t* guard;
 };
+
+__device__ __forceinline__ float sh_adam_isbc2(const ShGradArgs& a) { return a.ad_isbc2; }
+__device__ __forceinline__ float sh_adam_ss(const ShGradArgs& a, int t) { return t == 3 ? a.ad_ss0 : a.ad_ssr; }
 
 constexpr int kMaxViews = 64;
 
-template <int DEG>
+template <int DEG, bool ADAM>
 __global__ __launch_bounds__(kProjThreads) void sh_grad_views_kernel(const ShGradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (ADAM && guard_tripped(a.guard)) return;
     float* cam_pos = smem;                       // [kMaxViews * 3]
     float* tile = smem + kMaxViews * 3;          // [kProjThreads * (3K + 1)]
     const int64_t n0 = (int64_t)blockIdx.x * kProjThreads, n = n0 + threadIdx.x;
     if ((int)threadIdx.x < a.R) {
         Camera tmp;
         const float kid[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
-        make_camera(a.viewmats + 16 * threadIdx.x, kid, 1, 1, tmp);
+        make_camera(a.viewmats + a.cam_stride * threadIdx.x, kid, 1, 1, tmp);
         cam_pos[3 * threadIdx.x] = tmp.pos[0]; cam_pos[3 * threadIdx.x + 1] = tmp.pos[1]; cam_pos[3 * threadIdx.x + 2] = tmp.pos[2];
     }
     __syncthreads();
@@ -982,9 +929,11 @@ __global__ __launch_bounds__(kProjThreads) void sh_grad_views_kernel(const ShGra
     for (int i = 0; i < 3 * Ka; ++i) acc[i] = 0.f;
     if (n < a.N) {
         const float mean[3] = {a.means[3 * n], a.means[3 * n + 1], a.means[3 * n + 2]};
+        float rad = 0.f;
         for (int r = 0; r < a.R; ++r) {
-            const float* v = a.v_colors_pre + 3 * ((int64_t)r * a.N + n);
+            const float* v = a.v_colors_pre + (int64_t)r * a.view_stride + 3 * n;
             const float vr = v[0], vg = v[1], vb = v[2];
+            if (ADAM && a.radii_norm) rad = fmaxf(rad, a.radii_norm[(int64_t)r * a.view_stride + n]);
             if (vr == 0.f && vg == 0.f && vb == 0.f) continue;   // not visible in view r (x + 0 is exact)
             Camera cam;
             cam.pos[0] = cam_pos[3 * r]; cam.pos[1] = cam_pos[3 * r + 1]; cam.pos[2] = cam_pos[3 * r + 2];
@@ -996,122 +945,86 @@ __global__ __launch_bounds__(kProjThreads) void sh_grad_views_kernel(const ShGra
                 acc[3 * k] += Y[k] * vr; acc[3 * k + 1] += Y[k] * vg; acc[3 * k + 2] += Y[k] * vb;
             }
         }
+        if (ADAM && a.max_radii) a.max_radii[n] = fmaxf(a.max_radii[n], rad);
         float* my = tile + threadIdx.x * stride;
 #pragma unroll
-        for (int i = 0; i < 3 * Ka; ++i) my[i] = acc[i];
+        for (int i = 0; i < 3 * Ka; ++i) my[i] = ADAM ? acc[i] * a.grad_scale : acc[i];   // (gs_adam_step scales the gradient it reads the same way)
         for (int o = 3 * Ka; o < row_f; ++o) my[o] = 0.f;
     }
     __syncthreads();
-    write_sh_tile(tile, (int)min((int64_t)kProjThreads, a.N - n0), a.K, n0, a.v_colors, a.v_sh_rest, false);
+    const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
+    if (ADAM) {
+        if (a.K == 16) adam_sh_tile<16>(tile, rows, 16, n0, a);
+        else adam_sh_tile<0>(tile, rows, a.K, n0, a);
+    } else {
+        write_sh_tile(tile, rows, a.K, n0, a.v_colors, a.v_sh_rest, false);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Early colour gradient for the view-parallel exchange: v_colors_pre[f] = clamp-masked sum of the
-// colour lanes of Gaussian f's gradient rows (read from blend_bwd's compact rows_color copy) -- the only part of project_bwd's output other ranks
-// need.  Running it as its own light kernel right after blend_bwd lets the all-gather of
-// v_colors_pre overlap the (much longer) project_bwd.  Same row order as project_bwd -> same sums.
-// (lane-per-slot sum of the colour lanes, as row_sum_slots does for whole rows: a wave's small Gaussians pay a handful of
-//  round trips instead of one per slot of its longest Gaussian)
-__device__ __forceinline__ void color_sum_slots(const float4* __restrict__ rows_color, int row_quads, const uint8_t* __restrict__ qmask,
-                                                int cs, int base, float& sr, float& sg, float& sb, float* wl) {
-    const int lane = lane_id();
-    const int incl = wave_incl_scan_add(cs);
-    const int o = incl - cs;
-    const int T = __shfl(incl, 63, 64);
-    if (T == 0) return;
-    uint8_t* own = reinterpret_cast<uint8_t*>(wl);
-    float4* item = reinterpret_cast<float4*>(wl + kRowOwnerFloats);
-    for (int r = 0; r < cs; ++r) own[o + r] = (uint8_t)lane;
-    __builtin_amdgcn_wave_barrier();
-    const int n_items = (T + 63) >> 6;
-    for (int u0 = 0; u0 < n_items; u0 += 4) {
-        int sl[4], bt[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = 64 * (u0 + q) + lane;
-            const bool valid = j < T;
-            const int owner = valid ? (int)own[j] : 0;
-            sl[q] = __shfl(base, owner, 64) + j - __shfl(o, owner, 64);
-            bt[q] = valid ? (int)qmask[sl[q]] : 0;
-        }
-        float4 d[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {   // the colour quads of four items: every load issued before the first use
-            const float4* rp = rows_color + (int64_t)4 * row_quads * sl[q] + (row_quads > 1 ? 2 : 0);   // (colour lanes: third quad of a gradient row)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) d[q][k] = (bt[q] & (1 << k)) ? rp[k * row_quads] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (u0 + q < n_items) {   // wave-uniform
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { x.x += d[q][k].x; x.y += d[q][k].y; x.z += d[q][k].z; }
-                item[lane] = x;
-                __builtin_amdgcn_wave_barrier();
-                const int jb = 64 * (u0 + q);
-                const int lo = max(o, jb) - jb, hi = min(o + cs, jb + 64) - jb;
-                for (int r = lo; r < hi; ++r) { const float4 ix = item[r]; sr += ix.x; sg += ix.y; sb += ix.z; }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-}
+// Row sums of every Gaussian as a kernel of its own (view-parallel step): what project_bwd_kernel's phase 1 computes, with
+// the same function -> the same sums bit for bit.  Leaves row_sums[C*N][12] for gs_project_bwd(row_sums = ...) and, from
+// them, everything another rank needs of this view BEFORE the long projection backward runs: the clamp-masked pre-clamp
+// colour gradient v_colors_pre[f] (rounds 2-4: a second pass over the rows, gs_colors_pre_grad), optionally the
+// normalised radii (radius / max_hw, 0 for culled Gaussians: the MAX statistic of update_statistics) and a copy of the view
+// matrix -- the three pieces of the all-gather payload of distributed.ViewParallelStep.
+struct RowSumsArgs {
+    int64_t total;   // C * N
+    const int32_t *radii, *tiles_per_gauss, *cum_tiles;
+    const float* colors_post;
+    const float4* rows;
+    const uint8_t* qmask;
+    float4* row_sums;
+    float *v_colors_pre, *radii_norm, *cam_out;
+    const float* viewmats;
+    float inv_max_hw;
+    const int64_t* guard;
+};
 
-__global__ __launch_bounds__(256) void colors_pre_grad_kernel(int64_t total, const int32_t* __restrict__ radii,
-                                                              const float* __restrict__ colors_post,
-                                                              const int32_t* __restrict__ tiles_per_gauss,
-                                                              const int32_t* __restrict__ cum_tiles,
-                                                              const float4* __restrict__ rows_color, int row_quads,
-                                                              const uint8_t* __restrict__ qmask,
-                                                              float* __restrict__ v_colors_pre) {
-    __shared__ __attribute__((aligned(16))) float wl_all[4][kRowOwnerFloats + 64 * 4];
+__global__ __launch_bounds__(256) void row_sums_kernel(const RowSumsArgs a) {
+    __shared__ __attribute__((aligned(16))) float wl_all[4][kRowWaveFloats];
+    if (guard_tripped(a.guard)) return;
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = f < total;
-    const bool vis = in_range && radii[f] > 0;
-    const int cnt = vis ? tiles_per_gauss[f] : 0, base = vis ? cum_tiles[f] : 0;
-    float sr = 0.f, sg = 0.f, sb = 0.f;
-    color_sum_slots(rows_color, row_quads, qmask, cnt <= kCoopRows ? cnt : 0, base, sr, sg, sb, wl_all[threadIdx.x >> 6]);
-    if (cnt > kCoopRows) {   // the few Gaussians with many slots: their own lane walks them (mask one slot ahead)
-        int bits = (int)qmask[base];
-        for (int r = 0; r < cnt; ++r) {
-            const int bits_next = r + 1 < cnt ? (int)qmask[base + r + 1] : 0;
-            // row_quads = 1: blend_bwd's compact colour copy [I*4][4];  3: the gradient rows themselves [I*4][12], whose
-            // third quad holds the colour lanes (no second, scattered store per row in blend_bwd: 0.66 -> 0.48 ms there)
-            const float4* rp = rows_color + (int64_t)4 * row_quads * (base + r) + (row_quads > 1 ? 2 : 0);
-            float4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = (bits & (1 << q)) ? rp[q * row_quads] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { sr += v[q].x; sg += v[q].y; sb += v[q].z; }
-            bits = bits_next;
-        }
-    }
+    const bool in_range = f < a.total;
+    const int radius = in_range ? a.radii[f] : 0;
+    const bool vis = radius > 0;
+    const int cnt = vis ? a.tiles_per_gauss[f] : 0, base = vis ? a.cum_tiles[f] : 0;
+    float rgb[3] = {0.f, 0.f, 0.f};
+    if (vis) { rgb[0] = a.colors_post[3 * f]; rgb[1] = a.colors_post[3 * f + 1]; rgb[2] = a.colors_post[3 * f + 2]; }
+    if (a.cam_out && blockIdx.x == 0 && threadIdx.x < 16) a.cam_out[threadIdx.x] = a.viewmats[threadIdx.x];
+    RowSum s;
+    float* row_wl = wl_all[threadIdx.x >> 6];
+#include "gs_rowsum_body.inc"
     if (!in_range) return;
-    if (vis) {
-        sr = colors_post[3 * f] > 0.f ? sr : 0.f;
-        sg = colors_post[3 * f + 1] > 0.f ? sg : 0.f;
-        sb = colors_post[3 * f + 2] > 0.f ? sb : 0.f;
+    if (vis) {   // (culled Gaussians: gs_project_bwd does not read their sums)
+        float4* rs = a.row_sums + 3 * f;
+        rs[0] = make_float4(s.v[0], s.v[1], s.v[2], s.v[3]);
+        rs[1] = make_float4(s.v[4], s.v[5], s.v[6], s.v[7]);
+        rs[2] = make_float4(s.v[8], s.v[9], s.v[10], 0.f);
     }
-    v_colors_pre[3 * f] = sr; v_colors_pre[3 * f + 1] = sg; v_colors_pre[3 * f + 2] = sb;
+    float* d = a.v_colors_pre + 3 * f;   // (project_bwd_kernel's v_colors_pre: masked where the clamp max(c + 0.5, 0) is active)
+    d[0] = (vis && rgb[0] > 0.f) ? s.v[8] : 0.f; d[1] = (vis && rgb[1] > 0.f) ? s.v[9] : 0.f; d[2] = (vis && rgb[2] > 0.f) ? s.v[10] : 0.f;
+    if (a.radii_norm) a.radii_norm[f] = vis ? (float)radius * a.inv_max_hw : 0.f;
 }
 
 }  // namespace gs
 
 using namespace gs;
 
-extern "C" int gs_colors_pre_grad(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
-                                  const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows_color,
-                                  int row_floats, const uint8_t* qmask, float* v_colors_pre) {
-    GS_REQUIRE(C >= 1 && N >= 0, "C>=1, N>=0");
-    GS_REQUIRE(row_floats == 4 || row_floats == GS_ROW_FLOATS, "row_floats: 4 (compact colour rows) or GS_ROW_FLOATS (the gradient rows)");
-    if (N == 0) return GS_OK;
-    GS_REQUIRE(radii && colors_post && tiles_per_gauss && cum_tiles && rows_color && qmask && v_colors_pre, "null pointer");
-    const int64_t total = (int64_t)C * N;
-    hipLaunchKernelGGL(colors_pre_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
-                       radii, colors_post, tiles_per_gauss, cum_tiles, reinterpret_cast<const float4*>(rows_color), row_floats / 4, qmask,
-                       v_colors_pre);
-    GS_LAUNCH_CHECK("colors_pre_grad_kernel");
+static int sh_views_launch(hipStream_t st, int sh_degree, bool adam, const ShGradArgs& a) {
+    dim3 grid((unsigned)((a.N + kProjThreads - 1) / kProjThreads));
+    const size_t lds = sizeof(float) * (kMaxViews * 3 + (size_t)kProjThreads * (3 * a.K + 1));
+#define GS_SHV(D)                                                                                           \
+    if (adam) hipLaunchKernelGGL((sh_grad_views_kernel<D, true>), grid, dim3(kProjThreads), lds, st, a);    \
+    else hipLaunchKernelGGL((sh_grad_views_kernel<D, false>), grid, dim3(kProjThreads), lds, st, a)
+    switch (sh_degree) {
+        case 0: GS_SHV(0); break;
+        case 1: GS_SHV(1); break;
+        case 2: GS_SHV(2); break;
+        default: GS_SHV(3); break;
+    }
+#undef GS_SHV
+    GS_LAUNCH_CHECK("sh_grad_views_kernel");
     return GS_OK;
 }
 
@@ -1123,19 +1036,58 @@ extern "C" int gs_sh_grad_views(void* stream, int R, int64_t N, int K, int sh_de
     GS_REQUIRE(K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16, "K must hold (sh_degree+1)^2 coefficients and be <= 16");
     if (N == 0) return GS_OK;
     GS_REQUIRE(means && viewmats && v_colors_pre && v_colors, "null pointer");
-    ShGradArgs a;
+    ShGradArgs a = {};
     a.R = R; a.K = K; a.N = N; a.means = means; a.viewmats = viewmats; a.v_colors_pre = v_colors_pre;
+    a.view_stride = 3 * N; a.cam_stride = 16;
     a.v_colors = v_colors; a.v_sh_rest = v_sh_rest;
-    dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
-    const size_t lds = sizeof(float) * (kMaxViews * 3 + (size_t)kProjThreads * (3 * K + 1));
-    hipStream_t st = (hipStream_t)stream;
-    switch (sh_degree) {
-        case 0: hipLaunchKernelGGL(sh_grad_views_kernel<0>, grid, dim3(kProjThreads), lds, st, a); break;
-        case 1: hipLaunchKernelGGL(sh_grad_views_kernel<1>, grid, dim3(kProjThreads), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(sh_grad_views_kernel<2>, grid, dim3(kProjThreads), lds, st, a); break;
-        default: hipLaunchKernelGGL(sh_grad_views_kernel<3>, grid, dim3(kProjThreads), lds, st, a); break;
-    }
-    GS_LAUNCH_CHECK("sh_grad_views_kernel");
+    return sh_views_launch((hipStream_t)stream, sh_degree, false, a);
+}
+
+extern "C" int gs_sh_adam_views(void* stream, int R, int64_t N, int K, int sh_degree, const float* means, const float* payload,
+                                int64_t payload_stride, float* sh_0, float* sh_0_exp_avg, float* sh_0_exp_avg_sq, float* sh_rest,
+                                float* sh_rest_exp_avg, float* sh_rest_exp_avg_sq, float lr_sh_0, float lr_sh_rest, float beta1,
+                                float beta2, float eps, int64_t step, float grad_scale, float* max_radii) {
+    GS_REQUIRE(R >= 1 && R <= kMaxViews, "1..64 views");
+    GS_REQUIRE(N >= 0 && sh_degree >= 0 && sh_degree <= 3, "N >= 0 and sh_degree in 0..3");
+    GS_REQUIRE(K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16, "K must hold (sh_degree+1)^2 coefficients and be <= 16");
+    GS_REQUIRE(step >= 1, "step counts from 1");
+    GS_REQUIRE(payload_stride >= 4 * N + 16, "payload_stride must hold [3N colour gradients | N radii | 16 camera floats]");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(means && payload && sh_0 && sh_0_exp_avg && sh_0_exp_avg_sq, "null pointer");
+    GS_REQUIRE(K == 1 || (sh_rest && sh_rest_exp_avg && sh_rest_exp_avg_sq), "K > 1 needs sh_rest and its moments");
+    ShGradArgs a = {};
+    a.R = R; a.K = K; a.N = N; a.means = means;
+    a.v_colors_pre = payload; a.radii_norm = max_radii ? payload + 3 * N : nullptr; a.viewmats = payload + 4 * N;
+    a.view_stride = payload_stride; a.cam_stride = payload_stride;
+    a.max_radii = max_radii; a.grad_scale = grad_scale;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.ad_p[3] = sh_0; a.ad_m[3] = sh_0_exp_avg; a.ad_v[3] = sh_0_exp_avg_sq;
+    a.ad_p[4] = sh_rest; a.ad_m[4] = sh_rest_exp_avg; a.ad_v[4] = sh_rest_exp_avg_sq;
+    a.ad_isbc2 = (float)(1.0 / sqrt(bc2));   // (adam_launch's host arithmetic, gs_adam.hip)
+    a.ad_ss0 = (float)((double)lr_sh_0 / bc1); a.ad_ssr = (float)((double)lr_sh_rest / bc1);
+    a.ad_b1 = beta1; a.ad_b2 = beta2; a.ad_eps = eps;
+    a.guard = current_guard().info;
+    return sh_views_launch((hipStream_t)stream, sh_degree, true, a);
+}
+
+extern "C" int gs_row_sums(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
+                           const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
+                           float* row_sums, float* v_colors_pre, float* radii_norm, float max_hw, const float* viewmats,
+                           float* cam_out) {
+    GS_REQUIRE(C >= 1 && N >= 0, "C>=1, N>=0");
+    if (N == 0) return GS_OK;
+    GS_REQUIRE(radii && colors_post && tiles_per_gauss && cum_tiles && rows && qmask && row_sums && v_colors_pre, "null pointer");
+    GS_REQUIRE(((uintptr_t)row_sums & 15) == 0, "row_sums must be 16-byte aligned");
+    GS_REQUIRE(!radii_norm || max_hw > 0.f, "radii_norm needs a positive image extent");
+    GS_REQUIRE(!cam_out || (viewmats && C == 1), "cam_out: the single camera's view matrix");
+    RowSumsArgs a;
+    a.total = (int64_t)C * N; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss; a.cum_tiles = cum_tiles;
+    a.colors_post = colors_post; a.rows = reinterpret_cast<const float4*>(rows); a.qmask = qmask;
+    a.row_sums = reinterpret_cast<float4*>(row_sums); a.v_colors_pre = v_colors_pre; a.radii_norm = radii_norm;
+    a.cam_out = cam_out; a.viewmats = viewmats; a.inv_max_hw = radii_norm ? 1.f / max_hw : 0.f;
+    a.guard = current_guard().info;
+    hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    GS_LAUNCH_CHECK("row_sums_kernel");
     return GS_OK;
 }
 
@@ -1196,12 +1148,16 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
                               const float* rows, const uint8_t* qmask, float* v_means, float* v_quats, float* v_scales,
                               float* v_opacities, float* v_colors, float* v_sh_rest, float* v_means2d_abs,
                               float* v_means2d, float* v_conics, float* v_colors_post, float* v_colors_pre,
-                              const float* opacities, int activations, const float* sh_jac) {
+                              const float* opacities, int activations, const float* sh_jac, const float* row_sums,
+                              float* stat_grad_norm, float* stat_count) {
     GS_REQUIRE(C >= 1 && N >= 0 && width > 0 && height > 0, "C>=1, N>=0, positive image size");
+    GS_REQUIRE((stat_grad_norm == nullptr) == (stat_count == nullptr) && (!stat_count || (C == 1 && row_sums)),
+               "stat_grad_norm / stat_count: both or neither, single camera, together with row_sums");
     GS_REQUIRE(sh_degree <= 3, "sh_degree must be <= 3");
     GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
     if (N == 0) return GS_OK;
-    GS_REQUIRE(means && quats && scales && colors_in && viewmats && Ks && radii && colors_post && tiles_per_gauss && cum_tiles && rows && qmask, "null input pointer");
+    GS_REQUIRE(means && quats && scales && colors_in && viewmats && Ks && radii && colors_post && tiles_per_gauss && cum_tiles, "null input pointer");
+    GS_REQUIRE(row_sums || (rows && qmask), "the gradient rows (rows + qmask) or their sums (row_sums, from gs_row_sums)");
     GS_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_means2d_abs, "null output pointer");
     GS_REQUIRE(v_colors || sh_degree >= 0, "v_colors may be NULL only with SH colours (gradients rebuilt by gs_sh_grad_views)");
     ProjBwdArgs a;
@@ -1219,7 +1175,8 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.sh_jac = sh_degree >= 0 ? reinterpret_cast<const float4*>(sh_jac) : nullptr;
     a.guard = current_guard().info;
     a.adam = 0; a.ad_hyper = nullptr; a.ad_applied = nullptr; a.ad_b1 = a.ad_b2 = a.ad_eps = 0.f;
-    a.st_max_radii = a.st_grad_norm = a.st_counts = nullptr; a.st_max_hw = 1.f;
+    a.st_max_radii = a.st_grad_norm = a.st_counts = nullptr; a.st_max_hw = (float)(width > height ? width : height);
+    a.row_sums = row_sums; a.st_gn_out = stat_grad_norm; a.st_cnt_out = stat_count;
     for (int t = 0; t < 6; ++t) a.ad_p[t] = a.ad_m[t] = a.ad_v[t] = nullptr;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
     const size_t lds = proj_bwd_lds_bytes(K, sh_degree);
@@ -1228,13 +1185,17 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     // every launch, stream order serialises them) -> deterministic sum over cameras, no atomics.
     for (int c = 0; c < C; ++c) {
         a.cam = c; a.accumulate = c > 0;
+#define GS_PB(D)                                                                                                        \
+        if (row_sums) hipLaunchKernelGGL((project_bwd_kernel<D, false, true>), grid, dim3(kProjThreads), lds, st, a);      \
+        else hipLaunchKernelGGL((project_bwd_kernel<D, false, false>), grid, dim3(kProjThreads), lds, st, a)
         switch (sh_degree) {
-            case 0: hipLaunchKernelGGL((project_bwd_kernel<0, false>), grid, dim3(kProjThreads), lds, st, a); break;
-            case 1: hipLaunchKernelGGL((project_bwd_kernel<1, false>), grid, dim3(kProjThreads), lds, st, a); break;
-            case 2: hipLaunchKernelGGL((project_bwd_kernel<2, false>), grid, dim3(kProjThreads), lds, st, a); break;
-            case 3: hipLaunchKernelGGL((project_bwd_kernel<3, false>), grid, dim3(kProjThreads), lds, st, a); break;
-            default: hipLaunchKernelGGL((project_bwd_kernel<-1, false>), grid, dim3(kProjThreads), lds, st, a); break;
+            case 0: GS_PB(0); break;
+            case 1: GS_PB(1); break;
+            case 2: GS_PB(2); break;
+            case 3: GS_PB(3); break;
+            default: GS_PB(-1); break;
         }
+#undef GS_PB
         GS_LAUNCH_CHECK("project_bwd_kernel");
     }
     return GS_OK;
@@ -1277,17 +1238,22 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
                "the three statistics buffers come together or not at all");
     a.st_max_radii = max_radii; a.st_grad_norm = grad_norm_accum; a.st_counts = counts;
     a.st_max_hw = (float)(width > height ? width : height);
+    a.row_sums = nullptr; a.st_gn_out = a.st_cnt_out = nullptr;
     for (int t = 0; t < 6; ++t) { a.ad_p[t] = params + offsets_host[t]; a.ad_m[t] = exp_avg + offsets_host[t]; a.ad_v[t] = exp_avg_sq + offsets_host[t]; }
     a.cam = 0; a.accumulate = 0;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
     const size_t lds = proj_bwd_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;
+    // (no row_sums form of the fused kernel: its instantiation kept a dead 36-byte stack object, and a kernel that declares
+    //  scratch makes the runtime provision it -- gs_blend.hip, GS_FWD_TRAIN_WAVES_PER_EU)
+#define GS_PB(D) hipLaunchKernelGGL((project_bwd_kernel<D, true, false>), grid, dim3(kProjThreads), lds, st, a)
     switch (sh_degree) {
-        case 0: hipLaunchKernelGGL((project_bwd_kernel<0, true>), grid, dim3(kProjThreads), lds, st, a); break;
-        case 1: hipLaunchKernelGGL((project_bwd_kernel<1, true>), grid, dim3(kProjThreads), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((project_bwd_kernel<2, true>), grid, dim3(kProjThreads), lds, st, a); break;
-        default: hipLaunchKernelGGL((project_bwd_kernel<3, true>), grid, dim3(kProjThreads), lds, st, a); break;
+        case 0: GS_PB(0); break;
+        case 1: GS_PB(1); break;
+        case 2: GS_PB(2); break;
+        default: GS_PB(3); break;
     }
+#undef GS_PB
     GS_LAUNCH_CHECK("project_bwd_kernel (fused Adam)");
     return GS_OK;
 }

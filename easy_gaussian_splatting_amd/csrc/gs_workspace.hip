@@ -57,7 +57,6 @@ extern "C" int gs_workspace_query(int C, int64_t N, int width, int height, int64
         size[GS_WS_QMASK] = cap;
         size[GS_WS_UNIT_DESC] = 8 * cap_buckets * 16;
         size[GS_WS_ROWS] = 4 * cap * GS_ROW_FLOATS * 4;
-        if (flags & GS_WS_ROWS_COLOR) size[GS_WS_ROWS_COLOR_BUF] = 4 * cap * 16;
     }
     int64_t off[2] = {0, 0};
     for (int i = 0; i < GS_WS_SLOTS; ++i) {

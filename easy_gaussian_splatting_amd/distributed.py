@@ -12,12 +12,13 @@ Two exchange schemes:
   the step is built around moving fewer bytes.  The SH coefficients are 48 of the 59 parameters
   of a Gaussian, but their gradient is an outer product  v_sh[k] = Y_k(dir) * v_colour_pre  of a
   basis every rank can evaluate itself (it has the means and, after a 64-byte exchange, every
-  camera) and 3 numbers per view.  So ranks all-gather `colors_pre_grad` (12 B per Gaussian and
-  view, plus the 64-byte camera matrix) and rebuild the dense SH gradient locally (`gs_sh_grad_views`, views summed in rank order
-  -> bitwise identical replicas); only the 11 geometry gradients + 2 statistics per Gaussian go
-  through an all-reduce.  Per rank and step at SH3, 1M Gaussians, 8 ranks: 12 MB into an
-  all-gather + 52 MB all-reduce (+ 4 MB MAX for the radii) instead of a 236 MB all-reduce, and
-  the SH half of the Adam step runs while the all-reduce is still in flight.
+  camera) and 3 numbers per view.  So ranks all-gather ONE record per view -- `colors_pre_grad` (12 B per Gaussian), the
+  normalised radii (4 B per Gaussian: `update_statistics`' MAX) and the 64-byte camera matrix -- and apply the SH half of
+  Adam straight from the gathered records (`gs_sh_adam_views`, views summed in rank order -> bitwise identical replicas;
+  the dense SH gradient is never written); only the 11 geometry gradients + 2 statistics per Gaussian go
+  through an all-reduce.  Per rank and step at SH3, 1M Gaussians, 8 ranks: 16 MB into an
+  all-gather + 52 MB all-reduce instead of a 236 MB all-reduce + three statistics collectives -- two collectives per
+  step --, and the SH half of the Adam step runs while the all-reduce is still in flight.
 * `GradBucket` / `all_reduce_param_grads` -- the plain scheme (all six gradients all-reduced),
   kept for optimizers other than `optim.FusedAdam`.
 """
@@ -95,8 +96,17 @@ class ViewParallelStep:
     reference loop (/root/reference/train.py:36-43, 57-58).  The update equals the single-process
     step on the batch of all ranks' views with a mean-over-views loss.  With one rank it is exactly
     the reference sequence -- unless `force_exchange` is set: then a one-rank group still goes through every
-    collective of the scheme (camera all-gather, radii MAX, colour-gradient all-gather from inside `backward()`,
-    geometry all-reduce, split Adam), which is how the RCCL path is exercised on a one-GPU box."""
+    collective of the scheme, which is how the RCCL path is exercised on a one-GPU box.
+
+    TWO collectives per step (round 5; rounds 2-4: four):
+      (A) all-gather of one record per view, [3N pre-clamp colour gradients | N radii / max(H, W) | 16 floats of w2c]
+          -- everything `update_statistics`' MAX and the SH-gradient rebuild need from the other views.  On the GPU the
+          record is filled by ONE launch right after the blend backward (`gs_row_sums`, via `_view_payload`) and the
+          all-gather starts from inside `backward()`, in front of the projection backward it overlaps;
+      (B) all-reduce SUM of [means 3N | log_scales 3N | quats 4N | logit_opacities N | grad_norm N | count N] -- on the GPU
+          written in place by the projection backward (`_grad_out`), statistics segments included: no pack pass.
+    Then the SH half of Adam straight from the gathered records (`gs_sh_adam_views`: the dense SH gradient is never written)
+    while (B) is in flight, the geometry half of Adam and the two additive statistics after it."""
 
     SH = ("sh_0", "sh_rest")
     GEOMETRY = ("means", "log_scales", "quats", "logit_opacities")
@@ -109,19 +119,26 @@ class ViewParallelStep:
         self.exchange = self.world > 1 or bool(force_exchange)
         if self.exchange and not hasattr(optimizer, "moments_of"):
             raise TypeError("ViewParallelStep drives optim.FusedAdam (partial steps, folded 1/world scale)")
+        # native: the fused GPU path (payload filled by gs_row_sums, bucket written in place, gs_sh_adam_views).  A caller that
+        # brings its own `sh_grad_fn` (the CPU tests: float64 tensors, the torch oracle as renderer) gets the same exchange
+        # -- same records, same bucket, same two collectives -- spelled in torch ops.
+        self.native = bool(self.exchange and sh_grad_fn is None and model.means.is_cuda and model.means.dtype == torch.float32
+                           and hasattr(optimizer, "flat_param"))
         if sh_grad_fn is None:
             from .rendering import sh_grad_views as sh_grad_fn
         self.sh_grad_fn = sh_grad_fn
-        self._cams = self._rad = self._pre = None
         self.collectives = 0   # collectives issued so far (diagnostics / tests)
-        self._flat = self._offs = None
+        self._send = self._recv = self._flat = self._offs = self._go = None
+        self._gather = None    # (recv buffer, work) of the all-gather in flight
+        self._cam = self._rad = None
         if self.exchange:   # started from inside backward(), as soon as the colour gradient exists
-            model.on_colors_pre = self._gather_colors_pre
-            if model.means.is_cuda and model.means.dtype == torch.float32:
-                # the projection backward writes the four geometry gradients straight into the all-reduce bucket
-                model.grad_out = self._grad_views
+            model.on_colors_pre = self._on_colors_pre
+            if self.native:
+                model.grad_out = self._grad_views          # geometry gradients + statistics straight into the bucket
+                model.view_payload = self._payload_view    # the all-gather record straight into the send buffer
         model.sh_grads = "colors_pre" if self.exchange else "dense"
 
+    # ------------------------------------------------------------------------------------------ buffers
     def _layout(self):
         """Segments of the SUM all-reduce bucket [means 3N | log_scales 3N | quats 4N | logit_opacities N | grad_norm N | count N],
         each padded to 16 bytes (the layout gs_pack_view_step fills)."""
@@ -134,55 +151,93 @@ class ViewParallelStep:
             off = (off + n_el + 3) // 4 * 4
         return N, offs, off
 
-    def _grad_views(self):
-        """Called by the model's forward: the bucket's gradient segments as the rasterizer's `_grad_out` tensors (re-made
-        when N changed: densify_and_prune)."""
+    def _bucket(self):
         m = self.model
         N, offs, total = self._layout()
-        if self._flat is None or self._flat.numel() != total or self._flat.device != m.means.device:
-            self._flat = torch.zeros(total, dtype=torch.float32, device=m.means.device)   # (pads stay zero for good)
-            self._offs = offs
-        f = self._flat
-        return {"means": f[offs[0]:offs[0] + 3 * N].view(N, 3), "scales": f[offs[1]:offs[1] + 3 * N].view(N, 3),
-                "quats": f[offs[2]:offs[2] + 4 * N].view(N, 4), "opacities": f[offs[3]:offs[3] + N]}
+        if self._flat is None or self._flat.numel() != total or self._flat.device != m.means.device or self._flat.dtype != m.means.dtype:
+            self._flat = torch.zeros(total, dtype=m.means.dtype, device=m.means.device)   # (pads stay zero for good)
+        self._offs = offs
+        return N, offs, self._flat
 
-    # Optional hooks that move the two small collectives off the end of the step (every rank must make
-    # the same calls in the same order; `step` issues whatever was not issued before).
+    def _records(self):
+        """(send [P], recv [world * P]), P = 4 N + 16: one view's record of the all-gather (re-made when N changed)."""
+        m = self.model
+        P = 4 * m.means.shape[0] + 16
+        if self._send is None or self._send.numel() != P or self._send.device != m.means.device or self._send.dtype != m.means.dtype:
+            self._send = torch.zeros(P, dtype=m.means.dtype, device=m.means.device)
+            self._recv = torch.empty(self.world * P, dtype=m.means.dtype, device=m.means.device)
+        return self._send, self._recv
+
+    def _raw_parameters(self) -> bool:
+        """The model hands its RAW parameters to the rasterizer (exp / sigmoid inside the kernels): only then are the
+        rasterizer's gradients the parameters' gradients, and only then may it write them into the bucket itself (with
+        activated inputs autograd still has exp / sigmoid to go through: ADVICE r4)."""
+        m = self.model
+        return bool(m.means.is_cuda and getattr(m, "fuse_activations", True))
+
+    def _grad_views(self):
+        """Called by the model's forward: the bucket's segments as the rasterizer's `_grad_out` tensors (None when the model
+        does not pass raw parameters).  The rasterizer's backward marks the dict `_written` when it has filled them."""
+        self._go = None
+        if not self._raw_parameters():
+            return None
+        N, offs, f = self._bucket()
+        self._go = {"means": f[offs[0]:offs[0] + 3 * N].view(N, 3), "scales": f[offs[1]:offs[1] + 3 * N].view(N, 3),
+                    "quats": f[offs[2]:offs[2] + 4 * N].view(N, 4), "opacities": f[offs[3]:offs[3] + N],
+                    "grad_norm": f[offs[4]:offs[4] + N], "count": f[offs[5]:offs[5] + N]}
+        return self._go
+
+    def _payload_view(self):
+        """Called by the model's forward: this rank's all-gather record as the rasterizer's `_view_payload`."""
+        return self._records()[0]
+
+    # ------------------------------------------------------------------------------------------ hooks
+    # Optional hooks (every rank must make the same calls in the same order).  Since round 5 neither issues a collective:
+    # the camera and the radii travel inside the one all-gather.  They let the torch-op path start that all-gather from
+    # inside backward() (the GPU path gets both from the rasterizer's own launch and needs neither).
     def begin_step(self, data) -> None:
-        """Before the forward: exchange the cameras (64 B per rank)."""
-        if not self.exchange or self._cams is not None:
-            return
-        dt, dev = self.model.means.dtype, self.model.means.device
-        cams = torch.empty(self.world * 16, dtype=dt, device=dev)
-        work = dist.all_gather_into_tensor(cams, data["w2c"].to(dt).reshape(-1).contiguous(), group=self.group, async_op=True)
-        self._cams = (cams, work)
-        self.collectives += 1
+        """Before the forward: note this view's camera."""
+        if self.exchange:
+            self._cam = data["w2c"]
 
     def after_forward(self, data, out) -> None:
-        """After the forward: MAX all-reduce of the normalised radii, overlapped with loss + backward."""
-        if not self.exchange or self._rad is not None:
-            return
+        """After the forward: note this view's normalised radii (torch-op path)."""
+        if self.exchange and not self.native:
+            self._rad = self._radii_norm(data, out)
+
+    def _radii_norm(self, data, out) -> Tensor:
         dt = self.model.means.dtype
-        max_hw = float(max(data["height"], data["width"]))
         radii = out["batch_radii"][0]
-        visible = radii > 0
-        rad = torch.where(visible, radii.to(dt) / max_hw, 0.0)
-        work = dist.all_reduce(rad, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
-        self._rad = (rad, visible, work)
-        self.collectives += 1
+        return torch.where(radii > 0, radii.to(dt) / float(max(data["height"], data["width"])), 0.0)
 
-    def _gather_colors_pre(self, colors_pre_grad: Tensor) -> None:
-        """All-gather of this view's pre-clamp colour gradient [1,N,3] (flat 1-D buffers: the layout
-        every backend accepts).  Called by the rasterizer's backward between the blend backward and
-        the projection backward, so the transfer overlaps the latter; `step` calls it otherwise."""
-        if self._pre is not None:
+    def _on_colors_pre(self, colors_pre_grad: Tensor) -> None:
+        """Called by the rasterizer's backward between the row sums and the projection backward, so that the transfer
+        overlaps the latter; `step` calls `_start_gather` otherwise."""
+        send, _ = self._records()
+        N = self.model.means.shape[0]
+        if colors_pre_grad.data_ptr() == send.data_ptr():
+            self._start_gather()                       # the rasterizer filled the whole record (`_view_payload`)
+        elif self._cam is not None and self._rad is not None:
+            self._fill_record(colors_pre_grad, self._rad, self._cam)
+            self._start_gather()
+        # (else: radii / camera not known yet -- `step` has them)
+
+    def _fill_record(self, colors_pre_grad: Tensor, rad: Tensor, w2c: Tensor) -> None:
+        send, _ = self._records()
+        N = self.model.means.shape[0]
+        send[:3 * N].copy_(colors_pre_grad[0].reshape(-1))
+        send[3 * N:4 * N].copy_(rad)
+        send[4 * N:4 * N + 16].copy_(w2c.to(send.dtype).reshape(-1))
+
+    def _start_gather(self) -> None:
+        if self._gather is not None:
             return
-        mine = colors_pre_grad[0].reshape(-1).contiguous()
-        pre_all = torch.empty(self.world * mine.numel(), dtype=mine.dtype, device=mine.device)
-        work = dist.all_gather_into_tensor(pre_all, mine, group=self.group, async_op=True)
-        self._pre = (pre_all, work)
+        send, recv = self._records()
+        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)
+        self._gather = (recv, work)
         self.collectives += 1
 
+    # ------------------------------------------------------------------------------------------ the step
     def step(self, data, out) -> None:
         m, opt = self.model, self.opt
         if not self.exchange:
@@ -192,54 +247,57 @@ class ViewParallelStep:
             return
         world, group = self.world, self.group
         N = m.means.shape[0]
+        P = 4 * N + 16
         xys = out["batch_xys"]
         dt = m.means.dtype   # float32 in the product; the CPU tests drive this class in float64
-        f32 = dict(dtype=dt, device=m.means.device)
         max_hw = float(max(data["height"], data["width"]))
-        # (0) the small collectives, unless the hooks issued them already
-        self.begin_step(data)
-        self.after_forward(data, out)
-        (cams, w_cams), (rad, visible, w_max) = self._cams, self._rad
-        self._cams = self._rad = None
-        # (1) all-gather of every view's pre-clamp colour gradient (normally already in flight)
-        self._gather_colors_pre(xys.colors_pre_grad)
-        pre_all, w_gather = self._pre
-        self._pre = None
-        # (2) all-reduce SUM: geometry gradients + the two additive statistics of this view
+        # (A) the all-gather of the per-view records, unless backward() started it already
+        if self._gather is None:
+            self._fill_record(xys.colors_pre_grad, self._rad if self._rad is not None else self._radii_norm(data, out), data["w2c"])
+            self._start_gather()
+        recv, w_gather = self._gather
+        self._gather = self._cam = self._rad = None
+        # (B) all-reduce SUM: geometry gradients + the two additive statistics of this view
         #     (/root/reference/model/gaussian.py:188-197), segments padded to 16 bytes
         geo = [getattr(m, name) for name in self.GEOMETRY]
-        _, offs, off = self._layout()
-        if dt == torch.float32 and m.means.is_cuda:
+        _, offs, flat = self._bucket()
+        go, self._go = self._go, None
+        if go is not None and go.pop("_written", False):
+            # the projection backward wrote the four gradients and the two statistics segments into the bucket itself; whatever
+            # autograd holds besides (a regulariser on the raw parameters: `use_scale_regularization`) is added on top
+            for p, o in zip(geo, offs):
+                if p.grad is not None:
+                    flat[o:o + p.numel()].add_(p.grad.reshape(-1))
+                    p.grad = None
+        elif dt == torch.float32 and m.means.is_cuda:
+            # (a model whose forward did not take the bucket -- activated inputs, or no `grad_out` hook: pack what autograd holds)
             from . import _native as nat
-            in_place = self._flat is not None and self._flat.numel() == off and all(p.grad is None for p in geo)
-            if in_place:
-                # the projection backward wrote the four gradients into the bucket itself (`_grad_out`): one small pass
-                # derives the two statistics segments
-                flat, g = self._flat, [None] * 4
-            else:   # (a model whose forward did not take the bucket: pack the gradients autograd holds)
-                flat = torch.empty(off, **f32)
-                g = [p.grad.contiguous() for p in geo]
+            g = [p.grad.contiguous() for p in geo]
             with torch.cuda.device(m.means.device):
                 nat.check(nat.lib().gs_pack_view_step(
-                    torch.cuda.current_stream(m.means.device).cuda_stream, N, max_hw, *[None if t is None else t.data_ptr() for t in g],
+                    torch.cuda.current_stream(m.means.device).cuda_stream, N, max_hw, *[t.data_ptr() for t in g],
                     out["batch_radii"][0].contiguous().data_ptr(), xys.absgrad[0].contiguous().data_ptr(),
                     flat.data_ptr()), "gs_pack_view_step")
         else:   # the CPU tests drive this class with float64 tensors
+            visible = out["batch_radii"][0] > 0
             pieces = [p.grad for p in geo]
             pieces.append(torch.where(visible, torch.linalg.vector_norm(xys.absgrad[0], dim=-1) * max_hw, 0.0))
             pieces.append(visible.to(dt))
-            flat = torch.zeros(off, **f32)
             for t, o in zip(pieces, offs):
                 flat[o:o + t.numel()].copy_(t.reshape(-1))
         w_sum = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         self.collectives += 1
-        # SH half: rebuild the dense SH gradient of all views, update while (2) is in flight
-        w_cams.wait()
+        # SH half while (B) is in flight: the SH gradient of all views from the gathered records, views summed in rank order
         w_gather.wait()
-        v0, vr = self.sh_grad_fn(m.means, cams.view(world, 4, 4), pre_all.view(world, N, 3), m.active_sh_degree,
-                                 1 + m.sh_rest.shape[1])
-        m.sh_0.grad, m.sh_rest.grad = v0, vr
-        opt.step(only=self.SH, grad_scale=1.0 / world)
+        rec = recv.view(world, P)
+        if self.native:
+            self._sh_adam_native(recv, P)
+        else:
+            pre_all, rad_all, cams = rec[:, :3 * N].reshape(world, N, 3), rec[:, 3 * N:4 * N], rec[:, 4 * N:4 * N + 16].reshape(world, 4, 4)
+            v0, vr = self.sh_grad_fn(m.means, cams.contiguous(), pre_all.contiguous(), m.active_sh_degree, 1 + m.sh_rest.shape[1])
+            m.sh_0.grad, m.sh_rest.grad = v0, vr
+            opt.step(only=self.SH, grad_scale=1.0 / world)
+            torch.maximum(m.max_radii, rad_all.max(dim=0).values, out=m.max_radii)
         # geometry half
         w_sum.wait()
         for p, o in zip(geo, offs):
@@ -250,9 +308,27 @@ class ViewParallelStep:
         else:
             m.grad_norm_accum.add_(flat[offs[4]:offs[4] + N])
             m.collecting_counts.add_(flat[offs[5]:offs[5] + N].to(m.collecting_counts.dtype))
-        w_max.wait()
-        torch.maximum(m.max_radii, rad, out=m.max_radii)
         opt.zero_grad()
+
+    def _sh_adam_native(self, recv: Tensor, P: int) -> None:
+        """`gs_sh_adam_views`: sh_0 / sh_rest and their moments updated in place from the gathered records (== `gs_sh_grad_views`
+        + `opt.step(only=SH, grad_scale=1/world)` bit for bit), `max_radii` folded in; advances the optimizer's step count."""
+        from . import _native as nat
+        m, opt = self.model, self.opt
+        opt._check_views()
+        opt._step += 1
+        lr = {g.get("name"): float(g["lr"]) for g in opt.param_groups}
+        m0, v0 = opt.moments_of(m.sh_0)
+        K = 1 + m.sh_rest.shape[1]
+        mr, vr = opt.moments_of(m.sh_rest) if K > 1 else (None, None)
+        b1, b2 = opt.defaults["betas"]
+        ptr = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+        with torch.cuda.device(m.means.device):
+            nat.check(nat.lib().gs_sh_adam_views(
+                torch.cuda.current_stream(m.means.device).cuda_stream, self.world, m.means.shape[0], K, int(m.active_sh_degree),
+                m.means.data_ptr(), recv.data_ptr(), P, m.sh_0.data_ptr(), m0.data_ptr(), v0.data_ptr(),
+                ptr(m.sh_rest) if K > 1 else None, ptr(mr), ptr(vr), lr["sh_0"], lr["sh_rest"], float(b1), float(b2),
+                float(opt.defaults["eps"]), int(opt._step), 1.0 / self.world, m.max_radii.data_ptr()), "gs_sh_adam_views")
 
 
 def all_reduce_statistics(grad_norm: Tensor, counts: Tensor, max_radii: Tensor, group=None) -> None:

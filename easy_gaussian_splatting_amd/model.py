@@ -85,7 +85,18 @@ class GaussianModel(nn.Module):
     sh_grads = "dense"
     on_colors_pre = None
     grad_out = None             # callable -> {name: tensor}: caller-owned geometry-gradient tensors (distributed.ViewParallelStep)
+    view_payload = None         # callable -> tensor: this rank's all-gather record, filled by the rasterizer's backward (same)
     device_refine = True
+    # hooks a training driver installs on a live model (bound methods of distributed.ViewParallelStep): never pickled -- a
+    # checkpoint must not drag the step object, its optimizer and its exchange buffers along, nor name classes the reference
+    # cannot import; an unpickled model falls back to the class defaults above
+    _RUNTIME_HOOKS = ("on_colors_pre", "grad_out", "view_payload", "sh_grads")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._RUNTIME_HOOKS:
+            state.pop(k, None)
+        return state
 
     def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, sh_0: Tensor, sh_rest: Tensor,
                  logit_opacities: Tensor, sh_degree: int, sh_degree_interval: int = 0,
@@ -401,6 +412,7 @@ class GaussianModel(nn.Module):
             _activations="exp_sigmoid" if raw else "none",
             _on_colors_pre=getattr(self, "on_colors_pre", None),
             _grad_out=self.grad_out() if callable(getattr(self, "grad_out", None)) else None,
+            _view_payload=self.view_payload() if callable(getattr(self, "view_payload", None)) else None,
         )
         render_img = batch_render_imgs.squeeze(0)   # (a view both ways: `[0]` would cost a zero-fill + copy in backward)
         if clamp:

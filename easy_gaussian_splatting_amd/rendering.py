@@ -71,9 +71,6 @@ def profile_stages(enable: bool, repeat: Optional[Dict[str, int]] = None) -> Opt
     return {k: [s.elapsed_time(e) / n for s, e, n in v] for k, v in out.items()}
 
 
-# GS_DP_ROWS_COLOR=1: gs_blend_bwd also writes the compact copy of the rows' colour lanes that gs_colors_pre_grad can read instead
-# of the rows themselves (round 2's form; measured in round 3: the second scattered store per row costs blend_bwd 0.18 ms)
-_ROWS_COLOR_COPY = os.environ.get("GS_DP_ROWS_COLOR") == "1"
 # GS_SH_JAC=0: the backward stages the SH coefficients itself instead of using the forward's direction Jacobian (A/B, tests)
 _SH_JAC = os.environ.get("GS_SH_JAC", "1") != "0"
 # GS_FWD_SPLIT=1: projection and SH colour as two launches around the tile count (the form that hid the size read-back before
@@ -269,7 +266,7 @@ class _Holder:
     the node own its own output (the weak reference lets backward attach `.absgrad` to the very
     tensor object that was handed out in `meta`)."""
 
-    __slots__ = ("meta", "means2d_ref", "absgrad", "debug", "on_colors_pre", "grad_out", "lease_ref")
+    __slots__ = ("meta", "means2d_ref", "absgrad", "debug", "on_colors_pre", "grad_out", "view_payload", "lease_ref", "out_ptrs")
 
     def __init__(self, absgrad: bool):
         self.meta: Dict = {}
@@ -278,7 +275,9 @@ class _Holder:
         self.debug: Optional[Dict] = None
         self.on_colors_pre = None
         self.grad_out = None
+        self.view_payload = None
         self.lease_ref = None
+        self.out_ptrs = ()   # data pointers of the node's OUTPUTS (render_colors, render_alphas): see _lease_pack_hook
 
 
 class _ReferenceLists:
@@ -422,8 +421,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     shift = bin_shift_for(hint.get("footprint")) if two_level else 0
     eager_ids = os.environ.get("GS_EAGER_ISECT_IDS") == "1"   # (default: meta builds isect_ids on first access, _LazyMeta)
     factorised = cfg.get("sh_grads") == "colors_pre"
-    flags = ((WS.F_TRAIN if need_grad else 0) | (WS.F_TWO_LEVEL if two_level else 0) | (WS.F_ISECT_IDS if eager_ids else 0)
-             | (WS.F_ROWS_COLOR if (need_grad and factorised and _ROWS_COLOR_COPY) else 0))
+    flags = (WS.F_TRAIN if need_grad else 0) | (WS.F_TWO_LEVEL if two_level else 0) | (WS.F_ISECT_IDS if eager_ids else 0)
     # capacities: what earlier calls of this shape needed (+25 %), or a first guess
     cap = max(int(hint.get("cap", 0)), 2 * C * N + 4096 if not hint else 0, 4096)
     cap_tile = int(hint.get("cap_tile", 1024)) if not two_level else (1 << 30)
@@ -660,6 +658,7 @@ class _Rasterize(torch.autograd.Function):
         # would pin two full workspaces -- but by the saved tensors (`rasterization()` installs a pack hook that
         # attaches it): the engine drops those when a backward without retain_graph has finished, or when the graph dies.
         holder.lease_ref = state.pop("lease_ref")
+        holder.out_ptrs = (render_colors.data_ptr(), render_alphas.data_ptr())
         ctx.cfg, ctx.holder, ctx.state = cfg, holder, state
         ctx.split = colors_rest is not None
         if need_grad:
@@ -692,26 +691,37 @@ class _Rasterize(torch.autograd.Function):
         _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, P(WS.REC), P(WS.ISECT_OFFSETS),
                                  P(WS.BUCKET_OFFSETS), s["n_buckets"], P(WS.QLIST), P(WS.QCNT), P(WS.UNIT_COUNTER),
                                  P(WS.UNIT_DESC), P(WS.CKPT), _ptr(render_colors), _ptr(render_alphas),
-                                 _ptr(v_rc), _ptr(v_ra), P(WS.ROWS), P(WS.ROWS_COLOR)), "gs_blend_bwd"))
+                                 _ptr(v_rc), _ptr(v_ra), P(WS.ROWS)), "gs_blend_bwd"))
         go = holder.grad_out or {}   # (`_grad_out`: caller-owned gradient tensors; autograd then receives None for those inputs)
-        for k_, shp in (("means", (N, 3)), ("quats", (N, 4)), ("scales", (N, 3)), ("opacities", (N,))):
+        for k_, shp in (("means", (N, 3)), ("quats", (N, 4)), ("scales", (N, 3)), ("opacities", (N,)), ("grad_norm", (N,)), ("count", (N,))):
             if k_ in go and not (go[k_].shape == shp and go[k_].is_contiguous() and go[k_].dtype == torch.float32 and go[k_].device == dev):
                 raise ValueError(f"_grad_out['{k_}'] must be a contiguous float32 tensor of shape {shp} on {dev}")
+        if ("grad_norm" in go) != ("count" in go) or ("count" in go and not (factorised and C == 1)):
+            raise ValueError("_grad_out['grad_norm'] / ['count'] come together, with _sh_grads='colors_pre' and a single camera")
         v_means = go["means"] if "means" in go else torch.empty((N, 3), **f32)
         v_quats = go["quats"] if "quats" in go else torch.empty((N, 4), **f32)
         v_scales = go["scales"] if "scales" in go else torch.empty((N, 3), **f32)
         v_opac = go["opacities"] if "opacities" in go else torch.empty((N,), **f32)
         v_colors = None if factorised else torch.empty(colors.shape, **f32)
         v_rest = torch.empty(colors_rest.shape, **f32) if (ctx.split and not factorised) else None
-        v_pre = None
+        v_pre = row_sums = None
         if factorised:
-            # the colour gradient other ranks need, before the long projection backward: its exchange
-            # (holder.on_colors_pre, e.g. an all-gather) overlaps gs_project_bwd
-            v_pre = torch.empty((C, N, 3), **f32)
-            _stage("gs_colors_pre_grad", dev, lambda: nat.check(L.gs_colors_pre_grad(
-                st, C, N, _ptr(s["radii"]), P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES),
-                P(WS.ROWS_COLOR) if _ROWS_COLOR_COPY else P(WS.ROWS), 4 if _ROWS_COLOR_COPY else nat.GS_ROW_FLOATS, P(WS.QMASK),
-                _ptr(v_pre)), "gs_colors_pre_grad"))
+            # Row sums as a pass of their own (gs_row_sums): they yield the colour gradient other ranks need -- and, with
+            # `_view_payload`, this rank's whole all-gather record [3N colour gradients | N normalised radii | view matrix] --
+            # BEFORE the long projection backward, so that the exchange started by holder.on_colors_pre overlaps it;
+            # gs_project_bwd then takes the sums instead of walking the rows again.  (Rounds 2-4: gs_colors_pre_grad walked the
+            # rows' colour lanes a second time, 0.10 ms.)
+            row_sums = torch.empty((C * N, 12), **f32)
+            pay = holder.view_payload
+            if pay is not None:
+                if not (C == 1 and pay.dim() == 1 and pay.numel() >= 4 * N + 16 and pay.is_contiguous() and pay.dtype == torch.float32 and pay.device == dev):
+                    raise ValueError(f"_view_payload must be a contiguous 1-D float32 tensor of >= 4 N + 16 elements on {dev} (single camera)")
+                v_pre, rad_out, cam_out = pay[:3 * N].view(1, N, 3), pay[3 * N:4 * N], pay[4 * N:4 * N + 16]
+            else:
+                v_pre, rad_out, cam_out = torch.empty((C, N, 3), **f32), None, None
+            _stage("gs_row_sums", dev, lambda: nat.check(L.gs_row_sums(
+                st, C, N, _ptr(s["radii"]), P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES), P(WS.ROWS), P(WS.QMASK),
+                _ptr(row_sums), _ptr(v_pre), _ptr(rad_out), float(max(W, H)), _ptr(viewmats), _ptr(cam_out)), "gs_row_sums"))
             if holder.means2d_ref is not None and holder.means2d_ref() is not None:
                 holder.means2d_ref().colors_pre_grad = v_pre
             if holder.on_colors_pre is not None:
@@ -731,8 +741,10 @@ class _Rasterize(torch.autograd.Function):
                                    P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES),
                                    P(WS.ROWS), P(WS.QMASK), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
                                    _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), None,
-                                   _ptr(opacities), cfg.get("activations", 0), P(WS.SH_JAC) if s.get("sh_jac") else None),
-                                                        "gs_project_bwd"))
+                                   _ptr(opacities), cfg.get("activations", 0), P(WS.SH_JAC) if s.get("sh_jac") else None,
+                                   _ptr(row_sums), _ptr(go.get("grad_norm")), _ptr(go.get("count"))), "gs_project_bwd"))
+        if holder.grad_out is not None:
+            holder.grad_out["_written"] = True   # (the caller's own dict: it can tell that its tensors were filled by THIS backward)
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp,
                        rows=lease.view(WS.ROWS, max(s["n_isects"], 1) * 4 * nat.GS_ROW_FLOATS).clone().view(-1, nat.GS_ROW_FLOATS))
@@ -750,6 +762,21 @@ class _Rasterize(torch.autograd.Function):
                 v_opac if (ni[3] and "opacities" not in go) else None, v_colors if (ni[4] and not factorised) else None,
                 v_rest if (ctx.split and ni[5] and not factorised) else None,
                 None, None, None, None, None)
+
+
+def _lease_pack_hook(holder):
+    """Pack hook of the node's saved tensors: the INPUTS it saves carry the workspace lease (the engine drops saved tensors
+    when a backward without retain_graph has finished, or when the graph dies -- that is when the lease returns to its pool).
+    The node's own OUTPUTS (render_colors / render_alphas are saved for the backward) must not: a payload that holds the output
+    tensor itself closes a reference cycle output -> grad_fn -> saved payload -> output that Python's collector cannot see
+    through (THPFunction does not traverse hook payloads), and a grad-enabled forward whose backward never runs -- an eval
+    render, an exception in backward -- would leak the image, the node and the whole workspace.  Outputs are
+    therefore saved detached (backward only reads their values) and without the lease."""
+    def pack(t):
+        if t.data_ptr() in holder.out_ptrs:
+            return (t.detach(), None)
+        return (t, holder.lease_ref)
+    return pack
 
 
 def sh_grad_views(means: Tensor, viewmats: Tensor, colors_pre_grad: Tensor, sh_degree: int, K: int,
@@ -817,6 +844,7 @@ def rasterization(
     _activations: str = "none",
     _size_check: Optional[str] = None,
     _grad_out: Optional[Dict[str, Tensor]] = None,
+    _view_payload: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize 3D Gaussians to images; same tensor signature and return value as
     `gsplat.rendering.rasterization` (gsplat 1.0.0).
@@ -853,6 +881,13 @@ def rasterization(
     `_grad_out` (used by `distributed.ViewParallelStep`): {"means" | "quats" | "scales" | "opacities": tensor} -- gradient tensors
     the caller owns (e.g. segments of its all-reduce bucket); backward writes those gradients there and hands autograd `None`
     for the corresponding inputs (their `.grad` stays untouched), so no pack / copy pass stands between backward and exchange.
+    With `_sh_grads="colors_pre"` and one camera also "grad_norm" / "count" ([N] each): this view's two additive statistics of
+    /root/reference/model/gaussian.py:188-197, written (not accumulated) -- the last two segments of that bucket.
+
+    `_view_payload` (`_sh_grads="colors_pre"`, one camera): a flat float32 tensor of >= 4 N + 16 elements that backward fills,
+    in ONE launch right after the blend backward, with this rank's record of the view-parallel all-gather: [3N pre-clamp colour
+    gradients | N radii / max(W, H) (0 for culled Gaussians) | the 16 floats of the view matrix] (`gs_row_sums`;
+    `meta["means2d"].colors_pre_grad` is then a view of its first segment).
 
     `_size_check` ("immediate" | "deferred"; default: env GS_SIZE_CHECK or "immediate"): when the host looks at the list sizes
     the count kernels reported.  "immediate": before the call returns (one host wait per forward, never a stream drain).
@@ -937,8 +972,11 @@ def rasterization(
     holder.debug = _debug
     holder.on_colors_pre = _on_colors_pre
     holder.grad_out = _grad_out
+    holder.view_payload = _view_payload
+    if _view_payload is not None and _sh_grads != "colors_pre":
+        raise ValueError("_view_payload needs _sh_grads='colors_pre'")
     # (pack hook: every tensor the node saves for backward carries the workspace lease -- see _Rasterize.forward)
-    with torch.cuda.device(means.device), torch.autograd.graph.saved_tensors_hooks(lambda t: (t, holder.lease_ref), lambda p: p[0]):
+    with torch.cuda.device(means.device), torch.autograd.graph.saved_tensors_hooks(_lease_pack_hook(holder), lambda p: p[0]):
         render_colors, render_alphas = _Rasterize.apply(means_c, quats_c, scales_c, opac_c, colors_c, rest_c,
                                                         viewmats_c, Ks_c, bg_c, cfg, holder)
     holder.lease_ref = None   # (held by the saved tensors now, if anything was saved)

@@ -33,6 +33,7 @@ import ctypes as ct
 import math
 import time
 from collections import deque
+from collections.abc import Mapping
 from typing import Any, Dict, Optional
 
 import torch
@@ -100,6 +101,7 @@ class TrainStepGraph:
         self.issued = 0
         self.stats = {"captures": 0, "overflows": 0, "replayed_steps": 0, "rebuilds": 0}
         self._pool: Dict[str, Tensor] = {}
+        self._warm = set()     # (binning mode, tile-sort class) pairs that have run EAGERLY in this runner (warm-up steps)
         self._key = None
         self.confirmed_at_build = 0
         self._last_inputs = (data["w2c"], data["K"], gt_img, mask)
@@ -301,13 +303,14 @@ class TrainStepGraph:
         each `step()`): call it before reading parameters / statistics / outputs on the caller's stream in "lazy" mode."""
         torch.cuda.current_stream(self.dev).wait_stream(self.stream)
 
-    class _StepOutputs(dict):
+    class _StepOutputs(Mapping):
         """The runner's static output tensors; in `handback="lazy"` mode the first access orders the caller's current
-        stream behind the step that produced them."""
+        stream behind the step that produced them.  A read-only Mapping, not a dict subclass: `dict(out)`, `{**out}`, `.get`,
+        `.values()`, `.items()` all reach the tensors through `__getitem__` -- a dict subclass is read by the C-level fast
+        paths behind the fence's back."""
 
         def __init__(self, runner, items, lazy: bool):
-            super().__init__(items)
-            self._runner, self._pending = runner, lazy
+            self._items, self._runner, self._pending = dict(items), runner, lazy
 
         def _touch(self):
             if self._pending:
@@ -316,19 +319,13 @@ class TrainStepGraph:
 
         def __getitem__(self, k):
             self._touch()
-            return super().__getitem__(k)
+            return self._items[k]
 
-        def get(self, k, default=None):
-            self._touch()
-            return super().get(k, default)
+        def __iter__(self):
+            return iter(self._items)
 
-        def values(self):
-            self._touch()
-            return super().values()
-
-        def items(self):
-            self._touch()
-            return super().items()
+        def __len__(self):
+            return len(self._items)
 
     stop_after = int(__import__('os').environ.get('GS_TG_STOP_AFTER', '0'))
     project_rebuilds = __import__('os').environ.get('GS_TG_PROJECT_REBUILDS', '1') != '0'   # 0: every re-build probes and warms up
@@ -436,7 +433,7 @@ class TrainStepGraph:
                                        _p(b["one"]), _p(b["v_render"])), "gs_l1_ssim_bwd")
             self._ck(L.gs_blend_bwd(st, 1, W, H, _p(b["rec"]), _p(b["isect_offsets"]), _p(b["bucket_offsets"]), self.cap_buckets,
                                      _p(b["qlist"]), _p(b["qcnt"]), _p(b["unit_counter"]), _p(b["unit_desc"]), _p(b["ckpt"]),
-                                     _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"]), None),
+                                     _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"])),
                       "gs_blend_bwd")
             b1, b2 = opt.defaults["betas"]
             if self.fuse_adam:
@@ -454,7 +451,7 @@ class TrainStepGraph:
                                           0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]),
                                           _p(b["cum_tiles"]), _p(b["rows"]), _p(b["qmask"]), _p(g["means"]), _p(g["quats"]),
                                           _p(g["log_scales"]), _p(g["logit_opacities"]), _p(g["sh_0"]), _p(g["sh_rest"]), _p(b["v_abs"]),
-                                          None, None, None, None, _p(m.logit_opacities), 1, _p(b["sh_jac"])), "gs_project_bwd")
+                                          None, None, None, None, _p(m.logit_opacities), 1, _p(b["sh_jac"]), None, None, None), "gs_project_bwd")
                 self._ck(L.gs_update_statistics(st, N, float(max(H, W)), _p(b["radii"]), _p(b["v_abs"]), _p(m.max_radii),
                                                 _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_update_statistics")
                 ns = len(opt._plist)
@@ -487,6 +484,7 @@ class TrainStepGraph:
         names = ("max_radii", "grad_norm_accum", "collecting_counts")
         with torch.cuda.device(self.dev), self._on_stream():
             if warm_up:
+                self._warm.add((self.binning, self.cap_tile))
                 saved = [opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()] + [getattr(m, n).clone() for n in names]
                 self._hyper(max(opt._step, 0) + 1, [float(grp["lr"]) for grp, _ in opt._plist])
                 self._enqueue_step()
@@ -569,6 +567,12 @@ class TrainStepGraph:
             if (not size_changed and self.binning == "tiles" and self.seen_isects > 0 and growth <= 2.0 and self.project_rebuilds
                     and self._key is not None and self._state_key(W, H)[5:] == self._key[5:]):
                 projected = (min(int(self.seen_isects * growth), (1 << 29) // 2), max(int(self.seen_tile * min(growth, 1.25)), 64))
+                # ... but only into a tile-sort class this runner has already run EAGERLY: a class used for the first time is
+                # another kernel / another LDS size, whose attributes `ensure_lds` would raise -- and which would launch for the
+                # first time -- inside the stream capture (gs_binning.hip: the warm-up exists to avoid exactly that)
+                cls = next((c for c in _SORT_CLASSES if c >= int(projected[1] * self.margin)), 1 << 30)
+                if (self.binning, cls) not in self._warm:
+                    projected = None
             self.seen_isects = self.seen_tile = 0
             self.cap = 0
             self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None, projected=projected)

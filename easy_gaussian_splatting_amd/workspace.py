@@ -28,14 +28,14 @@ from . import _native as nat
 # slot indices / flags of include/gs_raster.h
 INFO, REC, BBOX, TILES_PER_GAUSS, CUM_TILES, COLORS_POST, ISECT_OFFSETS, BUCKET_OFFSETS, TILE_ORDER, QCNT, UNIT_COUNTER, SH_JAC = range(12)
 LIST_FIRST = 12
-BIN, COARSE_KEYS, KEYS_TMP, SLOT_GID, FLATTEN_IDS, SLOTS, ISECT_IDS, CKPT, QLIST, QMASK, UNIT_DESC, ROWS, ROWS_COLOR = range(12, 25)
-N_SLOTS = 25
-F_TRAIN, F_TWO_LEVEL, F_ISECT_IDS, F_ROWS_COLOR = 1, 2, 4, 8
+BIN, COARSE_KEYS, KEYS_TMP, SLOT_GID, FLATTEN_IDS, SLOTS, ISECT_IDS, CKPT, QLIST, QMASK, UNIT_DESC, ROWS = range(12, 24)
+N_SLOTS = 24
+F_TRAIN, F_TWO_LEVEL, F_ISECT_IDS = 1, 2, 4
 
 _DTYPES = {INFO: torch.int64, REC: torch.float32, BBOX: torch.int32, TILES_PER_GAUSS: torch.int32, CUM_TILES: torch.int32,
            COLORS_POST: torch.float32, ISECT_OFFSETS: torch.int32, BUCKET_OFFSETS: torch.int32, TILE_ORDER: torch.int32,
            QCNT: torch.int32, UNIT_COUNTER: torch.int32, SH_JAC: torch.float32, FLATTEN_IDS: torch.int32, SLOTS: torch.int32, ISECT_IDS: torch.int64,
-           QMASK: torch.uint8, ROWS: torch.float32, ROWS_COLOR: torch.float32, QLIST: torch.int32, UNIT_DESC: torch.int32,
+           QMASK: torch.uint8, ROWS: torch.float32, QLIST: torch.int32, UNIT_DESC: torch.int32,
            CKPT: torch.float32}
 
 stats = {"leases_created": 0, "acquires": 0, "fixed_allocs": 0, "list_allocs": 0, "list_grows": 0, "binds": 0}

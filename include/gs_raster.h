@@ -117,12 +117,10 @@ int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied
 #define GS_WS_QMASK 21          /* u8  [cap]                    (training) */
 #define GS_WS_UNIT_DESC 22      /* i32 [8*cap_buckets][4]       (training) */
 #define GS_WS_ROWS 23           /* f32 [4*cap][12]              (training: gs_blend_bwd -> gs_project_bwd) */
-#define GS_WS_ROWS_COLOR_BUF 24 /* f32 [4*cap][4]               (GS_WS_ROWS_COLOR) */
-#define GS_WS_SLOTS 25
+#define GS_WS_SLOTS 24
 #define GS_WS_TRAIN 1           /* flags: the backward's lists, checkpoints and rows */
 #define GS_WS_TWO_LEVEL 2       /*        two-level binning (coarse_cap, bin_shift) instead of the per-tile pipeline */
 #define GS_WS_ISECT_IDS 4       /*        gsplat's isect_ids written eagerly */
-#define GS_WS_ROWS_COLOR 8      /*        compact colour rows for the view-parallel exchange */
 int gs_workspace_query(int C, int64_t N, int width, int height, int64_t cap_isects, int64_t coarse_cap, int bin_shift, int flags,
                        int64_t* offsets, int64_t* arena_bytes);
 int gs_workspace_bind(void* stream, void* fixed_base, int64_t fixed_bytes, void* list_base, int64_t list_bytes,
@@ -257,7 +255,7 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
                  const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_counter,
                  const int32_t* unit_desc, const float* ckpt, const float* render_colors,
                  const float* render_alphas, const float* v_render_colors,
-                 const float* v_render_alphas, float* rows, float* rows_color);
+                 const float* v_render_alphas, float* rows);
 
 /* Row reduction + SH-bwd + P-bwd fused (replaces the atomics of the blend backward,
  * spherical_harmonics backward and fully_fused_projection backward).  Sums each Gaussian's rows
@@ -270,13 +268,17 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
  * Optional (may be NULL): v_means2d[C,N,2], v_conics[C,N,3], v_colors_post[C,N,3] (gradient of the
  * post-clamp colour), v_colors_pre[C,N,3] (SH colours only: gradient of the pre-clamp colour, zero
  * for culled Gaussians).  With SH colours v_colors (and v_sh_rest) may be NULL: the SH-parameter
- * gradients are then left to gs_sh_grad_views (fed by v_colors_pre from here or from
- * gs_colors_pre_grad).
+ * gradients are then left to gs_sh_grad_views / gs_sh_adam_views (fed by v_colors_pre from here or from
+ * gs_row_sums).
  * activations != 0 (both directions): `scales` / `opacities` are the reference model's log-scales and
  * logit opacities (/root/reference/model/gaussian.py:98-103); exp / sigmoid are applied inside and
  * v_scales / v_opacities are gradients w.r.t. those raw parameters.  0 = gsplat's contract.
  * sh_jac (optional, may be NULL): gs_project_fwd's direction Jacobian of the same inputs; with it colors_in / sh_rest are not
- * read (same gradients to rounding: the direction term of v_means is then summed as J^T v_pre instead of per coefficient). */
+ * read (same gradients to rounding: the direction term of v_means is then summed as J^T v_pre instead of per coefficient).
+ * row_sums[C*N][12] (optional, may be NULL): the row sums gs_row_sums left -- rows / qmask are then not read (may be NULL);
+ * same results bit for bit.  stat_grad_norm[N] / stat_count[N] (optional, both or neither; C = 1): this view's two additive
+ * statistics of /root/reference/model/gaussian.py:188-197, WRITTEN not accumulated -- |absgrad|_2 * max(width, height) and 1 for
+ * visible Gaussians, 0 for culled ones (the segments of the view-parallel step's SUM all-reduce, see gs_pack_view_step). */
 int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const float* means,
                    const float* quats, const float* scales, const float* colors_in,
                    const float* sh_rest, int colors_per_camera, const float* viewmats,
@@ -286,15 +288,19 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities,
                    float* v_colors, float* v_sh_rest, float* v_means2d_abs, float* v_means2d,
                    float* v_conics, float* v_colors_post, float* v_colors_pre,
-                   const float* opacities, int activations, const float* sh_jac);
+                   const float* opacities, int activations, const float* sh_jac, const float* row_sums,
+                   float* stat_grad_norm, float* stat_count);
 
-/* Row e (view sharding): v_colors_pre[C,N,3] alone -- identical to the optional output of gs_project_bwd, but available before
- * that (long) kernel runs, so that its exchange between ranks overlaps the rest of the backward.  rows_color: the gradient rows
- * of gs_blend_bwd themselves (row_floats = 12: the colour lanes are read out of each row's third quad), or that kernel's
- * optional compact copy rows_color[I*4][4] (row_floats = 4).  colors_post[C,N,3] from gs_project_fwd. */
-int gs_colors_pre_grad(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
-                       const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows_color, int row_floats,
-                       const uint8_t* qmask, float* v_colors_pre);
+/* Row e (view sharding): the row sums of every Gaussian as a pass of its own, and from them everything another rank needs of
+ * this view before the long projection backward runs.  row_sums[C*N][12] = the 11 sums gs_project_bwd forms first (same
+ * function, same bits; 12th float 0; rows of culled Gaussians are left unwritten) -> gs_project_bwd(..., row_sums);
+ * v_colors_pre[C*N*3] = the clamp-masked pre-clamp colour gradient (identical to gs_project_bwd's optional output);
+ * radii_norm[C*N] (optional) = radius / max_hw, 0 for culled Gaussians; cam_out[16] (optional, C = 1) = a
+ * copy of viewmats[0].  With v_colors_pre / radii_norm / cam_out pointing into one buffer [3N | N | 16] this launch fills a
+ * rank's whole all-gather payload of the view-parallel step (gs_sh_adam_views).  Honours the step guard. */
+int gs_row_sums(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
+                const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
+                float* row_sums, float* v_colors_pre, float* radii_norm, float max_hw, const float* viewmats, float* cam_out);
 
 /* Row e (view sharding): dense SH-parameter gradients of R views rebuilt from the per-view
  * pre-clamp colour gradients,  v_sh[n][k][:] = sum_r Y_k(dir(means[n], camera r)) * v_colors_pre[r][n][:]
@@ -305,6 +311,18 @@ int gs_colors_pre_grad(void* stream, int C, int64_t N, const int32_t* radii, con
 int gs_sh_grad_views(void* stream, int R, int64_t N, int K, int sh_degree, const float* means,
                      const float* viewmats, const float* v_colors_pre, float* v_colors,
                      float* v_sh_rest);
+
+/* Row e (view sharding): gs_sh_grad_views + the SH half of gs_adam_step in one pass -- the dense SH gradient (192 B per
+ * Gaussian at SH3) is never written or re-read.  payload: the all-gathered per-view records, view r at payload +
+ * r * payload_stride floats: [3N pre-clamp colour gradients | N normalised radii | 16 floats of the view matrix] (what
+ * gs_row_sums fills; payload_stride >= 4N + 16).  sh_0[N,1,3] / sh_rest[N,K-1,3] and their moments are updated in place with
+ * g = grad_scale * sum_r Y(dir(means[n], camera r)) (x) v_colors_pre[r][n] (r ascending: bitwise identical replicas), Adam
+ * arithmetic and bias corrections of gs_adam_step(step); max_radii[N] (optional) = max(max_radii, max_r radii[r]).
+ * Same update bit for bit as gs_sh_grad_views followed by gs_adam_step over the two SH segments.  Honours the step guard. */
+int gs_sh_adam_views(void* stream, int R, int64_t N, int K, int sh_degree, const float* means, const float* payload,
+                     int64_t payload_stride, float* sh_0, float* sh_0_exp_avg, float* sh_0_exp_avg_sq, float* sh_rest,
+                     float* sh_rest_exp_avg, float* sh_rest_exp_avg_sq, float lr_sh_0, float lr_sh_rest, float beta1, float beta2,
+                     float eps, int64_t step, float grad_scale, float* max_radii);
 
 /* ---- "next" row f-1: the loss that feeds v_render_colors ----
  * Fused L1 + (1 - SSIM) of /root/reference/model/gaussian.py:415-453 (torchmetrics SSIM:

@@ -151,7 +151,7 @@ def test_workspace_layout_query(native):
     tr = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 0, 0, WS.F_TRAIN)
     inf = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 0, 0, 0)
     big = WS.Layout(1, 1_000_000, 1920, 1080, 8_000_000, 0, 0, WS.F_TRAIN)
-    two = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 3_000_000, 2, WS.F_TRAIN | WS.F_TWO_LEVEL | WS.F_ROWS_COLOR | WS.F_ISECT_IDS)
+    two = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 3_000_000, 2, WS.F_TRAIN | WS.F_TWO_LEVEL | WS.F_ISECT_IDS)
     for lay in (tr, inf, big, two):
         for arena, lst in sizes(lay).items():
             offs = [o for o, _ in lst]
@@ -163,7 +163,7 @@ def test_workspace_layout_query(native):
     for slot in (WS.CKPT, WS.QLIST, WS.QMASK, WS.UNIT_DESC, WS.ROWS, WS.SLOTS, WS.SLOT_GID, WS.QCNT, WS.UNIT_COUNTER):
         assert tr.offsets[slot] >= 0 and inf.offsets[slot] == -1, slot
     assert inf.offsets[WS.KEYS_TMP] >= 0 and inf.offsets[WS.FLATTEN_IDS] >= 0
-    assert two.offsets[WS.COARSE_KEYS] >= 0 and two.offsets[WS.KEYS_TMP] == -1 and two.offsets[WS.ROWS_COLOR] >= 0 and two.offsets[WS.ISECT_IDS] >= 0
+    assert two.offsets[WS.COARSE_KEYS] >= 0 and two.offsets[WS.KEYS_TMP] == -1 and two.offsets[WS.ISECT_IDS] >= 0
     assert big.arena_bytes[0] == tr.arena_bytes[0] and big.arena_bytes[1] > 1.9 * tr.arena_bytes[1] - 2**27
     assert inf.arena_bytes[1] < tr.arena_bytes[1] / 10
     # errors: through the status code + gs_last_error, never a crash

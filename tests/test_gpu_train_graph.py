@@ -339,3 +339,61 @@ def test_soak_reference_loop_shape_captured_equals_eager():
     import parity_log
     parity_log.record(soak={"steps": 700, "n_gaussians": n_g, "loss_mean_last_50_per_100_captured": m_g,
                             "loss_mean_last_50_per_100_eager": m_e, "runner": rep})
+
+
+def test_projected_rebuild_never_enters_a_sort_class_for_the_first_time_under_capture():
+    """a re-build on PROJECTED capacities skips the probe and the eager warm-up step, on the premise that every kernel
+    has run in this process.  A projection that lands in a larger tile-sort class than any the runner has warmed up is another
+    kernel with another LDS size: the re-build must then take the warm-up path, and the trajectory stays the eager one."""
+    dev, make, datas, gts = _setup(n=8000, sh_degree=3)
+    (ma, oa), (mb, ob) = make(), make()
+    for m in (ma, mb):
+        m.DENSIFY_GRAD_THRESH = 0.0
+    lc = LossComputer(0.2, clamp_input=True)
+    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], check_every=2)
+    assert runner.binning == "tiles" and runner.cap_tile == 1024 and runner._warm == {("tiles", 1024)}
+    for it in range(4):
+        _eager_step(ma, oa, lc, datas[it % 3], gts[it % 3]); runner.step(datas[it % 3], gts[it % 3])
+    runner.finish()
+    # as if a view with a 900-entry tile list had been seen: 900 x growth x margin > 1024 -> the projection asks for class 4096
+    runner.seen_tile = 900
+    for m in (ma, mb):
+        m.densify_and_prune(generator=torch.Generator(device=dev).manual_seed(5))
+    before = runner.report().get("projected_rebuilds", 0)
+    for it in range(3):
+        _eager_step(ma, oa, lc, datas[it % 3], gts[it % 3]); runner.step(datas[it % 3], gts[it % 3])
+    runner.finish()
+    assert runner.report().get("projected_rebuilds", 0) == before, "the re-build entered an unwarmed sort class without a warm-up"
+    _assert_same(ma, oa, mb, ob, "after the probing re-build")
+    # ... while a projection that stays inside a warmed class needs no probe
+    for m in (ma, mb):
+        m.reset_opacities()
+    runner.seen_tile = min(runner.seen_tile, 200)
+    for it in range(2):
+        _eager_step(ma, oa, lc, datas[it], gts[it]); runner.step(datas[it], gts[it])
+    runner.finish()
+    assert runner.report().get("projected_rebuilds", 0) == before + 1
+    _assert_same(ma, oa, mb, ob, "after the projected re-build")
+
+
+def test_lazy_outputs_fence_on_every_way_of_reading_them():
+    """`dict(out)`, `{**out}`, `.get`, `.values()`, `.items()` of a lazy hand-back must order the caller's stream
+    behind the step like `out[...]` does (a dict subclass is read by C-level fast paths that never call `__getitem__`)."""
+    dev, make, datas, gts = _setup()
+    m, o = make()
+    lc = LossComputer(0.2, clamp_input=True)
+    runner = TrainStepGraph(m, o, lc, datas[0], gts[0], None, handback="lazy")
+    fences = []
+    real_fence = runner.fence
+    runner.fence = lambda: (fences.append(1), real_fence())[1]
+    readers = [lambda out: dict(out), lambda out: {**out}, lambda out: out.get("loss3"), lambda out: list(out.values()),
+               lambda out: list(out.items()), lambda out: out["render_img"]]
+    for read in readers:
+        out = runner.step()
+        assert set(out.keys()) == {"render_img", "loss3", "batch_radii", "absgrad"} and len(out) == 4 and not fences   # (names only: no fence)
+        read(out)
+        assert len(fences) == 1, read
+        read(out)
+        assert len(fences) == 1   # once per step
+        fences.clear()
+    runner.finish()

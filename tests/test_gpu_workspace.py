@@ -244,3 +244,30 @@ def test_lease_returns_when_backward_is_done_not_when_the_outputs_die():
     img2, _, meta2 = rasterization(*ins, t["viewmats"][0:1], t["Ks"][0:1], sc["width"], sc["height"], **kw)   # re-uses it
     del meta2
     assert free() == 0 and torch.equal(img2, img)
+
+
+def test_forward_without_backward_returns_its_lease_when_the_outputs_die():
+    """a grad-enabled forward whose backward never runs (an eval render, an exception in backward) must not leak:
+    the node saves its own outputs, and a pack-hook payload holding them closed a cycle the collector cannot break."""
+    import gc
+    import weakref
+    sc, t = _scene()
+    rendering.reset_hints()
+    free = lambda: sum(len(v) for v in WS.pool.free.values())
+    ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+    kw = dict(sh_degree=3, packed=False, backgrounds=t["backgrounds"][0:1], absgrad=True, _tile_culling="gsplat")
+    img, alpha, meta = rasterization(*ins, t["viewmats"][0:1], t["Ks"][0:1], sc["width"], sc["height"], **kw)
+    assert img.requires_grad and free() == 0
+    w_img = weakref.ref(img)
+    del img, alpha, meta
+    gc.collect()
+    assert w_img() is None, "the output image is still alive: reference cycle through the saved tensors"
+    assert free() == 1, "the workspace lease did not return to the pool"
+    # the same after an exception inside backward (here: a wrong-shaped upstream gradient is refused by autograd itself)
+    img, alpha, meta = rasterization(*ins, t["viewmats"][0:1], t["Ks"][0:1], sc["width"], sc["height"], **kw)
+    assert free() == 0   # (re-used)
+    with pytest.raises(RuntimeError):
+        torch.autograd.grad(img, ins, grad_outputs=torch.ones((1, 2, 3), device=img.device))
+    del img, alpha, meta
+    gc.collect()
+    assert free() == 1

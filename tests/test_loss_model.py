@@ -109,3 +109,88 @@ def test_scale_ratio_regulariser_and_total():
     assert np.abs(m.log_scales.grad.numpy() - exp_g).max() < 1e-5 * np.abs(exp_g).max()
     m.USE_SCALE_REGULARIZATION = False
     assert m.get_regularization_dict() == {}
+
+
+def test_lease_pack_hook_does_not_tie_a_node_to_its_own_outputs():
+    """ADVICE r4 (CPU form of tests/test_gpu_workspace.py::test_forward_without_backward_...): the pack hook of
+    rendering.rasterization attaches the workspace lease to the node's saved INPUTS and saves its OUTPUTS detached."""
+    import gc
+    import weakref
+    import torch
+    from easy_gaussian_splatting_amd.rendering import _Holder, _lease_pack_hook
+
+    class Lease:
+        pass
+
+    class Double(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, holder):
+            y = x * 2
+            holder.out_ptrs = (y.data_ptr(),)
+            ctx.save_for_backward(x, y)
+            return y
+
+        @staticmethod
+        def backward(ctx, g):
+            x, y = ctx.saved_tensors
+            assert torch.equal(y, 2 * x)
+            return g * 2, None
+
+    def forward(x):
+        lease, holder = Lease(), _Holder(False)
+        holder.lease_ref = lease
+        with torch.autograd.graph.saved_tensors_hooks(_lease_pack_hook(holder), lambda p: p[0]):
+            y = Double.apply(x, holder)
+        holder.lease_ref = None
+        return y, weakref.ref(lease)
+
+    x = torch.ones(3, requires_grad=True)
+    y, w_lease = forward(x)
+    assert w_lease() is not None          # held by the saved input
+    w_y = weakref.ref(y)
+    del y
+    gc.collect()
+    assert w_y() is None and w_lease() is None, "forward without backward leaked"
+    y, w_lease = forward(x)
+    y.sum().backward()
+    assert w_lease() is None and torch.equal(x.grad, torch.full((3,), 2.0))   # released at the end of backward, output alive
+
+
+def test_checkpoint_does_not_pickle_the_training_drivers_hooks(tmp_path):
+    """ViewParallelStep installs bound methods on the model (`on_colors_pre`, `grad_out`, `view_payload`); a
+    checkpoint written during a multi-rank run must not carry the step object, its optimizer and its exchange buffers, nor
+    name a class the reference cannot import."""
+    import pickle
+    import socket
+    import torch
+    import torch.distributed as dist
+    from easy_gaussian_splatting_amd import checkpoint as CK
+    from easy_gaussian_splatting_amd.distributed import ViewParallelStep
+    from easy_gaussian_splatting_amd.model import GaussianModel
+
+    n = 17
+    model = GaussianModel(means=torch.randn(n, 3), log_scales=torch.randn(n, 3), quats=torch.randn(n, 4), sh_0=torch.randn(n, 1, 3),
+                          sh_rest=torch.randn(n, 3, 3), logit_opacities=torch.randn(n), sh_degree=1)
+
+    class _Opt:   # (FusedAdam's interface; the real one steps on the GPU only)
+        param_groups = []
+
+        def moments_of(self, p):
+            raise KeyError
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        vp = ViewParallelStep(model, _Opt(), sh_grad_fn=lambda *a: None, force_exchange=True)
+        assert model.__dict__["on_colors_pre"].__self__ is vp and model.sh_grads == "colors_pre"
+        blob = pickle.dumps(model)
+        assert b"ViewParallelStep" not in blob and b"distributed" not in blob
+        CK.save_gaussian_model(tmp_path / "checkpoints" / "iterations_7.pth", model)
+        back = CK.load_gaussian_model(tmp_path, device="cpu")
+        for k in GaussianModel._RUNTIME_HOOKS:
+            assert k not in back.__dict__, k
+        assert back.on_colors_pre is None and back.grad_out is None and back.view_payload is None and back.sh_grads == "dense"
+        assert torch.equal(back.means, model.means)
+        assert model.__dict__["on_colors_pre"].__self__ is vp     # the live model keeps its hooks
+    finally:
+        dist.destroy_process_group()
