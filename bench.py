@@ -802,11 +802,14 @@ def run_rank(args) -> int:
 
     if world == 1 and not args.no_extras and graph_step is not None and not args.no_configs:
         # captured (hipGraph) train step on the real-capture-shaped workloads: heavy-tailed long lists, S3, S5
-        from easy_gaussian_splatting_amd.synthetic import config_long_lists, config_s3, config_s5
+        from easy_gaussian_splatting_amd.synthetic import config_heavy, config_long_lists, config_s3, config_s5
         from easy_gaussian_splatting_amd.train_graph import TrainStepGraph
         figs = {}
         for name, make, n_steps in (("long_lists_200k_1080p", lambda: config_long_lists(n=200_000, width=1920, height=1080), 30),
-                                    ("S3_2M_1080p", lambda: config_s3(), 30), ("S5_5M_4K", lambda: config_s5(), 10)):
+                                    ("S3_2M_1080p", lambda: config_s3(), 30), ("S5_5M_4K", lambda: config_s5(), 10),
+                                    # the metric's N on a realistic footprint: gsplat's lists hold ~29 entries per Gaussian
+                                    ("heavy_1M_1080p", lambda: config_heavy(n=1_000_000), 20),
+                                    ("heavy_2M_1080p", lambda: config_heavy(n=2_000_000), 20)):
             try:
                 t_build = time.perf_counter()
                 scx = make()
@@ -819,12 +822,16 @@ def run_rank(args) -> int:
                 outs = {}
                 for mode in ("gsplat_eager", "tight"):   # (gsplat's own lists walked by the captured step / the short lists)
                     mx.tile_culling = mode
+                    torch.cuda.reset_peak_memory_stats(device)
                     runner = TrainStepGraph(mx, ox, LossComputer(lambda_ssim=0.2, clamp_input=True), dx, gx, None)
                     ex, _, sx, _ = timed_loop(runner.step, n_steps, 5, finish=runner.finish, ev_stream=runner.stream)
                     rep = runner.report()
+                    torch.cuda.synchronize()
                     outs[mode] = {"train_iters_per_s": round(n_steps / ex, 2), "train_ms": _percentiles(sx),
-                                  "n_isects": rep["probed_isects"], "longest_list": rep["probed_longest_list"], "binning": rep["binning"],
-                                  "overflows": rep["overflows"], "captures": rep["captures"]}
+                                  "n_isects": rep["probed_isects"], "isects_per_gaussian": round(rep["probed_isects"] / max(1, scx["means"].shape[0]), 1),
+                                  "longest_list": rep["probed_longest_list"], "binning": rep["binning"],
+                                  "overflows": rep["overflows"], "captures": rep["captures"],
+                                  "peak_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
                     del runner
                 outs["n_gaussians"] = int(scx["means"].shape[0])
                 outs["image"] = f"{Wx}x{Hx}"

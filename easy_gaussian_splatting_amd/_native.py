@@ -92,6 +92,32 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_variant(name: str, extra_flags: str) -> str:
+    """A diagnostic variant of the library, `libgsraster_<name>.so` next to the product build, compiled with additional
+    flags from a scratch copy of the sources (so the product's objects are left alone).  Used by `__graft_entry__.build()` for
+    the `-DGS_BWD_CHECK` build that tests/test_gpu_contributors.py loads through GS_LIB_PATH in a child process; never loaded
+    by the package itself."""
+    import glob
+    import shutil
+    import tempfile
+    out = os.path.join(_HERE, f"libgsraster_{name}.so")
+    srcs = [f for pat in ("*.hip", "*.h", "*.inc", "Makefile") for f in glob.glob(os.path.join(CSRC_DIR, pat))]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(f) for f in srcs + [os.path.join(_HERE, "..", "include", "gs_raster.h")]):
+        return out
+    d = tempfile.mkdtemp(prefix=f"gsvar_{name}_")
+    try:
+        header = os.path.abspath(os.path.join(_HERE, "..", "include", "gs_raster.h"))
+        for f in srcs:
+            text = open(f).read().replace("../../include/gs_raster.h", header)
+            open(os.path.join(d, os.path.basename(f)), "w").write(text)
+        proc = subprocess.run(["make", "-C", d, "-j4", f"EXTRA={extra_flags}", f"LIB={out}"], capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise NativeLibraryError(f"building {out} failed:\n" + proc.stderr[-4000:])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def lib() -> ct.CDLL:
     """Load (once) and return the native library; raises if it is not built."""
     global _lib

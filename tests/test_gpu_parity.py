@@ -75,20 +75,41 @@ def run_oracle(sc, use_bg=True, dtype=np.float64):
 MAX_RAZOR_FRAC = 0.05   # scenes are built to stay off the blend thresholds (synthetic.dense_scene)
 
 
-def _affected_tiles(meta, fw, sel):
-    """[C,th,tw] mask of the tiles whose list may legitimately differ from the oracle's: every tile that the
-    rectangle of a Gaussian in `sel` touches, in either version, grown by one pixel."""
+def _affected_tiles(meta, fw, sel, lists=True):
+    """[C,th,tw] mask of the tiles whose list may legitimately differ from the oracle's because of the Gaussians in `sel`
+    (a radius that flipped by one, a rectangle edge on a tile boundary): the tiles in which such a Gaussian is listed on ONE
+    side only.  Everywhere else -- including the rest of its rectangle -- both sides list it, and the lists must agree.
+    (Rounds 1-4 exempted the Gaussian's whole rectangle: harmless while footprints are a handful of tiles; one flipped splat
+    of a heavy-tailed scene covers hundreds, and 24 of them exempted 15 % of a 1080p frame -- synthetic.config_heavy.)
+    `lists`: both sides hold gsplat's lists -> exact membership from the lists themselves.  Otherwise (the short-list mode;
+    the fp32 build of the oracle as reference): the symmetric difference of each side's own 3-sigma rectangle."""
     C, N = fw["radii"].shape
     tile = fw["_inputs"]["tile_size"]
     tw, th = fw["tile_width"], fw["tile_height"]
-    tmask = np.zeros((C, th, tw), bool)
-    rad_h = meta["radii"].cpu().numpy()
+    tmask = np.zeros((C * th * tw,), bool)
+    ids = np.nonzero(sel.reshape(-1))[0]
+    if lists:
+        fid_h = meta["flatten_ids"]
+        off_h = meta["isect_offsets"].reshape(-1).long()
+        fid_o, off_o = fw["flatten_ids"], fw["isect_offsets"].reshape(-1).astype(np.int64)
+        for g in ids:
+            pos_h = torch.nonzero(fid_h == int(g)).reshape(-1)
+            t_h = (torch.searchsorted(off_h, pos_h, right=True) - 1).cpu().numpy()
+            t_o = np.searchsorted(off_o, np.nonzero(fid_o == g)[0], side="right") - 1
+            tmask[np.setxor1d(t_h, t_o)] = True
+        return tmask.reshape(C, th, tw)
+    m2_h, r_h = meta["means2d"].detach().cpu().numpy().astype(np.float64), meta["radii"].cpu().numpy().astype(np.float64)
+    tmask = tmask.reshape(C, th, tw)
     for c, n in zip(*np.nonzero(sel)):
-        r = max(int(rad_h[c, n]), int(fw["radii"][c, n])) + 1
-        mx, my = fw["means2d"][c, n]
-        x0, x1 = int(np.clip(np.floor((mx - r) / tile), 0, tw)), int(np.clip(np.ceil((mx + r) / tile), 0, tw))
-        y0, y1 = int(np.clip(np.floor((my - r) / tile), 0, th)), int(np.clip(np.ceil((my + r) / tile), 0, th))
-        tmask[c, y0:y1, x0:x1] = True
+        cover = []
+        for m2, r in ((m2_h[c, n], r_h[c, n]), (fw["means2d"][c, n].astype(np.float64), float(fw["radii"][c, n]))):
+            k = np.zeros((th, tw), bool)
+            if r > 0:
+                x0, x1 = int(np.clip(np.floor((m2[0] - r) / tile), 0, tw)), int(np.clip(np.ceil((m2[0] + r) / tile), 0, tw))
+                y0, y1 = int(np.clip(np.floor((m2[1] - r) / tile), 0, th)), int(np.clip(np.ceil((m2[1] + r) / tile), 0, th))
+                k[y0:y1, x0:x1] = True
+            cover.append(k)
+        tmask[c] |= cover[0] ^ cover[1]
     return tmask
 
 
@@ -208,7 +229,7 @@ def forward_report(meta, fw, lists=True, geom_slack=1.0, max_flip_tile_frac=0.02
                    != rects(fw["means2d"].astype(np.float64), fw["radii"].astype(np.float64))).any(-1) & same
         assert shifted.sum() <= max(1, 2e-4 * shifted.size), f"{int(shifted.sum())} rectangles differ from the fp32 reference's"
         differ |= shifted
-    tmask = _affected_tiles(meta, fw, differ) if differ.any() else np.zeros((radii.shape[0], fw["tile_height"], fw["tile_width"]), bool)
+    tmask = _affected_tiles(meta, fw, differ, lists) if differ.any() else np.zeros((radii.shape[0], fw["tile_height"], fw["tile_width"]), bool)
     exact_lists = not differ.any()
     if lists:  # integer / index work is bit-exact wherever no rounding flip reaches
         if exact_lists:
@@ -272,11 +293,17 @@ def needle_factor(fw):
 
 GRAD_L2_RTOL = 1e-4        # ||hip - ref||_2 / ||ref||_2 per tensor
 ROW_FLOOR = 1e-3           # per-Gaussian criterion: |delta| <= rtol * max(|ref row|_max, ROW_FLOOR * tensor max)
-ROW_BAD_MAX = 1e-2         # fraction of Gaussians (rows) allowed beyond the per-Gaussian criterion, or ROW_BAD_ABS rows if that is more.
-ROW_BAD_ABS = 3            # Measured: <= 5.5e-4 over the suite's scenes (v_opacities); over 4500 sweep scenes of 40-10000 Gaussians the
-                           # worst are 8 of 1187 (v_opacities, 0.67 %), 15 of 3996 (v_means) and 3 of 117 -- rows whose pixel terms
-                           # cancel to 1e-3..1e-1 of the tensor's largest entry, where the fp32 sums' rounding is a few 1e-3 of what is
-                           # left (still inside the max-norm criterion by construction).  Reported per test in the parity report.
+ROW_BAD_MAX = 5e-3         # fraction of Gaussians (rows) allowed beyond the per-Gaussian criterion, or ROW_BAD_ABS rows if that is more ...
+ROW_BAD_ABS = 3
+ROW_BAD_HARD = 1e-2        # ... and, beyond that, at most what an INDEPENDENT fp32 evaluation of the same algorithm (the fp32 build of the C
+                           # oracle) leaves beyond the same per-row tolerance on the same scene, never more than 1e-2 (round 4's flat cap).
+                           # Settled by experiment in round 5 (tools/acc64_ab.py, profiles/r05_acc64_ab.json): the seven
+                           # worst sweep configurations (GS_FUZZ_SCALE=2: 176, 1444, 104; scale 1: 730, 113, 444, 254) hold 22 such rows --
+                           # all with a reference magnitude <= 4.3e-3 of their tensor's largest entry (pixel terms that cancel).  With the
+                           # 11 per-entry sums of blend_bwd in DOUBLE (-DGS_BWD_ACC64) the same 22 rows remain: it is not the accumulation;
+                           # the fp32 build of the oracle has 89 on the same scenes, 10 where the HIP path has its worst 8 (of 1187,
+                           # v_opacities): it is the fp32 rounding of the per-pixel terms themselves (exp2, alpha, the T chain), shared by
+                           # any fp32 evaluation -- not a defect of the s_vs / v_op path.  Suite scenes measure <= 5.5e-4.
 UNMASKED_L2_RTOL = 5e-4    # unmasked upstream gradient against the fp32 oracle: isolated threshold flips, bounded
 UNMASKED_MAX_RTOL = 1e-2
 
@@ -336,11 +363,25 @@ def check_backward(hip, fw, rtol=GRAD_RTOL, ref_transform=None):
                       max_row_bad_frac={k: v["row_bad"] for k, v in err.items()},
                       max_needle_factor=float(relax.max(initial=1.0)), n_needles_relaxed=int(((relax > 1.0) & vis).sum()),
                       n_visible_gaussians=int(vis.sum()))
+    err32 = None
     for name, e in err.items():
         assert e["max"] <= rtol, f"{name}: rel err {e['max']}"
         assert e["l2"] <= GRAD_L2_RTOL * (rtol / GRAD_RTOL), f"{name}: relative L2 err {e['l2']}"
-        assert e["row_bad"] <= max(ROW_BAD_MAX, (ROW_BAD_ABS + 0.5) / max(e["rows"], 1)), \
-            f"{name}: {e['row_bad']} of the {e['rows']} Gaussians beyond {rtol} of their own gradient"
+        allowed = max(ROW_BAD_MAX, (ROW_BAD_ABS + 0.5) / max(e["rows"], 1))
+        if e["row_bad"] > allowed:
+            # more rows off than the flat allowance: then no more than an independent fp32 evaluation of the same algorithm leaves
+            # (rows whose pixel terms cancel; ROW_BAD_HARD's comment), and never more than round 4's cap
+            if err32 is None:
+                bw32 = CO.backward(oracle_fp32(fw), hip["vc"].astype(np.float32), hip["va"].astype(np.float32))
+                err32 = {}
+                for nm in names:
+                    err32[nm] = _grad_metrics(ref_transform.get(nm, lambda x: x)(bw32[nm]), ref_transform.get(nm, lambda x: x)(bw[nm]), rtol,
+                                              relax if nm in ("v_quats", "v_scales") else None)
+                err32["absgrad"] = _grad_metrics(bw32["v_means2d_abs"].reshape(-1, 2), bw["v_means2d_abs"].reshape(-1, 2), rtol)
+                parity_log.record(n_row_criterion_fp32_oracle_uses=1, row_bad_frac_fp32_oracle={k: v["row_bad"] for k, v in err32.items()})
+                print(f"[parity] {name}: {e['row_bad']:.4f} of the rows beyond the per-Gaussian tolerance; the fp32 oracle leaves {err32[name]['row_bad']:.4f}")
+            allowed = min(ROW_BAD_HARD, max(allowed, err32[name]["row_bad"]))
+        assert e["row_bad"] <= allowed, f"{name}: {e['row_bad']} of the {e['rows']} Gaussians beyond {rtol} of their own gradient"
     return bw
 
 

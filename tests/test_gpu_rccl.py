@@ -39,8 +39,8 @@ def test_full_exchange_path_on_rccl_world_size_1(tmp_path):
     gloo = _child("gloo", tmp_path / "gloo.pt")
     plain = _child("plain", tmp_path / "plain.pt")
     assert nccl["backend"] == "nccl" and nccl["world"] == 1 and nccl["vp_exchange"] is True and plain["vp_exchange"] is False
-    # 3 steps x (cameras, radii MAX, colour all-gather, geometry all-reduce)
-    assert nccl["vp_collectives"] == gloo["vp_collectives"] == 12 and plain["vp_collectives"] == 0
+    # 3 steps x (all-gather of the per-view records, geometry + statistics all-reduce)
+    assert nccl["vp_collectives"] == gloo["vp_collectives"] == 6 and plain["vp_collectives"] == 0
     bitwise_vs_plain = True
     for k, v in nccl["vp"].items():
         assert torch.equal(v, gloo["vp"][k]), f"RCCL and gloo disagree on {k}"

@@ -50,8 +50,11 @@ def test_sh_grad_views_matches_dense_path(deg, split):
     g_dense, sh_dense, _ = run("dense")
     g_fact, sh_fact, meta = run("colors_pre")
     assert all(g is None for g in sh_fact), "factorised mode must not write SH gradients"
-    for a, b in zip(g_fact, g_dense):   # geometry gradients (incl. the SH -> direction -> mean term) untouched
-        assert torch.equal(a, b)
+    for a, b in zip(g_fact, g_dense):
+        # geometry gradients (incl. the SH -> direction -> mean term): the same row sums bit for bit (gs_row_sums runs the very
+        # statements of the projection backward's first phase), pushed through ANOTHER instantiation of the projection backward
+        # -- under -ffp-contract=fast the two may fuse a multiply-add differently: equal to an ulp or two, not bitwise
+        assert _rel(a, b) < 1e-6, _rel(a, b)
     pre = meta["means2d"].colors_pre_grad
     assert pre.shape == (3, 2500, 3)
     assert float(pre[meta["radii"] <= 0].abs().max()) == 0.0

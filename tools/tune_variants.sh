@@ -9,7 +9,7 @@ if [ "$mode" = build ]; then
   for v in "$@"; do
     name=${v%%:*}; flags=${v#*:}
     d=/tmp/gsvar_$name; rm -rf $d; mkdir -p $d
-    cp $root/easy_gaussian_splatting_amd/csrc/*.hip $root/easy_gaussian_splatting_amd/csrc/*.h $root/easy_gaussian_splatting_amd/csrc/Makefile $d/
+    cp $root/easy_gaussian_splatting_amd/csrc/*.hip $root/easy_gaussian_splatting_amd/csrc/*.h $root/easy_gaussian_splatting_amd/csrc/*.inc $root/easy_gaussian_splatting_amd/csrc/Makefile $d/
     sed -i "s|../../include/gs_raster.h|$root/include/gs_raster.h|g" $d/Makefile $d/*.h
     make -C $d -j4 EXTRA="$flags" LIB=$root/easy_gaussian_splatting_amd/libgsraster_$name.so 2>&1 | grep -E "error|Error" | head -3
     ls -la $root/easy_gaussian_splatting_amd/libgsraster_$name.so | awk '{print $5, $9}'
