@@ -390,7 +390,16 @@ constexpr int kBwdWaves = GS_BWD_WAVES;
 constexpr int kPipeLanes = 8;                       // lanes per systolic pipeline (two pipelines share a 16-lane DPP row)
 constexpr int kPerLane = kUnit / kPipeLanes;        // 4 entries per lane
 constexpr int kUnitsPerWave = 64 / kPipeLanes;      // 8
-constexpr int kBwdSteps = 64 + kPipeLanes - 1;      // 71
+// -DGS_EXP_HALFQ=155 (tools/blend_time.py A/B; numerically WRONG, timing only): the upper bound of half-quadrant (8 x 4 pixel) work
+// units for this kernel -- every unit streams 32 instead of 64 pixels (39 instead of 71 steps, half the pixel loads), and there
+// are GS_EXP_HALFQ / 100 times as many units (an entry that touches both halves of a quadrant is listed twice: 1.55 on the bench
+// scene, tools/unit_mask_stats.py); the surplus units re-run existing ones.  Round 5, DESIGN.md section 8.
+#ifdef GS_EXP_HALFQ
+constexpr int kUnitPixels = 32;
+#else
+constexpr int kUnitPixels = 64;
+#endif
+constexpr int kBwdSteps = kUnitPixels + kPipeLanes - 1;      // 71
 
 __device__ __forceinline__ float dpp_row_shr1(float v) {
     // lane r of each 16-lane row receives lane r-1's value; lane 0 keeps its own
@@ -460,11 +469,23 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pipe = lane / kPipeLanes, r = lane & (kPipeLanes - 1);
     if (guard_tripped(a.guard)) return;
+#ifdef GS_EXP_HALFQ
+    const int n_real = max(a.unit_counter[0], 1);
+    const int n_units = (int)((int64_t)n_real * GS_EXP_HALFQ / 100);
+    const int unit_run = ((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave + pipe;
+    const int unit = unit_run % n_real;
+    if (((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave >= n_units) return;
+#else
     const int n_units = a.unit_counter[0];
     const int unit = ((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave + pipe;
     if (((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave >= n_units) return;   // wave-uniform
+#endif
     GS_CLOCK_PROBE_SCOPE(2);
+#ifdef GS_EXP_HALFQ
+    const bool valid = unit_run < n_units;
+#else
     const bool valid = unit < n_units;
+#endif
     float4* sd0 = sd0_all[wave][pipe];
     float2* sck = sck_all[wave][pipe];
 
@@ -493,7 +514,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
         gs[i] = a.qlist[(size_t)ud.z + (en < n_in ? en : 0)];
         if (!valid) gs[i] = make_int2(0, 0);   // (pipelines past the last unit read pair 0, which nobody may have written)
     }
-    constexpr int kPix = 64 / kPipeLanes;
+    constexpr int kPix = kUnitPixels / kPipeLanes;
     float l_vr[kPix], l_vg[kPix], l_vb[kPix], l_oa[kPix], l_cr[kPix], l_cg[kPix], l_cb[kPix], l_va[kPix];
     float4 l_ck[kPix];
     const float* vap = a.v_alphas ? a.v_alphas : a.out_alphas;   // (one load either way; masked below)
@@ -560,8 +581,8 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
     for (int s = 0; s < kBwdSteps; ++s) {
         float T = dpp_row_shr1(T_out), P = dpp_row_shr1(P_out);
         const int p = s - r;
-        const bool act = (unsigned)p < 64u;
-        const int pc = min(max(p, 0), 63);
+        const bool act = (unsigned)p < (unsigned)kUnitPixels;
+        const int pc = min(max(p, 0), kUnitPixels - 1);
         const float4 d0 = sd0[pc];
         const float2 ck = sck[pc];
 #if GS_BWD_PXY_TABLE
@@ -711,7 +732,11 @@ extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const fl
     a.chk = g_bwd_check;
 #endif
     // upper bound on work units: 4 quadrant sublists per tile, each at most as long as the tile list
+#ifdef GS_EXP_HALFQ
+    const int64_t max_units = 8 * n_buckets * GS_EXP_HALFQ / 100 + 64;
+#else
     const int64_t max_units = 8 * n_buckets;
+#endif
     const unsigned grid = (unsigned)((max_units + kUnitsPerWave * kBwdWaves - 1) / (kUnitsPerWave * kBwdWaves));
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(kBwdWaves * 64), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("blend_bwd_kernel");

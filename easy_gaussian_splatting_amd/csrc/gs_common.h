@@ -94,6 +94,23 @@ __device__ __forceinline__ T wave_reduce_add(T v) {
     return v;
 }
 
+// Sum over the 64 lanes with DPP only (no LDS crossbar): two quad permutes and two mirrors leave every lane of a 16-lane row with
+// the row's sum, row_bcast:15 / row_bcast:31 carry the rows along; lane 63 holds the total, handed to every lane as a scalar.
+// Six full-rate v_add_f32_dpp per value instead of six ds_bpermute round trips (wave_reduce_add): for wave-wide sums on a
+// latency-bound path (gs_rowsum_body.inc).  Fixed order -> reproducible.
+__device__ __forceinline__ float wave_reduce_add_dpp(float v) {
+#define GS_DPP_ADD(ctrl, row_mask) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+    GS_DPP_ADD(0xB1, 0xf);    // quad_perm [1,0,3,2]
+    GS_DPP_ADD(0x4E, 0xf);    // quad_perm [2,3,0,1]
+    GS_DPP_ADD(0x141, 0xf);   // row_half_mirror
+    GS_DPP_ADD(0x140, 0xf);   // row_mirror
+    GS_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    GS_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef GS_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // Block-wide exclusive scan for blockDim.x <= 1024 (16 waves).  `scratch` >= 17 entries of T.
 template <typename T>
 __device__ __forceinline__ T block_excl_scan_add(T v, T* scratch, T* total) {

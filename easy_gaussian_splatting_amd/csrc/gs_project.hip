@@ -52,6 +52,30 @@ __device__ __forceinline__ void load_camera(const float* viewmats, const float* 
     for (int i = 0; i < (int)(sizeof(Camera) / 4); ++i) dst[i] = lds_cam[i];
 }
 
+// The same in two steps, for a kernel whose first phase does not need the camera: thread 0 leaves it in LDS (+ block barrier),
+// every thread reads it when it gets there -- the ~30 camera registers are then not live across that phase (project_bwd_kernel's
+// row sum is its register peak).
+__device__ __forceinline__ void stage_camera(const float* viewmats, const float* Ks, int c, int W, int H, float* lds_cam) {
+    if (threadIdx.x == 0) {
+        Camera tmp;
+        make_camera(viewmats + 16 * c, Ks + 9 * c, W, H, tmp);
+        const float* src = reinterpret_cast<const float*>(&tmp);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(Camera) / 4); ++i) lds_cam[i] = src[i];
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void read_camera(const float* lds_cam, Camera& cam) {
+    // (member by member: through a float* alias of the struct one instantiation kept the whole Camera as a 100-byte stack object)
+    static_assert(sizeof(Camera) == 21 * sizeof(float), "Camera layout");
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cam.R[i] = lds_cam[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { cam.t[i] = lds_cam[9 + i]; cam.pos[i] = lds_cam[12 + i]; }
+    cam.fx = lds_cam[15]; cam.fy = lds_cam[16]; cam.cx = lds_cam[17]; cam.cy = lds_cam[18];
+    cam.half_w = lds_cam[19]; cam.half_h = lds_cam[20];
+}
+
 // Cooperative global -> LDS copy of the first `ka3` floats of every visible Gaussian's SH row.
 // KC > 0 fixes K at compile time (K = 16 is the reference's SH3 layout) so the per-element
 // row/offset divisions become multiply-shifts; KC = 0 keeps K a run-time value.
@@ -355,7 +379,10 @@ struct ProjBwdArgs {
     // in place right where its gradient is formed.  Tensor order of the reference's param_names:
     // 0 means, 1 log_scales, 2 quats, 3 sh_0, 4 sh_rest, 5 logit_opacities.
     int adam;
-    float *ad_p[6], *ad_m[6], *ad_v[6];
+    // (three bases + six offsets instead of eighteen pointers: the fused kernel is SGPR-bound -- 106 live -- and every pointer it
+    //  keeps across the row sum is two of them; adam_p / adam_m / adam_v below)
+    float *ad_pbase, *ad_mbase, *ad_vbase;
+    int64_t ad_off[6];
     const float* ad_hyper;    // {1/sqrt(1-beta2^t), lr_k/(1-beta1^t) x 6}  (gs_adam_hyper)
     float ad_b1, ad_b2, ad_eps;
     int64_t* ad_applied;
@@ -370,6 +397,9 @@ struct ProjBwdArgs {
     float *st_gn_out, *st_cnt_out;    // optional [N] each (single camera)
 };
 
+__device__ __forceinline__ float* adam_p(const ProjBwdArgs& a, int t) { return a.ad_pbase + a.ad_off[t]; }
+__device__ __forceinline__ float* adam_m(const ProjBwdArgs& a, int t) { return a.ad_mbase + a.ad_off[t]; }
+__device__ __forceinline__ float* adam_v(const ProjBwdArgs& a, int t) { return a.ad_vbase + a.ad_off[t]; }
 __device__ __forceinline__ float sh_adam_isbc2(const ProjBwdArgs& a) { return a.ad_hyper[0]; }
 __device__ __forceinline__ float sh_adam_ss(const ProjBwdArgs& a, int t) { return a.ad_hyper[1 + t]; }
 
@@ -469,6 +499,9 @@ __device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K
 // (templated on the argument block: project_bwd_kernel reads the bias corrections from the device array gs_adam_hyper wrote,
 //  sh_grad_views_kernel<.., ADAM> carries them as kernel arguments; both expose ad_p / ad_m / ad_v [3], [4] and the betas)
 struct ProjBwdArgs;
+__device__ __forceinline__ float* adam_p(const ProjBwdArgs& a, int t);
+__device__ __forceinline__ float* adam_m(const ProjBwdArgs& a, int t);
+__device__ __forceinline__ float* adam_v(const ProjBwdArgs& a, int t);
 __device__ __forceinline__ float sh_adam_isbc2(const ProjBwdArgs& a);
 __device__ __forceinline__ float sh_adam_ss(const ProjBwdArgs& a, int t);
 template <int KC, class A>
@@ -477,7 +510,7 @@ __device__ __forceinline__ void adam_sh_tile(const float* tile, int rows, int Kr
     const int row_f = 3 * K, stride = row_f + 1;
     const float isbc2 = sh_adam_isbc2(a), ss0 = sh_adam_ss(a, 3), ssr = sh_adam_ss(a, 4);
     {
-        float *p0 = a.ad_p[3] + n0 * 3, *m0 = a.ad_m[3] + n0 * 3, *v0 = a.ad_v[3] + n0 * 3;
+        float *p0 = adam_p(a, 3) + n0 * 3, *m0 = adam_m(a, 3) + n0 * 3, *v0 = adam_v(a, 3) + n0 * 3;
         for (int e = threadIdx.x; e < rows * 3; e += blockDim.x) {
             const int g = e / 3;
             float p = p0[e], m = m0[e], v = v0[e];
@@ -487,7 +520,7 @@ __device__ __forceinline__ void adam_sh_tile(const float* tile, int rows, int Kr
     }
     if (K > 1) {
         const int rest_f = row_f - 3, total = rows * rest_f;
-        float *pr = a.ad_p[4] + n0 * rest_f, *mr = a.ad_m[4] + n0 * rest_f, *vr = a.ad_v[4] + n0 * rest_f;
+        float *pr = adam_p(a, 4) + n0 * rest_f, *mr = adam_m(a, 4) + n0 * rest_f, *vr = adam_v(a, 4) + n0 * rest_f;
         // (n0 is a multiple of the block size and rest_f * kProjThreads of 4: the block's slice starts 16-byte aligned
         //  whenever the tensor does)
         const bool aligned = ((((uintptr_t)pr | (uintptr_t)mr | (uintptr_t)vr) & 15) == 0);
@@ -547,7 +580,7 @@ __device__ __forceinline__ void adam_geo_tile(const float* tile, int rows, int64
 #pragma unroll
     for (int sgi = 0; sgi < kSeg; ++sgi) {   // every load first
         const int t = group[sgi], total = rows * width[sgi];
-        float *pp = a.ad_p[t] + n0 * width[sgi], *mm = a.ad_m[t] + n0 * width[sgi], *vv = a.ad_v[t] + n0 * width[sgi];
+        float *pp = adam_p(a, t) + n0 * width[sgi], *mm = adam_m(a, t) + n0 * width[sgi], *vv = adam_v(a, t) + n0 * width[sgi];
         const bool aligned = ((((uintptr_t)pp | (uintptr_t)mm | (uintptr_t)vv) & 15) == 0);
         has[sgi] = aligned && e4 < (total >> 2);
         if (has[sgi]) {
@@ -559,7 +592,7 @@ __device__ __forceinline__ void adam_geo_tile(const float* tile, int rows, int64
 #pragma unroll
     for (int sgi = 0; sgi < kSeg; ++sgi) {
         const int t = group[sgi], total = rows * width[sgi];
-        float *pp = a.ad_p[t] + n0 * width[sgi], *mm = a.ad_m[t] + n0 * width[sgi], *vv = a.ad_v[t] + n0 * width[sgi];
+        float *pp = adam_p(a, t) + n0 * width[sgi], *mm = adam_m(a, t) + n0 * width[sgi], *vv = adam_v(a, t) + n0 * width[sgi];
         const float ss = a.ad_hyper[1 + t];
         const float* g = tile + goff[sgi];
         if (has[sgi]) {
@@ -583,14 +616,20 @@ __device__ __forceinline__ void adam_geo_tile(const float* tile, int rows, int64
 }
 
 
-// ---- gradient rows of the wave's small Gaussians, one SLOT per lane ------------------------------------------------
+// ---- gradient rows of the wave's Gaussians, one SLOT per lane -----------------------------------------------------
 // A thread that walks its own Gaussian's rows pays one HBM round trip per slot, and the wave waits for its longest
-// Gaussian (15-48 slots) while most lanes hold 1-3: the row sum was latency, 0.13 ms of the fused kernel for 250 MB.
+// Gaussian while most lanes hold 1-3: the row sum was latency, 0.13 ms of the fused kernel for 250 MB.
 // Here the wave's slots -- contiguous per Gaussian, Gaussians in lane order -- are dealt out one per lane, 64 at a
-// time: masks of four such items in one round trip, the (up to four) quadrant rows of an item in one more, the next
+// time (an ITEM): masks of four items in one round trip, the (up to four) quadrant rows of an item in one more, the next
 // item's rows in flight while this one's are added.  Each lane adds its slot's rows in quadrant order and leaves the
 // 11 sums in LDS; the owner lanes then add their slots' sums in slot order (fixed order -> reproducible sums).
-// LDS of one wave: owner lane of every slot (u8, 64 * kCoopRows) + 64 item sums of 12 floats.
+// Who owns a slot (round 5): the owners whose range reaches into an item write their lane at the position where it starts
+// there; a ballot of those positions and a count-leading-zeros give every lane the start at or below its own position.
+// (Rounds 3-4: a byte per slot, filled by the owners -- 64 x kCoopRows bytes of LDS per wave, which capped the path at 48
+//  slots per Gaussian; on realistic footprints the whole-wave path beyond that was half of project_bwd.)
+// An item none of whose slots holds rows -- most of them once tiles saturate and abandon their list tails -- costs no row
+// load, no LDS traffic, no owner loop; an owner visits only its row-bearing slots.
+// LDS of one wave: 4 x 64 start lanes (int) + 64 item sums of 12 floats.
 #ifndef GS_ROWSUM_PER_GAUSSIAN
 #define GS_ROWSUM_PER_GAUSSIAN 0
 #endif
@@ -598,8 +637,14 @@ __device__ __forceinline__ void adam_geo_tile(const float* tile, int rows, int64
 #define GS_ROWSUM_DIAG 0
 #endif
 
-constexpr int kCoopRows = 48;  // Gaussians with more rows than this are summed by the whole wave
-constexpr int kRowOwnerFloats = 64 * kCoopRows / 4;
+// Gaussians with more slots than this are summed by the whole wave, one at a time (an owner adds its row-bearing slots
+// serially: bounded here).  Round 5, same box, project_bwd on heavy1M / on the 200 k long-list scene (tools/config_run.py):
+// 48 -> 0.312 / 0.162 ms, 128 -> 0.312 / 0.164, 256 -> 0.308 / 0.177, 1024 -> 0.329 / 0.249 (rounds 3-4, byte table, 48: 0.362 / 0.192).
+#ifndef GS_COOP_ROWS
+#define GS_COOP_ROWS 128
+#endif
+constexpr int kCoopRows = GS_COOP_ROWS;
+constexpr int kRowOwnerFloats = 4 * 64;
 constexpr int kRowWaveFloats = kRowOwnerFloats + 64 * 12;
 
 template <class A>
@@ -609,60 +654,83 @@ __device__ __forceinline__ void row_sum_slots(const A& a, int cs, int base, RowS
     const int o = incl - cs;
     const int T = __shfl(incl, 63, 64);
     if (T == 0) return;
-    uint8_t* own = reinterpret_cast<uint8_t*>(wl);
+    int* start = reinterpret_cast<int*>(wl);   // [4][64]: lane of the owner whose range starts at (or reaches into the item at) a position
     float4* item = reinterpret_cast<float4*>(wl + kRowOwnerFloats);
-    for (int r = 0; r < cs; ++r) own[o + r] = (uint8_t)lane;
-    __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in issue order)
     const int n_items = (T + 63) >> 6;
-    auto fetch = [&](float4 (&dst)[4][3], int slot, int bits) {
+    // (the third quad of a row holds three live floats: loaded as 12 bytes -- the double buffer below is the kernel's register
+    //  peak, and project_bwd_kernel sits on the 168-VGPR edge of three waves per SIMD)
+    struct Row { float4 a, b; float cx, cy, cz; };
+    auto zero_row = [](Row& r) { r.a = r.b = make_float4(0.f, 0.f, 0.f, 0.f); r.cx = r.cy = r.cz = 0.f; };
+    auto fetch = [&](Row (&dst)[4], int slot, int bits) {
 #if GS_ROWSUM_DIAG == 1   // timing only: the same loads under the same masks, but lane-contiguous addresses
         const float4* rp = a.rows + 12 * (int64_t)__shfl(slot, 0, 64) + lane;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (bits & (1 << q)) { dst[q][0] = rp[64 * (3 * q)]; dst[q][1] = rp[64 * (3 * q + 1)]; dst[q][2] = rp[64 * (3 * q + 2)]; }
-            else { dst[q][0] = dst[q][1] = dst[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            if (bits & (1 << q)) { dst[q].a = rp[64 * (3 * q)]; dst[q].b = rp[64 * (3 * q + 1)]; const float4 c = rp[64 * (3 * q + 2)]; dst[q].cx = c.x; dst[q].cy = c.y; dst[q].cz = c.z; }
+            else zero_row(dst[q]);
         }
 #elif GS_ROWSUM_DIAG == 2   // timing only: no row loads
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q][0] = dst[q][1] = dst[q][2] = make_float4((float)(bits & (1 << q)), 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) { zero_row(dst[q]); dst[q].a.x = (float)(bits & (1 << q)); }
 #else
         const float4* rp = a.rows + 4 * kRow4 * (int64_t)slot;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (bits & (1 << q)) { dst[q][0] = rp[kRow4 * q]; dst[q][1] = rp[kRow4 * q + 1]; dst[q][2] = rp[kRow4 * q + 2]; }
-            else { dst[q][0] = dst[q][1] = dst[q][2] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            if (bits & (1 << q)) {
+                dst[q].a = rp[kRow4 * q]; dst[q].b = rp[kRow4 * q + 1];
+                const float* c = reinterpret_cast<const float*>(rp + kRow4 * q + 2);
+                dst[q].cx = c[0]; dst[q].cy = c[1]; dst[q].cz = c[2];
+            } else zero_row(dst[q]);
         }
 #endif
     };
     for (int u0 = 0; u0 < n_items; u0 += 4) {
         int sl[4], bt[4];
 #pragma unroll
+        for (int q = 0; q < 4; ++q) start[64 * q + lane] = -1;
+        __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in issue order)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jb = 64 * (u0 + q);
+            if (cs > 0 && o < jb + 64 && o + cs > jb) start[64 * q + max(o, jb) - jb] = lane;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = 64 * (u0 + q) + lane;
             const bool valid = j < T;
-            const int owner = valid ? (int)own[j] : 0;
+            const unsigned long long starts = __ballot(start[64 * q + lane] >= 0);
+            // the start at or below this lane's position (position 0 of a valid item always is one)
+            const int sp = 63 - __builtin_clzll((starts & (~0ull >> (63 - lane))) | 1ull);
+            const int owner = valid ? start[64 * q + sp] : 0;
             sl[q] = __shfl(base, owner, 64) + j - __shfl(o, owner, 64);
             bt[q] = valid ? (int)a.qmask[sl[q]] : 0;
         }
-        float4 buf[2][4][3];
+        Row buf[2][4];
         fetch(buf[0], sl[0], bt[0]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (u0 + q < n_items) {   // wave-uniform
                 if (q + 1 < 4 && u0 + q + 1 < n_items) fetch(buf[(q + 1) & 1], sl[(q + 1) & 3], bt[(q + 1) & 3]);
-                float4 (&d)[4][3] = buf[q & 1];
+                // slots of this item that hold rows at all: on long lists most do not (a saturated tile abandons its tail), and
+                // an owner then visits only its row-bearing slots -- the skipped ones would have added exact zeros
+                const unsigned long long has = __ballot(bt[q] != 0);
+                if (has == 0ull) continue;   // wave-uniform
+                Row (&d)[4] = buf[q & 1];
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x, z = x;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    x.x += d[k][0].x; x.y += d[k][0].y; x.z += d[k][0].z; x.w += d[k][0].w;
-                    y.x += d[k][1].x; y.y += d[k][1].y; y.z += d[k][1].z; y.w += d[k][1].w;
-                    z.x += d[k][2].x; z.y += d[k][2].y; z.z += d[k][2].z;
+                    x.x += d[k].a.x; x.y += d[k].a.y; x.z += d[k].a.z; x.w += d[k].a.w;
+                    y.x += d[k].b.x; y.y += d[k].b.y; y.z += d[k].b.z; y.w += d[k].b.w;
+                    z.x += d[k].cx; z.y += d[k].cy; z.z += d[k].cz;
                 }
                 item[3 * lane] = x; item[3 * lane + 1] = y; item[3 * lane + 2] = z;
                 __builtin_amdgcn_wave_barrier();
                 const int jb = 64 * (u0 + q);
                 const int lo = max(o, jb) - jb, hi = min(o + cs, jb + 64) - jb;
-                for (int r = lo; r < hi; ++r) {
+                unsigned long long mine = hi > lo ? ((hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo) & has : 0ull;
+                for (; mine; mine &= mine - 1ull) {   // ascending slot order: the order of the sums is unchanged
+                    const int r = __builtin_ctzll(mine);
                     const float4 ix = item[3 * r], iy = item[3 * r + 1], iz = item[3 * r + 2];
                     s.v[0] += ix.x; s.v[1] += ix.y; s.v[2] += ix.z; s.v[3] += ix.w;
                     s.v[4] += iy.x; s.v[5] += iy.y; s.v[6] += iy.z; s.v[7] += iy.w;
@@ -690,8 +758,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     const int64_t n = n0 + threadIdx.x;
     const int64_t f = (int64_t)c * a.N + n;
     const bool in_range = n < a.N;
-    Camera cam;
-    load_camera(a.viewmats, a.Ks, c, a.W, a.H, lds_cam, cam);
+    stage_camera(a.viewmats, a.Ks, c, a.W, a.H, lds_cam);   // (read after the row sum: read_camera)
 
     const bool vis = in_range && a.radii[f] > 0;
     const int cnt = vis ? a.tiles_per_gauss[f] : 0;
@@ -712,9 +779,16 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     }
 
     // ---- 2. colour path
+    Camera cam;
+    read_camera(lds_cam, cam);
     float v_mean[3] = {0.f, 0.f, 0.f}, v_quat[4] = {0.f, 0.f, 0.f, 0.f}, v_scale[3] = {0.f, 0.f, 0.f};
     float mean[3] = {0.f, 0.f, 0.f};
-    if (in_range) { mean[0] = a.means[3 * n]; mean[1] = a.means[3 * n + 1]; mean[2] = a.means[3 * n + 2]; }
+    // (the fused form reads its parameters through the flat buffer it updates: six pointers fewer to keep in SGPRs)
+    const float* p_means = ADAM ? adam_p(a, 0) : a.means;
+    const float* p_scales = ADAM ? adam_p(a, 1) : a.scales;
+    const float* p_quats = ADAM ? adam_p(a, 2) : a.quats;
+    const float* p_opac = ADAM ? adam_p(a, 5) : a.opacities;
+    if (in_range) { mean[0] = p_means[3 * n]; mean[1] = p_means[3 * n + 1]; mean[2] = p_means[3 * n + 2]; }
     const float v_rgb[3] = {s.v[8], s.v[9], s.v[10]};
     if (DEG >= 0) {
         const int row_f = 3 * a.K, stride = row_f + 1;
@@ -783,10 +857,10 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     // ---- 3. projection VJP
     float sc_fac[3] = {1.f, 1.f, 1.f}, op_fac = 1.f;   // d activated / d raw (identity without activations)
     if (vis) {
-        const float4 q4 = reinterpret_cast<const float4*>(a.quats)[n];
+        const float4 q4 = reinterpret_cast<const float4*>(p_quats)[n];
         const float quat[4] = {q4.x, q4.y, q4.z, q4.w};
-        const float scale[3] = {act_scale(a.scales[3 * n], a.activations), act_scale(a.scales[3 * n + 1], a.activations),
-                                act_scale(a.scales[3 * n + 2], a.activations)};
+        const float scale[3] = {act_scale(p_scales[3 * n], a.activations), act_scale(p_scales[3 * n + 1], a.activations),
+                                act_scale(p_scales[3 * n + 2], a.activations)};
         if (a.activations) { sc_fac[0] = scale[0]; sc_fac[1] = scale[1]; sc_fac[2] = scale[2]; }
 #ifndef GS_BWD_REAL   // (diagnostic builds: -DGS_BWD_REAL=float prices the fp64 chain of the backward)
 #define GS_BWD_REAL preal
@@ -797,7 +871,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     }
     float geo_op = 0.f;
     if (in_range) {
-        if (a.activations && vis) { const float o = act_opacity(a.opacities[n], 1); op_fac = o * (1.f - o); }
+        if (a.activations && vis) { const float o = act_opacity(p_opac[n], 1); op_fac = o * (1.f - o); }
         v_scale[0] *= sc_fac[0]; v_scale[1] *= sc_fac[1]; v_scale[2] *= sc_fac[2];
         const float v_op = s.v[7] * op_fac;
         float* vm = a.v_means + 3 * n; float* vq = a.v_quats + 4 * n; float* vs = a.v_scales + 3 * n;
@@ -805,9 +879,9 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
 #if GS_GEO_ADAM_SCALAR
             const float isbc2 = a.ad_hyper[0];
             auto upd = [&](int t, int64_t idx, float g) {
-                float p = a.ad_p[t][idx], m = a.ad_m[t][idx], v = a.ad_v[t][idx];
+                float p = adam_p(a, t)[idx], m = adam_m(a, t)[idx], v = adam_v(a, t)[idx];
                 adam1(p, g, m, v, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, a.ad_hyper[1 + t]);
-                a.ad_p[t][idx] = p; a.ad_m[t][idx] = m; a.ad_v[t][idx] = v;
+                adam_p(a, t)[idx] = p; adam_m(a, t)[idx] = m; adam_v(a, t)[idx] = v;
             };
 #pragma unroll
             for (int k = 0; k < 3; ++k) { upd(0, 3 * n + k, v_mean[k]); upd(1, 3 * n + k, v_scale[k]); }
@@ -903,6 +977,9 @@ struct ShGradArgs {
     const int64_t* guard;
 };
 
+__device__ __forceinline__ float* adam_p(const ShGradArgs& a, int t) { return a.ad_p[t]; }
+__device__ __forceinline__ float* adam_m(const ShGradArgs& a, int t) { return a.ad_m[t]; }
+__device__ __forceinline__ float* adam_v(const ShGradArgs& a, int t) { return a.ad_v[t]; }
 __device__ __forceinline__ float sh_adam_isbc2(const ShGradArgs& a) { return a.ad_isbc2; }
 __device__ __forceinline__ float sh_adam_ss(const ShGradArgs& a, int t) { return t == 3 ? a.ad_ss0 : a.ad_ssr; }
 
@@ -1177,7 +1254,8 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.adam = 0; a.ad_hyper = nullptr; a.ad_applied = nullptr; a.ad_b1 = a.ad_b2 = a.ad_eps = 0.f;
     a.st_max_radii = a.st_grad_norm = a.st_counts = nullptr; a.st_max_hw = (float)(width > height ? width : height);
     a.row_sums = row_sums; a.st_gn_out = stat_grad_norm; a.st_cnt_out = stat_count;
-    for (int t = 0; t < 6; ++t) a.ad_p[t] = a.ad_m[t] = a.ad_v[t] = nullptr;
+    a.ad_pbase = a.ad_mbase = a.ad_vbase = nullptr;
+    for (int t = 0; t < 6; ++t) a.ad_off[t] = 0;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
     const size_t lds = proj_bwd_lds_bytes(K, sh_degree);
     hipStream_t st = (hipStream_t)stream;
@@ -1239,7 +1317,8 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     a.st_max_radii = max_radii; a.st_grad_norm = grad_norm_accum; a.st_counts = counts;
     a.st_max_hw = (float)(width > height ? width : height);
     a.row_sums = nullptr; a.st_gn_out = a.st_cnt_out = nullptr;
-    for (int t = 0; t < 6; ++t) { a.ad_p[t] = params + offsets_host[t]; a.ad_m[t] = exp_avg + offsets_host[t]; a.ad_v[t] = exp_avg_sq + offsets_host[t]; }
+    a.ad_pbase = params; a.ad_mbase = exp_avg; a.ad_vbase = exp_avg_sq;
+    for (int t = 0; t < 6; ++t) a.ad_off[t] = offsets_host[t];
     a.cam = 0; a.accumulate = 0;
     dim3 grid((unsigned)((N + kProjThreads - 1) / kProjThreads));
     const size_t lds = proj_bwd_lds_bytes(K, sh_degree);

@@ -115,7 +115,7 @@ def binning_mode() -> str:
 
 # mean tile-list entries per Gaussian from which sorting coarse bins beats sorting tiles (tools/binning_sweep.py on MI355X,
 # 1080p, per-tile vs two-level: 0.22 vs 0.23 ms at 4.8, 0.27 vs 0.23 at 9.5, 0.42 vs 0.23 at 21, 1.10 vs 0.30 at 106;
-# tools/stage_profile_s3_s5.py: 2 M Gaussians at 5.4 0.54 vs 0.47, 5 M at 4K and 7.6 1.86 vs 0.89)
+# round 3, HISTORY.md: 2 M Gaussians at 5.4 0.54 vs 0.47, 5 M at 4K and 7.6 1.86 vs 0.89)
 BINS_FROM_FOOTPRINT = 5.0
 
 
@@ -653,6 +653,8 @@ class _Rasterize(torch.autograd.Function):
             lease, tiles = state["lease"], meta["tile_width"] * meta["tile_height"]
             holder.debug.update(unit_counter=lease.view(WS.UNIT_COUNTER, 1).clone(),
                                 qcnt=lease.view(WS.QCNT, state["C"] * tiles * 4).clone(), unit_entries=nat.GS_UNIT)
+            if state["n_isects"] is not None:   # intersections the backward holds gradient rows for (the forward walked them and some pixel took them)
+                holder.debug["walked_isects"] = lease.view(WS.QMASK, max(state["n_isects"], 1))[: state["n_isects"]].count_nonzero()
         # The backward reads the forward's workspace (lists, checkpoints, records).  Its lease is NOT held by this ctx -- that
         # would keep it until the OUTPUT tensors die, and a loop that holds the previous image while the next forward runs
         # would pin two full workspaces -- but by the saved tensors (`rasterization()` installs a pack hook that

@@ -102,7 +102,7 @@ def config_s5(seed=42, n=5_000_000):
 def config_long_lists(seed=1, n=45_000, width=640, height=368):
     """Heavy-tailed footprints (what real captures look like to the tile lists): splats of up to several hundred tiles,
     mean list > 2 000 entries, every pixel saturating.  The full-size version (`n=200_000, width=1920, height=1080`,
-    I ~ 37 M, mean list 4.6 k) is bench.py's secondary `long_lists` timing and tools/stress_big_splats.py."""
+    I ~ 37 M, mean list 4.6 k) is bench.py's secondary `long_lists` timing (tools/long_lists_run.py)."""
     scale = (0.03, 0.4) if width < 1000 else (0.02, 0.3)
     return make_scene(n, width, height, sh_degree=3, seed=seed, extent=(4, 2.25, 4), scale_range=scale, dist=8.0, white_bg=False)
 

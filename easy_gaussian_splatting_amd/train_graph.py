@@ -563,7 +563,7 @@ class TrainStepGraph:
             # re-build needs no probe at all: the host never reads the device between the refinement and the next replay
             # (bench.py `real_loop`: a probing re-build cost 5.5 ms + a throw-away warm-up step per refinement, more than the
             # 100 captured steps in between had saved against the eager loop)
-            projected = None
+            projected = carried = None
             if (not size_changed and self.binning == "tiles" and self.seen_isects > 0 and growth <= 2.0 and self.project_rebuilds
                     and self._key is not None and self._state_key(W, H)[5:] == self._key[5:]):
                 projected = (min(int(self.seen_isects * growth), (1 << 29) // 2), max(int(self.seen_tile * min(growth, 1.25)), 64))
@@ -572,10 +572,14 @@ class TrainStepGraph:
                 # first time -- inside the stream capture (gs_binning.hip: the warm-up exists to avoid exactly that)
                 cls = next((c for c in _SORT_CLASSES if c >= int(projected[1] * self.margin)), 1 << 30)
                 if (self.binning, cls) not in self._warm:
-                    projected = None
+                    # (the probing re-build still takes the projection as a floor: its probe sees ONE view, the history all)
+                    carried, projected = projected, None
             self.seen_isects = self.seen_tile = 0
             self.cap = 0
-            self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None, projected=projected)
+            if projected is None and carried is not None:
+                self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None, min_cap=carried[0], min_cap_tile=carried[1])
+            else:
+                self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None, projected=projected)
         b = self.buf
         w2c = b["viewmats"][0] if data is None else data["w2c"]
         K = b["Ks"][0] if data is None else data["K"]

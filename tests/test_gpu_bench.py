@@ -57,5 +57,6 @@ def test_bench_gpus_2_launches_two_ranks():
     r = _bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--gaussians", "100000", "--no-cpu-baseline"],
                {"GS_BENCH_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "view-dp2" and r["config"]["exchange"] == "factorised"
-    assert r["config"]["exchange_bytes_per_rank"]["all_gather_colors_pre"] == 12 * 100000
+    assert r["config"]["exchange_bytes_per_rank"]["all_gather_view_record"] == 16 * 100000 + 64
+    assert r["config"]["exchange_bytes_per_rank"]["collectives_per_step"] == 2
     assert r["value"] > 0

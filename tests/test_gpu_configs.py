@@ -432,7 +432,7 @@ def test_heavy_footprint_against_oracle(n):
     t_or = time.time() - t0
     assert fw["n_isects"] >= 20 * n, (fw["n_isects"], n)
     hip = run_hip(sc, fw=fw, max_flip_tile_frac=0.05)
-    assert rendering.last_binning() == "bins"   # (footprints of this size take the two-level binning)
+    binning_first = rendering.last_binning()     # (the first call of a shape has no footprint history: per-tile pipeline)
     exact = check_forward(hip, fw, outlier_frac=1e-5, max_razor_frac=0.05, max_flip_tile_frac=0.05)
     check_forward(hip, fw32, geom_slack=1e3, max_razor_frac=0.05, max_flip_tile_frac=0.05)
     assert int(hip["meta"]["flatten_ids"].numel()) == fw["n_isects"] or not exact
@@ -441,7 +441,9 @@ def test_heavy_footprint_against_oracle(n):
     parity_log.record(oracle_forward_s=round(t_or, 1), oracle_backward_s=round(time.time() - t0, 1), n_isects_gsplat=int(fw["n_isects"]),
                       isects_per_gaussian=round(fw["n_isects"] / n, 1))
     hip_t = run_hip(sc, culling="tight", upstream=(hip["vc"], hip["va"]))
-    parity_log.record(n_isects_tight=int(hip_t["meta"]["flatten_ids"].numel()))
+    # (footprints of this size take the two-level binning as soon as a call of the shape has reported them)
+    assert rendering.binning_choice(fw["n_isects"] / n, 120 * 68) == "bins"
+    parity_log.record(n_isects_tight=int(hip_t["meta"]["flatten_ids"].numel()), binning={"first_call": binning_first, "later": rendering.last_binning()})
     assert hip_t["meta"]["flatten_ids"].numel() < hip["meta"]["flatten_ids"].numel()
     assert torch.equal(hip_t["img"], hip["img"]) and torch.equal(hip_t["alpha"], hip["alpha"])
     assert torch.equal(hip_t["meta"]["radii"], hip["meta"]["radii"]) and torch.equal(hip_t["meta"]["means2d"], hip["meta"]["means2d"])
