@@ -1,9 +1,11 @@
 #!/bin/bash
-# One GPU-box call that regenerates everything under profiles/ for a round:  tools/final_profiles.sh r04
-# (build the clock-probe variant in the container first: tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE";
-#  hipcc -O3 --offload-arch=gfx950 -o tools/micro/clock_probe tools/micro/clock_probe.hip)
+# One GPU-box call that regenerates everything under profiles/ for a round:  tools/final_profiles.sh r05
+# (build the diagnostic variants in the container first:
+#    tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE" "acc64:-DGS_BWD_ACC64" "exact:-DGS_BWD_ACC64 -DGS_EXACT_MATH" \
+#                                 "halfq100:-DGS_EXP_HALFQ=100" "halfq155:-DGS_EXP_HALFQ=155"
+#    hipcc -O3 --offload-arch=gfx950 -o tools/micro/clock_probe tools/micro/clock_probe.hip)
 # (SQ counters and HBM traffic first: bench.py quotes them in its roofline objects)
-tag=${1:-r04}
+tag=${1:-r05}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 # shader clock under load first (bench.py's roofline_compute reads profiles/<tag>_clock.json)
@@ -31,4 +33,15 @@ timeout 300 bash tools/micro/traffic_cal.sh $tag > gpurun_out/${tag}_traffic_cal
 timeout 900 python tools/config_table.py > gpurun_out/${tag}_configs.md 2> gpurun_out/${tag}_configs.err
 timeout 200 python tools/binning_sweep.py 2>/dev/null > gpurun_out/${tag}_binning_sweep.txt
 timeout 200 python tools/blend_time.py 2>/dev/null > gpurun_out/${tag}_blend_time.txt
+# the workloads beside the headline: kernel trace + FETCH / WRITE traffic of eager train steps (tools/config_run.py)
+for cfg in S3 S5 heavy1M; do
+  lc=$(echo $cfg | tr A-Z a-z)
+  timeout 600 bash tools/prof_cmd.sh ${tag}_${lc} tools/config_run.py $cfg 6 > /dev/null 2>&1
+  grep "^{" /tmp/${tag}_${lc}.log | tail -1 > gpurun_out/${tag}_${lc}_run.json
+  timeout 900 bash tools/prof_pmc.sh ${tag}_${lc} tools/config_run.py $cfg 3 > /dev/null 2>&1
+done
+# half-quadrant work units for blend_bwd, bounded (timing builds, numerically wrong on purpose)
+for v in "" _halfq100 _halfq155; do GS_LIB_PATH=$PWD/easy_gaussian_splatting_amd/libgsraster$v.so timeout 200 python tools/blend_time.py 2>/dev/null; done > gpurun_out/${tag}_halfq_bound.txt
+# per-Gaussian criterion: fp32 sums / fp64 sums / fp64 sums + exact exp2 and division / fp32 oracle
+timeout 900 python tools/acc64_ab.py gpurun_out/${tag}_acc64_ab.json > gpurun_out/${tag}_acc64_ab.log 2>&1
 head -c 600 gpurun_out/${tag}_bench_line.json; echo; tail -3 gpurun_out/${tag}_bench.err
