@@ -74,6 +74,7 @@ SIGNATURES = {
     "gs_workspace_query": (_I, [_I, _L, _I, _I, _L, _L, _I, _I, _P, _P]),
     "gs_workspace_bind": (_I, [_P, _P, _L, _P, _L, _P, _P]),
     "gs_adam_step": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F]),
+    "gs_adam_step_stats": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F, _L, _P, _P, _P, _P]),
 }
 
 

@@ -29,19 +29,30 @@ struct AdamArgs {
                                   // inv_sqrt_bc2 / step_size above, so a captured launch can be replayed with a new step count
     const int64_t* guard;         // step guard (gs_guard_set) or nullptr
     int64_t* applied;             // optional device counter of steps that were really applied (not skipped by the guard)
+    // Only the segments WITH a gradient are walked (a partial step -- the view-parallel step's geometry half is 11 of 59 floats
+    // per Gaussian -- does not pay for the quads it skips): act_end4[k] = quads of the active segments up to and including k.
+    int64_t act_end4[kMaxSeg];
+    int64_t n_act4;
+    // ... and two additive statistics ride along (optional; the view-parallel step's all-reduced |absgrad| and visibility count,
+    // /root/reference/model/gaussian.py:188-197): stat_dst[j][0..stat_n) += stat_src[j][0..stat_n), one launch instead of three
+    const float* stat_src[2];
+    float* stat_dst[2];
+    int64_t stat_n;
 };
 
 __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
     if (guard_tripped(a.guard)) return;
     if (a.applied != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.applied[0] += 1;
     const float isbc2 = a.hyper ? a.hyper[0] : a.inv_sqrt_bc2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.n_act4; j += (int64_t)gridDim.x * blockDim.x) {
         int s = 0;
 #pragma unroll
-        for (int k = 0; k < kMaxSeg - 1; ++k) s += (k < a.nseg - 1 && i >= a.seg_end4[k]) ? 1 : 0;
+        for (int k = 0; k < kMaxSeg - 1; ++k) s += (k < a.nseg - 1 && j >= a.act_end4[k]) ? 1 : 0;
         const float* gp = a.g[s];
-        if (gp == nullptr) continue;
-        const int64_t e = (i - a.seg_begin4[s]) << 2;   // element index inside the segment
+        if (gp == nullptr) continue;   // (cannot happen: inactive segments hold no quads of j's range)
+        const int64_t q = j - (s > 0 ? a.act_end4[s - 1] : 0);   // quad inside the segment
+        const int64_t i = a.seg_begin4[s] + q;                   // quad inside the flat buffers
+        const int64_t e = q << 2;                                // element index inside the segment
         const int64_t len = a.seg_len[s];
         float4 g;
         if (e + 4 <= len) {
@@ -60,6 +71,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const AdamArgs a) {
         a.p[i] = p;   // re-read by the next forward
         nt_store4(m, a.m + i); nt_store4(v, a.v + i);   // streamed once per step
     }
+    if (a.stat_n > 0) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.stat_n; i += (int64_t)gridDim.x * blockDim.x) {
+            a.stat_dst[0][i] += a.stat_src[0][i];
+            a.stat_dst[1][i] += a.stat_src[1][i];
+        }
+    }
 }
 
 }  // namespace gs
@@ -69,7 +86,9 @@ using namespace gs;
 static int adam_launch(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
                        int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
                        const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
-                       float beta2, float eps, int64_t step, float grad_scale, const float* hyper_dev, int64_t* applied_dev) {
+                       float beta2, float eps, int64_t step, float grad_scale, const float* hyper_dev, int64_t* applied_dev,
+                       int64_t stat_n = 0, const float* stat_src0 = nullptr, const float* stat_src1 = nullptr,
+                       float* stat_dst0 = nullptr, float* stat_dst1 = nullptr) {
     GS_REQUIRE(n >= 0 && (n & 3) == 0, "flat length must be a multiple of 4 (pad the buffers)");
     GS_REQUIRE(n_segments >= 1 && n_segments <= kMaxSeg, "1..8 segments");
     GS_REQUIRE(step >= 1, "step counts from 1");
@@ -97,7 +116,17 @@ static int adam_launch(void* stream, int64_t n, float* params, float* exp_avg, f
     }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     a.grad_scale = grad_scale;
-    const int64_t want = (a.n4 + 255) / 256;
+    int64_t act = 0;
+    for (int k = 0; k < kMaxSeg; ++k) {
+        if (k < n_segments && a.g[k] != nullptr) act += a.seg_end4[k] - a.seg_begin4[k];
+        a.act_end4[k] = act;
+    }
+    a.n_act4 = act;
+    GS_REQUIRE(stat_n >= 0 && (stat_n == 0 || (stat_src0 && stat_src1 && stat_dst0 && stat_dst1)), "statistics: four pointers or none");
+    a.stat_n = stat_n; a.stat_src[0] = stat_src0; a.stat_src[1] = stat_src1; a.stat_dst[0] = stat_dst0; a.stat_dst[1] = stat_dst1;
+    const int64_t work = a.n_act4 > stat_n ? a.n_act4 : stat_n;
+    if (work == 0) return GS_OK;
+    const int64_t want = (work + 255) / 256;
     const unsigned grid = (unsigned)(want < 256 * 16 ? want : 256 * 16);
     hipLaunchKernelGGL(adam_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("adam_step_kernel");
@@ -110,6 +139,15 @@ extern "C" int gs_adam_step(void* stream, int64_t n, float* params, float* exp_a
                             float beta2, float eps, int64_t step, float grad_scale) {
     return adam_launch(stream, n, params, exp_avg, exp_avg_sq, n_segments, seg_ends_host, seg_lens_host, seg_grads_host,
                        seg_lrs_host, beta1, beta2, eps, step, grad_scale, nullptr, nullptr);
+}
+
+extern "C" int gs_adam_step_stats(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
+                                  int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
+                                  const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
+                                  float beta2, float eps, int64_t step, float grad_scale, int64_t stat_n,
+                                  const float* stat_src0, const float* stat_src1, float* stat_dst0, float* stat_dst1) {
+    return adam_launch(stream, n, params, exp_avg, exp_avg_sq, n_segments, seg_ends_host, seg_lens_host, seg_grads_host,
+                       seg_lrs_host, beta1, beta2, eps, step, grad_scale, nullptr, nullptr, stat_n, stat_src0, stat_src1, stat_dst0, stat_dst1);
 }
 
 extern "C" int gs_adam_step_dev(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,

@@ -647,7 +647,10 @@ constexpr int kCoopRows = GS_COOP_ROWS;
 constexpr int kRowOwnerFloats = 4 * 64;
 constexpr int kRowWaveFloats = kRowOwnerFloats + 64 * 12;
 
-template <class A>
+// DOUBLE: the next item's rows are requested before this item's are added (two row buffers: 88 VGPRs, the register peak of
+// project_bwd_kernel, whose fp64 chain holds it to three waves per SIMD anyway).  row_sums_kernel has nothing else to keep:
+// single-buffered it fits five waves per SIMD, and a pass that is pure gather latency wants the waves, not the prefetch.
+template <bool DOUBLE, class A>
 __device__ __forceinline__ void row_sum_slots(const A& a, int cs, int base, RowSum& s, float* wl) {
     const int lane = lane_id();
     const int incl = wave_incl_scan_add(cs);
@@ -706,17 +709,18 @@ __device__ __forceinline__ void row_sum_slots(const A& a, int cs, int base, RowS
             sl[q] = __shfl(base, owner, 64) + j - __shfl(o, owner, 64);
             bt[q] = valid ? (int)a.qmask[sl[q]] : 0;
         }
-        Row buf[2][4];
-        fetch(buf[0], sl[0], bt[0]);
+        Row buf[DOUBLE ? 2 : 1][4];
+        if (DOUBLE) fetch(buf[0], sl[0], bt[0]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (u0 + q < n_items) {   // wave-uniform
-                if (q + 1 < 4 && u0 + q + 1 < n_items) fetch(buf[(q + 1) & 1], sl[(q + 1) & 3], bt[(q + 1) & 3]);
+                if (DOUBLE) { if (q + 1 < 4 && u0 + q + 1 < n_items) fetch(buf[(q + 1) & 1], sl[(q + 1) & 3], bt[(q + 1) & 3]); }
+                else fetch(buf[0], sl[q], bt[q]);
                 // slots of this item that hold rows at all: on long lists most do not (a saturated tile abandons its tail), and
                 // an owner then visits only its row-bearing slots -- the skipped ones would have added exact zeros
                 const unsigned long long has = __ballot(bt[q] != 0);
                 if (has == 0ull) continue;   // wave-uniform
-                Row (&d)[4] = buf[q & 1];
+                Row (&d)[4] = buf[DOUBLE ? (q & 1) : 0];
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x, z = x;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -775,6 +779,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         s.v[8] = z.x; s.v[9] = z.y; s.v[10] = z.z; s.v[11] = 0.f;
     } else {
         float* row_wl = tile + (threadIdx.x >> 6) * kRowWaveFloats;
+        constexpr bool kRowDouble = true;
 #include "gs_rowsum_body.inc"
     }
 
@@ -1071,6 +1076,7 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const RowSumsArgs a) {
     if (a.cam_out && blockIdx.x == 0 && threadIdx.x < 16) a.cam_out[threadIdx.x] = a.viewmats[threadIdx.x];
     RowSum s;
     float* row_wl = wl_all[threadIdx.x >> 6];
+    constexpr bool kRowDouble = false;
 #include "gs_rowsum_body.inc"
     if (!in_range) return;
     if (vis) {   // (culled Gaussians: gs_project_bwd does not read their sums)

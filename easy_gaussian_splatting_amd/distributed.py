@@ -302,6 +302,12 @@ class ViewParallelStep:
         w_sum.wait()
         for p, o in zip(geo, offs):
             p.grad = flat[o:o + p.numel()].view_as(p)
+        gn, cn = flat[offs[4]:offs[4] + N], flat[offs[5]:offs[5] + N]
+        if self.native and m.collecting_counts.dtype == dt and m.grad_norm_accum.is_contiguous() and m.collecting_counts.is_contiguous():
+            # the geometry half of Adam and the two additive statistics in ONE launch (gs_adam_step_stats)
+            opt.step(only=self.GEOMETRY, grad_scale=1.0 / world, advance=False, stats=(gn, cn, m.grad_norm_accum, m.collecting_counts))
+            opt.zero_grad()
+            return
         opt.step(only=self.GEOMETRY, grad_scale=1.0 / world, advance=False)
         if m.collecting_counts.dtype == dt:   # (one launch for both additive statistics)
             torch._foreach_add_([m.grad_norm_accum, m.collecting_counts], [flat[offs[4]:offs[4] + N], flat[offs[5]:offs[5] + N]])

@@ -149,11 +149,13 @@ class FusedAdam(torch.optim.Optimizer):
                                    "after the optimizer was built); rebuild the optimizer")
 
     @torch.no_grad()
-    def step(self, closure=None, *, only=None, grad_scale: float = 1.0, advance: bool = True):
+    def step(self, closure=None, *, only=None, grad_scale: float = 1.0, advance: bool = True, stats=None):
         """One Adam step.  `only`: iterable of group names -- update just those groups (the others are
         skipped like `grad is None`); with `advance=False` the step count is not incremented, so a
         step can be issued in two launches (`step(only=A)`, then `step(only=B, advance=False)`).
-        `grad_scale` multiplies every gradient first (1/world: mean over ranks of summed gradients)."""
+        `grad_scale` multiplies every gradient first (1/world: mean over ranks of summed gradients).
+        `stats` = (src0, src1, dst0, dst1), float32 tensors of one length: `dst0 += src0; dst1 += src1` in the same launch
+        (distributed.ViewParallelStep: the all-reduced statistics of `update_statistics`)."""
         if closure is not None:
             raise NotImplementedError("closures are not supported")
         from . import _native as nat
@@ -178,9 +180,18 @@ class FusedAdam(torch.optim.Optimizer):
         dev = self.flat_param.device
         st = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            nat.check(L.gs_adam_step(st, self.flat_param.numel(), self.flat_param.data_ptr(), self.exp_avg.data_ptr(),
-                                     self.exp_avg_sq.data_ptr(), ns, ends, lens, gptr, lrs, float(b1), float(b2),
-                                     float(self.defaults["eps"]), self._step, float(grad_scale)), "gs_adam_step")
+            if stats is not None:
+                s0, s1, d0, d1 = stats
+                if not all(t.is_contiguous() and t.dtype == torch.float32 and t.numel() == s0.numel() and t.device == dev for t in stats):
+                    raise ValueError("stats: four contiguous float32 tensors of one length on the optimizer's device")
+                nat.check(L.gs_adam_step_stats(st, self.flat_param.numel(), self.flat_param.data_ptr(), self.exp_avg.data_ptr(),
+                                               self.exp_avg_sq.data_ptr(), ns, ends, lens, gptr, lrs, float(b1), float(b2),
+                                               float(self.defaults["eps"]), self._step, float(grad_scale), s0.numel(), s0.data_ptr(),
+                                               s1.data_ptr(), d0.data_ptr(), d1.data_ptr()), "gs_adam_step_stats")
+            else:
+                nat.check(L.gs_adam_step(st, self.flat_param.numel(), self.flat_param.data_ptr(), self.exp_avg.data_ptr(),
+                                         self.exp_avg_sq.data_ptr(), ns, ends, lens, gptr, lrs, float(b1), float(b2),
+                                         float(self.defaults["eps"]), self._step, float(grad_scale)), "gs_adam_step")
 
     def zero_grad(self, set_to_none: bool = True):
         for _, p in self._plist:

@@ -358,6 +358,16 @@ int gs_adam_step(void* stream, int64_t n, float* params, float* exp_avg, float* 
                  const float* const* seg_grads_host, const float* seg_lrs_host, float beta1,
                  float beta2, float eps, int64_t step, float grad_scale);
 
+/* The same step with two additive statistics riding along in the launch (the view-parallel step's geometry half, row e):
+ * stat_dst0[i] += stat_src0[i], stat_dst1[i] += stat_src1[i] for i < stat_n -- the all-reduced |absgrad| norm and visibility
+ * count of /root/reference/model/gaussian.py:188-197 into grad_norm_accum / collecting_counts.  stat_n = 0: exactly gs_adam_step.
+ * (Both entry points walk only the segments that have a gradient.) */
+int gs_adam_step_stats(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq,
+                       int n_segments, const int64_t* seg_ends_host, const int64_t* seg_lens_host,
+                       const float* const* seg_grads_host, const float* seg_lrs_host, float beta1, float beta2,
+                       float eps, int64_t step, float grad_scale, int64_t stat_n, const float* stat_src0,
+                       const float* stat_src1, float* stat_dst0, float* stat_dst1);
+
 /* Replayable form of gs_adam_step for a captured step: bias corrections and learning rates come from the device
  * array hyper_dev[1 + n_segments] = {1/sqrt(1-beta2^t), lr_k/(1-beta1^t)...}, which gs_adam_hyper writes (values
  * travel as kernel arguments of a one-thread launch, so successive steps cannot race on a host buffer).

@@ -30,6 +30,8 @@ done
 GS_BINNING=bins timeout 300 bash tools/prof_pmc.sh ${tag}_longlists tools/long_lists_run.py tight 3 > /dev/null 2>&1
 timeout 300 bash tools/micro/traffic_cal.sh $tag > gpurun_out/${tag}_traffic_cal.log 2>&1
 (GS_BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 50 --warmup 10 > gpurun_out/${tag}_bench_forcedist_rccl.json 2> gpurun_out/${tag}_bench_forcedist.err)
+# ... and its kernel trace (row_sums_kernel, project_bwd_kernel<3, false, true>, sh_grad_views_kernel<3, true>, RCCL's own kernels)
+(cd /tmp && export TMPDIR=/tmp GS_BENCH_FORCE_DIST=1 && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/${tag}_fd -o fd -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 > /tmp/${tag}_fd.log 2>&1; f=$(find /tmp/${tag}_fd -name "*kernel_stats.csv" | head -1); cp "$f" $GRAFT_REPO_ROOT/gpurun_out/${tag}_forcedist_kernel_stats.csv)
 timeout 900 python tools/config_table.py > gpurun_out/${tag}_configs.md 2> gpurun_out/${tag}_configs.err
 timeout 200 python tools/binning_sweep.py 2>/dev/null > gpurun_out/${tag}_binning_sweep.txt
 timeout 200 python tools/blend_time.py 2>/dev/null > gpurun_out/${tag}_blend_time.txt
