@@ -84,14 +84,22 @@ def test_fused_adam_partial_steps_and_grad_scale():
     pa, oa = make()
     pb, ob = make()
     sh, geo = ("sh_0", "sh_rest"), ("means", "log_scales", "quats", "logit_opacities")
+    # two additive statistics ride along in the geometry launch (gs_adam_step_stats): dst += src, whatever the segments do
+    src = [torch.rand(1001, generator=g).to(dev) for _ in range(2)]
+    dst = [torch.rand(1001, generator=g).to(dev) for _ in range(2)]
+    want = [d.clone() for d in dst]
     for gs in grads:
         for k in shapes:
             pa[k].grad = (0.25 * gs[k]).to(dev)
             pb[k].grad = gs[k].to(dev)
         oa.step()
         ob.step(only=sh, grad_scale=0.25)
-        ob.step(only=geo, grad_scale=0.25, advance=False)
+        ob.step(only=geo, grad_scale=0.25, advance=False, stats=(src[0], src[1], dst[0], dst[1]))
+        want = [w + s_ for w, s_ in zip(want, src)]
     assert oa._step == ob._step == 3
+    assert torch.equal(dst[0], want[0]) and torch.equal(dst[1], want[1])
+    with pytest.raises(ValueError):
+        ob.step(only=geo, advance=False, stats=(src[0], src[1], dst[0], dst[1][:5]))
     for k in shapes:
         assert _rel(pb[k].detach(), pa[k].detach()) < 1e-6, k
         ma, va = oa.moments_of(pa[k]); mb, vb = ob.moments_of(pb[k])
@@ -278,14 +286,14 @@ def test_row_sums_record_and_in_place_bucket():
         run(_sh_grads="colors_pre", _view_payload=pay[:4 * N])
 
 
-@pytest.mark.parametrize("deg,R", [(3, 1), (3, 3), (1, 2), (0, 2)])
-def test_sh_adam_views_equals_rebuild_plus_adam(deg, R):
+@pytest.mark.parametrize("deg,R,K", [(3, 1, 16), (3, 3, 16), (1, 2, 16), (0, 2, 16), (0, 3, 1), (1, 2, 4)])
+def test_sh_adam_views_equals_rebuild_plus_adam(deg, R, K):
     """`gs_sh_adam_views` (SH gradient of R views formed in LDS and applied by Adam in place, `max_radii` folded in) ==
     `gs_sh_grad_views` + `FusedAdam.step(only=SH, grad_scale=1/R)` + `torch.maximum`, bit for bit, over two steps."""
     from easy_gaussian_splatting_amd import _native as nat
     from easy_gaussian_splatting_amd.optim import FusedAdam
     dev = torch.device("cuda:0")
-    N, K = 3001, 16
+    N = 3001
     g = torch.Generator().manual_seed(5 + deg)
     means = (torch.rand((N, 3), generator=g) * 2 - 1).to(dev)
     cams = torch.eye(4).repeat(R, 1, 1)
@@ -311,15 +319,16 @@ def test_sh_adam_views_equals_rebuild_plus_adam(deg, R):
         rec[:, :3 * N] = pre.reshape(R, -1); rec[:, 3 * N:4 * N] = rad; rec[:, 4 * N:] = cams.reshape(R, 16)
         # reference: dense rebuild, then the SH half of Adam
         v0, vr = sh_grad_views(means, cams, pre, deg, K)
-        pa["sh_0"].grad, pa["sh_rest"].grad = v0, vr
+        pa["sh_0"].grad, pa["sh_rest"].grad = v0, (vr if K > 1 else None)
         oa.step(only=("sh_0", "sh_rest"), grad_scale=1.0 / R)
         torch.maximum(rad_a, rad.max(0).values, out=rad_a)
         # fused
         ob._step += 1
         m0, s0 = ob.moments_of(pb["sh_0"]); mr, sr = ob.moments_of(pb["sh_rest"])
+        rest = (pb["sh_rest"].data_ptr(), mr.data_ptr(), sr.data_ptr()) if K > 1 else (None, None, None)   # (K = 1: no sh_rest at all)
         nat.check(nat.lib().gs_sh_adam_views(torch.cuda.current_stream().cuda_stream, R, N, K, deg, means.data_ptr(), rec.data_ptr(), P,
-                                             pb["sh_0"].data_ptr(), m0.data_ptr(), s0.data_ptr(), pb["sh_rest"].data_ptr(), mr.data_ptr(),
-                                             sr.data_ptr(), 1e-2, 2e-2, 0.9, 0.999, 1e-8, ob._step, 1.0 / R, rad_b.data_ptr()), "gs_sh_adam_views")
+                                             pb["sh_0"].data_ptr(), m0.data_ptr(), s0.data_ptr(), *rest,
+                                             1e-2, 2e-2, 0.9, 0.999, 1e-8, ob._step, 1.0 / R, rad_b.data_ptr()), "gs_sh_adam_views")
     assert oa._step == ob._step == 2
     for k in ("sh_0", "sh_rest"):
         assert torch.equal(pa[k].detach(), pb[k].detach()), k
