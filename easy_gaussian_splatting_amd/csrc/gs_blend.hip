@@ -424,6 +424,10 @@ struct EntryState {
     bool has;
 };
 
+// Round 5 tried the forward's own state encoding here (T alone: 0 = finished; alpha masked once; the stop rule behind a
+// wave-uniform branch on newly stopping pixels, or branch-free): 197 / 204 instead of 208 VALU per step in the ISA, and the
+// kernel 0.445 / 0.410 ms against 0.414 for this form on the same box -- a scalar branch per pair stalls three waves per SIMD more
+// than eleven selects cost them, and four instructions fewer are within the noise.  Not kept.
 // (pixels outside the pipeline window arrive with T < 0; slots past the end of the sublist have
 // opacity 0, hence alpha 0: neither needs a flag of its own)
 __device__ __forceinline__ void bwd_pair(EntryState& e, const float4 d0, const float2 d1, float& T, float& P) {

@@ -21,7 +21,10 @@ CHK_LIB = os.path.join(ROOT, "easy_gaussian_splatting_amd", "libgsraster_chk.so"
 
 
 def test_backward_rederives_the_forwards_contributor_set_bit_for_bit():
-    assert os.path.exists(CHK_LIB), f"{CHK_LIB} is missing: run __graft_entry__.build() (it builds the -DGS_BWD_CHECK variant)"
+    # (built by __graft_entry__.build(); re-made here if it is missing or older than a source file -- a stale variant lacks the
+    #  symbols newer sources export, and the package refuses to bind a library that does not hold every symbol of the header)
+    from easy_gaussian_splatting_amd import _native
+    assert _native.build_variant("chk", "-DGS_BWD_CHECK") == CHK_LIB and os.path.exists(CHK_LIB)
     env = dict(os.environ, GS_LIB_PATH=CHK_LIB)
     proc = subprocess.run([sys.executable, os.path.join(HERE, "contrib_child.py")], env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-3000:]

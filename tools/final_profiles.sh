@@ -8,6 +8,12 @@
 tag=${1:-r05}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+# the diagnostic variants, re-made on the box unless GS_SKIP_VARIANT_BUILD=1 (a variant older than the sources lacks the symbols newer
+# sources export, and the package refuses to bind such a library: the tools that load one would fail silently)
+if [ "$GS_SKIP_VARIANT_BUILD" != 1 ]; then
+  bash tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE" "acc64:-DGS_BWD_ACC64" "exact:-DGS_BWD_ACC64 -DGS_EXACT_MATH" "halfq100:-DGS_EXP_HALFQ=100" "halfq155:-DGS_EXP_HALFQ=155" > gpurun_out/${tag}_variants.log 2>&1
+  [ -x tools/micro/clock_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/clock_probe tools/micro/clock_probe.hip
+fi
 # shader clock under load first (bench.py's roofline_compute reads profiles/<tag>_clock.json)
 timeout 300 bash tools/clock_probe.sh $tag > gpurun_out/${tag}_clock_stdout.txt 2>&1
 cp gpurun_out/${tag}_clock.json profiles/ 2>/dev/null
