@@ -242,6 +242,42 @@ def test_two_ranks_equal_one_process_on_both_views(tmp_path, variant):
     np.testing.assert_array_equal(r0["rad"], ref["rad"])
 
 
+def test_row_sums_pass_on_gaussians_of_hundreds_of_slots():
+    """`gs_row_sums` on a heavy-tailed scene (synthetic.config_long_lists: splats of several hundred tiles, most list tails
+    abandoned by saturated tiles): the slot-per-lane path with its empty-item skip AND the whole-wave path of the > 128-slot
+    Gaussians, single-buffered in this kernel -- against the projection backward's own (double-buffered) row sum of the dense
+    mode: the same sums, hence the same colour gradient bit for bit and the same geometry gradients to an ulp or two."""
+    from scenes import config_long_lists
+    dev = torch.device("cuda:0")
+    sc = config_long_lists(seed=3, n=30_000, width=640, height=368)
+    W, H = 640, 368
+    t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
+    vc = torch.randn((1, H, W, 3), generator=torch.Generator().manual_seed(2)).to(dev)
+
+    def run(mode):
+        ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities")]
+        shs = t["shs"].clone().requires_grad_(True)
+        dbg = {}
+        img, _, meta = rasterization(*ins, shs, t["viewmats"], t["Ks"], W, H, sh_degree=3, packed=False, backgrounds=t["backgrounds"],
+                                     absgrad=True, _sh_grads=mode, _tile_culling="tight", _debug=dbg)
+        (img * vc).sum().backward()
+        return [p.grad for p in ins], shs.grad, meta, dbg
+
+    g_dense, sh_dense, meta_d, dbg_d = run("dense")
+    g_fact, sh_fact, meta_f, dbg_f = run("colors_pre")
+    tiles = meta_d["tiles_per_gauss"][0]
+    assert int((tiles > 128).sum()) > 50 and int(tiles.max()) > 1000, "the scene must exercise the whole-wave path"
+    # the sums themselves: bit for bit (debug outputs of the projection backward = what it was handed / what it summed)
+    for k in ("v_means2d", "v_conics", "v_colors_post"):
+        assert torch.equal(dbg_d[k], dbg_f[k]), k
+    assert torch.equal(meta_d["means2d"].absgrad, meta_f["means2d"].absgrad)
+    for a, b in zip(g_fact, g_dense):
+        assert _rel(a, b) < 1e-6, _rel(a, b)
+    assert sh_fact is None
+    rebuilt = sh_grad_views(t["means"], t["viewmats"], meta_f["means2d"].colors_pre_grad, 3, 16, split=False)
+    assert _rel(rebuilt, sh_dense) < 2e-6
+
+
 def test_row_sums_record_and_in_place_bucket():
     """`_view_payload` + `_grad_out` (what ViewParallelStep installs): ONE launch after the blend backward fills the rank's
     all-gather record [3N colour gradients | N radii / max(H, W) | w2c], the projection backward writes the geometry gradients
