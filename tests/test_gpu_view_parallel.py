@@ -249,8 +249,8 @@ def test_row_sums_pass_on_gaussians_of_hundreds_of_slots():
     mode: the same sums, hence the same colour gradient bit for bit and the same geometry gradients to an ulp or two."""
     from scenes import config_long_lists
     dev = torch.device("cuda:0")
-    sc = config_long_lists(seed=3, n=30_000, width=640, height=368)
-    W, H = 640, 368
+    sc = config_long_lists(seed=3, n=30_000, width=1920, height=1080)
+    W, H = 1920, 1080
     t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
     vc = torch.randn((1, H, W, 3), generator=torch.Generator().manual_seed(2)).to(dev)
 
@@ -266,7 +266,7 @@ def test_row_sums_pass_on_gaussians_of_hundreds_of_slots():
     g_dense, sh_dense, meta_d, dbg_d = run("dense")
     g_fact, sh_fact, meta_f, dbg_f = run("colors_pre")
     tiles = meta_d["tiles_per_gauss"][0]
-    assert int((tiles > 128).sum()) > 50 and int(tiles.max()) > 1000, "the scene must exercise the whole-wave path"
+    assert int((tiles > 128).sum()) > 50 and int(tiles.max()) > 300, ("the scene must exercise the whole-wave path", int((tiles > 128).sum()), int(tiles.max()))
     # the sums themselves: bit for bit (debug outputs of the projection backward = what it was handed / what it summed)
     for k in ("v_means2d", "v_conics", "v_colors_post"):
         assert torch.equal(dbg_d[k], dbg_f[k]), k
