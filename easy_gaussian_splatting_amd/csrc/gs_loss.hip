@@ -4,16 +4,19 @@
 // K1 = 0.01, K2 = 0.03, data_range 1, mean over the un-padded interior, where the reflect padding
 // never reaches -- every contributing window lies inside the image).
 //
-//   l1_ssim_fwd_kernel : one 32x32 tile per block.  Stages the tile + 5-pixel halo of both images
-//                        (mask-composited, all 3 channels, coalesced channel-last rows; all global
-//                        loads issued before the first LDS store) in LDS, runs the separable
-//                        11-tap window for the five moment maps with register sliding windows
-//                        (row x 8 columns, then column x 4 rows per thread), evaluates
-//                        SSIM and its three partial derivatives (wrt mu_x, E[x^2], E[xy]) per
-//                        pixel, and writes per-block partial sums (deterministic reduction).
+//   l1_ssim_fwd_kernel : one block per (32x32 tile, channel); XCD-aware block order (loss_tile).  Stages the
+//                        tile + 5-pixel halo of both images (mask-composited; all global loads issued
+//                        before the first LDS store) in LDS, runs the separable 11-tap window for the
+//                        five moment maps with register sliding windows (row x 6 columns, then column
+//                        x 4 rows per thread), evaluates SSIM and its three partial derivatives (wrt
+//                        mu_x, E[x^2], E[xy]) per pixel, and writes per-block partial sums
+//                        (deterministic reduction).
 //   l1_ssim_bwd_kernel : d loss / d render = window (*) derivative maps (+ L1 sign term), same
 //                        tiling; the mask composite's (1 - mask) factor is applied here.
 //   loss_reduce_kernel : single block, fixed order sum of the per-block partials.
+// Round 5: a block per channel instead of a three-channel loop per block (71 / 38 KB of LDS and 113 / 151 VGPRs held
+// the kernels to two / three blocks per CU; now 28 / 22 KB and 80 / 61 VGPRs), block-uniform bases with 32-bit byte offsets
+// instead of 64-bit index arithmetic per element (VALU per tile-channel 1135 -> 1025 and 917 -> 641): 64 + 59 us -> 56 + 33.
 // Pure HBM-streaming + LDS stencil work; no atomics.
 #include "gs_common.h"
 
@@ -24,8 +27,9 @@ constexpr int kHalo = 5;
 constexpr int kLR = kLT + 2 * kHalo;  // 42 staged rows / cols
 constexpr int kLRP = kLR + 1;         // padded row stride of the staged tiles
 constexpr int kHP = kLT + 1;          // row stride of the horizontal-pass buffers
-static_assert(kLT * (kLT / 4) == 256 && kLR * (kLT / 8) <= 256 && kLR * 6 <= 256, "thread mapping of the separable passes");
-static_assert(kLR % 2 == 0 && kLR * 3 <= 128, "staging: two 128-thread halves, one staged row each");
+static_assert(kLT * (kLT / 4) == 256 && kLR * 6 <= 256 && kLR % 6 == 0, "thread mapping of the staging and the separable passes");
+static_assert(kLR % 2 == 0 && kLR * 3 <= 128, "backward staging: two 128-thread halves, one staged row each");
+constexpr int64_t kLossMaxPixels = (int64_t)1 << 28;   // 12 bytes per pixel and plane under 2^32; rows and columns under 2^24
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 __device__ __constant__ float kWin[11] = {1.0283800845e-03f, 7.5987581352e-03f, 3.6000772128e-02f,
@@ -36,8 +40,10 @@ __device__ __constant__ float kWin[11] = {1.0283800845e-03f, 7.5987581352e-03f, 
 #ifndef GS_SSIM_IEEE_DIV
 #define GS_SSIM_IEEE_DIV 0
 #endif
-#ifndef GS_SSIM_HPASS_6
-#define GS_SSIM_HPASS_6 1
+// 1: the horizontal pass's sums are parked in registers across one more barrier and written OVER the staged tile, 28 / 22 KB of
+// LDS per block instead of 42 / 38: five / seven blocks per CU instead of three / four (forward 61 -> 56 us, backward 37 -> 33)
+#ifndef GS_LOSS_ALIAS_HP
+#define GS_LOSS_ALIAS_HP 1
 #endif
 struct LossArgs {
     int H, W;
@@ -51,160 +57,179 @@ struct LossArgs {
 };
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// base + 32-bit BYTE offset: with a block-uniform base this is one global_load with a scalar base and a vector offset
+__device__ __forceinline__ float ld_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st_off(float* base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// Block -> (tile, channel).  Consecutive block ids go round-robin over the eight XCDs, each with its own L2: XCD x takes the
+// contiguous row-major run of tiles [x * per, (x + 1) * per), and the three channels of a tile follow one another on the same
+// XCD -- halos, the channel-last image lines the three blocks share and the lines their strided stores fill are met in that L2.
+__device__ __forceinline__ bool loss_tile(const LossArgs& a, int& x0, int& y0, int& ch, int& slot) {
+    const int ntx = (a.W + kLT - 1) / kLT, nt = ntx * ((a.H + kLT - 1) / kLT), per = (nt + 7) >> 3;
+    const int id = blockIdx.x, k = id >> 3, local = k / 3, t = (id & 7) * per + local;
+    ch = k - 3 * local;
+    if (t >= nt) return false;
+    const int ty = t / ntx;
+    x0 = (t - ty * ntx) * kLT; y0 = ty * kLT; slot = 3 * t + ch;
+    return true;
+}
+
+// the separable window's horizontal pass over one staged row: thread = row x 6 output columns, register sliding window
+// (42 rows x 6 column groups; the last group starts at column 26 and recomputes two: 252 of the 256 threads work)
+constexpr int kHOut = 6, kHWin = kHOut + 10;
 
 __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sx = lds;                         // [3][kLR][kLRP]
-    float* sy = sx + 3 * kLR * kLRP;         // [3][kLR][kLRP]
-    float* hp = sy + 3 * kLR * kLRP;         // [5][kLR][kHP] horizontal pass of one channel
+#if GS_LOSS_ALIAS_HP
+    float* hp = lds;                         // [5][kLR][kHP], written over the staged tile once every thread has read its windows
+    float* sx = lds;
+#else
+    float* hp = lds + 2 * kLR * kLRP;
+    float* sx = lds;                         // [kLR][kLRP] render (composited), this block's channel
+#endif
+    float* sy = sx + kLR * kLRP;             // [kLR][kLRP] ground truth
     __shared__ float red[2][4];
-    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    int x0, y0, ch, slot;
+    if (!loss_tile(a, x0, y0, ch, slot)) return;
     const int tid = threadIdx.x;
-    // ---- stage tile + halo (coordinates clamped; clamped values only feed discarded outputs).
-    // All global loads of a thread are issued before its first LDS store: hipcc keeps a
-    // load -> LDS-store loop in program order (the store may alias the next load), which would
-    // cost one HBM round trip per element.
+    // ---- stage tile + halo of one channel (coordinates clamped; clamped values only feed discarded outputs): thread = one
+    // staged column x 7 rows.  All global loads of a thread are issued before its first LDS store: hipcc keeps a
+    // load -> LDS-store loop in program order (the store may alias the next load), one HBM round trip per element.
+    // Addresses: a block-uniform base (scalar registers) + a 32-bit byte offset per lane (the entry points bound H * W), a
+    // 24-bit multiply-add per row instead of 64-bit index arithmetic per element.
     float l1 = 0.f;
-    {
-        // Row-wise mapping: a staged row is one contiguous run of 42 x 3 floats in the channel-last
-        // images; thread j < 126 of each 128-thread half owns element j (column j/3, channel j%3,
-        // computed once) of every second row -- no per-element index arithmetic.
-        constexpr int kRowsPer = kLR / 2;   // 21 rows per half
-        const int half = tid >> 7, j = tid & 127;
-        const bool lane_on = j < kLR * 3;
-        const int col = j / 3, ch = j - col * 3;
+    const unsigned row_bytes = 12u * (unsigned)a.W;
+    const float* gt_c = a.gt + ch;
+    const float* render_c = a.render + ch;
+    if (tid < kLR * 6) {
+        constexpr int kPer = kLR / 6;   // 7 rows per thread
+        const int rg = tid / kLR, col = tid - rg * kLR;
         const int gx = x0 - kHalo + col, cx = clampi(gx, 0, a.W - 1);
         const bool col_own = col >= kHalo && col < kHalo + kLT && gx < a.W;
-        float rv[kRowsPer], gv[kRowsPer], mv[kRowsPer];
+        const int ytop = y0 - kHalo + rg;
+        float rv[kPer], gv[kPer], mv[kPer];
 #pragma unroll
-        for (int i = 0; i < kRowsPer; ++i) {
-            rv[i] = gv[i] = mv[i] = 0.f;
-            if (lane_on) {
-                const int cy = clampi(y0 - kHalo + half + 2 * i, 0, a.H - 1);
-                const size_t o = ((size_t)cy * a.W + cx) * 3 + ch;
-                gv[i] = a.gt[o]; rv[i] = a.render[o];
-                if (a.mask) mv[i] = a.mask[(size_t)cy * a.W + cx];
-            }
+        for (int i = 0; i < kPer; ++i) {
+            const unsigned cy = (unsigned)clampi(ytop + 6 * i, 0, a.H - 1);
+            const unsigned o = __umul24(cy, row_bytes) + 12u * (unsigned)cx;
+            gv[i] = ld_off(gt_c, o); rv[i] = ld_off(render_c, o);
+            if (a.mask) mv[i] = ld_off(a.mask, __umul24(cy, 4u * (unsigned)a.W) + 4u * (unsigned)cx);
         }
-        float* dx = sx + (ch * kLR + half) * kLRP + col;
-        float* dy = sy + (ch * kLR + half) * kLRP + col;
+        float* dx = sx + rg * kLRP + col;
+        float* dy = sy + rg * kLRP + col;
 #pragma unroll
-        for (int i = 0; i < kRowsPer; ++i) {
-            if (lane_on) {
-                const int row = half + 2 * i, gy = y0 - kHalo + row;
-                const float g = gv[i];
-                float r = rv[i];
-                if (a.clamp_input) r = fminf(fmaxf(r, 0.f), 1.f);   // torch.clamp(render, 0, 1) of the model, folded in
-                if (a.mask) r = mv[i] * g + (1.f - mv[i]) * r;
-                dx[2 * i * kLRP] = r;
-                dy[2 * i * kLRP] = g;
-                if (col_own && row >= kHalo && row < kHalo + kLT && gy < a.H) l1 += fabsf(r - g);
-            }
+        for (int i = 0; i < kPer; ++i) {
+            const int row = rg + 6 * i, gy = y0 - kHalo + row;
+            const float g = gv[i];
+            float r = rv[i];
+            if (a.clamp_input) r = fminf(fmaxf(r, 0.f), 1.f);   // torch.clamp(render, 0, 1) of the model, folded in
+            if (a.mask) r = mv[i] * g + (1.f - mv[i]) * r;
+            dx[6 * i * kLRP] = r;
+            dy[6 * i * kLRP] = g;
+            if (col_own && row >= kHalo && row < kHalo + kLT && gy < a.H) l1 += fabsf(r - g);
         }
     }
     __syncthreads();
     float ssim_sum = 0.f;
-    const size_t plane = (size_t)a.H * a.W;
-    for (int ch = 0; ch < 3; ++ch) {
-        const float* X = sx + ch * kLR * kLRP;
-        const float* Y = sy + ch * kLR * kLRP;
-        // horizontal 11-tap pass with a register sliding window: one thread = one staged row x 8
-        // output columns (18 + 18 LDS reads feed 8 x 5 outputs); lanes run down the rows, so the
-        // odd row strides keep the reads and the writes conflict-free
-#if GS_SSIM_HPASS_6
-        // 42 rows x 6 column groups of 6 outputs (the last group starts at column 26 and recomputes two): 252 of the 256
-        // threads work, 330 instead of 440 FMAs on the longest path (42 x 4 groups of 8 left a third of the block idle)
-        if (tid < kLR * 6) {
-            constexpr int kOut = 6, kWinN = kOut + 10;
-            const int g = tid / kLR, row = tid - g * kLR, c0 = min(kOut * g, kLT - kOut);
-#else
-        if (tid < kLR * (kLT / 8)) {
-            constexpr int kOut = 8, kWinN = kOut + 10;
-            const int g = tid / kLR, row = tid - g * kLR, c0 = 8 * g;
-#endif
-            float xv[kWinN], yv[kWinN], xx[kWinN], yy[kWinN], xy[kWinN];
+    float* maps_c = a.maps + (size_t)ch * a.H * a.W * 3;
+    {
+        // horizontal pass: 16 + 16 LDS reads feed 6 x 5 outputs; lanes run down the rows, the odd row strides keep reads and
+        // writes conflict-free
+        const bool h_on = tid < kLR * 6;
+        const int g = tid / kLR, row = tid - g * kLR, c0 = min(kHOut * g, kLT - kHOut);
+        float ho[5][kHOut];
+        if (h_on) {
+            float xv[kHWin], yv[kHWin];
 #pragma unroll
-            for (int i = 0; i < kWinN; ++i) {
-                xv[i] = X[row * kLRP + c0 + i]; yv[i] = Y[row * kLRP + c0 + i];
-                xx[i] = xv[i] * xv[i]; yy[i] = yv[i] * yv[i]; xy[i] = xv[i] * yv[i];
+            for (int i = 0; i < kHWin; ++i) { xv[i] = sx[row * kLRP + c0 + i]; yv[i] = sy[row * kLRP + c0 + i]; }
+#pragma unroll
+            for (int j = 0; j < kHOut; ++j) {
+                float m0 = kWin[0] * xv[j], m1 = kWin[0] * yv[j], m2 = kWin[0] * (xv[j] * xv[j]), m3 = kWin[0] * (yv[j] * yv[j]),
+                      m4 = kWin[0] * (xv[j] * yv[j]);   // (first tap as a product: no zero to materialise per sum)
+#pragma unroll
+                for (int k = 1; k < 11; ++k) {
+                    const float w = kWin[k], x = xv[j + k], y = yv[j + k];
+                    m0 = fmaf(w, x, m0); m1 = fmaf(w, y, m1); m2 = fmaf(w, x * x, m2);
+                    m3 = fmaf(w, y * y, m3); m4 = fmaf(w, x * y, m4);
+                }
+                ho[0][j] = m0; ho[1][j] = m1; ho[2][j] = m2; ho[3][j] = m3; ho[4][j] = m4;
             }
+        }
+#if GS_LOSS_ALIAS_HP
+        __syncthreads();
+#endif
+        if (h_on) {
             float* h = hp + row * kHP + c0;
 #pragma unroll
-            for (int j = 0; j < kOut; ++j) {
-                float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+            for (int mi = 0; mi < 5; ++mi)
 #pragma unroll
-                for (int k = 0; k < 11; ++k) {
-                    const float w = kWin[k];
-                    m0 = fmaf(w, xv[j + k], m0); m1 = fmaf(w, yv[j + k], m1); m2 = fmaf(w, xx[j + k], m2);
-                    m3 = fmaf(w, yy[j + k], m3); m4 = fmaf(w, xy[j + k], m4);
-                }
-                h[j] = m0; h[kLR * kHP + j] = m1; h[2 * kLR * kHP + j] = m2; h[3 * kLR * kHP + j] = m3; h[4 * kLR * kHP + j] = m4;
-            }
+                for (int j = 0; j < kHOut; ++j) h[mi * kLR * kHP + j] = ho[mi][j];
         }
-        __syncthreads();
-        // vertical pass + SSIM: one thread = one column x 4 output rows (14 LDS reads per map)
-        {
-            const int q = tid / kLT, col = tid - q * kLT, r0 = 4 * q;
-            float mom[5][4];
+    }
+    __syncthreads();
+    // vertical pass + SSIM: one thread = one column x 4 output rows (14 LDS reads per map)
+    {
+        const int q = tid / kLT, col = tid - q * kLT, r0 = 4 * q;
+        float mom[5][4];
 #pragma unroll
-            for (int mi = 0; mi < 5; ++mi) {
-                float hv[14];
+        for (int mi = 0; mi < 5; ++mi) {
+            float hv[14];
 #pragma unroll
-                for (int i = 0; i < 14; ++i) hv[i] = hp[mi * kLR * kHP + (r0 + i) * kHP + col];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 11; ++k) acc = fmaf(kWin[k], hv[j + k], acc);
-                    mom[mi][j] = acc;
-                }
-            }
-            const int gx = x0 + col;
+            for (int i = 0; i < 14; ++i) hv[i] = hp[mi * kLR * kHP + (r0 + i) * kHP + col];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int gy = y0 + r0 + j;
-                const float mu_x = mom[0][j], mu_y = mom[1][j], exx = mom[2][j], eyy = mom[3][j], exy = mom[4][j];
-                const bool interior = gy >= kHalo && gy < a.H - kHalo && gx >= kHalo && gx < a.W - kHalo;
-                if (gy < a.H && gx < a.W) {
-                    float dmu = 0.f, dxx = 0.f, dxy = 0.f;
-                    if (interior) {
-                        const float sxx = exx - mu_x * mu_x, syy = eyy - mu_y * mu_y, sxy = exy - mu_x * mu_y;
-                        const float n1 = 2.f * mu_x * mu_y + kC1, n2 = 2.f * sxy + kC2;
-                        const float d1 = mu_x * mu_x + mu_y * mu_y + kC1, d2 = sxx + syy + kC2;
-#if GS_SSIM_IEEE_DIV
-                        const float inv = 1.f / (d1 * d2);
-                        const float s = n1 * n2 * inv;
-                        ssim_sum += s;
-                        dxx = -s / d2;
-                        dxy = 2.f * n1 * inv;
-                        dmu = 2.f * mu_y * (n2 - n1) * inv - 2.f * mu_x * s / d1 + 2.f * mu_x * s / d2;
-#else
-                        // two hardware reciprocals (1 ulp) instead of four IEEE divisions (~10 instructions each on gfx950):
-                        // the kernel is VALU-bound, and d1, d2 >= C1, C2 > 0 are far from any range the refinement steps guard
-                        const float i1 = __builtin_amdgcn_rcpf(d1), i2 = __builtin_amdgcn_rcpf(d2), inv = i1 * i2;
-                        const float s = n1 * n2 * inv;
-                        ssim_sum += s;
-                        dxx = -s * i2;
-                        dxy = 2.f * n1 * inv;
-                        dmu = 2.f * mu_y * (n2 - n1) * inv + 2.f * mu_x * s * (i2 - i1);
-#endif
-                    }
-                    const size_t o = (size_t)gy * a.W + gx;
-                    float* mp = a.maps + ((size_t)ch * plane + o) * 3;   // [ch][H][W][dmu, dxx, dxy]
-                    mp[0] = dmu; mp[1] = dxx; mp[2] = dxy;
-                }
+                float acc = kWin[0] * hv[j];
+#pragma unroll
+                for (int k = 1; k < 11; ++k) acc = fmaf(kWin[k], hv[j + k], acc);
+                mom[mi][j] = acc;
             }
         }
-        __syncthreads();
+        const int gx = x0 + col;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gy = y0 + r0 + j;
+            const float mu_x = mom[0][j], mu_y = mom[1][j], exx = mom[2][j], eyy = mom[3][j], exy = mom[4][j];
+            const bool interior = gy >= kHalo && gy < a.H - kHalo && gx >= kHalo && gx < a.W - kHalo;
+            if (gy < a.H && gx < a.W) {
+                float dmu = 0.f, dxx = 0.f, dxy = 0.f;
+                if (interior) {
+                    const float sxx = exx - mu_x * mu_x, syy = eyy - mu_y * mu_y, sxy = exy - mu_x * mu_y;
+                    const float n1 = 2.f * mu_x * mu_y + kC1, n2 = 2.f * sxy + kC2;
+                    const float d1 = mu_x * mu_x + mu_y * mu_y + kC1, d2 = sxx + syy + kC2;
+#if GS_SSIM_IEEE_DIV
+                    const float inv = 1.f / (d1 * d2);
+                    const float s = n1 * n2 * inv;
+                    ssim_sum += s;
+                    dxx = -s / d2;
+                    dxy = 2.f * n1 * inv;
+                    dmu = 2.f * mu_y * (n2 - n1) * inv - 2.f * mu_x * s / d1 + 2.f * mu_x * s / d2;
+#else
+                    // two hardware reciprocals (1 ulp) instead of four IEEE divisions (~10 instructions each on gfx950):
+                    // d1, d2 >= C1, C2 > 0 are far from any range the refinement steps guard
+                    const float i1 = __builtin_amdgcn_rcpf(d1), i2 = __builtin_amdgcn_rcpf(d2), inv = i1 * i2;
+                    const float s = n1 * n2 * inv;
+                    ssim_sum += s;
+                    dxx = -s * i2;
+                    dxy = 2.f * n1 * inv;
+                    dmu = 2.f * mu_y * (n2 - n1) * inv + 2.f * mu_x * s * (i2 - i1);
+#endif
+                }
+                const unsigned o = __umul24((unsigned)gy, row_bytes) + 12u * (unsigned)gx;   // [ch][H][W][dmu, dxx, dxy]
+                st_off(maps_c, o, dmu); st_off(maps_c, o + 4u, dxx); st_off(maps_c, o + 8u, dxy);
+            }
+        }
     }
     l1 = wave_reduce_add(l1);
     ssim_sum = wave_reduce_add(ssim_sum);
     if (lane_id() == 0) { red[0][tid >> 6] = l1; red[1][tid >> 6] = ssim_sum; }
     __syncthreads();
     if (tid == 0) {
-        const int bidx = blockIdx.y * gridDim.x + blockIdx.x;
-        a.partial[2 * bidx] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        a.partial[2 * bidx + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        a.partial[2 * slot] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        a.partial[2 * slot + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -229,101 +254,118 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(int nblocks, const flo
 
 __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sm = lds;                       // [3 maps][kLR][kLRP] of one channel
-    float* hp = sm + 3 * kLR * kLRP;       // [3][kLR][kHP]
-    const int x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    float* sm = lds;                       // [3 maps][kLR][kLRP] of this block's channel
+#if GS_LOSS_ALIAS_HP
+    float* hp = lds;                       // [3][kLR][kHP], over the staged maps once every thread holds its windows' sums
+#else
+    float* hp = sm + 3 * kLR * kLRP;
+#endif
+    int x0, y0, ch, slot;
+    if (!loss_tile(a, x0, y0, ch, slot)) return;
     const int tid = threadIdx.x;
     const size_t plane = (size_t)a.H * a.W;
     const float g = a.gout[0];
     const float cnt = (float)(a.H - 2 * kHalo) * (float)(a.W - 2 * kHalo) * 3.f;
     const float k_ssim = -g * a.lambda_ssim / cnt;                     // d(1 - mean ssim)
     const float k_l1 = g * (1.f - a.lambda_ssim) / ((float)a.H * (float)a.W * 3.f);
-    // Row-wise mapping as in the forward kernel: a tile row of one channel's derivative maps is one contiguous run of
-    // 42 x 3 floats.  The NEXT channel's maps are requested while this channel's two passes run (a block is a chain of
-    // three load -> stage -> filter rounds otherwise: 68 us for 22 us worth of HBM traffic).
-    constexpr int kRowsPer = kLR / 2;
-    const int half = tid >> 7, jj = tid & 127;
-    const int scol = jj / 3, smi = jj - scol * 3;
-    const int sgx = x0 - kHalo + scol;
-    const bool lane_on = jj < kLR * 3 && sgx >= 0 && sgx < a.W;
-    float v[kRowsPer];
-    auto fetch = [&](int ch) {
+    // this thread's four output pixels (one column x 4 rows): their images are requested first, the answers are due last
+    const unsigned row_bytes = 12u * (unsigned)a.W;
+    const int q = tid / kLT, ocol = tid - q * kLT, r0 = 4 * q, ogx = x0 + ocol;
+    const bool col_in = ogx < a.W;
+    const unsigned o0 = __umul24((unsigned)min(y0 + r0, a.H - 1), row_bytes) + 12u * (unsigned)min(ogx, a.W - 1);
+    const float* gt_c = a.gt + ch;
+    const float* render_c = a.render + ch;
+    float gtv[4], rr[4], mk[4];
 #pragma unroll
-        for (int i = 0; i < kRowsPer; ++i) {
-            const int gy = y0 - kHalo + half + 2 * i;
-            v[i] = 0.f;   // derivative maps are zero outside the image (and outside the interior)
-            if (lane_on && gy >= 0 && gy < a.H) v[i] = a.maps[((size_t)ch * plane + (size_t)gy * a.W + sgx) * 3 + smi];
-        }
-    };
-    fetch(0);
-    for (int ch = 0; ch < 3; ++ch) {
+    for (int j = 0; j < 4; ++j) {
+        const unsigned o = o0 + (y0 + r0 + j < a.H ? j * row_bytes : 0u);   // (rows below the image re-read a valid one; never stored)
+        gtv[j] = ld_off(gt_c, o); rr[j] = ld_off(render_c, o);
+        if (a.mask) mk[j] = ld_off(a.mask, o / 3u);
+    }
+    {
+        // a tile row of one channel's derivative maps is one contiguous run of 42 x 3 floats: lane j < 126 of each 128-thread
+        // half owns element j (column j / 3, map j % 3) of every second row.  The half, hence the row, is uniform over a
+        // wave: the row's address and its in-image test live in scalar registers, the lane adds one constant offset.
+        constexpr int kRowsPer = kLR / 2;
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 7), jj = tid & 127;
+        const int scol = jj / 3, smi = jj - scol * 3;
+        const int sgx = x0 - kHalo + scol;
+        const float* maps_c = a.maps + (size_t)ch * plane * 3;
         if (jj < kLR * 3) {
+            const bool col_ok = sgx >= 0 && sgx < a.W;
+            const unsigned lane_off = 4u * (unsigned)(clampi(sgx, 0, a.W - 1) * 3 + smi);
+            float v[kRowsPer];
+            const int gy0 = y0 - kHalo + half;
+            const char* rowp = reinterpret_cast<const char*>(maps_c) + (int64_t)gy0 * row_bytes;   // scalar, stepped by two rows
+#pragma unroll
+            for (int i = 0; i < kRowsPer; ++i) {
+                const int gy = gy0 + 2 * i;
+                v[i] = 0.f;   // derivative maps are zero outside the image (and outside the interior)
+                if (gy >= 0 && gy < a.H) v[i] = ld_off(reinterpret_cast<const float*>(rowp), lane_off);
+                rowp += 2 * row_bytes;
+            }
             float* d = sm + (smi * kLR + half) * kLRP + scol;
 #pragma unroll
-            for (int i = 0; i < kRowsPer; ++i) d[2 * i * kLRP] = v[i];
+            for (int i = 0; i < kRowsPer; ++i) d[2 * i * kLRP] = col_ok ? v[i] : 0.f;
         }
-#ifndef GS_LOSS_BWD_PREFETCH
-#define GS_LOSS_BWD_PREFETCH 1
-#endif
-        if (GS_LOSS_BWD_PREFETCH && ch < 2) fetch(ch + 1);
-        __syncthreads();
-#if GS_SSIM_HPASS_6
-        if (tid < kLR * 6) {   // horizontal pass, sliding window: one row x 6 columns per thread (see the forward kernel)
-            constexpr int kOut = 6, kWinN = kOut + 10;
-            const int g = tid / kLR, row = tid - g * kLR, c0 = min(kOut * g, kLT - kOut);
-#else
-        if (tid < kLR * (kLT / 8)) {   // horizontal pass, sliding window: one row x 8 columns per thread
-            constexpr int kOut = 8, kWinN = kOut + 10;
-            const int g = tid / kLR, row = tid - g * kLR, c0 = 8 * g;
-#endif
+    }
+    __syncthreads();
+    {   // horizontal pass, sliding window: one row x 6 columns per thread (see the forward kernel)
+        const bool h_on = tid < kLR * 6;
+        const int hg = tid / kLR, row = tid - hg * kLR, c0 = min(kHOut * hg, kLT - kHOut);
+        float ho[3][kHOut];
+        if (h_on) {
 #pragma unroll
             for (int mi = 0; mi < 3; ++mi) {
-                float w[kWinN];
+                float w[kHWin];
 #pragma unroll
-                for (int i = 0; i < kWinN; ++i) w[i] = sm[(mi * kLR + row) * kLRP + c0 + i];
+                for (int i = 0; i < kHWin; ++i) w[i] = sm[(mi * kLR + row) * kLRP + c0 + i];
 #pragma unroll
-                for (int j = 0; j < kOut; ++j) {
-                    float acc = 0.f;
+                for (int j = 0; j < kHOut; ++j) {
+                    float acc = kWin[0] * w[j];
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) acc = fmaf(kWin[k], w[j + k], acc);
-                    hp[mi * kLR * kHP + row * kHP + c0 + j] = acc;
+                    for (int k = 1; k < 11; ++k) acc = fmaf(kWin[k], w[j + k], acc);
+                    ho[mi][j] = acc;
                 }
             }
         }
+#if GS_LOSS_ALIAS_HP
         __syncthreads();
-        {   // vertical pass: one column x 4 rows per thread
-            const int q = tid / kLT, col = tid - q * kLT, r0 = 4 * q;
-            float c[3][4];
+#endif
+        if (h_on) {
 #pragma unroll
-            for (int mi = 0; mi < 3; ++mi) {
-                float hv[14];
+            for (int mi = 0; mi < 3; ++mi)
 #pragma unroll
-                for (int i = 0; i < 14; ++i) hv[i] = hp[mi * kLR * kHP + (r0 + i) * kHP + col];
+                for (int j = 0; j < kHOut; ++j) hp[mi * kLR * kHP + row * kHP + c0 + j] = ho[mi][j];
+        }
+    }
+    __syncthreads();
+    {   // vertical pass: one column x 4 rows per thread
+        float c[3][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float acc = 0.f;
+        for (int mi = 0; mi < 3; ++mi) {
+            float hv[14];
 #pragma unroll
-                    for (int k = 0; k < 11; ++k) acc = fmaf(kWin[k], hv[j + k], acc);
-                    c[mi][j] = acc;
-                }
-            }
-            const int gx = x0 + col;
+            for (int i = 0; i < 14; ++i) hv[i] = hp[mi * kLR * kHP + (r0 + i) * kHP + ocol];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int gy = y0 + r0 + j;
-                if (gy >= a.H || gx >= a.W) continue;
-                const size_t o = ((size_t)gy * a.W + gx) * 3 + ch;
-                const float gtv = a.gt[o];
-                float r = a.render[o], keep = 1.f;
-                if (a.clamp_input) { keep = (r >= 0.f && r <= 1.f) ? 1.f : 0.f; r = fminf(fmaxf(r, 0.f), 1.f); }   // clamp's backward
-                if (a.mask) { const float m = a.mask[(size_t)gy * a.W + gx]; r = m * gtv + (1.f - m) * r; keep *= 1.f - m; }
-                const float d = r - gtv;
-                const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-                a.v_render[o] = keep * (k_ssim * (c[0][j] + 2.f * r * c[1][j] + gtv * c[2][j]) + k_l1 * sgn);
+                float acc = kWin[0] * hv[j];
+#pragma unroll
+                for (int k = 1; k < 11; ++k) acc = fmaf(kWin[k], hv[j + k], acc);
+                c[mi][j] = acc;
             }
         }
-        if (!GS_LOSS_BWD_PREFETCH && ch < 2) fetch(ch + 1);
-        __syncthreads();
+        float* out_c = a.v_render + ch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (y0 + r0 + j >= a.H || !col_in) continue;
+            float r = rr[j], keep = 1.f;
+            if (a.clamp_input) { keep = (r >= 0.f && r <= 1.f) ? 1.f : 0.f; r = fminf(fmaxf(r, 0.f), 1.f); }   // clamp's backward
+            if (a.mask) { r = mk[j] * gtv[j] + (1.f - mk[j]) * r; keep *= 1.f - mk[j]; }
+            const float d = r - gtv[j];
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            st_off(out_c, o0 + j * row_bytes, keep * (k_ssim * (c[0][j] + 2.f * r * c[1][j] + gtv[j] * c[2][j]) + k_l1 * sgn));
+        }
     }
 }
 
@@ -367,28 +409,29 @@ extern "C" int gs_clamp01(void* stream, int64_t n, const float* x, const float* 
     return GS_OK;
 }
 
+static int loss_tile_count(int height, int width) { return ((width + kLT - 1) / kLT) * ((height + kLT - 1) / kLT); }
+static dim3 loss_grid(int nt) { return dim3((unsigned)(8 * ((nt + 7) / 8) * 3)); }   // see loss_tile()
+
 extern "C" size_t gs_loss_workspace_floats(int height, int width) {
     const size_t nb = (size_t)((width + kLT - 1) / kLT) * ((height + kLT - 1) / kLT);
-    return 9 * (size_t)height * width + 2 * nb;
+    return 9 * (size_t)height * width + 2 * 3 * nb;   // derivative maps + (l1, ssim) partial sums per (tile, channel)
 }
 
 extern "C" int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_ssim, const float* render,
                               const float* gt, const float* mask, int clamp_input, float* workspace, float* out3) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
+    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels, "image too large for the loss kernels' 32-bit byte offsets");
     GS_REQUIRE(render && gt && workspace && out3, "null pointer");
     LossArgs a;
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;
     a.clamp_input = clamp_input != 0;
     a.maps = workspace; a.partial = workspace + 9 * (size_t)height * width; a.gout = nullptr; a.v_render = nullptr;
-    dim3 grid((width + kLT - 1) / kLT, (height + kLT - 1) / kLT);
-    const size_t lds = sizeof(float) * (6 * kLR * kLRP + 5 * kLR * (kLT + 1));
+    const int nt = loss_tile_count(height, width);
+    const size_t lds = sizeof(float) * (GS_LOSS_ALIAS_HP ? 5 * kLR * kHP : 2 * kLR * kLRP + 5 * kLR * kHP);
     hipStream_t st = (hipStream_t)stream;
-    if (lds > 64 * 1024)
-        GS_HIP_CHECK(hipFuncSetAttribute((const void*)l1_ssim_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL(l1_ssim_fwd_kernel, loss_grid(nt), dim3(256), lds, st, a);
     GS_LAUNCH_CHECK("l1_ssim_fwd_kernel");
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, (int)(grid.x * grid.y), a.partial, height, width,
-                       lambda_ssim, out3);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, 3 * nt, a.partial, height, width, lambda_ssim, out3);
     GS_LAUNCH_CHECK("loss_reduce_kernel");
     return GS_OK;
 }
@@ -397,14 +440,14 @@ extern "C" int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_
                               const float* gt, const float* mask, int clamp_input, const float* workspace,
                               const float* v_total, float* v_render) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
+    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels, "image too large for the loss kernels' 32-bit byte offsets");
     GS_REQUIRE(render && gt && workspace && v_total && v_render, "null pointer");
     LossArgs a;
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;
     a.clamp_input = clamp_input != 0;
     a.maps = const_cast<float*>(workspace); a.partial = nullptr; a.gout = v_total; a.v_render = v_render;
-    dim3 grid((width + kLT - 1) / kLT, (height + kLT - 1) / kLT);
-    const size_t lds = sizeof(float) * (3 * kLR * kLRP + 3 * kLR * (kLT + 1));
-    hipLaunchKernelGGL(l1_ssim_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    const size_t lds = sizeof(float) * (GS_LOSS_ALIAS_HP ? 3 * kLR * kLRP : 3 * kLR * kLRP + 3 * kLR * kHP);
+    hipLaunchKernelGGL(l1_ssim_bwd_kernel, loss_grid(loss_tile_count(height, width)), dim3(256), lds, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("l1_ssim_bwd_kernel");
     return GS_OK;
 }
