@@ -4,19 +4,18 @@
 // K1 = 0.01, K2 = 0.03, data_range 1, mean over the un-padded interior, where the reflect padding
 // never reaches -- every contributing window lies inside the image).
 //
-//   l1_ssim_fwd_kernel : one block per (32x32 tile, channel); XCD-aware block order (loss_tile).  Stages the
-//                        tile + 5-pixel halo of both images (mask-composited; all global loads issued
-//                        before the first LDS store) in LDS, runs the separable 11-tap window for the
-//                        five moment maps with register sliding windows (row x 6 columns, then column
-//                        x 4 rows per thread), evaluates SSIM and its three partial derivatives (wrt
-//                        mu_x, E[x^2], E[xy]) per pixel, and writes per-block partial sums
-//                        (deterministic reduction).
+//   l1_ssim_fwd_kernel : one block per 32x32 tile, XCD-aware block order (loss_tile).  Requests the tile + 5-pixel
+//                        halo of both images once (whole 12-byte pixels, coalesced), then per channel: stages it
+//                        (mask-composited) in LDS, runs the separable 11-tap window for the five moment maps
+//                        with register sliding windows (row x 6 columns, then column x 4 rows per thread),
+//                        evaluates SSIM and its three partial derivatives (wrt mu_x, E[x^2], E[xy]) per pixel
+//                        (one 12-byte store), and writes per-block partial sums (deterministic reduction).
 //   l1_ssim_bwd_kernel : d loss / d render = window (*) derivative maps (+ L1 sign term), same
 //                        tiling; the mask composite's (1 - mask) factor is applied here.
 //   loss_reduce_kernel : single block, fixed order sum of the per-block partials.
-// Round 5: a block per channel instead of a three-channel loop per block (71 / 38 KB of LDS and 113 / 151 VGPRs held
-// the kernels to two / three blocks per CU; now 28 / 22 KB and 80 / 61 VGPRs), block-uniform bases with 32-bit byte offsets
-// instead of 64-bit index arithmetic per element (VALU per tile-channel 1135 -> 1025 and 917 -> 641): 64 + 59 us -> 56 + 33.
+// Round 5: a channel at a time in 28 / 22 KB of LDS (the horizontal sums parked in registers and written
+// over the staged tile) instead of 71 / 38 KB, block-uniform bases with 32-bit byte offsets instead of 64-bit index arithmetic
+// per element, the window taps as literal operands, whole-pixel global accesses.
 // Pure HBM-streaming + LDS stencil work; no atomics.
 #include "gs_common.h"
 
@@ -32,18 +31,14 @@ static_assert(kLR % 2 == 0 && kLR * 3 <= 128, "backward staging: two 128-thread 
 constexpr int64_t kLossMaxPixels = (int64_t)1 << 28;   // 12 bytes per pixel and plane under 2^32; rows and columns under 2^24
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
-__device__ __constant__ float kWin[11] = {1.0283800845e-03f, 7.5987581352e-03f, 3.6000772128e-02f,
-                                          1.0936068951e-01f, 2.1300553771e-01f, 2.6601172486e-01f,
-                                          2.1300553771e-01f, 1.0936068951e-01f, 3.6000772128e-02f,
-                                          7.5987581352e-03f, 1.0283800845e-03f};
+// The window as compile-time constants: every tap is a LITERAL operand of its FMA.  From __constant__ memory the taps sat in
+// scalar registers, and a VALU instruction with a scalar-register source issues every 4.4 cycles on gfx950 against 3.0 with
+// vector-register or literal sources (tools/micro/valu_enc.hip) -- two thirds of these kernels' instructions.
+#define GS_WIN_TAPS {1.0283800845e-03f, 7.5987581352e-03f, 3.6000772128e-02f, 1.0936068951e-01f, 2.1300553771e-01f, \
+                     2.6601172486e-01f, 2.1300553771e-01f, 1.0936068951e-01f, 3.6000772128e-02f, 7.5987581352e-03f, 1.0283800845e-03f}
 
 #ifndef GS_SSIM_IEEE_DIV
 #define GS_SSIM_IEEE_DIV 0
-#endif
-// 1: the horizontal pass's sums are parked in registers across one more barrier and written OVER the staged tile, 28 / 22 KB of
-// LDS per block instead of 42 / 38: five / seven blocks per CU instead of three / four (forward 61 -> 56 us, backward 37 -> 33)
-#ifndef GS_LOSS_ALIAS_HP
-#define GS_LOSS_ALIAS_HP 1
 #endif
 struct LossArgs {
     int H, W;
@@ -65,16 +60,34 @@ __device__ __forceinline__ void st_off(float* base, unsigned byte_off, float v) 
     *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
-// Block -> (tile, channel).  Consecutive block ids go round-robin over the eight XCDs, each with its own L2: XCD x takes the
-// contiguous row-major run of tiles [x * per, (x + 1) * per), and the three channels of a tile follow one another on the same
-// XCD -- halos, the channel-last image lines the three blocks share and the lines their strided stores fill are met in that L2.
-__device__ __forceinline__ bool loss_tile(const LossArgs& a, int& x0, int& y0, int& ch, int& slot) {
+struct F3 { float x, y, z; };   // one pixel of a channel-last image / one pixel's three derivative maps: a 12-byte access
+__device__ __forceinline__ F3 ld3_off(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const F3*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st3_off(float* base, unsigned byte_off, float x, float y, float z) {
+    *reinterpret_cast<F3*>(reinterpret_cast<char*>(base) + byte_off) = F3{x, y, z};
+}
+
+// Block -> tile.  Consecutive block ids go round-robin over the eight XCDs, each with its own L2: XCD x takes the contiguous
+// row-major run of tiles [x * per, (x + 1) * per) -- the halos neighbouring tiles share are met in that L2.
+__device__ __forceinline__ bool loss_tile(const LossArgs& a, int& x0, int& y0) {
+    const int ntx = (a.W + kLT - 1) / kLT, nt = ntx * ((a.H + kLT - 1) / kLT), per = (nt + 7) >> 3;
+    const int id = blockIdx.x, t = (id & 7) * per + (id >> 3);
+    if ((id >> 3) >= per || t >= nt) return false;
+    const int ty = t / ntx;
+    x0 = (t - ty * ntx) * kLT; y0 = ty * kLT;
+    return true;
+}
+
+// Block -> (tile, channel) for the backward kernel: the same XCD runs, the three channels of a tile one after the other on the
+// same XCD (the channel-last image lines the three blocks share and the lines their strided stores fill are met in that L2).
+__device__ __forceinline__ bool loss_tile_channel(const LossArgs& a, int& x0, int& y0, int& ch) {
     const int ntx = (a.W + kLT - 1) / kLT, nt = ntx * ((a.H + kLT - 1) / kLT), per = (nt + 7) >> 3;
     const int id = blockIdx.x, k = id >> 3, local = k / 3, t = (id & 7) * per + local;
     ch = k - 3 * local;
     if (t >= nt) return false;
     const int ty = t / ntx;
-    x0 = (t - ty * ntx) * kLT; y0 = ty * kLT; slot = 3 * t + ch;
+    x0 = (t - ty * ntx) * kLT; y0 = ty * kLT;
     return true;
 }
 
@@ -82,154 +95,173 @@ __device__ __forceinline__ bool loss_tile(const LossArgs& a, int& x0, int& y0, i
 // (42 rows x 6 column groups; the last group starts at column 26 and recomputes two: 252 of the 256 threads work)
 constexpr int kHOut = 6, kHWin = kHOut + 10;
 
+// One block per tile.  The tile + halo of both images is requested ONCE, a whole pixel (12 bytes, three channels) per lane
+// and row: 7 + 7 (+ 7 mask) fully coalesced loads per thread; the three channels then take turns in the same 37 KB of LDS
+// (four blocks per CU, four waves per SIMD at 124 registers), and a pixel's three derivatives leave as one 12-byte store.
+// Measured at 1080p with a mask on inputs that are cold in every cache, as in the train step (tools/loss_time.py; the
+// forward entry including its one-block reduction): round 4's three-channel block with 71 KB of LDS 68 us; a block per
+// (tile, channel) with 4-byte accesses at a 12-byte stride 58-64; this form with five moment maps 51, with four 44-48.
+// Timing builds (-DGS_LOSS_EXP=1 no stores, =2 synthetic pixels instead of loads, =3 both; wrong on purpose): 52 -> 47 / 42 /
+// 39 us without a mask, and the memory side alone (tools/micro/tile_stream.hip: the same loads and stores, no arithmetic)
+// 23 us: the kernel is bound by its ~900 VALU instructions per tile and channel, with the memory side two thirds hidden.
+template <bool MASK>
 __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
+    constexpr float kWin[11] = GS_WIN_TAPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-#if GS_LOSS_ALIAS_HP
-    float* hp = lds;                         // [5][kLR][kHP], written over the staged tile once every thread has read its windows
-    float* sx = lds;
-#else
-    float* hp = lds + 2 * kLR * kLRP;
-    float* sx = lds;                         // [kLR][kLRP] render (composited), this block's channel
-#endif
+    float* sx = lds;                         // [kLR][kLRP] render (composited), one channel
     float* sy = sx + kLR * kLRP;             // [kLR][kLRP] ground truth
+    float* hp = sy + kLR * kLRP;             // [4][kLR][kHP] horizontal sums (a buffer of their own: parked in registers across a
+                                             // barrier and written over the staged tile they cost this kernel its fourth wave)
     __shared__ float red[2][4];
-    int x0, y0, ch, slot;
-    if (!loss_tile(a, x0, y0, ch, slot)) return;
+    int x0, y0;
+    if (!loss_tile(a, x0, y0)) {   // (a block past the end of its XCD's run: the reduction sums every block's pair)
+        if (threadIdx.x == 0) { a.partial[2 * blockIdx.x] = 0.f; a.partial[2 * blockIdx.x + 1] = 0.f; }
+        return;
+    }
     const int tid = threadIdx.x;
-    // ---- stage tile + halo of one channel (coordinates clamped; clamped values only feed discarded outputs): thread = one
-    // staged column x 7 rows.  All global loads of a thread are issued before its first LDS store: hipcc keeps a
-    // load -> LDS-store loop in program order (the store may alias the next load), one HBM round trip per element.
-    // Addresses: a block-uniform base (scalar registers) + a 32-bit byte offset per lane (the entry points bound H * W), a
-    // 24-bit multiply-add per row instead of 64-bit index arithmetic per element.
-    float l1 = 0.f;
     const unsigned row_bytes = 12u * (unsigned)a.W;
-    const float* gt_c = a.gt + ch;
-    const float* render_c = a.render + ch;
+    // ---- staging role: thread = one staged column x 7 rows (coordinates clamped; clamped values only feed discarded
+    // outputs).  Addresses: a block-uniform base (scalar registers) + a 32-bit byte offset per lane (the entry points bound
+    // H * W), a 24-bit multiply-add per row.
+    constexpr int kPer = kLR / 6;   // 7 rows per thread
+    float rv[kPer][3], gv[kPer][3], mv[MASK ? kPer : 1];
     if (tid < kLR * 6) {
-        constexpr int kPer = kLR / 6;   // 7 rows per thread
         const int rg = tid / kLR, col = tid - rg * kLR;
-        const int gx = x0 - kHalo + col, cx = clampi(gx, 0, a.W - 1);
-        const bool col_own = col >= kHalo && col < kHalo + kLT && gx < a.W;
-        const int ytop = y0 - kHalo + rg;
-        float rv[kPer], gv[kPer], mv[kPer];
+        const int cx = clampi(x0 - kHalo + col, 0, a.W - 1), ytop = y0 - kHalo + rg;
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
             const unsigned cy = (unsigned)clampi(ytop + 6 * i, 0, a.H - 1);
             const unsigned o = __umul24(cy, row_bytes) + 12u * (unsigned)cx;
-            gv[i] = ld_off(gt_c, o); rv[i] = ld_off(render_c, o);
-            if (a.mask) mv[i] = ld_off(a.mask, __umul24(cy, 4u * (unsigned)a.W) + 4u * (unsigned)cx);
-        }
-        float* dx = sx + rg * kLRP + col;
-        float* dy = sy + rg * kLRP + col;
-#pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            const int row = rg + 6 * i, gy = y0 - kHalo + row;
-            const float g = gv[i];
-            float r = rv[i];
-            if (a.clamp_input) r = fminf(fmaxf(r, 0.f), 1.f);   // torch.clamp(render, 0, 1) of the model, folded in
-            if (a.mask) r = mv[i] * g + (1.f - mv[i]) * r;
-            dx[6 * i * kLRP] = r;
-            dy[6 * i * kLRP] = g;
-            if (col_own && row >= kHalo && row < kHalo + kLT && gy < a.H) l1 += fabsf(r - g);
+#if GS_LOSS_EXP & 2
+            const F3 g3 = F3{(float)(o & 255u) * 0.003f, (float)(o & 127u) * 0.006f, 0.5f}, r3 = F3{(float)(o & 63u) * 0.01f, 0.25f, (float)(o & 31u) * 0.03f};
+#else
+            const F3 g3 = ld3_off(a.gt, o), r3 = ld3_off(a.render, o);
+#endif
+            gv[i][0] = g3.x; gv[i][1] = g3.y; gv[i][2] = g3.z;
+            rv[i][0] = r3.x; rv[i][1] = r3.y; rv[i][2] = r3.z;
+            if (MASK) mv[i] = ld_off(a.mask, __umul24(cy, 4u * (unsigned)a.W) + 4u * (unsigned)cx);
         }
     }
-    __syncthreads();
-    float ssim_sum = 0.f;
-    float* maps_c = a.maps + (size_t)ch * a.H * a.W * 3;
-    {
-        // horizontal pass: 16 + 16 LDS reads feed 6 x 5 outputs; lanes run down the rows, the odd row strides keep reads and
-        // writes conflict-free
-        const bool h_on = tid < kLR * 6;
-        const int g = tid / kLR, row = tid - g * kLR, c0 = min(kHOut * g, kLT - kHOut);
-        float ho[5][kHOut];
-        if (h_on) {
-            float xv[kHWin], yv[kHWin];
+    float l1 = 0.f, ssim_sum = 0.f;
+#pragma unroll 1
+    for (int ch = 0; ch < 3; ++ch) {
+        // (the thread's roles are re-derived from an opaque copy of its index every round: hoisted out of the loop, the
+        //  addresses and predicates of all four phases sit in some 40 registers and cost the kernel a wave per SIMD)
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const bool st_on = t < kLR * 6;
+        const int rg = t / kLR, col = t - rg * kLR;
+        if (st_on) {
+            const int gx = x0 - kHalo + col;
+            const bool col_own = col >= kHalo && col < kHalo + kLT && gx < a.W;
+            float* dx = sx + rg * kLRP + col;
+            float* dy = sy + rg * kLRP + col;
 #pragma unroll
-            for (int i = 0; i < kHWin; ++i) { xv[i] = sx[row * kLRP + c0 + i]; yv[i] = sy[row * kLRP + c0 + i]; }
-#pragma unroll
-            for (int j = 0; j < kHOut; ++j) {
-                float m0 = kWin[0] * xv[j], m1 = kWin[0] * yv[j], m2 = kWin[0] * (xv[j] * xv[j]), m3 = kWin[0] * (yv[j] * yv[j]),
-                      m4 = kWin[0] * (xv[j] * yv[j]);   // (first tap as a product: no zero to materialise per sum)
-#pragma unroll
-                for (int k = 1; k < 11; ++k) {
-                    const float w = kWin[k], x = xv[j + k], y = yv[j + k];
-                    m0 = fmaf(w, x, m0); m1 = fmaf(w, y, m1); m2 = fmaf(w, x * x, m2);
-                    m3 = fmaf(w, y * y, m3); m4 = fmaf(w, x * y, m4);
-                }
-                ho[0][j] = m0; ho[1][j] = m1; ho[2][j] = m2; ho[3][j] = m3; ho[4][j] = m4;
+            for (int i = 0; i < kPer; ++i) {
+                const int row = rg + 6 * i, gy = y0 - kHalo + row;
+                const float g = gv[i][0];
+                float r = rv[i][0];
+                if (a.clamp_input) r = fminf(fmaxf(r, 0.f), 1.f);   // torch.clamp(render, 0, 1) of the model, folded in
+                if (MASK) r = mv[i] * g + (1.f - mv[i]) * r;
+                dx[6 * i * kLRP] = r;
+                dy[6 * i * kLRP] = g;
+                if (col_own && row >= kHalo && row < kHalo + kLT && gy < a.H) l1 += fabsf(r - g);
+                gv[i][0] = gv[i][1]; gv[i][1] = gv[i][2];   // the next channel moves up (a rolled loop cannot index registers)
+                rv[i][0] = rv[i][1]; rv[i][1] = rv[i][2];
             }
         }
-#if GS_LOSS_ALIAS_HP
         __syncthreads();
-#endif
-        if (h_on) {
-            float* h = hp + row * kHP + c0;
+        float* maps_c = a.maps + (size_t)ch * a.H * a.W * 3;
+        {
+            // horizontal pass: 16 + 16 LDS reads feed 6 x 4 outputs; lanes run down the rows, the odd row strides keep reads and
+            // writes conflict-free.  FOUR moment maps, not five: SSIM and its derivatives see E[xx] and E[yy] only through
+            // their sum (d2 = sxx + syy + C2), so x^2 + y^2 goes through the window as one map.
+            const bool h_on = st_on;
+            const int row = col, c0 = min(kHOut * rg, kLT - kHOut);
+            if (h_on) {
+                float* h = hp + row * kHP + c0;
+                float xv[kHWin], yv[kHWin];
 #pragma unroll
-            for (int mi = 0; mi < 5; ++mi)
+                for (int i = 0; i < kHWin; ++i) { xv[i] = sx[row * kLRP + c0 + i]; yv[i] = sy[row * kLRP + c0 + i]; }
 #pragma unroll
-                for (int j = 0; j < kHOut; ++j) h[mi * kLR * kHP + j] = ho[mi][j];
+                for (int j = 0; j < kHOut; ++j) {
+                    float m0 = kWin[0] * xv[j], m1 = kWin[0] * yv[j], m2 = kWin[0] * fmaf(xv[j], xv[j], yv[j] * yv[j]),
+                          m3 = kWin[0] * (xv[j] * yv[j]);   // (first tap as a product: no zero to materialise per sum)
+#pragma unroll
+                    for (int kk = 1; kk < 11; ++kk) {
+                        const float w = kWin[kk], x = xv[j + kk], y = yv[j + kk];
+                        m0 = fmaf(w, x, m0); m1 = fmaf(w, y, m1); m2 = fmaf(w, fmaf(x, x, y * y), m2); m3 = fmaf(w, x * y, m3);
+                    }
+                    h[j] = m0; h[kLR * kHP + j] = m1; h[2 * kLR * kHP + j] = m2; h[3 * kLR * kHP + j] = m3;
+                }
+            }
         }
-    }
-    __syncthreads();
-    // vertical pass + SSIM: one thread = one column x 4 output rows (14 LDS reads per map)
-    {
-        const int q = tid / kLT, col = tid - q * kLT, r0 = 4 * q;
-        float mom[5][4];
+        __syncthreads();
+        // vertical pass + SSIM: one thread = one column x 4 output rows (14 LDS reads per map)
+        {
+            const int q = t / kLT, vcol = t - q * kLT, r0 = 4 * q;
+            float mom[4][4];
 #pragma unroll
-        for (int mi = 0; mi < 5; ++mi) {
-            float hv[14];
+            for (int mi = 0; mi < 4; ++mi) {
+                float hv[14];
 #pragma unroll
-            for (int i = 0; i < 14; ++i) hv[i] = hp[mi * kLR * kHP + (r0 + i) * kHP + col];
+                for (int i = 0; i < 14; ++i) hv[i] = hp[mi * kLR * kHP + (r0 + i) * kHP + vcol];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc = kWin[0] * hv[j];
+#pragma unroll
+                    for (int kk = 1; kk < 11; ++kk) acc = fmaf(kWin[kk], hv[j + kk], acc);
+                    mom[mi][j] = acc;
+                }
+            }
+            const int gx = x0 + vcol;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float acc = kWin[0] * hv[j];
-#pragma unroll
-                for (int k = 1; k < 11; ++k) acc = fmaf(kWin[k], hv[j + k], acc);
-                mom[mi][j] = acc;
-            }
-        }
-        const int gx = x0 + col;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gy = y0 + r0 + j;
-            const float mu_x = mom[0][j], mu_y = mom[1][j], exx = mom[2][j], eyy = mom[3][j], exy = mom[4][j];
-            const bool interior = gy >= kHalo && gy < a.H - kHalo && gx >= kHalo && gx < a.W - kHalo;
-            if (gy < a.H && gx < a.W) {
-                float dmu = 0.f, dxx = 0.f, dxy = 0.f;
-                if (interior) {
-                    const float sxx = exx - mu_x * mu_x, syy = eyy - mu_y * mu_y, sxy = exy - mu_x * mu_y;
-                    const float n1 = 2.f * mu_x * mu_y + kC1, n2 = 2.f * sxy + kC2;
-                    const float d1 = mu_x * mu_x + mu_y * mu_y + kC1, d2 = sxx + syy + kC2;
+                const int gy = y0 + r0 + j;
+                const float mu_x = mom[0][j], mu_y = mom[1][j], ess = mom[2][j], exy = mom[3][j];   // ess = E[xx] + E[yy]
+                const bool interior = gy >= kHalo && gy < a.H - kHalo && gx >= kHalo && gx < a.W - kHalo;
+                if (gy < a.H && gx < a.W) {
+                    float dmu = 0.f, dxx = 0.f, dxy = 0.f;
+                    if (interior) {
+                        const float mm = mu_x * mu_x + mu_y * mu_y, sxy = exy - mu_x * mu_y;
+                        const float n1 = 2.f * mu_x * mu_y + kC1, n2 = 2.f * sxy + kC2;
+                        const float d1 = mm + kC1, d2 = (ess - mm) + kC2;
 #if GS_SSIM_IEEE_DIV
-                    const float inv = 1.f / (d1 * d2);
-                    const float s = n1 * n2 * inv;
-                    ssim_sum += s;
-                    dxx = -s / d2;
-                    dxy = 2.f * n1 * inv;
-                    dmu = 2.f * mu_y * (n2 - n1) * inv - 2.f * mu_x * s / d1 + 2.f * mu_x * s / d2;
+                        const float inv = 1.f / (d1 * d2);
+                        const float sv = n1 * n2 * inv;
+                        ssim_sum += sv;
+                        dxx = -sv / d2;
+                        dxy = 2.f * n1 * inv;
+                        dmu = 2.f * mu_y * (n2 - n1) * inv - 2.f * mu_x * sv / d1 + 2.f * mu_x * sv / d2;
 #else
-                    // two hardware reciprocals (1 ulp) instead of four IEEE divisions (~10 instructions each on gfx950):
-                    // d1, d2 >= C1, C2 > 0 are far from any range the refinement steps guard
-                    const float i1 = __builtin_amdgcn_rcpf(d1), i2 = __builtin_amdgcn_rcpf(d2), inv = i1 * i2;
-                    const float s = n1 * n2 * inv;
-                    ssim_sum += s;
-                    dxx = -s * i2;
-                    dxy = 2.f * n1 * inv;
-                    dmu = 2.f * mu_y * (n2 - n1) * inv + 2.f * mu_x * s * (i2 - i1);
+                        // two hardware reciprocals (1 ulp) instead of four IEEE divisions (~10 instructions each on gfx950):
+                        // d1, d2 >= C1, C2 > 0 are far from any range the refinement steps guard
+                        const float i1 = __builtin_amdgcn_rcpf(d1), i2 = __builtin_amdgcn_rcpf(d2), inv = i1 * i2;
+                        const float sv = n1 * n2 * inv;
+                        ssim_sum += sv;
+                        dxx = -sv * i2;
+                        dxy = 2.f * n1 * inv;
+                        dmu = 2.f * mu_y * (n2 - n1) * inv + 2.f * mu_x * sv * (i2 - i1);
+#endif
+                    }
+                    // [ch][H][W][dmu, dxx, dxy]: one 12-byte store per pixel, a tile row one contiguous run
+#if GS_LOSS_EXP & 1
+                    if (dmu == 123.f) st3_off(maps_c, __umul24((unsigned)gy, row_bytes) + 12u * (unsigned)gx, dmu, dxx, dxy);
+#else
+                    st3_off(maps_c, __umul24((unsigned)gy, row_bytes) + 12u * (unsigned)gx, dmu, dxx, dxy);
 #endif
                 }
-                const unsigned o = __umul24((unsigned)gy, row_bytes) + 12u * (unsigned)gx;   // [ch][H][W][dmu, dxx, dxy]
-                st_off(maps_c, o, dmu); st_off(maps_c, o + 4u, dxx); st_off(maps_c, o + 8u, dxy);
             }
         }
+        if (ch < 2) __syncthreads();   // the next channel is staged over the buffers the vertical pass has just read
     }
     l1 = wave_reduce_add(l1);
     ssim_sum = wave_reduce_add(ssim_sum);
     if (lane_id() == 0) { red[0][tid >> 6] = l1; red[1][tid >> 6] = ssim_sum; }
     __syncthreads();
     if (tid == 0) {
-        a.partial[2 * slot] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        a.partial[2 * slot + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        a.partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        a.partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -252,16 +284,17 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(int nblocks, const flo
     }
 }
 
+// One block per (tile, channel): the derivative maps are channel-planar, a channel's tile rows contiguous runs.  (A block per
+// tile with a channel loop, the images as whole pixels and the three answers as one 12-byte store, needs 163 registers for the
+// prefetched maps, the twelve pixels and the answers: three blocks per CU, 37 us against 34.)
 __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
+    constexpr float kWin[11] = GS_WIN_TAPS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sm = lds;                       // [3 maps][kLR][kLRP] of this block's channel
-#if GS_LOSS_ALIAS_HP
-    float* hp = lds;                       // [3][kLR][kHP], over the staged maps once every thread holds its windows' sums
-#else
-    float* hp = sm + 3 * kLR * kLRP;
-#endif
-    int x0, y0, ch, slot;
-    if (!loss_tile(a, x0, y0, ch, slot)) return;
+    float* hp = lds;                       // [3][kLR][kHP], written OVER the staged maps once every thread holds its windows' sums
+                                           // in registers: 22 KB per block instead of 38, seven blocks per CU instead of four (37 -> 33 us)
+    int x0, y0, ch;
+    if (!loss_tile_channel(a, x0, y0, ch)) return;
     const int tid = threadIdx.x;
     const size_t plane = (size_t)a.H * a.W;
     const float g = a.gout[0];
@@ -329,9 +362,7 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
                 }
             }
         }
-#if GS_LOSS_ALIAS_HP
         __syncthreads();
-#endif
         if (h_on) {
 #pragma unroll
             for (int mi = 0; mi < 3; ++mi)
@@ -410,11 +441,11 @@ extern "C" int gs_clamp01(void* stream, int64_t n, const float* x, const float* 
 }
 
 static int loss_tile_count(int height, int width) { return ((width + kLT - 1) / kLT) * ((height + kLT - 1) / kLT); }
-static dim3 loss_grid(int nt) { return dim3((unsigned)(8 * ((nt + 7) / 8) * 3)); }   // see loss_tile()
+static dim3 loss_grid(int nt) { return dim3((unsigned)(8 * ((nt + 7) / 8))); }   // see loss_tile()
 
 extern "C" size_t gs_loss_workspace_floats(int height, int width) {
     const size_t nb = (size_t)((width + kLT - 1) / kLT) * ((height + kLT - 1) / kLT);
-    return 9 * (size_t)height * width + 2 * 3 * nb;   // derivative maps + (l1, ssim) partial sums per (tile, channel)
+    return 9 * (size_t)height * width + 2 * (nb + 8);   // derivative maps + (l1, ssim) partial sums per forward block
 }
 
 extern "C" int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_ssim, const float* render,
@@ -426,12 +457,13 @@ extern "C" int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;
     a.clamp_input = clamp_input != 0;
     a.maps = workspace; a.partial = workspace + 9 * (size_t)height * width; a.gout = nullptr; a.v_render = nullptr;
-    const int nt = loss_tile_count(height, width);
-    const size_t lds = sizeof(float) * (GS_LOSS_ALIAS_HP ? 5 * kLR * kHP : 2 * kLR * kLRP + 5 * kLR * kHP);
+    const int blocks = (int)loss_grid(loss_tile_count(height, width)).x;
+    const size_t lds = sizeof(float) * (2 * kLR * kLRP + 4 * kLR * kHP);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(l1_ssim_fwd_kernel, loss_grid(nt), dim3(256), lds, st, a);
+    if (mask) hipLaunchKernelGGL(l1_ssim_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(l1_ssim_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     GS_LAUNCH_CHECK("l1_ssim_fwd_kernel");
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, 3 * nt, a.partial, height, width, lambda_ssim, out3);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, blocks, a.partial, height, width, lambda_ssim, out3);
     GS_LAUNCH_CHECK("loss_reduce_kernel");
     return GS_OK;
 }
@@ -446,8 +478,8 @@ extern "C" int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;
     a.clamp_input = clamp_input != 0;
     a.maps = const_cast<float*>(workspace); a.partial = nullptr; a.gout = v_total; a.v_render = v_render;
-    const size_t lds = sizeof(float) * (GS_LOSS_ALIAS_HP ? 3 * kLR * kLRP : 3 * kLR * kLRP + 3 * kLR * kHP);
-    hipLaunchKernelGGL(l1_ssim_bwd_kernel, loss_grid(loss_tile_count(height, width)), dim3(256), lds, (hipStream_t)stream, a);
+    const size_t lds = sizeof(float) * (3 * kLR * kLRP);
+    hipLaunchKernelGGL(l1_ssim_bwd_kernel, dim3(3 * loss_grid(loss_tile_count(height, width)).x), dim3(256), lds, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("l1_ssim_bwd_kernel");
     return GS_OK;
 }

@@ -196,12 +196,16 @@ __device__ __forceinline__ void sh_rows_issue(const float* __restrict__ sh0, con
 }
 
 __device__ __forceinline__ void sh_rows_commit(const ShPrefetch& pf, const float* __restrict__ shr, int64_t n0, int rows,
-                                               const int* vis, float* tile) {
+                                               float* tile) {
+    // Every row is written, visible or not (the loads were unconditional; a test per element was an LDS read of the flag, a
+    // compare and an exec-mask round trip in front of each of the 51 LDS writes).  Element e of the sh_rest stream lies in row
+    // g = e / 45 at tile[49 g + 3 + (e - 45 g)] = tile[e + 4 g + 3]: one division per quad, the row stepped where a quad
+    // straddles two rows.
     constexpr int rest_f = 45, stride = 49;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const int e = threadIdx.x + q * kProjThreads;
-        if (e < rows * 3) { const int g = e / 3; if (vis[g]) tile[g * stride + (e - 3 * g)] = pf.s0[q]; }
+        if (e < rows * 3) { const int g = e / 3; tile[g * stride + (e - 3 * g)] = pf.s0[q]; }
     }
     const int total = rows * rest_f, total4 = total >> 2;
 #pragma unroll
@@ -209,17 +213,16 @@ __device__ __forceinline__ void sh_rows_commit(const ShPrefetch& pf, const float
         const int e4 = threadIdx.x + q * kProjThreads;
         if (e4 < total4) {
             const float vv[4] = {pf.v[q].x, pf.v[q].y, pf.v[q].z, pf.v[q].w};
+            const int e = e4 << 2, g = e / rest_f, o = e - g * rest_f;
+            float* d = tile + e + 4 * g + 3;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = (e4 << 2) + i, g = e / rest_f, o = e - g * rest_f;
-                if (vis[g]) tile[g * stride + 3 + o] = vv[i];
-            }
+            for (int i = 0; i < 4; ++i) d[i + (o + i >= rest_f ? 4 : 0)] = vv[i];
         }
     }
     const float* src = shr + n0 * rest_f;
     for (int e = (total & ~3) + threadIdx.x; e < total; e += blockDim.x) {   // (the last block's 0-3 trailing floats)
-        const int g = e / rest_f, o = e - g * rest_f;
-        if (vis[g]) tile[g * stride + 3 + o] = src[e];
+        const int g = e / rest_f;
+        tile[e + 4 * g + 3] = src[e];
     }
 }
 
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(kProjThreads) void project_fwd_kernel(const ProjFwd
             const int rows = (int)min((int64_t)kProjThreads, a.N - n0);
             constexpr int ka3 = 3 * (DEG + 1) * (DEG + 1);
             if (STAGE == 0 && DEG == 3 && prefetch_sh) {
-                sh_rows_commit(pf, a.sh_rest, n0, rows, vis_s, tile);
+                sh_rows_commit(pf, a.sh_rest, n0, rows, tile);
             } else if (a.sh_rest) {
                 if (a.K == 16) stage_sh_rows_split<16>(a.colors_in, a.sh_rest, n0, rows, 16, ka3, vis_s, tile);
                 else stage_sh_rows_split<0>(a.colors_in, a.sh_rest, n0, rows, a.K, ka3, vis_s, tile);

@@ -19,6 +19,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
         if (MODE == 9) { REP16(asm volatile("v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1\n v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1" : "+v"(p0), "+v"(p1) : "v"(p2), "v"(p3));) }
         if (MODE == 10) { REP16(asm volatile("v_pk_mul_f32 %0, %2, %0\n v_pk_mul_f32 %1, %2, %1\n v_pk_mul_f32 %0, %2, %0\n v_pk_mul_f32 %1, %2, %1" : "+v"(p0), "+v"(p1) : "v"(p2), "v"(p3));) }
         if (MODE == 11) { REP16(asm volatile("v_pk_add_f32 %0, %2, %0\n v_pk_add_f32 %1, %2, %1\n v_pk_add_f32 %0, %2, %0\n v_pk_add_f32 %1, %2, %1" : "+v"(p0), "+v"(p1) : "v"(p2), "v"(p3));) }
+        if (MODE == 12) { REP16(asm volatile("v_fmac_f32_e32 %0, s20, %4\n v_fmac_f32_e32 %1, s21, %4\n v_fmac_f32_e32 %2, s22, %4\n v_fmac_f32_e32 %3, s23, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c) : "s20", "s21", "s22", "s23");) }
+        if (MODE == 13) { REP16(asm volatile("v_fmac_f32_e32 %0, 0x3e99999a, %4\n v_fmac_f32_e32 %1, 0x3e99999a, %4\n v_fmac_f32_e32 %2, 0x3e99999a, %4\n v_fmac_f32_e32 %3, 0x3e99999a, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c));) }
+        if (MODE == 14) { REP16(asm volatile("v_mul_f32_e32 %0, s20, %0\n v_mul_f32_e32 %1, s21, %1\n v_mul_f32_e32 %2, s22, %2\n v_mul_f32_e32 %3, s23, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : : "s20", "s21", "s22", "s23");) }
         if (MODE == 8) { REP16(asm volatile("v_mov_b32_e32 %0, %4\n v_mov_b32_e32 %1, %4\n v_mov_b32_e32 %2, %4\n v_mov_b32_e32 %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y;
@@ -37,10 +40,10 @@ template <int MODE> float run(float* out, int grid, int iters) {
 int main() {
     float* out; (void)hipMalloc(&out, 256 * 4096 * sizeof(float));
     const int iters = 2000, wps = 4, grid = 256 * wps;
-    const char* names[] = {"v_fmac_f32_e32 (VOP2)", "v_fma_f32 (VOP3, 3 vgpr)", "v_mul_f32_e32", "v_add_f32_e32", "v_add_f32_e64 |abs|", "v_cmp_e32+v_cndmask_e32 (vcc)", "v_cmp_e64+v_cndmask_e64 (sgpr)", "v_exp_f32", "v_mov_b32", "v_pk_fma_f32 (vgpr pairs)", "v_pk_mul_f32", "v_pk_add_f32"};
-    float ms[12] = {run<0>(out, grid, iters), run<1>(out, grid, iters), run<2>(out, grid, iters), run<3>(out, grid, iters), run<4>(out, grid, iters),
-                   run<5>(out, grid, iters), run<6>(out, grid, iters), run<7>(out, grid, iters), run<8>(out, grid, iters), run<9>(out, grid, iters), run<10>(out, grid, iters), run<11>(out, grid, iters)};
-    for (int m = 0; m < 12; ++m) {
+    const char* names[] = {"v_fmac_f32_e32 (VOP2)", "v_fma_f32 (VOP3, 3 vgpr)", "v_mul_f32_e32", "v_add_f32_e32", "v_add_f32_e64 |abs|", "v_cmp_e32+v_cndmask_e32 (vcc)", "v_cmp_e64+v_cndmask_e64 (sgpr)", "v_exp_f32", "v_mov_b32", "v_pk_fma_f32 (vgpr pairs)", "v_pk_mul_f32", "v_pk_add_f32", "v_fmac_f32_e32 (sgpr src0)", "v_fmac_f32_e32 (literal src0)", "v_mul_f32_e32 (sgpr src0)"};
+    float ms[15] = {run<0>(out, grid, iters), run<1>(out, grid, iters), run<2>(out, grid, iters), run<3>(out, grid, iters), run<4>(out, grid, iters),
+                   run<5>(out, grid, iters), run<6>(out, grid, iters), run<7>(out, grid, iters), run<8>(out, grid, iters), run<9>(out, grid, iters), run<10>(out, grid, iters), run<11>(out, grid, iters), run<12>(out, grid, iters), run<13>(out, grid, iters), run<14>(out, grid, iters)};
+    for (int m = 0; m < 15; ++m) {
         const double instr = (double)iters * 64;   // 64 instructions per iteration per wave in every mode
         printf("%-34s %.3f ms -> %.2f cycles per wave-instruction per SIMD (2.4 GHz, %d waves/SIMD)\n", names[m], ms[m], ms[m] * 1e-3 * 2.4e9 / (instr * wps), wps);
     }
