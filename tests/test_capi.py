@@ -80,6 +80,21 @@ def test_forward_and_backward_round_alpha_and_transmittance_with_the_same_instru
     assert trees == {"fma(fma(sub(x,x),x,mul(sub(x,x),x)),sub(x,x),mul(mul(sub(x,x),x),sub(x,x)))"}, trees
 
 
+def test_loss_entries_refuse_images_beyond_their_32_bit_offsets(native):
+    """The loss kernels address a pixel by a 32-bit byte offset from a block-uniform base: the entry points refuse more than 2^28
+    pixels (and images smaller than the 11 x 11 window) before anything is launched -- checked without a GPU."""
+    import ctypes as ct
+    L = native.lib()
+    dummy = (ct.c_float * 4)()
+    p = ct.addressof(dummy)
+    assert L.gs_l1_ssim_fwd(None, 20000, 20000, 0.2, p, p, None, 0, p, p) == -1
+    assert b"too large" in L.gs_last_error()
+    assert L.gs_l1_ssim_bwd(None, 20000, 20000, 0.2, p, p, None, 0, p, p, p) == -1
+    assert L.gs_l1_ssim_fwd(None, 10, 64, 0.2, p, p, None, 0, p, p) == -1
+    assert b"larger than the 11x11 window" in L.gs_last_error()
+    assert L.gs_loss_workspace_floats(1080, 1920) == 9 * 1080 * 1920 + 2 * (60 * 34 + 8)
+
+
 def test_identity_and_layout_queries(native):
     lib = native.lib()
     assert lib.gs_version() >= 100

@@ -8,7 +8,9 @@ from easy_gaussian_splatting_amd.loss import LossComputer
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("H,W,use_mask", [(75, 100, False), (64, 96, True), (33, 45, True), (1080, 1920, False)])
+# (129 x 257: 5 x 9 = 45 tiles, not a multiple of the eight XCD runs the blocks are dealt over; 200 x 333: ragged right and bottom tiles)
+@pytest.mark.parametrize("H,W,use_mask", [(75, 100, False), (64, 96, True), (33, 45, True), (129, 257, True), (200, 333, False),
+                                          (1080, 1920, False), (1080, 1920, True)])
 def test_fused_loss_matches_torch(H, W, use_mask):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(H * W)

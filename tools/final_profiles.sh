@@ -48,6 +48,12 @@ for cfg in S3 S5 heavy1M; do
   grep "^{" /tmp/${tag}_${lc}.log | tail -1 > gpurun_out/${tag}_${lc}_run.json
   timeout 900 bash tools/prof_pmc.sh ${tag}_${lc} tools/config_run.py $cfg 3 > /dev/null 2>&1
 done
+# the loss kernels alone (cold inputs, with and without a mask), the issue cost per operand kind, the loss forward's memory side alone
+(timeout 120 python tools/loss_time.py; GS_LOSS_MASK=0 timeout 120 python tools/loss_time.py) 2>/dev/null > gpurun_out/${tag}_loss_time.txt
+[ -x tools/micro/valu_enc ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/valu_enc tools/micro/valu_enc.hip
+[ -x tools/micro/tile_stream ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/tile_stream tools/micro/tile_stream.hip
+timeout 60 tools/micro/valu_enc > gpurun_out/${tag}_valu_enc.txt 2>/dev/null
+timeout 60 tools/micro/tile_stream > gpurun_out/${tag}_tile_stream.txt 2>/dev/null
 # half-quadrant work units for blend_bwd, bounded (timing builds, numerically wrong on purpose)
 for v in "" _halfq100 _halfq155; do GS_LIB_PATH=$PWD/easy_gaussian_splatting_amd/libgsraster$v.so timeout 200 python tools/blend_time.py 2>/dev/null; done > gpurun_out/${tag}_halfq_bound.txt
 # per-Gaussian criterion: fp32 sums / fp64 sums / fp64 sums + exact exp2 and division / fp32 oracle
