@@ -29,7 +29,8 @@ constexpr int kLRP = kLR + 1;         // padded row stride of the staged tiles
 constexpr int kHP = kLT + 1;          // row stride of the horizontal-pass buffers
 static_assert(kLT * (kLT / 4) == 256 && kLR * 6 <= 256 && kLR % 6 == 0, "thread mapping of the staging and the separable passes");
 static_assert(kLR % 2 == 0 && kLR * 3 <= 128, "backward staging: two 128-thread halves, one staged row each");
-constexpr int64_t kLossMaxPixels = (int64_t)1 << 28;   // 12 bytes per pixel and plane under 2^32; rows and columns under 2^24
+constexpr int64_t kLossMaxPixels = (int64_t)1 << 28;   // 12 bytes per pixel and plane under 2^32
+constexpr int kLossMaxWidth = 1 << 20;                 // a row's 12 W bytes and every row index under 2^24 (24-bit multiplies)
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 // The window as compile-time constants: every tap is a LITERAL operand of its FMA.  From __constant__ memory the taps sat in
@@ -452,7 +453,7 @@ extern "C" size_t gs_loss_workspace_floats(int height, int width) {
 extern "C" int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_ssim, const float* render,
                               const float* gt, const float* mask, int clamp_input, float* workspace, float* out3) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
-    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels, "image too large for the loss kernels' 32-bit byte offsets");
+    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels && width <= kLossMaxWidth, "image too large for the loss kernels' 32-bit byte offsets");
     GS_REQUIRE(render && gt && workspace && out3, "null pointer");
     LossArgs a;
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;
@@ -473,7 +474,7 @@ extern "C" int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_
                               const float* gt, const float* mask, int clamp_input, const float* workspace,
                               const float* v_total, float* v_render) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
-    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels, "image too large for the loss kernels' 32-bit byte offsets");
+    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels && width <= kLossMaxWidth, "image too large for the loss kernels' 32-bit byte offsets");
     GS_REQUIRE(render && gt && workspace && v_total && v_render, "null pointer");
     LossArgs a;
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;

@@ -90,6 +90,7 @@ def test_loss_entries_refuse_images_beyond_their_32_bit_offsets(native):
     assert L.gs_l1_ssim_fwd(None, 20000, 20000, 0.2, p, p, None, 0, p, p) == -1
     assert b"too large" in L.gs_last_error()
     assert L.gs_l1_ssim_bwd(None, 20000, 20000, 0.2, p, p, None, 0, p, p, p) == -1
+    assert L.gs_l1_ssim_fwd(None, 16, 1 << 21, 0.2, p, p, None, 0, p, p) == -1   # (a row of 12 W bytes beyond the 24-bit multiply)
     assert L.gs_l1_ssim_fwd(None, 10, 64, 0.2, p, p, None, 0, p, p) == -1
     assert b"larger than the 11x11 window" in L.gs_last_error()
     assert L.gs_loss_workspace_floats(1080, 1920) == 9 * 1080 * 1920 + 2 * (60 * 34 + 8)
