@@ -56,6 +56,8 @@ SIGNATURES = {
     "gs_loss_workspace_floats": (_Z, [_I, _I]),
     "gs_l1_ssim_fwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _I, _P, _P]),
     "gs_l1_ssim_bwd": (_I, [_P, _I, _I, _F, _P, _P, _P, _I, _P, _P, _P]),
+    "gs_l1_ssim_fwd_slots": (_I, [_P, _I, _I, _F, _P, _P, _I, _I, _P, _P]),
+    "gs_l1_ssim_bwd_slots": (_I, [_P, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
     "gs_clamp01": (_I, [_P, _L, _P, _P, _P]),
     "gs_pack_view_step": (_I, [_P, _L, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_update_statistics": (_I, [_P, _L, _F, _P, _P, _P, _P, _P]),
@@ -64,6 +66,7 @@ SIGNATURES = {
     "gs_info_mirror_set": (_I, [_P]),
     "gs_step_status": (_I, [_P, _P, _P, _P, _P, _P, _I]),
     "gs_adam_hyper": (_I, [_P, _I, _P, _F, _F, _L, _P]),
+    "gs_step_inputs": (_I, [_P, _I, _P, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_adam_step_dev": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P, _P]),
     "gs_scan_rows_workspace_ints": (_Z, [_I, _L]),
     "gs_scan_rows_i32": (_I, [_P, _I, _L, _P, _P, _P]),

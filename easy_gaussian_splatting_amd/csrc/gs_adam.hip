@@ -182,6 +182,48 @@ extern "C" int gs_adam_hyper(void* stream, int n_segments, const float* seg_lrs_
     return GS_OK;
 }
 
+// Everything that changes from one captured step to the next, in ONE launch in front of the replay (gs_step_inputs): Adam's
+// bias corrections and learning rates as gs_adam_hyper writes them, the camera (two device-to-device copies of 16 + 9 floats)
+// and the POINTERS to the step's ground-truth image and mask, which the loss entries read through (gs_l1_ssim_fwd_slots):
+// a step on another view used to cost three copy launches and 24 H W bytes of traffic for an image nobody changes.
+namespace gs {
+struct StepInputArgs {
+    HyperArgs h;
+    float* hyper;
+    const float *vm_src, *k_src;
+    float *vm_dst, *k_dst;
+    const float *gt, *mask;
+    const float** slots;
+};
+__global__ void step_inputs_kernel(const StepInputArgs a) {
+    const unsigned t = threadIdx.x;
+    if (t < (unsigned)a.h.n) a.hyper[t] = a.h.v[t];
+    if (a.vm_src && t < 16u) a.vm_dst[t] = a.vm_src[t];
+    if (a.k_src && t < 9u) a.k_dst[t] = a.k_src[t];
+    if (a.slots && t == 0u) { a.slots[0] = a.gt; a.slots[1] = a.mask; }
+}
+}  // namespace gs
+
+extern "C" int gs_step_inputs(void* stream, int n_segments, const float* seg_lrs_host, float beta1, float beta2, int64_t step,
+                              float* hyper_dev, const float* viewmat_src, float* viewmat_dst, const float* K_src, float* K_dst,
+                              const float* gt, const float* mask, const float** slots_dev) {
+    GS_REQUIRE(n_segments >= 1 && n_segments <= kMaxSeg && seg_lrs_host && hyper_dev, "1..8 segments, non-null pointers");
+    GS_REQUIRE(step >= 1, "step counts from 1");
+    GS_REQUIRE((viewmat_src == nullptr || viewmat_dst != nullptr) && (K_src == nullptr || K_dst != nullptr), "a source needs its destination");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    gs::StepInputArgs a;
+    a.h.n = 1 + n_segments;
+    a.h.v[0] = (float)(1.0 / sqrt(bc2));
+    for (int k = 0; k < kMaxSeg; ++k) a.h.v[1 + k] = k < n_segments ? (float)((double)seg_lrs_host[k] / bc1) : 0.f;
+    a.hyper = hyper_dev;
+    a.vm_src = viewmat_src; a.vm_dst = viewmat_dst; a.k_src = K_src; a.k_dst = K_dst;
+    a.gt = gt; a.mask = mask; a.slots = slots_dev;
+    // values travel as kernel arguments (copied at launch): no host buffer that a later call could overwrite
+    hipLaunchKernelGGL(gs::step_inputs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    GS_LAUNCH_CHECK("step_inputs_kernel");
+    return GS_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // update_statistics (/root/reference/model/gaussian.py:188-197) as ONE launch: the consumer of the
 // `.absgrad` / `radii` side channels.  For visible Gaussians (radius > 0):

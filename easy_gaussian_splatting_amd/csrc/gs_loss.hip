@@ -47,6 +47,7 @@ struct LossArgs {
     int clamp_input;                   // render is the un-clamped image: clamp to [0,1] on load, mask the gradient
     float lambda_ssim;
     const float *render, *gt, *mask;   // [H,W,3], [H,W,3], [H,W] or null
+    const float* const* slots;         // optional: {gt, mask} read from device memory at kernel start instead (gs_step_inputs)
     float* maps;                       // [3 ch][H][W][3 (dmu, dxx, dxy)]: a tile row of one channel is one contiguous run
     float* partial;                    // [nblocks][2] (l1 sum, ssim sum)
     const float* gout;                 // device scalar: d loss_total
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
     }
     const int tid = threadIdx.x;
     const unsigned row_bytes = 12u * (unsigned)a.W;
+    const float* gt_img = a.slots ? a.slots[0] : a.gt;        // (block-uniform scalar loads)
+    const float* mask_img = a.slots ? a.slots[1] : a.mask;
     // ---- staging role: thread = one staged column x 7 rows (coordinates clamped; clamped values only feed discarded
     // outputs).  Addresses: a block-uniform base (scalar registers) + a 32-bit byte offset per lane (the entry points bound
     // H * W), a 24-bit multiply-add per row.
@@ -137,11 +140,11 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
 #if GS_LOSS_EXP & 2
             const F3 g3 = F3{(float)(o & 255u) * 0.003f, (float)(o & 127u) * 0.006f, 0.5f}, r3 = F3{(float)(o & 63u) * 0.01f, 0.25f, (float)(o & 31u) * 0.03f};
 #else
-            const F3 g3 = ld3_off(a.gt, o), r3 = ld3_off(a.render, o);
+            const F3 g3 = ld3_off(gt_img, o), r3 = ld3_off(a.render, o);
 #endif
             gv[i][0] = g3.x; gv[i][1] = g3.y; gv[i][2] = g3.z;
             rv[i][0] = r3.x; rv[i][1] = r3.y; rv[i][2] = r3.z;
-            if (MASK) mv[i] = ld_off(a.mask, __umul24(cy, 4u * (unsigned)a.W) + 4u * (unsigned)cx);
+            if (MASK) mv[i] = ld_off(mask_img, __umul24(cy, 4u * (unsigned)a.W) + 4u * (unsigned)cx);
         }
     }
     float l1 = 0.f, ssim_sum = 0.f;
@@ -308,14 +311,15 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
     const int q = tid / kLT, ocol = tid - q * kLT, r0 = 4 * q, ogx = x0 + ocol;
     const bool col_in = ogx < a.W;
     const unsigned o0 = __umul24((unsigned)min(y0 + r0, a.H - 1), row_bytes) + 12u * (unsigned)min(ogx, a.W - 1);
-    const float* gt_c = a.gt + ch;
+    const float* mask_img = a.slots ? a.slots[1] : a.mask;   // (block-uniform scalar loads)
+    const float* gt_c = (a.slots ? a.slots[0] : a.gt) + ch;
     const float* render_c = a.render + ch;
     float gtv[4], rr[4], mk[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned o = o0 + (y0 + r0 + j < a.H ? j * row_bytes : 0u);   // (rows below the image re-read a valid one; never stored)
         gtv[j] = ld_off(gt_c, o); rr[j] = ld_off(render_c, o);
-        if (a.mask) mk[j] = ld_off(a.mask, o / 3u);
+        if (mask_img) mk[j] = ld_off(mask_img, o / 3u);
     }
     {
         // a tile row of one channel's derivative maps is one contiguous run of 42 x 3 floats: lane j < 126 of each 128-thread
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(const LossArgs a) {
             if (y0 + r0 + j >= a.H || !col_in) continue;
             float r = rr[j], keep = 1.f;
             if (a.clamp_input) { keep = (r >= 0.f && r <= 1.f) ? 1.f : 0.f; r = fminf(fmaxf(r, 0.f), 1.f); }   // clamp's backward
-            if (a.mask) { r = mk[j] * gtv[j] + (1.f - mk[j]) * r; keep *= 1.f - mk[j]; }
+            if (mask_img) { r = mk[j] * gtv[j] + (1.f - mk[j]) * r; keep *= 1.f - mk[j]; }
             const float d = r - gtv[j];
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
             st_off(out_c, o0 + j * row_bytes, keep * (k_ssim * (c[0][j] + 2.f * r * c[1][j] + gtv[j] * c[2][j]) + k_l1 * sgn));
@@ -450,19 +454,19 @@ extern "C" size_t gs_loss_workspace_floats(int height, int width) {
     return 9 * (size_t)height * width + 2 * (nb + 8);   // derivative maps + (l1, ssim) partial sums per forward block
 }
 
-extern "C" int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_ssim, const float* render,
-                              const float* gt, const float* mask, int clamp_input, float* workspace, float* out3) {
+static int loss_fwd_launch(void* stream, int height, int width, float lambda_ssim, const float* render, const float* gt,
+                           const float* mask, const float* const* slots, bool has_mask, int clamp_input, float* workspace, float* out3) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
     GS_REQUIRE((int64_t)height * width <= kLossMaxPixels && width <= kLossMaxWidth, "image too large for the loss kernels' 32-bit byte offsets");
-    GS_REQUIRE(render && gt && workspace && out3, "null pointer");
+    GS_REQUIRE(render && (gt || slots) && workspace && out3, "null pointer");
     LossArgs a;
-    a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;
+    a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask; a.slots = slots;
     a.clamp_input = clamp_input != 0;
     a.maps = workspace; a.partial = workspace + 9 * (size_t)height * width; a.gout = nullptr; a.v_render = nullptr;
     const int blocks = (int)loss_grid(loss_tile_count(height, width)).x;
     const size_t lds = sizeof(float) * (2 * kLR * kLRP + 4 * kLR * kHP);
     hipStream_t st = (hipStream_t)stream;
-    if (mask) hipLaunchKernelGGL(l1_ssim_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    if (has_mask) hipLaunchKernelGGL(l1_ssim_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     else hipLaunchKernelGGL(l1_ssim_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     GS_LAUNCH_CHECK("l1_ssim_fwd_kernel");
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, blocks, a.partial, height, width, lambda_ssim, out3);
@@ -470,18 +474,45 @@ extern "C" int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_
     return GS_OK;
 }
 
-extern "C" int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const float* render,
-                              const float* gt, const float* mask, int clamp_input, const float* workspace,
-                              const float* v_total, float* v_render) {
+static int loss_bwd_launch(void* stream, int height, int width, float lambda_ssim, const float* render, const float* gt,
+                           const float* mask, const float* const* slots, int clamp_input, const float* workspace,
+                           const float* v_total, float* v_render) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
     GS_REQUIRE((int64_t)height * width <= kLossMaxPixels && width <= kLossMaxWidth, "image too large for the loss kernels' 32-bit byte offsets");
-    GS_REQUIRE(render && gt && workspace && v_total && v_render, "null pointer");
+    GS_REQUIRE(render && (gt || slots) && workspace && v_total && v_render, "null pointer");
     LossArgs a;
-    a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask;
+    a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask; a.slots = slots;
     a.clamp_input = clamp_input != 0;
     a.maps = const_cast<float*>(workspace); a.partial = nullptr; a.gout = v_total; a.v_render = v_render;
     const size_t lds = sizeof(float) * (3 * kLR * kLRP);
     hipLaunchKernelGGL(l1_ssim_bwd_kernel, dim3(3 * loss_grid(loss_tile_count(height, width)).x), dim3(256), lds, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("l1_ssim_bwd_kernel");
     return GS_OK;
+}
+
+extern "C" int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_ssim, const float* render,
+                              const float* gt, const float* mask, int clamp_input, float* workspace, float* out3) {
+    return loss_fwd_launch(stream, height, width, lambda_ssim, render, gt, mask, nullptr, mask != nullptr, clamp_input, workspace, out3);
+}
+
+extern "C" int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const float* render,
+                              const float* gt, const float* mask, int clamp_input, const float* workspace,
+                              const float* v_total, float* v_render) {
+    return loss_bwd_launch(stream, height, width, lambda_ssim, render, gt, mask, nullptr, clamp_input, workspace, v_total, v_render);
+}
+
+// The same two entries with the ground truth and the mask read THROUGH device memory: slots_dev[0] = gt, slots_dev[1] = mask
+// (NULL: none), written by gs_step_inputs in front of every replay of a captured step -- the graph's kernel arguments are
+// frozen at capture, the image a step trains on is not.  has_mask selects the instantiation (known at capture).
+extern "C" int gs_l1_ssim_fwd_slots(void* stream, int height, int width, float lambda_ssim, const float* render,
+                                    const float* const* slots_dev, int has_mask, int clamp_input, float* workspace, float* out3) {
+    GS_REQUIRE(slots_dev != nullptr, "slots_dev is required");
+    return loss_fwd_launch(stream, height, width, lambda_ssim, render, nullptr, nullptr, slots_dev, has_mask != 0, clamp_input, workspace, out3);
+}
+
+extern "C" int gs_l1_ssim_bwd_slots(void* stream, int height, int width, float lambda_ssim, const float* render,
+                                    const float* const* slots_dev, int clamp_input, const float* workspace,
+                                    const float* v_total, float* v_render) {
+    GS_REQUIRE(slots_dev != nullptr, "slots_dev is required");
+    return loss_bwd_launch(stream, height, width, lambda_ssim, render, nullptr, nullptr, slots_dev, clamp_input, workspace, v_total, v_render);
 }

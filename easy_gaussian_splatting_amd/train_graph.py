@@ -135,8 +135,9 @@ class TrainStepGraph:
         b = self.buf = {}
         b["viewmats"] = torch.empty((1, 4, 4), **f32)
         b["Ks"] = torch.empty((1, 3, 3), **f32)
-        b["gt"] = torch.empty((H, W, 3), **f32)
-        b["mask"] = torch.empty((H, W), **f32) if self.has_mask else None
+        # {gt, mask} POINTERS of the step about to run (gs_step_inputs writes them, the loss entries read through them): the
+        # target image of a step is the caller's own tensor -- kept alive by the pending entry --, never copied
+        b["img_slots"] = torch.zeros((2,), dtype=torch.int64, device=dev)
         b["bg"] = m.BACKGROUND.detach().reshape(1, 3).to(dev, torch.float32).contiguous().clone()
         b["radii"] = self._take("radii", (1, N), torch.int32)
         b["means2d"] = self._take("means2d", (1, N, 2), torch.float32)
@@ -171,7 +172,7 @@ class TrainStepGraph:
             "sh_rest": torch.empty((N, self.K - 1, 3), **f32) if self.K > 1 else None,
             "logit_opacities": torch.empty((N,), **f32)}
         b["hyper"] = torch.zeros((16,), **f32)
-        self._set_inputs(data["w2c"], data["K"], gt_img, mask)
+        self._stage_inputs(max(self.opt._step, 0) + 1, [float(grp["lr"]) for grp, _ in self.opt._plist], data["w2c"], data["K"], gt_img, mask)
         if projected is not None:
             n_isects, max_tile = projected
             self.cap = int(n_isects * self.margin) + 4096
@@ -251,23 +252,47 @@ class TrainStepGraph:
                         snap = static.clone()
                     e[i] = snap[0] if (e[i].dim() < static.dim()) else snap
 
-    def _set_inputs(self, w2c: Tensor, K: Tensor, gt: Tensor, mask: Optional[Tensor]):
-        b = self.buf
+    def _image(self, t: Tensor, shape) -> Tensor:
+        """The caller's image as the loss kernels read it: float32, contiguous, on the runner's device (a tensor that already is
+        comes back as it is -- the usual case; anything else is converted once)."""
+        if t.device != self.dev or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != tuple(shape):
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"TrainStepGraph: image of shape {tuple(t.shape)}, expected {tuple(shape)}")
+            t = t.to(device=self.dev, dtype=torch.float32).contiguous()
+        return t
+
+    def _stage_inputs(self, t: int, lrs, w2c: Tensor, K: Tensor, gt: Tensor, mask: Optional[Tensor]):
+        """Everything that differs from the previous step, in ONE launch on the current stream (gs_step_inputs): Adam's bias
+        corrections / learning rates, the camera into the static buffers, and the POINTERS to the target image and mask.
+        Returns the (gt, mask) tensors whose pointers went in -- the caller keeps them alive until the step is applied."""
+        L, b, opt = nat.lib(), self.buf, self.opt
+        ok = lambda x, n: x.device == self.dev and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == n   # noqa: E731
+        vm_src = k_src = None
         if w2c.data_ptr() != b["viewmats"].data_ptr():   # (the static buffer itself = "same as last step")
             self._protect_pending(b["viewmats"])
-            b["viewmats"][0].copy_(w2c, non_blocking=True)
+            if ok(w2c, 16):
+                vm_src = w2c
+            else:
+                b["viewmats"][0].copy_(w2c, non_blocking=True)
         if K.data_ptr() != b["Ks"].data_ptr():
             self._protect_pending(b["Ks"])
-            b["Ks"][0].copy_(K, non_blocking=True)
-        if gt.data_ptr() != b["gt"].data_ptr():
-            self._protect_pending(b["gt"])
-            b["gt"].copy_(gt, non_blocking=True)
+            if ok(K, 9):
+                k_src = K
+            else:
+                b["Ks"][0].copy_(K, non_blocking=True)
+        gt = self._image(gt, (self.H, self.W, 3))
         if self.has_mask:
             if mask is None:
                 raise ValueError("this runner was built with a mask; pass one every step")
-            if mask.data_ptr() != b["mask"].data_ptr():
-                self._protect_pending(b["mask"])
-                b["mask"].copy_(mask, non_blocking=True)
+            mask = self._image(mask, (self.H, self.W))
+        else:
+            mask = None
+        ns = len(opt._plist)
+        b1, b2 = opt.defaults["betas"]
+        nat.check(L.gs_step_inputs(self._st(), ns, (ct.c_float * ns)(*lrs), float(b1), float(b2), int(t), _p(b["hyper"]), _p(vm_src),
+                                   _p(b["viewmats"]), _p(k_src), _p(b["Ks"]), _p(gt), _p(mask), _p(b["img_slots"])), "gs_step_inputs")
+        self._cur_images = (gt, mask)
+        return gt, mask
 
     def _st(self) -> int:
         return torch.cuda.current_stream(self.dev).cuda_stream
@@ -427,10 +452,10 @@ class TrainStepGraph:
                                      _p(b["render_alphas"]), _p(b["ckpt"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["qmask"]),
                                      _p(b["unit_counter"]), _p(b["unit_desc"])), "gs_blend_fwd")
             lam = float(self.lc.lambda_ssim)
-            self._ck(L.gs_l1_ssim_fwd(st, H, W, lam, _p(b["render_colors"]), _p(b["gt"]), _p(b["mask"]), 1, _p(b["loss_ws"]),
-                                       _p(b["loss3"])), "gs_l1_ssim_fwd")
-            self._ck(L.gs_l1_ssim_bwd(st, H, W, lam, _p(b["render_colors"]), _p(b["gt"]), _p(b["mask"]), 1, _p(b["loss_ws"]),
-                                       _p(b["one"]), _p(b["v_render"])), "gs_l1_ssim_bwd")
+            self._ck(L.gs_l1_ssim_fwd_slots(st, H, W, lam, _p(b["render_colors"]), _p(b["img_slots"]), int(self.has_mask), 1, _p(b["loss_ws"]),
+                                             _p(b["loss3"])), "gs_l1_ssim_fwd_slots")
+            self._ck(L.gs_l1_ssim_bwd_slots(st, H, W, lam, _p(b["render_colors"]), _p(b["img_slots"]), 1, _p(b["loss_ws"]),
+                                             _p(b["one"]), _p(b["v_render"])), "gs_l1_ssim_bwd_slots")
             self._ck(L.gs_blend_bwd(st, 1, W, H, _p(b["rec"]), _p(b["isect_offsets"]), _p(b["bucket_offsets"]), self.cap_buckets,
                                      _p(b["qlist"]), _p(b["qcnt"]), _p(b["unit_counter"]), _p(b["unit_desc"]), _p(b["ckpt"]),
                                      _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"])),
@@ -521,8 +546,7 @@ class TrainStepGraph:
         # stream holds neither -- skips it.  The wait is free when the caller's stream is idle, i.e. with handback="lazy" in a
         # loop that reads nothing between steps; behind an eager hand-back it costs two cross-queue signal hops.
         with torch.cuda.device(self.dev), self._on_stream(wait_outer=not ready, hand_back=self.handback == "eager"):
-            self._set_inputs(w2c, K, gt, mask)
-            self._hyper(t, lrs)
+            entry[4], entry[5] = self._stage_inputs(t, lrs, w2c, K, gt, mask)   # (the tensors the step reads: kept by the entry)
             if self.graph is not None:
                 self.graph.replay()
             else:
@@ -549,8 +573,8 @@ class TrainStepGraph:
                 cur = (data["w2c"], data["K"], gt_img, mask)
                 self.W, self.H = W, H
             else:
-                cur = self._last_inputs if data is None else (data["w2c"], data["K"], gt_img if gt_img is not None else self.buf["gt"],
-                                                              mask if mask is not None else self.buf.get("mask"))
+                cur = self._last_inputs if data is None else (data["w2c"], data["K"], gt_img if gt_img is not None else self._last_inputs[2],
+                                                              mask if mask is not None else self._last_inputs[3])
                 # (old static buffers named here stay alive through `cur` until the new ones have been filled from them)
             # the largest list the status words showed since the last build, scaled to the new model size: a refinement
             # re-captures on whichever view comes next, and a capacity learnt from that one view alone overflows on the first
@@ -583,8 +607,13 @@ class TrainStepGraph:
         b = self.buf
         w2c = b["viewmats"][0] if data is None else data["w2c"]
         K = b["Ks"][0] if data is None else data["K"]
-        gt = b["gt"] if gt_img is None else gt_img
-        mk = (b["mask"] if mask is None else mask) if self.has_mask else None
+        gt = self._last_inputs[2] if gt_img is None else gt_img   # (the previous step's own tensors, by reference)
+        mk = (self._last_inputs[3] if mask is None else mask) if self.has_mask else None
+        gt = self._image(gt, (self.H, self.W, 3))   # (validated / converted BEFORE the step is counted)
+        if self.has_mask:
+            if mk is None:
+                raise ValueError("this runner was built with a mask; pass one every step")
+            mk = self._image(mk, (self.H, self.W))
         self._last_inputs = (w2c, K, gt, mk)
         opt = self.opt
         opt._step += 1

@@ -342,6 +342,15 @@ int gs_l1_ssim_bwd(void* stream, int height, int width, float lambda_ssim, const
                    const float* gt, const float* mask, int clamp_input, const float* workspace,
                    const float* v_total, float* v_render);
 
+/* The same two entries for a CAPTURED step (the graph's kernel arguments are frozen at capture, the image a step trains on is
+ * not): ground truth and mask are read through device memory, slots_dev[0] = gt, slots_dev[1] = mask, which gs_step_inputs
+ * writes in front of every replay.  has_mask (known at capture) selects the forward's instantiation; the backward tests the slot. */
+int gs_l1_ssim_fwd_slots(void* stream, int height, int width, float lambda_ssim, const float* render,
+                         const float* const* slots_dev, int has_mask, int clamp_input, float* workspace, float* out3);
+int gs_l1_ssim_bwd_slots(void* stream, int height, int width, float lambda_ssim, const float* render,
+                         const float* const* slots_dev, int clamp_input, const float* workspace,
+                         const float* v_total, float* v_render);
+
 /* Row a-2: `torch.clamp(render, 0, 1)` of /root/reference/model/gaussian.py:368 as one pass.
  * v_out == NULL: out = clamp(x, 0, 1).  v_out != NULL: out = v_out where 0 <= x <= 1, else 0 (the
  * backward of that clamp).  n floats, 16-byte aligned buffers. */
@@ -376,6 +385,13 @@ int gs_adam_step_stats(void* stream, int64_t n, float* params, float* exp_avg, f
  * applied_dev (optional): device counter incremented by every launch the step guard did not skip. */
 int gs_adam_hyper(void* stream, int n_segments, const float* seg_lrs_host, float beta1, float beta2, int64_t step,
                   float* hyper_dev);
+/* gs_adam_hyper + everything else that changes from one replay of a captured step to the next, in ONE launch (values travel
+ * as kernel arguments): viewmat_dst[16] <- viewmat_src[16] and K_dst[9] <- K_src[9] (device pointers; a NULL source leaves
+ * its destination alone), slots_dev[0] = gt, slots_dev[1] = mask (the POINTERS gs_l1_ssim_*_slots read through; slots_dev
+ * may be NULL).  A step on another view costs no copy of its ground-truth image. */
+int gs_step_inputs(void* stream, int n_segments, const float* seg_lrs_host, float beta1, float beta2, int64_t step,
+                   float* hyper_dev, const float* viewmat_src, float* viewmat_dst, const float* K_src, float* K_dst,
+                   const float* gt, const float* mask, const float** slots_dev);
 int gs_adam_step_dev(void* stream, int64_t n, float* params, float* exp_avg, float* exp_avg_sq, int n_segments,
                      const int64_t* seg_ends_host, const int64_t* seg_lens_host, const float* const* seg_grads_host,
                      float beta1, float beta2, float eps, float grad_scale, const float* hyper_dev, int64_t* applied_dev);

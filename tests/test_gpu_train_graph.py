@@ -397,3 +397,40 @@ def test_lazy_outputs_fence_on_every_way_of_reading_them():
         assert len(fences) == 1   # once per step
         fences.clear()
     runner.finish()
+
+
+def test_targets_are_read_in_place_through_pointer_slots():
+    """The captured step reads the ground-truth image and the mask THROUGH device pointers that `gs_step_inputs` rewrites in front
+    of every replay (round 5): a float32 contiguous target on the device is used where it lies -- no copy, no static image buffer
+    --, anything else (another dtype, a strided view, a host tensor) is converted once, and `step()` without a target re-uses
+    the previous step's.  Bitwise equal to the eager loop throughout."""
+    dev, make, datas, gts = _setup(n=20000, n_views=3)
+    (ma, oa), (mb, ob) = make(), make()
+    lc = LossComputer(0.2, clamp_input=True)
+    H, W = gts[0].shape[:2]
+    mask = torch.zeros((H, W), device=dev)
+    mask[20:60, 50:120] = 1.0
+    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], mask, check_every=4)
+    assert "gt" not in runner.buf and "mask" not in runner.buf          # no static copies of the images
+    wide = torch.rand((H, 2 * W, 3), device=dev)
+    odd = {
+        "strided view": wide[:, ::2],                                    # not contiguous
+        "float64": gts[1].double(),
+        "host tensor": gts[2].cpu(),
+    }
+    seq = [(0, gts[0]), (1, gts[1]), (2, odd["strided view"]), (1, odd["float64"]), (0, odd["host tensor"]), (2, gts[2])]
+    for v, gt in seq:
+        _eager_step(ma, oa, lc, datas[v], gt.to(dev, torch.float32).contiguous(), mask)
+        runner.step(datas[v], gt, mask)
+        staged = runner._cur_images[0]
+        if gt.device == dev and gt.dtype == torch.float32 and gt.is_contiguous():
+            assert staged.data_ptr() == gt.data_ptr()                   # read where it lies
+        assert int(runner.buf["img_slots"][0]) == staged.data_ptr() and int(runner.buf["img_slots"][1]) == mask.data_ptr()
+    _eager_step(ma, oa, lc, datas[2], gts[2], mask)
+    runner.step()                                                        # "the same frame again"
+    runner.finish()
+    _assert_same(ma, oa, mb, ob, "pointer slots")
+    t0 = ob._step
+    with pytest.raises(ValueError):
+        runner.step(datas[0], torch.rand((H + 1, W, 3), device=dev), mask)
+    assert ob._step == t0                                                # refused before the step was counted
