@@ -622,11 +622,11 @@ def run_rank(args) -> int:
         lazy_handback = {"train_iters_per_s": round(args.steps / e_l, 2), "train_ms": _percentiles(s_l),
                          "note": "the headline loop with TrainStepGraph(handback='lazy') -- opt-in: the caller's stream is ordered behind a step only "
                                  "when the caller touches the returned outputs or calls fence(); rounds 4's headline mode"}
-    # the round-1..3 headline, kept for comparison: ONE static camera, no input copies, no LR change
+    # the round-1..3 headline, kept for comparison: ONE static camera and target, no LR change
     static_view = None
     if world == 1 and not force_dist:
         if graph_step is not None:
-            graph_step.step(data, gt_img, mask)   # (the static buffers now hold view `view`; argument-less steps re-use them)
+            graph_step.step(data, gt_img, mask)   # (argument-less steps re-use this view's camera and target)
         sfn = (lambda: graph_step.step()) if graph_step is not None else train_step
         e_s, _, s_s, _ = timed_loop(sfn, args.steps, 10, finish=None if graph_step is None else graph_step.finish, ev_stream=g_stream)
         static_view = {"train_iters_per_s": round(args.steps / e_s, 2), "train_ms": _percentiles(s_s),

@@ -556,8 +556,9 @@ class TrainStepGraph:
 
     def step(self, data: Optional[Dict[str, Any]] = None, gt_img: Optional[Tensor] = None, mask: Optional[Tensor] = None,
              inputs_ready: bool = False):
-        """One training iteration.  `data` / `gt_img` / `mask` default to the previous step's (static buffers are
-        re-used as they are).  Returns the runner's static output tensors (valid until the next `step()` is CALLED: reads
+        """One training iteration.  `data` / `gt_img` / `mask` default to the previous step's (the camera's static buffers are
+        re-used as they are; the target image and the mask are the previous step's own tensors, read in place).  Returns the
+        runner's static output tensors (valid until the next `step()` is CALLED: reads
         enqueued on the caller's stream before that call are ordered in front of the replay that overwrites them).
         `inputs_ready=True` is the caller's promise that no work still pending on its stream (a) writes the tensors handed
         in, (b) reads the outputs of an earlier step, the model's parameters or its statistics: the step then does not wait
@@ -618,9 +619,10 @@ class TrainStepGraph:
         opt = self.opt
         opt._step += 1
         # The queued entry is what an overflow recovery replays.  Inputs are kept by reference: a caller must not write
-        # into a camera / target / mask tensor it has handed in before `finish()` (or `check_every` further steps).  Entries
-        # that alias the runner's OWN static buffers (data=None / gt_img=None steps) are snapshotted right before a later
-        # step overwrites those buffers (`_protect_pending`), so a skipped step is always replayed with its own inputs.
+        # into a camera / target / mask tensor it has handed in before `finish()` (or `check_every` further steps) -- the
+        # target and the mask are not even copied: the step reads them where they lie (`_stage_inputs`).  Entries that alias the
+        # runner's OWN static camera buffers (data=None steps) are snapshotted right before a later step overwrites those
+        # buffers (`_protect_pending`), so a skipped step is always replayed with its own inputs.
         self._issue([opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk, bool(inputs_ready)])
         if self.issued % self.check_every == 0:
             self._poll(block=False)
