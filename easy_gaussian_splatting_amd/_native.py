@@ -13,15 +13,20 @@ import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (GS_LIB_PATH: a tuning variant of the same library, tools/tune_variants.sh; the product loads the in-tree build)
+# The product loads the in-tree build.  GS_LIB_PATH names another build of the same library -- a diagnostic VARIANT
+# (`build_variant`: -DGS_BWD_CHECK, -DGS_BWD_ACC64, -DGS_EXACT_MATH, -DGS_CLOCK_PROBE, tuning constants) -- and is honoured only
+# together with GS_ALLOW_VARIANT=1: every library names the flags it was built with (`gs_build_flags`), and one whose flags
+# are not empty is refused otherwise, so that a stray environment variable cannot put a timing or checking build behind
+# the numbers and the parity results.
 LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsraster.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
+VARIANT_DIR = os.path.join(os.path.dirname(_HERE), "build", "variants")   # never the package directory
 
 GS_TILE = 16
 GS_BUCKET = 64
 GS_UNIT = 32
 GS_REC_FLOATS = 12
-GS_ROW_FLOATS = int(os.environ.get("GS_ROW_FLOATS", "12"))   # (env: tuning variants built with -DGS_ROW_FLOATS=...)
+GS_ROW_FLOATS = 12
 
 _lib: Optional[ct.CDLL] = None
 _lock = threading.Lock()
@@ -35,6 +40,7 @@ _Z = ct.c_size_t
 # name -> (restype, argtypes); must list every symbol include/gs_raster.h declares
 SIGNATURES = {
     "gs_version": (_I, []),
+    "gs_build_flags": (ct.c_char_p, []),
     "gs_last_error": (ct.c_char_p, []),
     "gs_arch": (ct.c_char_p, []),
     "gs_bin_groups": (_I, [_L]),
@@ -46,8 +52,9 @@ SIGNATURES = {
     "gs_bins_workspace_bytes": (_Z, [_I, _L, _I, _I, _I, _L]),
     "gs_bins_count": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _P, _Z, _P, _L, _L, _P, _P, _P, _P, _P, _P]),
     "gs_bins_lists": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _Z, _P, _L, _P, _P, _P, _P, _P, _P]),
-    "gs_blend_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_walk_state_ints": (_Z, [_L]),
+    "gs_blend_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
+    "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_project_bwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F,
                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "gs_row_sums": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
@@ -64,7 +71,8 @@ SIGNATURES = {
     "gs_guard_set": (_I, [_P, _L, _L]),
     "gs_guard_set_call": (_I, [_P, _L, _L]),
     "gs_info_mirror_set": (_I, [_P]),
-    "gs_step_status": (_I, [_P, _P, _P, _P, _P, _P, _I]),
+    "gs_walk_mirror_set": (_I, [_P]),
+    "gs_step_status": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "gs_adam_hyper": (_I, [_P, _I, _P, _F, _F, _L, _P]),
     "gs_step_inputs": (_I, [_P, _I, _P, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_adam_step_dev": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P, _P]),
@@ -74,8 +82,8 @@ SIGNATURES = {
     "gs_refine_apply": (_I, [_P, _L, _I, _I, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_project_bwd_adam": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P,
                                   _P, _P, _P, _P]),
-    "gs_workspace_query": (_I, [_I, _L, _I, _I, _L, _L, _I, _I, _P, _P]),
-    "gs_workspace_bind": (_I, [_P, _P, _L, _P, _L, _P, _P]),
+    "gs_workspace_query": (_I, [_I, _L, _I, _I, _L, _L, _L, _L, _I, _I, _P, _P]),
+    "gs_workspace_bind": (_I, [_P, _P, _L, _P, _L, _P, _L, _P, _P]),
     "gs_adam_step": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F]),
     "gs_adam_step_stats": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _P, _F, _F, _F, _L, _F, _L, _P, _P, _P, _P]),
 }
@@ -85,8 +93,11 @@ class NativeLibraryError(RuntimeError):
     pass
 
 
-def build(verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+def build(verbose: bool = False, clean: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU).  `clean`: from scratch -- no object of an
+    earlier build (another revision, other flags) can end up in the library."""
+    if clean:
+        subprocess.run(["make", "-C", CSRC_DIR, "clean"], capture_output=True, text=True)
     proc = subprocess.run(["make", "-C", CSRC_DIR, "-j4"], capture_output=True, text=True)
     if verbose or proc.returncode != 0:
         print(proc.stdout)
@@ -97,14 +108,15 @@ def build(verbose: bool = False) -> str:
 
 
 def build_variant(name: str, extra_flags: str) -> str:
-    """A diagnostic variant of the library, `libgsraster_<name>.so` next to the product build, compiled with additional
-    flags from a scratch copy of the sources (so the product's objects are left alone).  Used by `__graft_entry__.build()` for
-    the `-DGS_BWD_CHECK` build that tests/test_gpu_contributors.py loads through GS_LIB_PATH in a child process; never loaded
-    by the package itself."""
+    """A diagnostic variant of the library, `build/variants/libgsraster_<name>.so` (outside the package), compiled with
+    additional flags from a scratch copy of the sources (so the product's objects are left alone).  It reports those flags
+    through `gs_build_flags`; a process loads it through GS_LIB_PATH + GS_ALLOW_VARIANT=1 (tests/test_gpu_contributors.py does,
+    in a child process); never loaded by the package on its own."""
     import glob
     import shutil
     import tempfile
-    out = os.path.join(_HERE, f"libgsraster_{name}.so")
+    os.makedirs(VARIANT_DIR, exist_ok=True)
+    out = os.path.join(VARIANT_DIR, f"libgsraster_{name}.so")
     srcs = [f for pat in ("*.hip", "*.h", "*.inc", "Makefile") for f in glob.glob(os.path.join(CSRC_DIR, pat))]
     if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(f) for f in srcs + [os.path.join(_HERE, "..", "include", "gs_raster.h")]):
         return out
@@ -138,8 +150,18 @@ def lib() -> ct.CDLL:
                     fn = getattr(L, name)  # AttributeError => header/library mismatch
                     fn.restype = res
                     fn.argtypes = args
+                flags = L.gs_build_flags().decode("utf-8", "replace")
+                if flags and os.environ.get("GS_ALLOW_VARIANT") != "1":
+                    raise NativeLibraryError(
+                        f"{LIB_PATH} is a diagnostic variant of the rasterizer library (built with `{flags}`), not the product "
+                        "build: refusing to run on it.  Unset GS_LIB_PATH, or set GS_ALLOW_VARIANT=1 if that is what you want.")
                 _lib = L
     return _lib
+
+
+def build_flags() -> str:
+    """The extra preprocessor flags the loaded library was built with ("" = the product build)."""
+    return lib().gs_build_flags().decode("utf-8", "replace")
 
 
 def check(rc: int, what: str) -> None:

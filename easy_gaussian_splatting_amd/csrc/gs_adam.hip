@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) void update_statistics_kernel(int64_t n, float
     const int r = radii[i];
     if (r > 0) {
         const float2 g = absgrad[i];
-        max_radii[i] = fmaxf(max_radii[i], (float)r / max_hw);
+        // (radius * (1 / max_hw), not radius / max_hw: the reference's `radii / max_hw` is torch's division of a CUDA tensor by a
+        //  Python scalar, which multiplies by the reciprocal -- one arithmetic on every path that forms this statistic)
+        max_radii[i] = fmaxf(max_radii[i], (float)r * (1.f / max_hw));
         grad_norm_accum[i] += sqrtf(g.x * g.x + g.y * g.y) * max_hw;
         counts[i] += 1.f;
     }

@@ -13,7 +13,12 @@
 // In training mode the forward also emits, per quadrant, the COMPACTED depth-ordered sublist of
 // the entries that touch it (ranks from popcounts of the ballots), a checkpoint of the quadrant's
 // 64 pixel states (T, accumulated rgb) every 32 sublist entries, and one work-unit descriptor per
-// such 32-entry work unit.
+// such 32-entry work unit.  All three live in storage allocated PER WORK UNIT as the walk opens it
+// (round 6): a tile takes chunks of kChunk storage units from one device counter, a unit's checkpoint
+// is row `storage` of ckpt, its 32 sublist pairs block `storage` of qlist -- what the training forward
+// leaves scales with what it WALKED, not with what is listed (a saturated tile abandons the rest of
+// its list; on realistic footprints 1-3 % of the listed entries are ever walked).  A last pass scans
+// the quadrant masks into row_base[slot]: the gradient rows of the backward are compact as well.
 //
 // Backward: GAUSSIAN-parallel, no cross-lane reductions, no atomics.  A wavefront runs eight
 // independent 8-lane systolic pipelines (two per 16-lane DPP row); a pipeline owns one work unit =
@@ -24,8 +29,9 @@
 // is fed from the checkpoint.  71 steps cover 64 pixels x 32 entries (10 % pipeline fill; the 16-lane,
 // 64-entry form it replaces paid 19 % and wasted half a bucket per sublist on average instead of a
 // quarter), and only (entry, quadrant) pairs the forward actually walked are ever evaluated.
-// Each lane finally stores 48-byte gradient rows at rows[slot*4 + quadrant]; gs_project_bwd sums
-// the rows of every Gaussian (contiguous slots) with plain coalesced loads.
+// Each lane finally stores 48-byte gradient rows at rows[row_base[slot] + rank of the quadrant among
+// the slot's existing rows]: the rows of a Gaussian (contiguous slots) are contiguous, and so are the
+// rows of consecutive Gaussians -- gs_project_bwd sums them with plain coalesced loads.
 //
 // Forward and backward evaluate alpha, w = alpha*T and T' = fma(-alpha, T, T) with the same
 // instruction sequence on the same inputs, so the backward re-derives the forward's contributor
@@ -49,36 +55,52 @@ struct BwdCheck {
     float* fwd_T;        // [C*H*W]
     int32_t* fwd_cnt;    // [C*H*W]
     float2* unit_out;    // [units][64]  (T behind the unit, contributors inside the unit)
-    int2* unit_hdr;      // [units]      (tile * 4 + quadrant, checkpoint row = position of the unit in its sublist's order)
+    int2* unit_hdr;      // [units]      (tile * 4 + quadrant, position of the unit in its sublist)
 };
 static BwdCheck g_bwd_check = {nullptr, nullptr, nullptr, nullptr};
+#define GS_IF_CHECK(...) __VA_ARGS__
+#else
+#define GS_IF_CHECK(...)
 #endif
+
+// Work unit of the backward: kUnit consecutive entries of one quadrant sublist (half a 64-entry bucket), with a
+// checkpoint of the quadrant's 64 pixel states in front of it.
+constexpr int kUnit = GS_UNIT;
+// Storage units a tile takes from its range's counter at a time (one returning atomic per kChunk work units; what a tile
+// leaves unused of its last chunk costs memory only -- the work-unit descriptors are published densely, see unit log).
+// Round 6, same box, blend_fwd stage at 1 M / 1080p: ONE counter for all tiles, chunks of 8 / 32 / 64: 0.47 / 0.395 / 0.398 ms
+// (30 k / 10 k / 8 k same-address device-scope atomics per frame) -- hence GS_WALK_RANGES counters, a cache line each.
+#ifndef GS_EXP_CHUNK
+#define GS_EXP_CHUNK 8
+#endif
+constexpr int kChunk = GS_EXP_CHUNK;
+// Work units a tile-wave has opened and not yet published, in LDS: (storage unit, position in the sublist * 4 + quadrant).
+// Published -- one atomic for the lot, descriptors dense in launch order -- when the log fills up and at the end of the tile.
+constexpr int kUnitLog = 128;
+// words of the walk state (include/gs_raster.h: GS_WALK_*)
+constexpr int kWalkUnits = GS_WALK_UNITS, kWalkStorage = GS_WALK_STORAGE, kWalkRows = GS_WALK_ROWS,
+              kWalkFlags = GS_WALK_FLAGS, kWalkSkip = GS_WALK_SKIP;
+constexpr int kScanThreads = 256, kScanPerThread = 32, kScanChunk = kScanThreads * kScanPerThread;   // 8192 slots per block
 
 struct BlendFwdArgs {
     const int32_t* tile_order;   // optional (gs_bin_count)
     int C, W, H, tw, tiles;
     const float4* rec;
     const float* bg;
-    const int32_t *isect_offsets, *bucket_offsets, *flatten_ids, *slots;
+    const int32_t *isect_offsets, *flatten_ids, *slots;
     float *out_colors, *out_alphas;
     // training-mode outputs
-    float4* ckpt;          // [8*n_buckets][64]  work-unit checkpoints
-    int2* qlist;           // [4*I] (flatten id, row slot): per tile 4 sublists of capacity len(tile)
+    float4* ckpt;          // [cap_units][64]    the pixel states in front of a work unit
+    int2* qlist;           // [cap_units][32]    (flatten id, row slot) pairs of a work unit, in sublist order
     int32_t* qcnt;         // [C*tiles*4]        sublist lengths
     uint8_t* qmask;        // [I] by slot        which quadrant rows of an intersection exist
-    int tail_clear;        // (GS_FWD_QMASK_SCATTER variant) 1: a tile that stops early zeroes the masks of the rest of its list itself
-    int32_t* unit_counter; // [1]
-    int4* unit_desc;       // [8*n_buckets]      (tile*4+quadrant, entries in the unit, first qlist pair, checkpoint row)
+    int4* unit_desc;       // [cap_units]        (tile*4+quadrant, position of the unit in its sublist, storage unit, 0)
+    int32_t* walk;         // walk state: counters (GS_WALK_*) + the chunk counts of the row-base scan
+    int cap_units;
+    unsigned long long* flags;   // the guard's flag word (overflow bits are ORed in) or nullptr
     const int64_t* guard;  // step guard (gs_guard_set) or nullptr
-#ifdef GS_BWD_CHECK
-    BwdCheck chk;
-#endif
+    GS_IF_CHECK(BwdCheck chk;)
 };
-
-// Work unit of the backward: kUnit consecutive entries of one quadrant sublist (half a 64-entry bucket), with a
-// checkpoint of the quadrant's 64 pixel states in front of it.
-constexpr int kUnit = 32;
-constexpr int kUnitFirst = 0x100;   // unit_desc.y flag: first unit of its sublist (no checkpoint was written for it)
 
 // -DGS_CLOCK_PROBE (tools/clock_probe.sh; never in the product build): every wave of the two blend kernels adds the shader-clock
 // cycles (s_memtime) and the constant-rate ticks (s_memrealtime) between its first and last instruction to two device
@@ -141,21 +163,33 @@ __device__ __forceinline__ void blend_pair(const float alpha, const bool ok, con
     T = Tn;
 }
 
-// The training instantiation needs 90 VGPRs left to itself (5 waves / SIMD: the 8160 tile-waves of a 1080p frame then run
-// in 1.6 rounds); held to 80 (5 spilled to scratch) it keeps 6 resident and is 2-3 % faster back to back -- but a kernel
+// The training instantiation is held to 5 waves / SIMD (the 8160 tile-waves of a 1080p frame then run in 1.6 rounds); held
+// to 80 VGPRs (5 spilled to scratch) it keeps 6 resident and is 2-3 % faster back to back -- but a kernel
 // that needs SCRATCH makes the runtime (re-)provision scratch memory for the queue it is launched on: once another
 // stream of the process had run the captured step, every eager launch of this kernel on the caller's stream stalled 0.5-2 ms
 // behind that (bench.py's eager stage profile read 0.76-2.4 ms for a 0.28 ms kernel on some boxes; HISTORY.md section 8b).
 // No kernel of the library uses scratch (tests/test_capi.py checks the compiler's resource report).  Inference: 8 waves.
-#ifndef GS_FWD_TRAIN_WAVES_PER_EU
-#define GS_FWD_TRAIN_WAVES_PER_EU 5
-#endif
-#define GS_FWD_ATTR __attribute__((amdgpu_waves_per_eu(CKPT ? GS_FWD_TRAIN_WAVES_PER_EU : 1, 8)))
-// Streaming clear of the quadrant masks (16-byte stores; `n` bytes from an arbitrarily aligned pointer) + the work-unit counter.
-__global__ __launch_bounds__(256) void qmask_clear_kernel(uint8_t* __restrict__ q, int64_t n, int32_t* __restrict__ unit_counter,
+#define GS_FWD_ATTR __attribute__((amdgpu_waves_per_eu(CKPT ? 5 : 1, 8)))
+
+// The number of list entries the training passes over the slots cover: the caller's n (a capacity under the step guard), cut
+// to the count the tile scan left in the guard's info block.
+__device__ __forceinline__ int64_t slots_in_use(int64_t n, const int64_t* guard) {
+    return guard != nullptr ? min(n, guard[0]) : n;
+}
+
+// Streaming clear of the quadrant masks (16-byte stores; `n` bytes from an arbitrarily aligned pointer) + of the walk state
+// (counters; the chunk counts of the row-base scan are written before they are read).
+__global__ __launch_bounds__(256) void qmask_clear_kernel(uint8_t* __restrict__ q, int64_t n_cap, int32_t* __restrict__ walk, int walk_ints,
                                                           const int64_t* __restrict__ guard) {
-    if (guard_tripped(guard)) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) unit_counter[0] = 0;
+    // The step guard as it stands when the CALL starts decides for all three of its kernels (walk[kWalkSkip]): the overflow flags
+    // this call's own blend raises must not stop its later tiles (the image stays complete) nor its scan (which reports what
+    // the walk needed).
+    const bool skip = guard_tripped(guard);
+    if (blockIdx.x == 0 && threadIdx.x == 0) walk[kWalkSkip] = skip ? 1 : 0;
+    if (skip) return;
+    const int64_t n = slots_in_use(n_cap, guard);
+    for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < walk_ints; i += (int)gridDim.x * 256)
+        if (i != kWalkSkip) walk[i] = 0;
     const int64_t head = min(n, (int64_t)((16 - ((uintptr_t)q & 15)) & 15));
     const int64_t n16 = (n - head) >> 4;
     uint4* q16 = reinterpret_cast<uint4*>(q + head);
@@ -167,26 +201,15 @@ __global__ __launch_bounds__(256) void qmask_clear_kernel(uint8_t* __restrict__ 
     }
 }
 
-// 1: the forward does not store the checkpoint in front of a sublist's FIRST work unit (its content is known: T = 1 inside
-// the image, nothing accumulated; the backward never reads it).  Measured on MI355X (tools/tune_variants.sh, round 3): 33 MB
-// fewer writes per frame, and the kernel 0.30 -> 0.35 ms -- same registers, same spills; not understood, so the stores stay.
-#ifndef GS_FWD_SKIP_FIRST_CKPT
-#define GS_FWD_SKIP_FIRST_CKPT 0
-#endif
-#ifndef GS_EXP_CKPT_EVERY
-#define GS_EXP_CKPT_EVERY 1   // (timing experiment only: > 1 breaks the backward)
-#endif
-#ifndef GS_FWD_QMASK_SCATTER
-#define GS_FWD_QMASK_SCATTER 0   // 1: the round-2 form (every entry stores its mask byte, tails cleared by the tile itself)
-#endif
-
 template <bool CKPT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const BlendFwdArgs a) {
     __shared__ float4 srec_all[WAVES][GS_BUCKET * 3];
+    __shared__ int2 ulog_all[CKPT ? WAVES : 1][CKPT ? kUnitLog : 1];
     float4* srec = srec_all[threadIdx.x >> 6];
+    int2* ulog = ulog_all[CKPT ? (threadIdx.x >> 6) : 0];
     const int ti = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
     if (ti >= a.C * a.tiles) return;   // wave-uniform
-    if (guard_tripped(a.guard)) return;
+    if (CKPT ? a.walk[kWalkSkip] != 0 : guard_tripped(a.guard)) return;   // (training: the guard at the start of the call, qmask_clear_kernel)
     GS_CLOCK_PROBE_SCOPE(0);
     const int t = a.tile_order ? a.tile_order[ti] : ti;   // launch slot -> tile (longest lists first)
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
@@ -198,14 +221,19 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
     const int lo = a.isect_offsets[t], hi = a.isect_offsets[t + 1];
     const int len = hi - lo;
     const int nb = (len + GS_BUCKET - 1) / GS_BUCKET;
-    const int bucket0 = a.bucket_offsets[t];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     float T[4], cr[4], cg[4], cb[4];   // T <= 1: live; T > 2^32: finished, T * 2^-64 final (blend_pair)
     int cnt[4] = {0, 0, 0, 0};   // wave-uniform sublist lengths
-#ifdef GS_BWD_CHECK
-    int taken[4] = {0, 0, 0, 0};   // per pixel: entries blended
-#endif
+    // storage of the work units a bucket's sublist entries can fall into (wave-uniform): [k][0] the unit that holds position
+    // cnt[k] at the start of the bucket (carried over when it is part-filled), [k][1..2] the units opened behind it
+    int us[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    int pool_next = 0, pool_left = 0, log_n = 0;   // this tile's chunk of storage units; unpublished work units in `ulog`
+    // the storage range this tile draws from: 1/32 of [0, cap_units) with a counter in a cache line of its own (launch slots
+    // take the ranges in turn: the tiles come longest list first, every range sees the same mix)
+    const int range_len = (a.cap_units / GS_WALK_RANGES) & ~(kChunk - 1), range0 = (ti & (GS_WALK_RANGES - 1)) * range_len;
+    int32_t* range_ctr = a.walk + GS_WALK_RANGE0 + 32 * (ti & (GS_WALK_RANGES - 1));
+    GS_IF_CHECK(int taken[4] = {0, 0, 0, 0};)   // per pixel: entries blended
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         cr[k] = cg[k] = cb[k] = 0.f;
@@ -215,19 +243,29 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
     const float qxlo[2] = {(float)x0 + 0.5f, (float)x0 + 8.5f}, qxhi[2] = {(float)x0 + 7.5f, (float)x0 + 15.5f};
     const float qylo[2] = {(float)y0 + 0.5f, (float)y0 + 8.5f}, qyhi[2] = {(float)y0 + 7.5f, (float)y0 + 15.5f};
 
+    // publishes the logged work units: one atomic for the lot, descriptors dense behind it
+    auto publish = [&]() {
+        if (log_n == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.walk + kWalkUnits, log_n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        __builtin_amdgcn_wave_barrier();   // (the log was written by lane 0; LDS operations of one wave complete in issue order)
+        for (int j = lane; j < log_n; j += 64) {
+            const int2 e = ulog[j];
+            if (base + j < a.cap_units) a.unit_desc[base + j] = make_int4(4 * t + (e.y & 3), e.y >> 2, e.x, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        log_n = 0;
+    };
+
     for (int b = 0; b < nb; ++b) {
         bool qa[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) qa[k] = __builtin_amdgcn_ballot_w64(px_live(T[k])) != 0ull;
-        if (!(qa[0] || qa[1] || qa[2] || qa[3])) {
-            // every pixel of the tile is finished: the rest of the list contributes nothing (its quadrant masks already
-            // read "no rows": the mask array is cleared by one streaming pass in front of the kernel)
-#if GS_FWD_QMASK_SCATTER
-            if (CKPT && a.tail_clear)
-                for (int i = lo + b * GS_BUCKET + lane; i < hi; i += 64) a.qmask[a.slots[i]] = 0;
-#endif
-            break;
-        }
+        // every pixel of the tile is finished: the rest of the list contributes nothing (its quadrant masks already
+        // read "no rows": the mask array is cleared by one streaming pass in front of the kernel)
+        if (!(qa[0] || qa[1] || qa[2] || qa[3])) break;
+        if (CKPT && log_n > kUnitLog - 8) publish();   // (a bucket opens at most two units per quadrant)
         const int first = lo + b * GS_BUCKET;
         const int m = min(GS_BUCKET, hi - first);
         bool hx[2] = {false, false}, hy[2] = {false, false};
@@ -287,63 +325,69 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
                     const bool ok = px_live(T[k]) && sigma >= 0.f && alpha >= kAlphaMin;
                     if (CKPT) {
                         if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;   // no pixel of the quadrant takes it: nothing to blend, nothing to list
-                        // the sublist entry that opens a new work unit saves the pixel states before it
+                        // the sublist entry that opens a new work unit takes a storage unit and saves the pixel states before it
                         const int pos = cnt[k] + (int)__popcll(cq[k]);
-                        if ((pos & (kUnit * GS_EXP_CKPT_EVERY - 1)) == 0 && (pos != 0 || !GS_FWD_SKIP_FIRST_CKPT))
-                            a.ckpt[((size_t)8 * bucket0 + (size_t)k * (2 * nb) + pos / kUnit) * 64 + lane] =
-                                make_float4(px_live(T[k]) ? T[k] : -1.f, cr[k], cg[k], cb[k]);   // (the backward's "finished" is T < 0)
+                        if ((pos & (kUnit - 1)) == 0) {
+                            if (pool_left == 0) {
+                                int base = 0;
+                                if (lane == 0) base = atomicAdd(range_ctr, kChunk);
+                                base = __builtin_amdgcn_readfirstlane(base);
+                                if (base + kChunk > range_len) {
+                                    // out of storage: the call is void (flag; every kernel behind it is a no-op under the step guard,
+                                    // the caller re-sizes from the counters, which keep counting) -- its stores land in the range's
+                                    // first chunk
+                                    if (lane == 0) {
+                                        atomicOr(a.walk + kWalkFlags, GS_FLAG_UNITS);
+                                        if (a.flags) atomicOr(a.flags, (unsigned long long)GS_FLAG_UNITS);
+                                    }
+                                    base = 0;
+                                }
+                                pool_next = range0 + base; pool_left = kChunk;
+                            }
+                            const int su = pool_next++;
+                            --pool_left;
+                            a.ckpt[(size_t)su * 64 + lane] = make_float4(px_live(T[k]) ? T[k] : -1.f, cr[k], cg[k], cb[k]);   // (the backward's "finished" is T < 0)
+                            if (lane == 0) ulog[log_n] = make_int2(su, (pos / kUnit) * 4 + k);
+                            ++log_n;
+                            const int w = pos / kUnit - cnt[k] / kUnit;
+                            if (w == 0) us[k][0] = su; else if (w == 1) us[k][1] = su; else us[k][2] = su;
+                        }
                         cq[k] |= 1ull << j;
                     }
-#ifdef GS_BWD_CHECK
-                    const float T_before = T[k];
-#endif
+                    GS_IF_CHECK(const float T_before = T[k];)
                     blend_pair(alpha, ok, r, g, bl, T[k], cr[k], cg[k], cb[k]);
-#ifdef GS_BWD_CHECK
-                    taken[k] += T[k] < T_before ? 1 : 0;   // (blended: T shrinks and stays live; stop rule: T jumps beyond 2^32; not taken: unchanged)
-#endif
+                    GS_IF_CHECK(taken[k] += T[k] < T_before ? 1 : 0;)   // (blended: T shrinks and stays live; stop rule: T jumps beyond 2^32; not taken: unchanged)
                 }
             }
         }
-        if (CKPT) {   // compacted quadrant sublists of (flatten id, slot) pairs, in list order
+        if (CKPT) {   // compacted quadrant sublists of (flatten id, slot) pairs, in list order, into the units' blocks
             int mybits = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                const int n_new = (int)__popcll(cq[k]);
                 if ((cq[k] >> lane) & 1) {
-                    a.qlist[(size_t)4 * lo + (size_t)k * len + cnt[k] + __popcll(cq[k] & lt_mask)] = make_int2(my_gid, my_slot);
+                    const int p = cnt[k] + (int)__popcll(cq[k] & lt_mask);
+                    const int w = p / kUnit - cnt[k] / kUnit;
+                    const int su = w == 0 ? us[k][0] : (w == 1 ? us[k][1] : us[k][2]);
+                    a.qlist[(size_t)su * kUnit + (p & (kUnit - 1))] = make_int2(my_gid, my_slot);
                     mybits |= 1 << k;
                 }
-                cnt[k] += __popcll(cq[k]);
+                if (n_new) {   // (wave-uniform) the unit the next bucket's first entry falls into, if it is part-filled
+                    const int w = (cnt[k] + n_new - 1) / kUnit - cnt[k] / kUnit;
+                    us[k][0] = w == 0 ? us[k][0] : (w == 1 ? us[k][1] : us[k][2]);
+                    cnt[k] += n_new;
+                }
             }
             // a scattered one-byte store leaves L2 as a 32-byte partial write (profiles/r03_traffic_calibration.json): only the
-            // entries some quadrant takes store their mask, the others keep the memset's zero
-#if GS_FWD_QMASK_SCATTER
-            if (lane < m) a.qmask[my_slot] = (uint8_t)mybits;
-#else
+            // entries some quadrant takes store their mask, the others keep the clear's zero
             if (mybits) a.qmask[my_slot] = (uint8_t)mybits;
-#endif
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (CKPT) {
-        // publish sublist lengths and one work unit per kUnit sublist entries
-        int nu[4], tot = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { nu[k] = (cnt[k] + kUnit - 1) / kUnit; tot += nu[k]; }
+        // publish the sublist lengths and the work units still in the log
         if (lane < 4) a.qcnt[4 * t + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
-        int base = 0;
-        if (tot > 0) {
-            if (lane == 0) base = atomicAdd(a.unit_counter, tot);
-            base = __builtin_amdgcn_readfirstlane(base);
-            int off = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // everything the backward needs to start on the unit without a second round of dependent loads
-                for (int u = lane; u < nu[k]; u += 64)
-                    a.unit_desc[base + off + u] = make_int4(4 * t + k, min(kUnit, cnt[k] - u * kUnit) | (u == 0 ? kUnitFirst : 0),
-                                                            4 * lo + k * len + u * kUnit, 8 * bucket0 + k * (2 * nb) + u);
-                off += nu[k];
-            }
-        }
+        publish();
     }
     float bgr = 0.f, bgg = 0.f, bgb = 0.f;
     if (a.bg) { bgr = a.bg[3 * cam]; bgg = a.bg[3 * cam + 1]; bgb = a.bg[3 * cam + 2]; }
@@ -357,10 +401,124 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
             a.out_colors[3 * o + 1] = cg[k] + Tf * bgg;
             a.out_colors[3 * o + 2] = cb[k] + Tf * bgb;
             a.out_alphas[o] = 1.f - Tf;
-#ifdef GS_BWD_CHECK
-            if (CKPT && a.chk.fwd_T) { a.chk.fwd_T[o] = Tf; a.chk.fwd_cnt[o] = taken[k]; }
-#endif
+            GS_IF_CHECK(if (CKPT && a.chk.fwd_T) { a.chk.fwd_T[o] = Tf; a.chk.fwd_cnt[o] = taken[k]; })
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row_base[s] = number of gradient rows in front of slot s = exclusive scan of popcount(qmask), s = 0 .. n (n + 1 entries: the
+// last one is the total).  Three small launches over chunks of 8192 slots: per-chunk counts, a one-block scan of the counts
+// (which also publishes the total, checks it against cap_rows and writes the call's walk record), per-chunk scan + offset.
+// (A chained single-pass scan with decoupled look-back was measured first: one thread walking back over the descriptors of
+//  400 co-resident blocks cost 0.25 ms at 3.3 M slots and 3.7 ms at 57 M -- every hop an uncached device-scope load.)
+struct RowScanArgs {
+    const uint8_t* qmask;
+    int32_t* row_base;
+    int32_t* walk;       // counters; the chunk counts / offsets live behind them (walk + GS_WALK_WORDS)
+    int64_t n_cap, cap_rows;
+    unsigned long long* flags;
+    const int64_t* guard;
+    volatile int64_t* mirror;   // page-locked host memory (gs_walk_mirror_set) or nullptr
+};
+
+// the 32 mask bytes of a thread as 8 words of per-byte popcounts (bytes at or beyond n count as 0: they may never have been
+// cleared); returns their sum
+__device__ __forceinline__ int32_t row_counts32(const uint8_t* __restrict__ qmask, int64_t i0, int64_t n, uint32_t (&w)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = 0u;
+    if (i0 + kScanPerThread <= n) {
+        const uint4 x = reinterpret_cast<const uint4*>(qmask + i0)[0], y = reinterpret_cast<const uint4*>(qmask + i0)[1];
+        w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; w[4] = y.x; w[5] = y.y; w[6] = y.z; w[7] = y.w;
+    } else {
+        for (int j = 0; j < kScanPerThread; ++j)
+            if (i0 + j < n) w[j >> 2] |= (uint32_t)qmask[i0 + j] << (8 * (j & 3));
+    }
+    int32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        // bytes hold 4-bit masks: per-byte popcounts by two fold steps; their sum by one multiply
+        uint32_t v = w[j] & 0x0f0f0f0fu;
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        w[j] = v;
+        tot += (int32_t)((v * 0x01010101u) >> 24);
+    }
+    return tot;
+}
+
+__global__ __launch_bounds__(kScanThreads) void row_count_kernel(const RowScanArgs a) {
+    __shared__ int32_t scratch[20];
+    if (a.walk[kWalkSkip] != 0) return;
+    const int64_t n = slots_in_use(a.n_cap, a.guard);
+    const int64_t c0 = (int64_t)blockIdx.x * kScanChunk;
+    if (c0 > n) return;   // (block-uniform; entry n -- the total -- belongs to the chunk that holds it)
+    uint32_t w[8];
+    const int32_t tot = row_counts32(a.qmask, c0 + (int64_t)threadIdx.x * kScanPerThread, n, w);
+    int32_t block_tot;
+    block_excl_scan_add<int32_t>(tot, scratch, &block_tot);
+    if (threadIdx.x == 0) a.walk[GS_WALK_WORDS + blockIdx.x] = block_tot;
+}
+
+__global__ __launch_bounds__(1024) void row_chunk_scan_kernel(const RowScanArgs a) {
+    __shared__ int32_t scratch[20];
+    if (a.walk[kWalkSkip] != 0) return;
+    const int64_t n = slots_in_use(a.n_cap, a.guard);
+    const int nb = (int)(n / kScanChunk) + 1;
+    int32_t* part = a.walk + GS_WALK_WORDS;
+    // thread t owns the contiguous run [t * per, (t + 1) * per) of chunk counts
+    const int per = (nb + 1023) / 1024;
+    const int j0 = (int)threadIdx.x * per, j1 = min(nb, j0 + per);
+    int32_t mine = 0;
+    for (int j = j0; j < j1; ++j) mine += part[j];
+    int32_t total;
+    int32_t run = block_excl_scan_add<int32_t>(mine, scratch, &total);
+    for (int j = j0; j < j1; ++j) { const int32_t c = part[j]; part[j] = run; run += c; }
+    if (threadIdx.x == 0) {
+        // what the walk needed of cap_units: every range as long as the fullest one
+        int32_t fullest = 0;
+        for (int r = 0; r < GS_WALK_RANGES; ++r) fullest = max(fullest, a.walk[GS_WALK_RANGE0 + 32 * r]);
+        a.walk[kWalkStorage] = GS_WALK_RANGES * fullest;
+        a.walk[kWalkRows] = total;
+        int fl = a.walk[kWalkFlags];   // (the blend's tiles have all finished: its flag is final)
+        if ((int64_t)total > a.cap_rows) {
+            fl |= GS_FLAG_ROWS;
+            a.walk[kWalkFlags] = fl;
+            if (a.flags) atomicOr(a.flags, (unsigned long long)GS_FLAG_ROWS);
+        }
+        if (a.mirror) {   // the call's walk record, for a host that waits on an event behind this launch
+            a.mirror[0] = a.walk[kWalkUnits]; a.mirror[1] = a.walk[kWalkStorage]; a.mirror[2] = total; a.mirror[3] = fl;
+            __threadfence_system();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void row_base_kernel(const RowScanArgs a) {
+    __shared__ int32_t scratch[20];
+    if (a.walk[kWalkSkip] != 0) return;
+    const int64_t n = slots_in_use(a.n_cap, a.guard);
+    const int64_t c0 = (int64_t)blockIdx.x * kScanChunk;
+    if (c0 > n) return;
+    const int64_t i0 = c0 + (int64_t)threadIdx.x * kScanPerThread;
+    uint32_t w[8];
+    const int32_t tot = row_counts32(a.qmask, i0, n, w);
+    int32_t block_tot;
+    int32_t run = block_excl_scan_add<int32_t>(tot, scratch, &block_tot) + a.walk[GS_WALK_WORDS + blockIdx.x];
+    int32_t o[kScanPerThread];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t ex = w[j] * 0x01010100u;   // exclusive prefix of the four byte counts (sums stay below 256)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) o[4 * j + bb] = run + (int32_t)((ex >> (8 * bb)) & 0xffu);
+        run += (int32_t)((w[j] * 0x01010101u) >> 24);
+    }
+    if (i0 + kScanPerThread <= n + 1) {
+        int4* dst = reinterpret_cast<int4*>(a.row_base + i0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = make_int4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
+    } else {
+        for (int j = 0; j < kScanPerThread; ++j)
+            if (i0 + j <= n) a.row_base[i0 + j] = o[j];
     }
 }
 
@@ -368,37 +526,27 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
 struct BlendBwdArgs {
     int C, W, H, tw, tiles;
     const float4* rec;
-    const int32_t* unit_counter;
+    const int32_t* walk;
     const int2* qlist;
+    const int32_t* qcnt;
     const int4* unit_desc;
     const float4* ckpt;
+    const uint8_t* qmask;
+    const int32_t* row_base;
+    int cap_units;
     const float *out_colors, *out_alphas, *v_colors, *v_alphas;
-    float4* rows;   // [I*4][3]
+    float4* rows;   // [row pairs][3]
     const int64_t* guard;
-#ifdef GS_BWD_CHECK
-    BwdCheck chk;
-#endif
+    GS_IF_CHECK(BwdCheck chk;)
 };
 
-#ifndef GS_BWD_WAVES
-#define GS_BWD_WAVES 4
-#endif
-#ifndef GS_BWD_PXY_TABLE
-#define GS_BWD_PXY_TABLE 0
-#endif
-constexpr int kBwdWaves = GS_BWD_WAVES;
+constexpr int kBwdWaves = 4;
 constexpr int kPipeLanes = 8;                       // lanes per systolic pipeline (two pipelines share a 16-lane DPP row)
 constexpr int kPerLane = kUnit / kPipeLanes;        // 4 entries per lane
 constexpr int kUnitsPerWave = 64 / kPipeLanes;      // 8
-// -DGS_EXP_HALFQ=155 (tools/blend_time.py A/B; numerically WRONG, timing only): the upper bound of half-quadrant (8 x 4 pixel) work
-// units for this kernel -- every unit streams 32 instead of 64 pixels (39 instead of 71 steps, half the pixel loads), and there
-// are GS_EXP_HALFQ / 100 times as many units (an entry that touches both halves of a quadrant is listed twice: 1.55 on the bench
-// scene, tools/unit_mask_stats.py); the surplus units re-run existing ones.  Round 5, DESIGN.md section 8.
-#ifdef GS_EXP_HALFQ
-constexpr int kUnitPixels = 32;
-#else
+// (Round 5 bounded half-quadrant -- 8 x 4 pixel -- work units with a timing build: -15 to -23 us for this kernel at the 1.55 x
+//  unit count they would have, before twice the rows in the row sum; not built.  HISTORY.md, profiles/r05_halfq_bound.txt.)
 constexpr int kUnitPixels = 64;
-#endif
 constexpr int kBwdSteps = kUnitPixels + kPipeLanes - 1;      // 71
 
 __device__ __forceinline__ float dpp_row_shr1(float v) {
@@ -457,66 +605,45 @@ __device__ __forceinline__ void bwd_pair(EntryState& e, const float4 d0, const f
     P = Pn;
 }
 
-#ifdef GS_BWD_WAVES_PER_EU
-#define GS_BWD_ATTR __attribute__((amdgpu_waves_per_eu(GS_BWD_WAVES_PER_EU, GS_BWD_WAVES_PER_EU)))
-#else
-#define GS_BWD_ATTR
-#endif
-__global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(const BlendBwdArgs a) {
+__global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBwdArgs a) {
     __shared__ float4 sd0_all[kBwdWaves][kUnitsPerWave][64];   // 8 KB per wave: v_r, v_g, v_b, E of the unit's 64 pixels
     __shared__ float2 sck_all[kBwdWaves][kUnitsPerWave][64];   // 4 KB per wave: checkpoint T, P = checkpoint colour . v
-#if GS_BWD_PXY_TABLE
-    __shared__ float2 pxy[64];   // (p & 7, p >> 3) as floats: one LDS read instead of and / shift / two conversions per step
-    if (threadIdx.x < 64) pxy[threadIdx.x] = make_float2((float)(threadIdx.x & 7), (float)(threadIdx.x >> 3));
-    __syncthreads();
-#endif
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pipe = lane / kPipeLanes, r = lane & (kPipeLanes - 1);
     if (guard_tripped(a.guard)) return;
-#ifdef GS_EXP_HALFQ
-    const int n_real = max(a.unit_counter[0], 1);
-    const int n_units = (int)((int64_t)n_real * GS_EXP_HALFQ / 100);
-    const int unit_run = ((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave + pipe;
-    const int unit = unit_run % n_real;
-    if (((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave >= n_units) return;
-#else
-    const int n_units = a.unit_counter[0];
+    const int n_units = min(a.walk[kWalkUnits], a.cap_units);
     const int unit = ((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave + pipe;
     if (((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave >= n_units) return;   // wave-uniform
-#endif
     GS_CLOCK_PROBE_SCOPE(2);
-#ifdef GS_EXP_HALFQ
-    const bool valid = unit_run < n_units;
-#else
     const bool valid = unit < n_units;
-#endif
     float4* sd0 = sd0_all[wave][pipe];
     float2* sck = sck_all[wave][pipe];
 
     int4 ud = make_int4(0, 0, 0, 0);
     if (valid) ud = a.unit_desc[unit];
-    const int tq = ud.x, n_in = ud.y & (kUnitFirst - 1);
-    const bool first_unit = (ud.y & kUnitFirst) != 0;   // the sublist starts here: every pixel inside the image has T = 1, no colour yet
+    const int tq = ud.x, su = ud.z;
+    const bool first_unit = ud.y == 0;   // the sublist starts here: every pixel inside the image has T = 1, no colour yet
     const int t = tq >> 2, q = tq & 3;
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
     const int tyi = tt / a.tw, txi = tt - tyi * a.tw;
     const int qx0 = txi * GS_TILE + 8 * (q & 1), qy0 = tyi * GS_TILE + 8 * (q >> 1);
     const float fx0 = (float)qx0 + 0.5f, fy0 = (float)qy0 + 0.5f;
     // the unit's checkpoint: 64 pixel states in front of its first entry (T < 0: pixel finished or outside the image)
-    const float4* ckp = a.ckpt + (size_t)ud.w * 64;
+    const float4* ckp = a.ckpt + (size_t)su * 64;
 
     // ---- prologue, three dependent memory round trips in all (unit descriptor above; everything below in two batches).
     // Written branch-free on purpose: with the loads inside `if (inside the image)` / `if (entry exists)` blocks hipcc waits
     // for each pixel's and each entry's loads before it issues the next ones -- 8 + 2 x 4 serialised round trips per wave in
     // front of a main loop of comparable length, with three waves per SIMD to hide them (round 3: 0.45 -> see DESIGN.md).
     // Out-of-range pixels / entries load from a clamped, valid address and are masked afterwards.
-    // batch 1: the sublist's (flatten id, slot) pairs and the quadrant's 64 pixels, 8 per lane of the pipeline
+    // batch 1: the sublist's length, this lane's four (flatten id, slot) pairs -- 32 contiguous bytes of the unit's block; pairs
+    // past the end of the sublist are whatever the block held before -- and the quadrant's 64 pixels, 8 per lane of the pipeline
+    const int n_sub = valid ? a.qcnt[tq] : 0;
     int2 gs[kPerLane];
-#pragma unroll
-    for (int i = 0; i < kPerLane; ++i) {
-        const int en = kPerLane * r + i;
-        gs[i] = a.qlist[(size_t)ud.z + (en < n_in ? en : 0)];
-        if (!valid) gs[i] = make_int2(0, 0);   // (pipelines past the last unit read pair 0, which nobody may have written)
+    {
+        const int4* qp = reinterpret_cast<const int4*>(a.qlist + (size_t)su * kUnit + kPerLane * r);
+        const int4 g0 = qp[0], g1 = qp[1];
+        gs[0] = make_int2(g0.x, g0.y); gs[1] = make_int2(g0.z, g0.w); gs[2] = make_int2(g1.x, g1.y); gs[3] = make_int2(g1.z, g1.w);
     }
     constexpr int kPix = kUnitPixels / kPipeLanes;
     float l_vr[kPix], l_vg[kPix], l_vb[kPix], l_oa[kPix], l_cr[kPix], l_cg[kPix], l_cb[kPix], l_va[kPix];
@@ -533,12 +660,18 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
         l_va[i] = vap[o];
         l_ck[i] = ckp[p];
     }
-    // batch 2: the entries' packed records (addresses from batch 1), in flight while the pixels are staged
+    // batch 2: the entries' packed records, their slots' row bases and quadrant masks (addresses from batch 1), in flight
+    // while the pixels are staged
+    const int n_in = min(kUnit, n_sub - ud.y * kUnit);   // entries of the sublist that fall into this unit
     float4 rq[kPerLane][3];
+    int rbase[kPerLane], rmask[kPerLane];
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
-        const float4* rp = a.rec + 3 * (size_t)gs[i].x;
+        const bool has = kPerLane * r + i < n_in;
+        const float4* rp = a.rec + 3 * (size_t)(has ? gs[i].x : 0);
         rq[i][0] = rp[0]; rq[i][1] = rp[1]; rq[i][2] = rp[2];
+        const int sl = has ? gs[i].y : 0;
+        rbase[i] = a.row_base[sl]; rmask[i] = (int)a.qmask[sl];
     }
 #pragma unroll
     for (int i = 0; i < kPix; ++i) {
@@ -557,12 +690,13 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
     }
 
     EntryState e[kPerLane];
-    int slot[kPerLane];
+    int row[kPerLane];
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
         const int en = kPerLane * r + i;
         e[i].has = en < n_in;
-        slot[i] = e[i].has ? gs[i].y : 0;
+        // the row of (slot, quadrant): the slot's first row + the number of its existing rows in front of this quadrant
+        row[i] = rbase[i] + __popc((unsigned)rmask[i] & ((1u << q) - 1u));
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 q0 = e[i].has ? rq[i][0] : z4, q1 = e[i].has ? rq[i][1] : z4, q2 = e[i].has ? rq[i][2] : z4;
         e[i].mx = q0.x; e[i].my = q0.y; e[i].hA = q0.z; e[i].Bc = q0.w; e[i].hC = q1.x; e[i].op = q1.y;
@@ -575,13 +709,8 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
     __builtin_amdgcn_wave_barrier();
 
     float T_out = -1.f, P_out = 0.f;
-#ifdef GS_BWD_CHECK
-    float D_out = -1.f, C_out = 0.f;   // travel with the pixel like T and P: last live transmittance, entries taken in this unit
-    if (valid && r == 0 && a.chk.unit_hdr) a.chk.unit_hdr[unit] = make_int2(tq, ud.w);
-#endif
-#ifdef GS_BWD_UNROLL
-#pragma unroll GS_BWD_UNROLL
-#endif
+    // (check build: D and C travel with the pixel like T and P -- last live transmittance, entries taken in this unit)
+    GS_IF_CHECK(float D_out = -1.f, C_out = 0.f; if (valid && r == 0 && a.chk.unit_hdr) a.chk.unit_hdr[unit] = make_int2(tq, ud.y);)
     for (int s = 0; s < kBwdSteps; ++s) {
         float T = dpp_row_shr1(T_out), P = dpp_row_shr1(P_out);
         const int p = s - r;
@@ -589,37 +718,25 @@ __global__ __launch_bounds__(kBwdWaves * 64) GS_BWD_ATTR void blend_bwd_kernel(c
         const int pc = min(max(p, 0), kUnitPixels - 1);
         const float4 d0 = sd0[pc];
         const float2 ck = sck[pc];
-#if GS_BWD_PXY_TABLE
-        const float2 rel = pxy[pc];
-        const float2 d1 = make_float2(fx0 + rel.x, fy0 + rel.y);   // pixel centre
-#else
         const float2 d1 = make_float2(fx0 + (float)(pc & 7), fy0 + (float)(pc >> 3));   // pixel centre
-#endif
         if (r == 0) { T = ck.x; P = ck.y; }   // head of the pipeline: fed from the checkpoint, not from the lane below
         T = act ? T : -1.f;   // pipeline fill / drain: nothing contributes
-#ifdef GS_BWD_CHECK
-        float D = dpp_row_shr1(D_out), Cn = dpp_row_shr1(C_out);
-        if (r == 0) { D = ck.x; Cn = 0.f; }
-        if (!act) { D = -1.f; Cn = 0.f; }
+        GS_IF_CHECK(float D = dpp_row_shr1(D_out), Cn = dpp_row_shr1(C_out); if (r == 0) { D = ck.x; Cn = 0.f; } if (!act) { D = -1.f; Cn = 0.f; })
 #pragma unroll
         for (int i = 0; i < kPerLane; ++i) {
-            const float T_before = T;
+            GS_IF_CHECK(const float T_before = T;)
             bwd_pair(e[i], d0, d1, T, P);
-            if (T > 0.f && T < T_before) { D = T; Cn += 1.f; }   // (contributed; the stop rule leaves T = -1 and D at the final value)
+            GS_IF_CHECK(if (T > 0.f && T < T_before) { D = T; Cn += 1.f; })   // (contributed; the stop rule leaves T = -1 and D at the final value)
         }
-        D_out = D; C_out = Cn;
-        if (valid && act && r == kPipeLanes - 1 && a.chk.unit_out) a.chk.unit_out[(size_t)unit * 64 + p] = make_float2(D, Cn);
-#else
-#pragma unroll
-        for (int i = 0; i < kPerLane; ++i) bwd_pair(e[i], d0, d1, T, P);
-#endif
+        GS_IF_CHECK(D_out = D; C_out = Cn;
+                    if (valid && act && r == kPipeLanes - 1 && a.chk.unit_out) a.chk.unit_out[(size_t)unit * 64 + p] = make_float2(D, Cn);)
         T_out = T; P_out = P;
     }
 
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
         if (e[i].has) {
-            float4* rp = a.rows + (GS_ROW_FLOATS / 4) * ((size_t)slot[i] * 4 + q);
+            float4* rp = a.rows + (GS_ROW_FLOATS / 4) * (size_t)row[i];
             // v_opacity = sum vis * v_alpha = -sum(vs) / opacity   (vs = -opacity*vis*v_alpha)
             const float v_op = e[i].op > 0.f ? (float)(-e[i].s_vs / (acc_t)e[i].op) : 0.f;
             rp[0] = make_float4((float)e[i].s_mx, (float)e[i].s_my, (float)e[i].s_ax, (float)e[i].s_ay);
@@ -650,98 +767,93 @@ extern "C" int gs_debug_clock_probe(int64_t* out4, int reset) {
 }
 #endif
 
+extern "C" size_t gs_walk_state_ints(int64_t n_isects) {
+    if (n_isects < 0) return 0;
+    return (size_t)GS_WALK_WORDS + (size_t)(n_isects / kScanChunk + 1);
+}
+
 extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
-                            const float* backgrounds, const int32_t* isect_offsets,
-                            const int32_t* bucket_offsets, const int32_t* tile_order, const int32_t* flatten_ids,
-                            const int32_t* slots, int64_t n_isects, float* render_colors,
-                            float* render_alphas, float* ckpt, int32_t* qlist, int32_t* qcnt,
-                            uint8_t* qmask, int32_t* unit_counter, int32_t* unit_desc) {
+                            const float* backgrounds, const int32_t* isect_offsets, const int32_t* tile_order,
+                            const int32_t* flatten_ids, const int32_t* slots, int64_t n_isects, float* render_colors,
+                            float* render_alphas, float* ckpt, int32_t* qlist, int32_t* qcnt, uint8_t* qmask,
+                            int32_t* unit_desc, int64_t cap_units, int32_t* row_base, int64_t cap_rows, int32_t* walk_state) {
     GS_REQUIRE(C >= 1 && width > 0 && height > 0 && n_isects >= 0, "C>=1, positive image size, n_isects>=0");
-    GS_REQUIRE(isect_offsets && bucket_offsets && render_colors && render_alphas, "null pointer");
+    GS_REQUIRE(isect_offsets && render_colors && render_alphas, "null pointer");
     const bool train = ckpt != nullptr;
-    GS_REQUIRE(!train || (qlist && qcnt && qmask && unit_counter && unit_desc && slots), "training mode needs every list output");
-    // work-unit descriptors carry the index of a unit's first qlist pair (< 4 * I) as int32
-    GS_REQUIRE(!train || 4 * n_isects <= (int64_t)INT32_MAX, "training mode holds at most 2^29 intersections per call (int32 work-unit descriptors)");
+    GS_REQUIRE(!train || (qlist && qcnt && qmask && unit_desc && row_base && walk_state && slots), "training mode needs every list output");
+    GS_REQUIRE(!train || (cap_units >= kChunk * GS_WALK_RANGES && cap_units < (1ll << 26) && cap_rows >= 0 && cap_rows < (1ll << 31)),
+               "training mode: 256 <= cap_units < 2^26 work units, cap_rows < 2^31 gradient rows");
+    GS_REQUIRE(!train || n_isects < (1ll << 31) - kScanChunk, "training mode: the slots of a call are indexed by int32");
+    GS_REQUIRE(!train || (((uintptr_t)qmask & 15) == 0 && ((uintptr_t)row_base & 15) == 0 && ((uintptr_t)walk_state & 7) == 0),
+               "training mode: qmask / row_base 16-byte aligned, walk_state 8-byte aligned");
     BlendFwdArgs a;
     a.C = C; a.W = width; a.H = height;
     a.tw = (width + GS_TILE - 1) / GS_TILE;
     a.tiles = a.tw * ((height + GS_TILE - 1) / GS_TILE);
     a.rec = reinterpret_cast<const float4*>(rec); a.bg = backgrounds; a.isect_offsets = isect_offsets;
-    a.bucket_offsets = bucket_offsets; a.flatten_ids = flatten_ids; a.slots = slots;
+    a.flatten_ids = flatten_ids; a.slots = slots;
     a.out_colors = render_colors; a.out_alphas = render_alphas;
     a.ckpt = reinterpret_cast<float4*>(ckpt); a.qlist = reinterpret_cast<int2*>(qlist); a.qcnt = qcnt; a.qmask = qmask;
-    a.unit_counter = unit_counter; a.unit_desc = reinterpret_cast<int4*>(unit_desc);
+    a.unit_desc = reinterpret_cast<int4*>(unit_desc); a.walk = walk_state; a.cap_units = (int)cap_units;
     a.tile_order = tile_order;
     a.guard = current_guard().info;
-#ifdef GS_BWD_CHECK
-    a.chk = g_bwd_check;
-#endif
+    a.flags = a.guard ? reinterpret_cast<unsigned long long*>(const_cast<int64_t*>(a.guard) + 3) : nullptr;
+    GS_IF_CHECK(a.chk = g_bwd_check;)
     const unsigned n_tiles = (unsigned)(C * a.tiles);
     hipStream_t st = (hipStream_t)stream;
     // 4 tiles (waves) per workgroup: measured equal to single-wave workgroups (0.33-0.36 ms at the bench
     // size).  One box of the pool ran the single-wave form at 0.63 ms with every other kernel at its usual
     // time; the cause was not established, a quarter of the workgroups is the conservative launch shape.
-#ifndef GS_FWD_WAVES
-#define GS_FWD_WAVES 4
-#endif
-    constexpr int kFwdWaves = GS_FWD_WAVES;
+    constexpr int kFwdWaves = 4;
     const dim3 grid((n_tiles + kFwdWaves - 1) / kFwdWaves), block(64 * kFwdWaves);
-    a.tail_clear = 1;
     if (train) {
-#if GS_FWD_QMASK_SCATTER
-        a.tail_clear = !(n_isects / (int64_t)n_tiles >= 1024);
-        if (!a.tail_clear) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
-        GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));
-#elif defined(GS_FWD_QMASK_HIPMEMSET)
-        if (n_isects > 0) GS_HIP_CHECK(hipMemsetAsync(qmask, 0, (size_t)n_isects, st));
-        GS_HIP_CHECK(hipMemsetAsync(unit_counter, 0, sizeof(int32_t), st));
-#else
-        // one streaming clear of the quadrant masks (I bytes, 16-byte stores) and of the work-unit counter: entries no quadrant
+        // one streaming clear of the quadrant masks (I bytes, 16-byte stores) and of the walk state: entries no quadrant
         // takes, and the tails of lists a saturated tile abandons, then need no store at all
+        const int walk_ints = (int)gs_walk_state_ints(n_isects);
         const unsigned cg = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (n_isects / 16 + 255) / 256));
-        hipLaunchKernelGGL(qmask_clear_kernel, dim3(cg), dim3(256), 0, st, qmask, n_isects, unit_counter, a.guard);
+        hipLaunchKernelGGL(qmask_clear_kernel, dim3(cg), dim3(256), 0, st, qmask, n_isects, walk_state, walk_ints, a.guard);
         GS_LAUNCH_CHECK("qmask_clear_kernel");
-#endif
         hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves>), grid, block, 0, st, a);
+        GS_LAUNCH_CHECK("blend_fwd_kernel");
+        RowScanArgs s;
+        s.qmask = qmask; s.row_base = row_base; s.walk = walk_state; s.n_cap = n_isects; s.cap_rows = cap_rows;
+        s.flags = a.flags; s.guard = a.guard; s.mirror = current_walk_mirror();
+        const unsigned chunks = (unsigned)(n_isects / kScanChunk + 1);
+        hipLaunchKernelGGL(row_count_kernel, dim3(chunks), dim3(kScanThreads), 0, st, s);
+        hipLaunchKernelGGL(row_chunk_scan_kernel, dim3(1), dim3(1024), 0, st, s);
+        hipLaunchKernelGGL(row_base_kernel, dim3(chunks), dim3(kScanThreads), 0, st, s);
+        GS_LAUNCH_CHECK("row_base_kernel");
     } else {
         hipLaunchKernelGGL((blend_fwd_kernel<false, kFwdWaves>), grid, block, 0, st, a);
+        GS_LAUNCH_CHECK("blend_fwd_kernel");
     }
-    GS_LAUNCH_CHECK("blend_fwd_kernel");
     return GS_OK;
 }
 
 extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
-                            const int32_t* isect_offsets, const int32_t* bucket_offsets,
-                            int64_t n_buckets,
-                            const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_counter,
-                            const int32_t* unit_desc, const float* ckpt, const float* render_colors,
-                            const float* render_alphas, const float* v_render_colors,
+                            const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_desc, int64_t cap_units,
+                            const float* ckpt, const uint8_t* qmask, const int32_t* row_base, const int32_t* walk_state,
+                            const float* render_colors, const float* render_alphas, const float* v_render_colors,
                             const float* v_render_alphas, float* rows) {
-    GS_REQUIRE(C >= 1 && width > 0 && height > 0 && n_buckets >= 0, "C>=1, positive image size, n_buckets>=0");
-    if (n_buckets == 0) return GS_OK;
-    GS_REQUIRE(rec && isect_offsets && bucket_offsets && qlist && qcnt && unit_counter && unit_desc && ckpt, "null list pointer");
+    GS_REQUIRE(C >= 1 && width > 0 && height > 0 && cap_units >= 0 && cap_units < (1ll << 26), "C>=1, positive image size, 0 <= cap_units < 2^26");
+    if (cap_units == 0) return GS_OK;
+    GS_REQUIRE(rec && qlist && qcnt && unit_desc && ckpt && qmask && row_base && walk_state, "null list pointer");
     GS_REQUIRE(render_colors && render_alphas && v_render_colors && rows, "null image pointer");
     BlendBwdArgs a;
     a.C = C; a.W = width; a.H = height;
     a.tw = (width + GS_TILE - 1) / GS_TILE;
     a.tiles = a.tw * ((height + GS_TILE - 1) / GS_TILE);
     a.rec = reinterpret_cast<const float4*>(rec);
-    a.qlist = reinterpret_cast<const int2*>(qlist); a.unit_counter = unit_counter;
-    a.unit_desc = reinterpret_cast<const int4*>(unit_desc);
-    a.ckpt = reinterpret_cast<const float4*>(ckpt); a.out_colors = render_colors;
+    a.qlist = reinterpret_cast<const int2*>(qlist); a.qcnt = qcnt; a.walk = walk_state;
+    a.unit_desc = reinterpret_cast<const int4*>(unit_desc); a.cap_units = (int)cap_units;
+    a.ckpt = reinterpret_cast<const float4*>(ckpt); a.qmask = qmask; a.row_base = row_base;
+    a.out_colors = render_colors;
     a.out_alphas = render_alphas; a.v_colors = v_render_colors; a.v_alphas = v_render_alphas;
     a.rows = reinterpret_cast<float4*>(rows);
     a.guard = current_guard().info;
-#ifdef GS_BWD_CHECK
-    a.chk = g_bwd_check;
-#endif
-    // upper bound on work units: 4 quadrant sublists per tile, each at most as long as the tile list
-#ifdef GS_EXP_HALFQ
-    const int64_t max_units = 8 * n_buckets * GS_EXP_HALFQ / 100 + 64;
-#else
-    const int64_t max_units = 8 * n_buckets;
-#endif
-    const unsigned grid = (unsigned)((max_units + kUnitsPerWave * kBwdWaves - 1) / (kUnitsPerWave * kBwdWaves));
+    GS_IF_CHECK(a.chk = g_bwd_check;)
+    // one pipeline per work unit, eight per wave: the grid covers the capacity, waves past the published count return at once
+    const unsigned grid = (unsigned)((cap_units + kUnitsPerWave * kBwdWaves - 1) / (kUnitsPerWave * kBwdWaves));
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(kBwdWaves * 64), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("blend_bwd_kernel");
     return GS_OK;

@@ -16,10 +16,17 @@ static thread_local Guard g_guard = {nullptr, 0, 0, 0};
 Guard current_guard() { return g_guard; }
 static thread_local int64_t* g_info_mirror = nullptr;
 int64_t* current_info_mirror() { return g_info_mirror; }
+static thread_local int64_t* g_walk_mirror = nullptr;
+int64_t* current_walk_mirror() { return g_walk_mirror; }
 }  // namespace gs
 
 extern "C" int gs_info_mirror_set(int64_t* info_host_mapped) {
     gs::g_info_mirror = info_host_mapped;
+    return GS_OK;
+}
+
+extern "C" int gs_walk_mirror_set(int64_t* walk_host_mapped) {
+    gs::g_walk_mirror = walk_host_mapped;
     return GS_OK;
 }
 
@@ -44,9 +51,12 @@ extern "C" int gs_guard_set_call(const int64_t* info_dev, int64_t cap_isects, in
 namespace gs {
 __global__ void step_status_kernel(const int64_t* __restrict__ info, const int64_t* __restrict__ applied,
                                    volatile int64_t* __restrict__ status, const float* __restrict__ loss3,
-                                   float* __restrict__ loss_ring, int ring_len) {
+                                   float* __restrict__ loss_ring, int ring_len, const int32_t* __restrict__ walk) {
     if (threadIdx.x < 4) status[threadIdx.x] = info[threadIdx.x];
     if (threadIdx.x == 4) status[4] = applied ? applied[0] : 0;
+    // what the walk of this step needed (a step the guard skipped before its blend leaves the cleared words of the step before)
+    if (threadIdx.x == 5) status[5] = walk ? walk[GS_WALK_STORAGE] : 0;
+    if (threadIdx.x == 6) status[6] = walk ? walk[GS_WALK_ROWS] : 0;
     // per-step loss log: slot (applied - 1) mod ring_len, written only by steps the guard did not skip, so a replayed
     // step overwrites nothing but its own slot
     if (loss_ring != nullptr && applied != nullptr && info[3] == 0 && threadIdx.x < 3 && applied[0] > 0)
@@ -56,17 +66,24 @@ __global__ void step_status_kernel(const int64_t* __restrict__ info, const int64
 }  // namespace gs
 
 extern "C" int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied_dev, int64_t* status,
-                              const float* loss3_dev, float* loss_ring_dev, int ring_len) {
+                              const float* loss3_dev, float* loss_ring_dev, int ring_len, const int32_t* walk_state) {
     if (!info_dev || !status || (loss_ring_dev && (!loss3_dev || ring_len <= 0))) {
         gs::set_error("invalid argument: null pointer / empty ring");
         return GS_ERR_ARG;
     }
     hipLaunchKernelGGL(gs::step_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info_dev, applied_dev, status, loss3_dev,
-                       loss_ring_dev, ring_len);
+                       loss_ring_dev, ring_len, walk_state);
     GS_LAUNCH_CHECK("step_status_kernel");
     return GS_OK;
 }
 
-extern "C" int gs_version(void) { return 200; }
+extern "C" int gs_version(void) { return 300; }
+// The preprocessor flags beyond the Makefile's own this library was built with ("" = the product build): a -DGS_BWD_CHECK,
+// -DGS_BWD_ACC64, -DGS_EXACT_MATH or -DGS_CLOCK_PROBE diagnostic variant names itself, and the Python binding refuses to load
+// one unless it is asked to (easy_gaussian_splatting_amd/_native.py).
+#ifndef GS_BUILD_FLAGS
+#define GS_BUILD_FLAGS ""
+#endif
+extern "C" const char* gs_build_flags(void) { return GS_BUILD_FLAGS; }
 extern "C" const char* gs_last_error(void) { return gs::g_err; }
 extern "C" const char* gs_arch(void) { return "gfx950"; }

@@ -54,6 +54,8 @@ Guard current_guard();
 // Host mirror of the info block (gs_info_mirror_set): page-locked, device-visible host memory the tile scan writes the
 // eight info words into directly -- the eager seam learns the list sizes without a device-to-host copy on the stream.
 int64_t* current_info_mirror();
+// Host mirror of a training forward's walk record (gs_walk_mirror_set): int64[4] {work units, storage units, rows, flags}.
+int64_t* current_walk_mirror();
 __device__ __forceinline__ bool guard_tripped(const int64_t* info) { return info != nullptr && info[3] != 0; }
 
 // Workspace layout of the binning stage (all offsets in bytes, 256-B aligned).

@@ -1,7 +1,7 @@
 // gs_project.hip -- per-Gaussian stages for gfx950:
 //   project_fwd_kernel : P-fwd + SH-fwd fused (one pass over means/quats/scales/shs); when training with SH colours it
 //                        also leaves d colour / d view direction (sh_jac), so that the backward reads no coefficient
-//   project_bwd_kernel : gradient-row reduction (a lane per slot: row_sum_slots) + SH-bwd + P-bwd fused, no atomics;
+//   project_bwd_kernel : gradient-row reduction (compact rows, a row per lane: row_sum_wave) + SH-bwd + P-bwd fused, no atomics;
 //                        <DEG, true>: Adam and update_statistics applied in the same pass (gs_project_bwd_adam)
 // The [N,K,3] SH block (192 B per Gaussian at SH3) is moved through LDS with coalesced 16-byte accesses and read per
 // thread at an odd row stride (3K+1 dwords) so the per-thread walk over its own row is bank-conflict free.  The
@@ -371,7 +371,7 @@ struct ProjBwdArgs {
     const float *means, *quats, *scales, *colors_in, *sh_rest, *viewmats, *Ks, *colors_post;
     const int32_t *radii, *tiles_per_gauss, *cum_tiles;
     const float4* rows;      // [I*4][3]: one row per (intersection slot, tile quadrant)
-    const uint8_t* qmask;    // [I] by slot: which of the four quadrant rows exist
+    const int32_t* row_base; // [I+1] by slot: gradient rows in front of the slot (gs_blend_fwd's scan of the quadrant masks)
     const float4* sh_jac;    // optional, from gs_project_fwd ([C*N][8] + [C*N]): the SH rows are then not read at all
     float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_sh_rest, *v_means2d_abs, *v_means2d,
         *v_conics, *v_colors_post, *v_colors_pre;
@@ -410,21 +410,6 @@ struct RowSum {
     float v[12];
 };
 constexpr int kRow4 = GS_ROW_FLOATS / 4;   // float4 per gradient row (include/gs_raster.h)
-
-// adds the existing quadrant rows of one intersection slot (fixed order -> reproducible sums)
-__device__ __forceinline__ void row_add(RowSum& s, const float4* __restrict__ rows, const uint8_t* __restrict__ qmask, int64_t slot) {
-    const int bits = qmask[slot];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (bits & (1 << q)) {
-            const float4* r = rows + kRow4 * (slot * 4 + q);
-            const float4 a = r[0], b = r[1], c = r[2];
-            s.v[0] += a.x; s.v[1] += a.y; s.v[2] += a.z; s.v[3] += a.w;
-            s.v[4] += b.x; s.v[5] += b.y; s.v[6] += b.z; s.v[7] += b.w;
-            s.v[8] += c.x; s.v[9] += c.y; s.v[10] += c.z;
-        }
-    }
-}
 
 // Dense, coalesced write-out of one block's SH-gradient tile (LDS rows of 3K floats, row stride
 // 3K+1) to v_shs[n0 : n0+rows]: unsplit [N,K,3] or split v_sh_0[N,1,3] + v_sh_rest[N,K-1,3].
@@ -619,133 +604,79 @@ __device__ __forceinline__ void adam_geo_tile(const float* tile, int rows, int64
 }
 
 
-// ---- gradient rows of the wave's Gaussians, one SLOT per lane -----------------------------------------------------
-// A thread that walks its own Gaussian's rows pays one HBM round trip per slot, and the wave waits for its longest
-// Gaussian while most lanes hold 1-3: the row sum was latency, 0.13 ms of the fused kernel for 250 MB.
-// Here the wave's slots -- contiguous per Gaussian, Gaussians in lane order -- are dealt out one per lane, 64 at a
-// time (an ITEM): masks of four items in one round trip, the (up to four) quadrant rows of an item in one more, the next
-// item's rows in flight while this one's are added.  Each lane adds its slot's rows in quadrant order and leaves the
-// 11 sums in LDS; the owner lanes then add their slots' sums in slot order (fixed order -> reproducible sums).
-// Who owns a slot (round 5): the owners whose range reaches into an item write their lane at the position where it starts
-// there; a ballot of those positions and a count-leading-zeros give every lane the start at or below its own position.
-// (Rounds 3-4: a byte per slot, filled by the owners -- 64 x kCoopRows bytes of LDS per wave, which capped the path at 48
-//  slots per Gaussian; on realistic footprints the whole-wave path beyond that was half of project_bwd.)
-// An item none of whose slots holds rows -- most of them once tiles saturate and abandon their list tails -- costs no row
-// load, no LDS traffic, no owner loop; an owner visits only its row-bearing slots.
-// LDS of one wave: 4 x 64 start lanes (int) + 64 item sums of 12 floats.
-#ifndef GS_ROWSUM_PER_GAUSSIAN
-#define GS_ROWSUM_PER_GAUSSIAN 0
-#endif
-#ifndef GS_ROWSUM_DIAG
-#define GS_ROWSUM_DIAG 0
-#endif
+// ---- gradient rows of the wave's Gaussians -------------------------------------------------------------------------
+// blend_bwd leaves one 48-byte row per (intersection, quadrant) some pixel took, COMPACT and in slot order (round 6:
+// row_base = gs_blend_fwd's scan of the quadrant masks): the rows of a Gaussian are contiguous, the Gaussians of a wave follow
+// one another with nothing in between -- the wave's rows are ONE contiguous range [R0, R0 + T), read 64 rows at a time (an
+// ITEM), a row per lane, 3 KB of fully used cache lines per item and the next item in flight while this one is added.
+// (Rounds 3-5 kept a row per LISTED (intersection, quadrant): 192 bytes per list entry, found through a mask byte per entry;
+// a lane gathered up to four predicated rows, an owner lookup through LDS told it whose they were, and on realistic
+// footprints -- where 1-3 % of the listed entries are walked -- the pass read masks of rows that did not exist.)
+// Each lane leaves its row in LDS; every Gaussian adds the rows of its own range [lo, hi) of the item in row order.  An item
+// that lies inside ONE Gaussian's range is not staged at all: the lanes keep partial sums in registers across such items and
+// one DPP reduction closes the run (a splat over the whole image holds 10^5 rows).  Fixed order -> reproducible sums, and the
+// same bits from project_bwd_kernel and row_sums_kernel.
+constexpr int kRowWaveFloats = 64 * 12;   // LDS of one wave: an item's 64 rows
 
-// Gaussians with more slots than this are summed by the whole wave, one at a time (an owner adds its row-bearing slots
-// serially: bounded here).  Round 5, same box, project_bwd on heavy1M / on the 200 k long-list scene (tools/config_run.py):
-// 48 -> 0.312 / 0.162 ms, 128 -> 0.312 / 0.164, 256 -> 0.308 / 0.177, 1024 -> 0.329 / 0.249 (rounds 3-4, byte table, 48: 0.362 / 0.192).
-#ifndef GS_COOP_ROWS
-#define GS_COOP_ROWS 128
-#endif
-constexpr int kCoopRows = GS_COOP_ROWS;
-constexpr int kRowOwnerFloats = 4 * 64;
-constexpr int kRowWaveFloats = kRowOwnerFloats + 64 * 12;
-
-// DOUBLE: the next item's rows are requested before this item's are added (two row buffers: 88 VGPRs, the register peak of
-// project_bwd_kernel, whose fp64 chain holds it to three waves per SIMD anyway).  row_sums_kernel has nothing else to keep:
-// single-buffered it fits five waves per SIMD, and a pass that is pure gather latency wants the waves, not the prefetch.
-template <bool DOUBLE, class A>
-__device__ __forceinline__ void row_sum_slots(const A& a, int cs, int base, RowSum& s, float* wl) {
+template <class A>
+__device__ __forceinline__ void row_sum_wave(const A& a, int nr, int r0, RowSum& s, float* wl) {
     const int lane = lane_id();
-    const int incl = wave_incl_scan_add(cs);
-    const int o = incl - cs;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s.v[i] = 0.f;
+    const int incl = wave_incl_scan_add(nr);
+    const int o = incl - nr;
     const int T = __shfl(incl, 63, 64);
-    if (T == 0) return;
-    int* start = reinterpret_cast<int*>(wl);   // [4][64]: lane of the owner whose range starts at (or reaches into the item at) a position
-    float4* item = reinterpret_cast<float4*>(wl + kRowOwnerFloats);
+    if (T == 0) return;   // wave-uniform
+    const int64_t R0 = __shfl(r0, __builtin_ctzll(__ballot(nr > 0)), 64);
+    float4* item = reinterpret_cast<float4*>(wl);
     const int n_items = (T + 63) >> 6;
-    // (the third quad of a row holds three live floats: loaded as 12 bytes -- the double buffer below is the kernel's register
-    //  peak, and project_bwd_kernel sits on the 168-VGPR edge of three waves per SIMD)
+    // (the third quad of a row holds three live floats: loaded as 12 bytes)
     struct Row { float4 a, b; float cx, cy, cz; };
-    auto zero_row = [](Row& r) { r.a = r.b = make_float4(0.f, 0.f, 0.f, 0.f); r.cx = r.cy = r.cz = 0.f; };
-    auto fetch = [&](Row (&dst)[4], int slot, int bits) {
-#if GS_ROWSUM_DIAG == 1   // timing only: the same loads under the same masks, but lane-contiguous addresses
-        const float4* rp = a.rows + 12 * (int64_t)__shfl(slot, 0, 64) + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (bits & (1 << q)) { dst[q].a = rp[64 * (3 * q)]; dst[q].b = rp[64 * (3 * q + 1)]; const float4 c = rp[64 * (3 * q + 2)]; dst[q].cx = c.x; dst[q].cy = c.y; dst[q].cz = c.z; }
-            else zero_row(dst[q]);
+    auto fetch = [&](Row& d, int it) {
+        const int j = 64 * it + lane;
+        d.a = d.b = make_float4(0.f, 0.f, 0.f, 0.f); d.cx = d.cy = d.cz = 0.f;
+        if (j < T) {
+            const float4* rp = a.rows + kRow4 * (R0 + j);
+            d.a = rp[0]; d.b = rp[1];
+            const float* c = reinterpret_cast<const float*>(rp + 2);
+            d.cx = c[0]; d.cy = c[1]; d.cz = c[2];
         }
-#elif GS_ROWSUM_DIAG == 2   // timing only: no row loads
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { zero_row(dst[q]); dst[q].a.x = (float)(bits & (1 << q)); }
-#else
-        const float4* rp = a.rows + 4 * kRow4 * (int64_t)slot;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (bits & (1 << q)) {
-                dst[q].a = rp[kRow4 * q]; dst[q].b = rp[kRow4 * q + 1];
-                const float* c = reinterpret_cast<const float*>(rp + kRow4 * q + 2);
-                dst[q].cx = c[0]; dst[q].cy = c[1]; dst[q].cz = c[2];
-            } else zero_row(dst[q]);
-        }
-#endif
     };
-    for (int u0 = 0; u0 < n_items; u0 += 4) {
-        int sl[4], bt[4];
+    Row cur, nxt;
+    fetch(cur, 0);
+    RowSum p;   // partial sums of a run of items that belong to one Gaussian
 #pragma unroll
-        for (int q = 0; q < 4; ++q) start[64 * q + lane] = -1;
-        __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in issue order)
+    for (int i = 0; i < 12; ++i) p.v[i] = 0.f;
+    for (int it = 0; it < n_items; ++it) {
+        if (it + 1 < n_items) fetch(nxt, it + 1);
+        const int jb = 64 * it;
+        const int lo = max(o, jb) - jb, hi = min(o + nr, jb + 64) - jb;   // this Gaussian's rows inside the item
+        const unsigned long long whole = __ballot(nr > 0 && lo == 0 && hi == 64);
+        if (whole) {   // wave-uniform: the item lies inside one Gaussian's range
+            p.v[0] += cur.a.x; p.v[1] += cur.a.y; p.v[2] += cur.a.z; p.v[3] += cur.a.w;
+            p.v[4] += cur.b.x; p.v[5] += cur.b.y; p.v[6] += cur.b.z; p.v[7] += cur.b.w;
+            p.v[8] += cur.cx; p.v[9] += cur.cy; p.v[10] += cur.cz;
+            const int owner = __builtin_ctzll(whole);
+            if (__shfl(o + nr, owner, 64) < jb + 128) {   // the next item is not all this Gaussian's: close the run
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int jb = 64 * (u0 + q);
-            if (cs > 0 && o < jb + 64 && o + cs > jb) start[64 * q + max(o, jb) - jb] = lane;
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = 64 * (u0 + q) + lane;
-            const bool valid = j < T;
-            const unsigned long long starts = __ballot(start[64 * q + lane] >= 0);
-            // the start at or below this lane's position (position 0 of a valid item always is one)
-            const int sp = 63 - __builtin_clzll((starts & (~0ull >> (63 - lane))) | 1ull);
-            const int owner = valid ? start[64 * q + sp] : 0;
-            sl[q] = __shfl(base, owner, 64) + j - __shfl(o, owner, 64);
-            bt[q] = valid ? (int)a.qmask[sl[q]] : 0;
-        }
-        Row buf[DOUBLE ? 2 : 1][4];
-        if (DOUBLE) fetch(buf[0], sl[0], bt[0]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (u0 + q < n_items) {   // wave-uniform
-                if (DOUBLE) { if (q + 1 < 4 && u0 + q + 1 < n_items) fetch(buf[(q + 1) & 1], sl[(q + 1) & 3], bt[(q + 1) & 3]); }
-                else fetch(buf[0], sl[q], bt[q]);
-                // slots of this item that hold rows at all: on long lists most do not (a saturated tile abandons its tail), and
-                // an owner then visits only its row-bearing slots -- the skipped ones would have added exact zeros
-                const unsigned long long has = __ballot(bt[q] != 0);
-                if (has == 0ull) continue;   // wave-uniform
-                Row (&d)[4] = buf[DOUBLE ? (q & 1) : 0];
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x, z = x;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    x.x += d[k].a.x; x.y += d[k].a.y; x.z += d[k].a.z; x.w += d[k].a.w;
-                    y.x += d[k].b.x; y.y += d[k].b.y; y.z += d[k].b.z; y.w += d[k].b.w;
-                    z.x += d[k].cx; z.y += d[k].cy; z.z += d[k].cz;
+                for (int i = 0; i < 11; ++i) {
+                    const float t = wave_reduce_add_dpp(p.v[i]);
+                    if (lane == owner) s.v[i] += t;
+                    p.v[i] = 0.f;
                 }
-                item[3 * lane] = x; item[3 * lane + 1] = y; item[3 * lane + 2] = z;
-                __builtin_amdgcn_wave_barrier();
-                const int jb = 64 * (u0 + q);
-                const int lo = max(o, jb) - jb, hi = min(o + cs, jb + 64) - jb;
-                unsigned long long mine = hi > lo ? ((hi - lo >= 64 ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo) & has : 0ull;
-                for (; mine; mine &= mine - 1ull) {   // ascending slot order: the order of the sums is unchanged
-                    const int r = __builtin_ctzll(mine);
-                    const float4 ix = item[3 * r], iy = item[3 * r + 1], iz = item[3 * r + 2];
-                    s.v[0] += ix.x; s.v[1] += ix.y; s.v[2] += ix.z; s.v[3] += ix.w;
-                    s.v[4] += iy.x; s.v[5] += iy.y; s.v[6] += iy.z; s.v[7] += iy.w;
-                    s.v[8] += iz.x; s.v[9] += iz.y; s.v[10] += iz.z;
-                }
-                __builtin_amdgcn_wave_barrier();
             }
+        } else {
+            item[3 * lane] = cur.a; item[3 * lane + 1] = cur.b; item[3 * lane + 2] = make_float4(cur.cx, cur.cy, cur.cz, 0.f);
+            __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in issue order)
+            for (int r = lo; r < hi; ++r) {
+                const float4 ix = item[3 * r], iy = item[3 * r + 1], iz = item[3 * r + 2];
+                s.v[0] += ix.x; s.v[1] += ix.y; s.v[2] += ix.z; s.v[3] += ix.w;
+                s.v[4] += iy.x; s.v[5] += iy.y; s.v[6] += iy.z; s.v[7] += iy.w;
+                s.v[8] += iz.x; s.v[9] += iz.y; s.v[10] += iz.z;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
+        cur = nxt;
     }
 }
 
@@ -770,8 +701,10 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     const bool vis = in_range && a.radii[f] > 0;
     const int cnt = vis ? a.tiles_per_gauss[f] : 0;
     const int base = vis ? a.cum_tiles[f] : 0;
+    int r0 = 0, nr = 0;   // this Gaussian's gradient rows: [r0, r0 + nr)
+    if (!SUMS && cnt > 0) { r0 = a.row_base[base]; nr = a.row_base[base + cnt] - r0; }
 
-    // ---- 1. sum this Gaussian's gradient rows (contiguous, written once each by blend_bwd) -- or take the sums gs_row_sums
+    // ---- 1. sum this Gaussian's gradient rows (contiguous and compact, written once each by blend_bwd) -- or take the sums gs_row_sums
     //         left (a.row_sums: the view-parallel step forms them early, for the colour-gradient exchange)
     RowSum s;
     if (SUMS) {
@@ -781,9 +714,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         s.v[0] = x.x; s.v[1] = x.y; s.v[2] = x.z; s.v[3] = x.w; s.v[4] = y.x; s.v[5] = y.y; s.v[6] = y.z; s.v[7] = y.w;
         s.v[8] = z.x; s.v[9] = z.y; s.v[10] = z.z; s.v[11] = 0.f;
     } else {
-        float* row_wl = tile + (threadIdx.x >> 6) * kRowWaveFloats;
-        constexpr bool kRowDouble = true;
-#include "gs_rowsum_body.inc"
+        row_sum_wave(a, nr, r0, s, tile + (threadIdx.x >> 6) * kRowWaveFloats);
     }
 
     // ---- 2. colour path
@@ -900,7 +831,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
             geo_op = v_op;   // (applied block-wide below: adam_geo_tile)
 #endif
             if (a.st_max_radii != nullptr && vis) {   // same arithmetic as update_statistics_kernel
-                a.st_max_radii[n] = fmaxf(a.st_max_radii[n], (float)a.radii[f] / a.st_max_hw);
+                a.st_max_radii[n] = fmaxf(a.st_max_radii[n], (float)a.radii[f] * (1.f / a.st_max_hw));
                 a.st_grad_norm[n] += sqrtf(s.v[2] * s.v[2] + s.v[3] * s.v[3]) * a.st_max_hw;
                 a.st_counts[n] += 1.f;
             }
@@ -1058,11 +989,11 @@ struct RowSumsArgs {
     const int32_t *radii, *tiles_per_gauss, *cum_tiles;
     const float* colors_post;
     const float4* rows;
-    const uint8_t* qmask;
+    const int32_t* row_base;
     float4* row_sums;
     float *v_colors_pre, *radii_norm, *cam_out;
     const float* viewmats;
-    float inv_max_hw;
+    float max_hw;
     const int64_t* guard;
 };
 
@@ -1074,13 +1005,13 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const RowSumsArgs a) {
     const int radius = in_range ? a.radii[f] : 0;
     const bool vis = radius > 0;
     const int cnt = vis ? a.tiles_per_gauss[f] : 0, base = vis ? a.cum_tiles[f] : 0;
+    int r0 = 0, nr = 0;
+    if (cnt > 0) { r0 = a.row_base[base]; nr = a.row_base[base + cnt] - r0; }
     float rgb[3] = {0.f, 0.f, 0.f};
     if (vis) { rgb[0] = a.colors_post[3 * f]; rgb[1] = a.colors_post[3 * f + 1]; rgb[2] = a.colors_post[3 * f + 2]; }
     if (a.cam_out && blockIdx.x == 0 && threadIdx.x < 16) a.cam_out[threadIdx.x] = a.viewmats[threadIdx.x];
     RowSum s;
-    float* row_wl = wl_all[threadIdx.x >> 6];
-    constexpr bool kRowDouble = false;
-#include "gs_rowsum_body.inc"
+    row_sum_wave(a, nr, r0, s, wl_all[threadIdx.x >> 6]);
     if (!in_range) return;
     if (vis) {   // (culled Gaussians: gs_project_bwd does not read their sums)
         float4* rs = a.row_sums + 3 * f;
@@ -1090,7 +1021,7 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const RowSumsArgs a) {
     }
     float* d = a.v_colors_pre + 3 * f;   // (project_bwd_kernel's v_colors_pre: masked where the clamp max(c + 0.5, 0) is active)
     d[0] = (vis && rgb[0] > 0.f) ? s.v[8] : 0.f; d[1] = (vis && rgb[1] > 0.f) ? s.v[9] : 0.f; d[2] = (vis && rgb[2] > 0.f) ? s.v[10] : 0.f;
-    if (a.radii_norm) a.radii_norm[f] = vis ? (float)radius * a.inv_max_hw : 0.f;
+    if (a.radii_norm) a.radii_norm[f] = vis ? (float)radius * (1.f / a.max_hw) : 0.f;   // (update_statistics_kernel's arithmetic)
 }
 
 }  // namespace gs
@@ -1157,20 +1088,20 @@ extern "C" int gs_sh_adam_views(void* stream, int R, int64_t N, int K, int sh_de
 }
 
 extern "C" int gs_row_sums(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
-                           const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
+                           const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
                            float* row_sums, float* v_colors_pre, float* radii_norm, float max_hw, const float* viewmats,
                            float* cam_out) {
     GS_REQUIRE(C >= 1 && N >= 0, "C>=1, N>=0");
     if (N == 0) return GS_OK;
-    GS_REQUIRE(radii && colors_post && tiles_per_gauss && cum_tiles && rows && qmask && row_sums && v_colors_pre, "null pointer");
+    GS_REQUIRE(radii && colors_post && tiles_per_gauss && cum_tiles && rows && row_base && row_sums && v_colors_pre, "null pointer");
     GS_REQUIRE(((uintptr_t)row_sums & 15) == 0, "row_sums must be 16-byte aligned");
     GS_REQUIRE(!radii_norm || max_hw > 0.f, "radii_norm needs a positive image extent");
     GS_REQUIRE(!cam_out || (viewmats && C == 1), "cam_out: the single camera's view matrix");
     RowSumsArgs a;
     a.total = (int64_t)C * N; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss; a.cum_tiles = cum_tiles;
-    a.colors_post = colors_post; a.rows = reinterpret_cast<const float4*>(rows); a.qmask = qmask;
+    a.colors_post = colors_post; a.rows = reinterpret_cast<const float4*>(rows); a.row_base = row_base;
     a.row_sums = reinterpret_cast<float4*>(row_sums); a.v_colors_pre = v_colors_pre; a.radii_norm = radii_norm;
-    a.cam_out = cam_out; a.viewmats = viewmats; a.inv_max_hw = radii_norm ? 1.f / max_hw : 0.f;
+    a.cam_out = cam_out; a.viewmats = viewmats; a.max_hw = max_hw;
     a.guard = current_guard().info;
     hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("row_sums_kernel");
@@ -1231,7 +1162,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
                               int height, float eps2d, float near_plane, float far_plane,
                               const int32_t* radii, const float* colors_post,
                               const int32_t* tiles_per_gauss, const int32_t* cum_tiles,
-                              const float* rows, const uint8_t* qmask, float* v_means, float* v_quats, float* v_scales,
+                              const float* rows, const int32_t* row_base, float* v_means, float* v_quats, float* v_scales,
                               float* v_opacities, float* v_colors, float* v_sh_rest, float* v_means2d_abs,
                               float* v_means2d, float* v_conics, float* v_colors_post, float* v_colors_pre,
                               const float* opacities, int activations, const float* sh_jac, const float* row_sums,
@@ -1243,7 +1174,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
     if (N == 0) return GS_OK;
     GS_REQUIRE(means && quats && scales && colors_in && viewmats && Ks && radii && colors_post && tiles_per_gauss && cum_tiles, "null input pointer");
-    GS_REQUIRE(row_sums || (rows && qmask), "the gradient rows (rows + qmask) or their sums (row_sums, from gs_row_sums)");
+    GS_REQUIRE(row_sums || (rows && row_base), "the gradient rows (rows + row_base) or their sums (row_sums, from gs_row_sums)");
     GS_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_means2d_abs, "null output pointer");
     GS_REQUIRE(v_colors || sh_degree >= 0, "v_colors may be NULL only with SH colours (gradients rebuilt by gs_sh_grad_views)");
     ProjBwdArgs a;
@@ -1252,7 +1183,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.means = means; a.quats = quats; a.scales = scales; a.colors_in = colors_in; a.viewmats = viewmats;
     a.sh_rest = sh_degree >= 0 ? sh_rest : nullptr; a.v_sh_rest = a.sh_rest ? v_sh_rest : nullptr;
     a.Ks = Ks; a.colors_post = colors_post; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss;
-    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.qmask = qmask;
+    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.row_base = row_base;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_opacities = v_opacities;
     a.v_colors = v_colors; a.v_means2d_abs = v_means2d_abs; a.v_means2d = v_means2d;
     a.v_conics = v_conics; a.v_colors_post = v_colors_post; a.v_colors_pre = sh_degree >= 0 ? v_colors_pre : nullptr;
@@ -1298,7 +1229,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
 extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree, float* params, float* exp_avg, float* exp_avg_sq,
                                    const int64_t* offsets_host, const float* viewmats, const float* Ks, int width, int height,
                                    float eps2d, float near_plane, float far_plane, const int32_t* radii, const float* colors_post,
-                                   const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
+                                   const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
                                    float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev,
                                    int64_t* applied_dev, float* max_radii, float* grad_norm_accum, float* counts,
                                    const float* sh_jac) {
@@ -1306,7 +1237,7 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     GS_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16, "SH colours: 0 <= degree <= 3, (degree+1)^2 <= K <= 16");
     if (N == 0) return GS_OK;
     GS_REQUIRE(params && exp_avg && exp_avg_sq && offsets_host && viewmats && Ks && radii && colors_post && tiles_per_gauss &&
-               cum_tiles && rows && qmask && v_means2d_abs && hyper_dev, "null pointer");
+               cum_tiles && rows && row_base && v_means2d_abs && hyper_dev, "null pointer");
     ProjBwdArgs a;
     a.C = 1; a.N = N; a.K = K; a.colors_per_camera = 0; a.W = width; a.H = height;
     a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
@@ -1315,7 +1246,7 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     a.opacities = params + offsets_host[5]; a.activations = 1;
     GS_REQUIRE(((uintptr_t)a.quats & 15) == 0, "the quaternion tensor must be 16-byte aligned");
     a.viewmats = viewmats; a.Ks = Ks; a.colors_post = colors_post; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss;
-    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.qmask = qmask;
+    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.row_base = row_base;
     a.v_means = a.v_quats = a.v_scales = a.v_opacities = a.v_colors = a.v_sh_rest = nullptr;
     a.v_means2d_abs = v_means2d_abs; a.v_means2d = a.v_conics = a.v_colors_post = a.v_colors_pre = nullptr;
     a.sh_jac = reinterpret_cast<const float4*>(sh_jac);

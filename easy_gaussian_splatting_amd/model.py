@@ -383,6 +383,9 @@ class GaussianModel(nn.Module):
             m, v = self._moments(name)
             new_m[name], new_v[name] = (torch.zeros_like(m), torch.zeros_like(v)) if name == "logit_opacities" else (m, v)
         self._replace_parameters(new, new_m, new_v)
+        # (how far the blend walks into its lists jumps with this call -- nothing saturates any more --: a captured step runner
+        #  sizes what the walk leaves from a fresh probe instead of from the steps before, train_graph.TrainStepGraph.step)
+        self.opacity_resets = getattr(self, "opacity_resets", 0) + 1
 
     def forward(self, data: Dict[str, Any], clamp: bool = True) -> Dict[str, Optional[Tensor]]:
         """`clamp=False` returns the un-clamped image for `LossComputer(clamp_input=True)` (the clamp of

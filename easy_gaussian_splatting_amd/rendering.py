@@ -142,7 +142,7 @@ def binning_choice(footprint, tiles: int = 0) -> str:
 
 # host-side diagnostics: time spent blocked on the list-size read-back (bench.py reports it; a wait
 # near zero means the host, not the GPU, paces the loop)
-stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0, "overflow_reruns": 0, "deferred_calls": 0, "late_overflows": 0}
+stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0, "overflow_reruns": 0, "walk_reruns": 0, "deferred_calls": 0, "late_overflows": 0}
 
 
 def _quantize_up(x: int) -> int:
@@ -166,6 +166,29 @@ def _pinned_info(device: torch.device) -> Tensor:
         ring = cache[key] = [torch.empty((_INFO_RING, 8), dtype=torch.int64, pin_memory=True), 0]
     ring[1] = (ring[1] + 1) % _INFO_RING
     return ring[0][ring[1]]
+
+
+class _WalkRecord:
+    """Page-locked int64[4] landing buffer {work units, storage units, gradient rows, flags} of ONE training forward: the row-base
+    scan behind its blend writes it (gs_walk_mirror_set), the call's backward reads it -- as plain memory, behind an event that
+    has long passed -- before it launches anything that walks the units.  Buffers are recycled per host thread (a pinned
+    allocation per call would cost more than the forward)."""
+    __slots__ = ("host", "event", "_pool")
+
+    def __init__(self):
+        pool = getattr(_tls, "walk_pool", None)
+        if pool is None:
+            pool = _tls.walk_pool = []
+        self._pool = pool
+        self.host = pool.pop() if pool else torch.zeros((4,), dtype=torch.int64, pin_memory=True)
+        self.host.fill_(-1)   # (a record the device never wrote -- every attempt of the call skipped by the guard -- is told apart)
+        self.event = None
+
+    def __del__(self):
+        try:
+            self._pool.append(self.host)
+        except Exception:   # interpreter shutdown
+            pass
 
 
 def _pending_checks() -> list:
@@ -430,11 +453,17 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     # (capacities in steps of ~3 %: the hint drifts a little with every frame, the LAYOUT should not -- a lease whose arenas
     #  and layout are those of the last call is not re-bound: no validation, no memset on the stream)
     cap, coarse_cap = _quantize_up(cap), (_quantize_up(coarse_cap) if two_level else 0)
+    # training: what the forward WALKS -- work units (checkpoints, quadrant sublists) and gradient rows -- has capacities of its
+    # own, learnt from the walk records of earlier calls (first call: a guess; a walk that outgrows them is repeated by the
+    # call's backward, `_settle_walk`)
+    cap_units = cap_rows = 0
     if need_grad:
-        cap = min(cap, (1 << 29) - 1)
+        cap_units = _quantize_up(max(int(hint.get("cap_units", 0)), (cap // 16 + 12 * C * tiles) if "cap_units" not in hint else 0, 256))
+        cap_rows = _quantize_up(max(int(hint.get("cap_rows", 0)), cap if "cap_rows" not in hint else 0, 4096))
+    walk = _WalkRecord() if need_grad else None
 
     lease = WS.pool.acquire(dev, st)
-    lease.bind(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags), st)
+    lease.bind(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags, max(cap_units, 256), cap_rows), st)
     P = lease.ptr
     info_dev = lease.view(WS.INFO, 8)
     info_host = _pinned_info(dev)
@@ -471,10 +500,19 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
                 st, C, N, tw, th, P(WS.BBOX), _ptr(depths), P(WS.BIN), bin_bytes(), P(WS.ISECT_OFFSETS), cap,
                 min(cap_tile, cap), P(WS.KEYS_TMP), P(WS.SLOT_GID), P(WS.CUM_TILES), P(WS.ISECT_IDS), P(WS.FLATTEN_IDS),
                 P(WS.SLOTS)), "gs_bin_emit_sort"))
-        _stage("gs_blend_fwd", dev, lambda: nat.check(L.gs_blend_fwd(
-            st, C, W, H, P(WS.REC), _ptr(backgrounds), P(WS.ISECT_OFFSETS), P(WS.BUCKET_OFFSETS), P(WS.TILE_ORDER),
-            P(WS.FLATTEN_IDS), P(WS.SLOTS), cap, _ptr(render_colors), _ptr(render_alphas), P(WS.CKPT), P(WS.QLIST), P(WS.QCNT),
-            P(WS.QMASK), P(WS.UNIT_COUNTER), P(WS.UNIT_DESC)), "gs_blend_fwd"))
+        if walk is not None:
+            nat.check(L.gs_walk_mirror_set(walk.host.data_ptr()), "gs_walk_mirror_set")
+        try:
+            _stage("gs_blend_fwd", dev, lambda: nat.check(L.gs_blend_fwd(
+                st, C, W, H, P(WS.REC), _ptr(backgrounds), P(WS.ISECT_OFFSETS), P(WS.TILE_ORDER),
+                P(WS.FLATTEN_IDS), P(WS.SLOTS), cap, _ptr(render_colors), _ptr(render_alphas), P(WS.CKPT), P(WS.QLIST), P(WS.QCNT),
+                P(WS.QMASK), P(WS.UNIT_DESC), lease.layout.cap_units, P(WS.ROW_BASE), lease.layout.cap_rows, P(WS.WALK_STATE)),
+                "gs_blend_fwd"))
+        finally:
+            if walk is not None:
+                L.gs_walk_mirror_set(None)
+                walk.event = torch.cuda.Event()
+                walk.event.record(tstream)
 
     # 1. geometry; 2. tile counts under the guard (flags = capacity exceeded) and their 64-byte copy to the host;
     # 3. SH colours; 4. lists + blend, speculatively; 5. only now the host looks at the sizes.
@@ -535,7 +573,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
                 cap_tile = _sort_class(max_tile)
         with _state_lock:
             stats["overflow_reruns"] += 1
-        lease.grow_lists(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags), st)
+        lease.grow_lists(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags, max(cap_units, 256), cap_rows), st)
         info_dev = lease.view(WS.INFO, 8)
         info_dev.zero_()
         return False
@@ -630,11 +668,60 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     if not lazy_ref:
         meta._lease = ref   # (the list lazies above read the arenas; in the "gsplat" mode nothing in meta does)
     state = dict(C=C, N=N, K=K, deg=deg, per_cam=per_cam, sh_jac=use_jac, n_isects=n_isects, n_buckets=n_buckets, radii=radii, lease=lease,
-                 lease_ref=WS.LeaseRef(lease) if need_grad else None, factorised=factorised, pending=pending, late=state_late)
+                 lease_ref=WS.LeaseRef(lease) if need_grad else None, factorised=factorised, pending=pending, late=state_late,
+                 walk=walk, hint_key=hint_key, backgrounds=backgrounds)
     if pending is not None:
         pending.lease_ref = WS.LeaseRef(lease)   # (a repair needs the arenas: leased until the check has run)
     del ref   # (the lease goes back to its pool here unless meta or the autograd node holds it)
     return render_colors, render_alphas, meta, state
+
+
+def _settle_walk(s: dict, cfg: dict, render_colors: Tensor, render_alphas: Tensor) -> int:
+    """Reads the walk record of a training forward (page-locked memory behind an event recorded in the forward: no stream
+    synchronisation) before its backward launches anything that follows the work units.  A walk that outgrew its capacities left
+    the image complete but the checkpoints / sublists / row bases void: the walk arena is replaced and the blend repeated (into
+    scratch images: same bits) with what the record says was needed; the capacity hints of the call shape follow.  Returns the
+    number of gradient rows."""
+    walk, lease = s.get("walk"), s["lease"]
+    if walk is None:
+        return 0
+    L = nat.lib()
+    dev = render_colors.device
+    walk.event.synchronize()
+    units, storage, rows, fl = (int(v) for v in walk.host.tolist())
+    if fl < 0:
+        raise nat.NativeLibraryError("rasterization: the forward of this call left no walk record (was it skipped by a step guard?)")
+    tries = 0
+    while fl & (WS.FLAG_UNITS | WS.FLAG_ROWS):
+        tries += 1
+        if tries > 3:
+            raise nat.NativeLibraryError(f"rasterization: the walk capacities did not settle (units {storage}, rows {rows}, flags {fl})")
+        lay = lease.layout
+        cu = _quantize_up(storage + (storage >> 2) + 512) if fl & WS.FLAG_UNITS else lay.cap_units
+        cr = _quantize_up(rows + (rows >> 2) + 4096) if fl & WS.FLAG_ROWS else lay.cap_rows
+        C, N, W, H, cap, coarse_cap, shift, flags = lay.key[:8]
+        lease.grow_walk(WS.Layout(C, N, W, H, cap, coarse_cap, shift, flags, cu, cr))
+        P = lease.ptr
+        with _state_lock:
+            stats["walk_reruns"] += 1
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            sc, sa = torch.empty_like(render_colors), torch.empty_like(render_alphas)
+            nat.check(L.gs_walk_mirror_set(walk.host.data_ptr()), "gs_walk_mirror_set")
+            try:
+                nat.check(L.gs_blend_fwd(st, C, W, H, P(WS.REC), _ptr(s["backgrounds"]), P(WS.ISECT_OFFSETS), P(WS.TILE_ORDER),
+                                         P(WS.FLATTEN_IDS), P(WS.SLOTS), s["n_isects"], _ptr(sc), _ptr(sa), P(WS.CKPT), P(WS.QLIST),
+                                         P(WS.QCNT), P(WS.QMASK), P(WS.UNIT_DESC), cu, P(WS.ROW_BASE), cr, P(WS.WALK_STATE)), "gs_blend_fwd")
+            finally:
+                L.gs_walk_mirror_set(None)
+            torch.cuda.current_stream(dev).synchronize()   # (rare: the capacities follow the largest recent frame)
+        units, storage, rows, fl = (int(v) for v in walk.host.tolist())
+    with _state_lock:
+        old = _hints.get(s["hint_key"])
+        if old is not None:
+            old["cap_units"] = max(storage + (storage >> 2) + 512, int(old.get("cap_units", 0) * 0.995))
+            old["cap_rows"] = max(rows + (rows >> 2) + 4096, int(old.get("cap_rows", 0) * 0.995))
+    return rows
 
 
 class _Rasterize(torch.autograd.Function):
@@ -651,7 +738,8 @@ class _Rasterize(torch.autograd.Function):
         holder.meta = meta
         if holder.debug is not None and need_grad:   # work-unit counters of the backward (bench.py's compute roofline): copies
             lease, tiles = state["lease"], meta["tile_width"] * meta["tile_height"]
-            holder.debug.update(unit_counter=lease.view(WS.UNIT_COUNTER, 1).clone(),
+            wstate = lease.view(WS.WALK_STATE, 8).clone()   # {work units, storage units, -, gradient rows, flags}
+            holder.debug.update(unit_counter=wstate[WS.WALK_UNITS:WS.WALK_UNITS + 1], walk_state=wstate,
                                 qcnt=lease.view(WS.QCNT, state["C"] * tiles * 4).clone(), unit_entries=nat.GS_UNIT)
             if state["n_isects"] is not None:   # intersections the backward holds gradient rows for (the forward walked them and some pixel took them)
                 holder.debug["walked_isects"] = lease.view(WS.QMASK, max(state["n_isects"], 1))[: state["n_isects"]].count_nonzero()
@@ -690,10 +778,10 @@ class _Rasterize(torch.autograd.Function):
                                    "memory.  Re-run the step (the capacities have been raised), or use the default immediate size check.")
             s["n_isects"], s["n_buckets"] = s["late"]["n_isects"], s["late"]["n_buckets"]
         P = lease.ptr
-        _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, P(WS.REC), P(WS.ISECT_OFFSETS),
-                                 P(WS.BUCKET_OFFSETS), s["n_buckets"], P(WS.QLIST), P(WS.QCNT), P(WS.UNIT_COUNTER),
-                                 P(WS.UNIT_DESC), P(WS.CKPT), _ptr(render_colors), _ptr(render_alphas),
-                                 _ptr(v_rc), _ptr(v_ra), P(WS.ROWS)), "gs_blend_bwd"))
+        n_rows = _settle_walk(s, cfg, render_colors, render_alphas)
+        _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, P(WS.REC), P(WS.QLIST), P(WS.QCNT),
+                                 P(WS.UNIT_DESC), lease.layout.cap_units, P(WS.CKPT), P(WS.QMASK), P(WS.ROW_BASE), P(WS.WALK_STATE),
+                                 _ptr(render_colors), _ptr(render_alphas), _ptr(v_rc), _ptr(v_ra), P(WS.ROWS)), "gs_blend_bwd"))
         go = holder.grad_out or {}   # (`_grad_out`: caller-owned gradient tensors; autograd then receives None for those inputs)
         for k_, shp in (("means", (N, 3)), ("quats", (N, 4)), ("scales", (N, 3)), ("opacities", (N,)), ("grad_norm", (N,)), ("count", (N,))):
             if k_ in go and not (go[k_].shape == shp and go[k_].is_contiguous() and go[k_].dtype == torch.float32 and go[k_].device == dev):
@@ -722,7 +810,7 @@ class _Rasterize(torch.autograd.Function):
             else:
                 v_pre, rad_out, cam_out = torch.empty((C, N, 3), **f32), None, None
             _stage("gs_row_sums", dev, lambda: nat.check(L.gs_row_sums(
-                st, C, N, _ptr(s["radii"]), P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES), P(WS.ROWS), P(WS.QMASK),
+                st, C, N, _ptr(s["radii"]), P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES), P(WS.ROWS), P(WS.ROW_BASE),
                 _ptr(row_sums), _ptr(v_pre), _ptr(rad_out), float(max(W, H)), _ptr(viewmats), _ptr(cam_out)), "gs_row_sums"))
             if holder.means2d_ref is not None and holder.means2d_ref() is not None:
                 holder.means2d_ref().colors_pre_grad = v_pre
@@ -741,7 +829,7 @@ class _Rasterize(torch.autograd.Function):
                                    _ptr(colors_rest), s["per_cam"], _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
                                    cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
                                    P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES),
-                                   P(WS.ROWS), P(WS.QMASK), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
+                                   P(WS.ROWS), P(WS.ROW_BASE), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
                                    _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), None,
                                    _ptr(opacities), cfg.get("activations", 0), P(WS.SH_JAC) if s.get("sh_jac") else None,
                                    _ptr(row_sums), _ptr(go.get("grad_norm")), _ptr(go.get("count"))), "gs_project_bwd"))
@@ -749,7 +837,7 @@ class _Rasterize(torch.autograd.Function):
             holder.grad_out["_written"] = True   # (the caller's own dict: it can tell that its tensors were filled by THIS backward)
         if dbg is not None:
             dbg.update(v_means2d=v_m2, v_conics=v_cn, v_colors_post=v_cp,
-                       rows=lease.view(WS.ROWS, max(s["n_isects"], 1) * 4 * nat.GS_ROW_FLOATS).clone().view(-1, nat.GS_ROW_FLOATS))
+                       rows=lease.view(WS.ROWS, max(n_rows, 1) * nat.GS_ROW_FLOATS)[: n_rows * nat.GS_ROW_FLOATS].clone().view(-1, nat.GS_ROW_FLOATS))
         if m2_out is not None:
             if holder.absgrad:
                 m2_out.absgrad = v_abs

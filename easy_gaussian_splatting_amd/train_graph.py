@@ -11,8 +11,11 @@ through the C ABI of include/gs_raster.h directly -- the same kernels, in the sa
 inputs as `model(data)` / `LossComputer` / `loss.backward()` / `update_statistics` / `FusedAdam.step` issue
 them, so the two paths agree bit for bit (tests/test_gpu_train_graph.py) -- but
 
-* every buffer lives in a persistent workspace sized by CAPACITY (high-water mark of the intersection count
-  + margin), nothing is allocated per step and the host never reads a size back: the list kernels, the
+* every buffer lives in a persistent workspace sized by CAPACITY -- of LISTED intersections (keys, sorted lists, quadrant
+  masks, row bases: 13-25 bytes each) and of what the forward WALKS (work units with their checkpoints and sublists, gradient
+  rows; round 6: rounds 1-5 sized those by the list capacity, 355 bytes per listed entry, 25 GB at 2 M Gaussians on a realistic
+  footprint of which 1.6 % was ever walked) -- high-water marks + margin; nothing is allocated per step and the host never
+  reads a size back: the list kernels, the
   statistics and Adam run under the library's step guard (`gs_guard_set`) -- a step whose lists outgrow the
   capacity is a device-side no-op, and so is every step queued behind it;
 * the whole sequence is captured once into a hipGraph and replayed: per step the host enqueues the input
@@ -88,9 +91,14 @@ class TrainStepGraph:
         # need the runtime knob.)
         self.stream = torch.cuda.Stream(self.dev)
         self.cap = 0
+        self.cap_units = self.cap_rows = 0   # capacities of what the forward walks: work units (storage units), gradient rows
         self.cap_floor = 0   # capacity carried over a rebuild: the probe sees ONE view, the steps before saw them all
+        self.walk_floor = (0, 0)
         self.seen_isects = 0  # largest intersection count the status words have shown since the last (re-)build
         self.seen_tile = 0    # ... and the longest tile list
+        self.seen_units = self.seen_rows = 0   # ... and the most storage units / gradient rows a step's walk took
+        self.probed_walk = (0, 0)
+        self._walk_history_void = False
         self.binning = None
         self.probed = (0, 0)
         self.cap_tile = _SORT_CLASSES[0]
@@ -116,10 +124,10 @@ class TrainStepGraph:
                 m.collecting_counts.data_ptr(), m.active_sh_degree, getattr(m, "tile_culling", "tight"),
                 self.W if W is None else int(W), self.H if H is None else int(H))
 
-    def _build(self, data, gt_img, mask, min_cap: int = 0, min_cap_tile: int = 0, projected=None):
+    def _build(self, data, gt_img, mask, min_cap: int = 0, min_cap_tile: int = 0, projected=None, min_walk=(0, 0)):
         """(Re-)allocates the workspace for the model as it is now, learns the capacities from one blocking probe
         of the list sizes if needed, warms every kernel up eagerly and captures the step.
-        `projected` = (I, longest tile list) carried over from the steps before a refinement (`step()`): no probe, no
+        `projected` = (I, longest tile list, storage units, gradient rows) carried over from the steps before a refinement (`step()`): no probe, no
         warm-up step -- the re-build is allocation + capture and never touches the device's queue.  (A projection that
         does not hold trips the step guard like any overflow; `_recover` then probes.)"""
         m, dev = self.model, self.dev
@@ -164,7 +172,6 @@ class TrainStepGraph:
         b["one"] = torch.ones((), **f32)
         b["v_render"] = torch.empty((H, W, 3), **f32)
         b["qcnt"] = torch.empty((tiles * 4,), **i32)
-        b["unit_counter"] = torch.zeros((1,), **i32)
         b["v_abs"] = self._take("v_abs", (1, N, 2), torch.float32)
         self.grads = None if self.fuse_adam else {
             "means": torch.empty((N, 3), **f32), "log_scales": torch.empty((N, 3), **f32),
@@ -173,21 +180,48 @@ class TrainStepGraph:
             "logit_opacities": torch.empty((N,), **f32)}
         b["hyper"] = torch.zeros((16,), **f32)
         self._stage_inputs(max(self.opt._step, 0) + 1, [float(grp["lr"]) for grp, _ in self.opt._plist], data["w2c"], data["K"], gt_img, mask)
+        probe_walk = False
         if projected is not None:
-            n_isects, max_tile = projected
+            n_isects, max_tile, units, rows = projected
             self.cap = int(n_isects * self.margin) + 4096
             need_tile = int(max_tile * self.margin)
             self.cap_tile = next((c for c in _SORT_CLASSES if c >= need_tile), 1 << 30)
+            self.cap_units, self.cap_rows = int(units * self.margin) + 512, int(rows * self.margin) + 4096
             self.stats["projected_rebuilds"] = self.stats.get("projected_rebuilds", 0) + 1
-        elif self.cap == 0 or min_cap or min_cap_tile:
+        elif self.cap == 0 or min_cap or min_cap_tile or min_walk[0] or min_walk[1]:
             n_isects, max_tile = self._probe()
             self.probed = (n_isects, max_tile)
             self.cap = max(int(max(n_isects, min_cap) * self.margin) + 4096, self.cap, self.cap_floor)
             need_tile = max(int(max(max_tile, min_cap_tile) * self.margin), self.cap_tile)   # (same head-room as the lists)
             self.cap_tile = next((c for c in _SORT_CLASSES if c >= need_tile), 1 << 30)
+            probe_walk = True
         self._alloc_binning()
         self._alloc_lists()
+        if probe_walk:
+            # what the forward WALKS on this view: one guarded forward on first-guess capacities, repeated with what it reports
+            floor = (max(min_walk[0], self.walk_floor[0]), max(min_walk[1], self.walk_floor[1]))
+            self.cap_units = max(self.cap_units, int(floor[0] * self.margin) + 512, self.cap // 64 + 4 * tiles + 512)
+            self.cap_rows = max(self.cap_rows, int(floor[1] * self.margin) + 4096, self.cap // 8 + 4096)
+            while True:
+                self._alloc_walk()
+                units, rows, fl = self._probe_walk()
+                if not fl:
+                    break
+                self.cap_units = max(self.cap_units, int(units * self.margin) + 512)
+                self.cap_rows = max(self.cap_rows, int(rows * self.margin) + 4096)
+            self.probed_walk = (units, rows)
+            # The probe saw ONE view.  The list capacity carries the history of all of them (cap_floor); the walk is scaled to
+            # it -- and after an opacity reset, when the history of the walk is void (nothing saturates any more, how deep a
+            # view walks is anybody's guess: 1.1 to 2.6 M rows over the six views of tests/test_gpu_train_graph.py's soak),
+            # with twice the head-room until the next re-build has steps to go by.
+            scale = max(1.0, (self.cap / self.margin) / max(n_isects, 1))
+            wm = self.margin * (2.0 if self._walk_history_void else 1.0)
+            self.cap_units = max(int(max(units * scale, floor[0]) * wm) + 512, 256)
+            self.cap_rows = max(int(max(rows * scale, floor[1]) * wm) + 4096, 4096)
+            self._walk_history_void = False
+        self._alloc_walk()
         self._key = self._state_key()
+        self._opacity_resets = getattr(m, "opacity_resets", 0)
         # eager warm-up of the guarded pipeline (raises every kernel attribute; also a functional check before capture)
         t_cap = time.perf_counter()
         self._capture(warm_up=projected is None)
@@ -196,7 +230,7 @@ class TrainStepGraph:
         self.stats["build_ms"] = round(self.stats.get("build_ms", 0.0) + 1e3 * (now - t_build), 2)        # whole (re-)builds, wall clock
         self.stats["capture_ms"] = round(self.stats.get("capture_ms", 0.0) + 1e3 * (now - t_cap), 2)    # ... of which warm-up + capture
 
-    def _take(self, name: str, shape, dtype) -> Tensor:
+    def _take(self, name: str, shape, dtype, shrink: bool = False) -> Tensor:
         """A buffer of the workspace from the runner's pool: re-used across re-builds while it fits, re-allocated with head-room
         when it does not (a model that has been refined once will be refined again: `densify_and_prune` grows N by 20-30 % per
         call, and a re-build that has to `hipMalloc` twenty-five new buffers cost 16 ms per refinement on some boxes of the
@@ -205,6 +239,8 @@ class TrainStepGraph:
         for d in shape:
             n *= int(d)
         t = self._pool.get(name)
+        if shrink and t is not None and t.numel() > 2 * n + 4096:
+            t = None   # (a first-guess buffer of the walk probe several times what the walk turned out to need: let it go)
         if t is None or t.dtype != dtype or t.numel() < n:
             slack = 1.0 if self.stats["rebuilds"] == 0 else 1.6
             t = torch.empty((int(n * slack) + 16,), dtype=dtype, device=self.dev)
@@ -228,18 +264,44 @@ class TrainStepGraph:
         b["ws"] = self._take("ws", (ws,), torch.uint8)
 
     def _alloc_lists(self):
-        b, dev, cap = self.buf, self.dev, self.cap
-        tiles = self.tw * self.th
-        f32 = dict(dtype=torch.float32, device=dev)
-        i32 = dict(dtype=torch.int32, device=dev)
-        self.cap_buckets = cap // nat.GS_BUCKET + tiles + 1
+        """What is sized by the LISTED intersections: the sorted lists, a quadrant-mask byte and a row base per entry."""
+        b, cap = self.buf, self.cap
         b["flatten_ids"] = self._take("flatten_ids", (cap,), torch.int32)
         b["slots"] = self._take("slots", (cap,), torch.int32)
-        b["ckpt"] = self._take("ckpt", (8 * self.cap_buckets, 64, 4), torch.float32)
-        b["qlist"] = self._take("qlist", (4 * cap, 2), torch.int32)
-        b["qmask"] = self._take("qmask", (cap,), torch.uint8)
-        b["unit_desc"] = self._take("unit_desc", (8 * self.cap_buckets, 4), torch.int32)
-        b["rows"] = self._take("rows", (4 * cap, nat.GS_ROW_FLOATS), torch.float32)
+        b["qmask"] = self._take("qmask", (cap + 16,), torch.uint8)
+        b["row_base"] = self._take("row_base", (cap + 4,), torch.int32)
+        b["walk_state"] = self._take("walk_state", (int(nat.lib().gs_walk_state_ints(cap)),), torch.int32)
+
+    def _alloc_walk(self):
+        """What is sized by what the forward WALKS: a checkpoint, a sublist block and a descriptor per work unit, the gradient rows."""
+        b = self.buf
+        cu, cr = max(int(self.cap_units), 256), max(int(self.cap_rows), 1)
+        self.cap_units, self.cap_rows = cu, cr
+        b["ckpt"] = self._take("ckpt", (cu, 64, 4), torch.float32, shrink=True)
+        b["qlist"] = self._take("qlist", (cu, nat.GS_UNIT, 2), torch.int32, shrink=True)
+        b["unit_desc"] = self._take("unit_desc", (cu, 4), torch.int32, shrink=True)
+        b["rows"] = self._take("rows", (cr, nat.GS_ROW_FLOATS), torch.float32, shrink=True)
+
+    def _probe_walk(self):
+        """One guarded forward (projection .. blend) on the current capacities; returns (storage units, gradient rows, flags) of
+        its walk -- the counters keep counting past the capacities.  Build time only (blocking)."""
+        b = self.buf
+        with torch.cuda.device(self.dev), self._on_stream():
+            nat.check(nat.lib().gs_guard_set(_p(b["info"]), self.cap, self.cap_tile), "gs_guard_set")
+            try:
+                self._stage_no = 0
+                self._enqueue_forward()
+            except TrainStepGraph._Stop:
+                pass
+            finally:
+                nat.lib().gs_guard_set(None, 0, 0)
+        self.stream.synchronize()
+        info = b["info"].tolist()
+        w = b["walk_state"][:8].tolist()
+        b["info"].zero_()
+        if int(info[3]) & ~48:
+            raise RuntimeError(f"TrainStepGraph: the probed list capacities do not hold their own view {info}")
+        return int(w[1]), int(w[3]), int(info[3]) & 48
 
     def _protect_pending(self, static: Tensor):
         """`static` (one of the runner's input buffers) is about to be overwritten: steps still pending that were issued
@@ -429,6 +491,27 @@ class TrainStepGraph:
         b["info"].zero_()
         return n_isects, max_tile
 
+    def _enqueue_forward(self):
+        """Projection, tile lists and the training blend on the current stream (the caller holds the step guard)."""
+        L, b = nat.lib(), self.buf
+        st = self._st()
+        N, W, H = self.N, self.W, self.H
+        self._project()
+        self._count()
+        if self.binning == "bins":
+            self._ck(L.gs_bins_lists(st, 1, N, self.tw, self.th, self.bin_shift, _p(b["bbox"]), _p(b["ws"]), self.ws_bytes,
+                                      _p(b["coarse_keys"]), self.cap_coarse, _p(b["cum_tiles"]), _p(b["isect_offsets"]),
+                                      None, _p(b["flatten_ids"]), _p(b["slots"]), _p(b["info"])), "gs_bins_lists")
+        else:
+            self._ck(L.gs_bin_emit_sort(st, 1, N, self.tw, self.th, _p(b["bbox"]), _p(b["depths"]), _p(b["ws"]), self.ws_bytes,
+                                         _p(b["isect_offsets"]), self.cap, self.cap_tile, _p(b["keys_tmp"]), _p(b["slot_gid"]),
+                                         _p(b["cum_tiles"]), None, _p(b["flatten_ids"]), _p(b["slots"])), "gs_bin_emit_sort")
+        self._ck(L.gs_blend_fwd(st, 1, W, H, _p(b["rec"]), _p(b["bg"]), _p(b["isect_offsets"]),
+                                 _p(b["tile_order"]), _p(b["flatten_ids"]), _p(b["slots"]), self.cap, _p(b["render_colors"]),
+                                 _p(b["render_alphas"]), _p(b["ckpt"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["qmask"]),
+                                 _p(b["unit_desc"]), self.cap_units, _p(b["row_base"]), self.cap_rows, _p(b["walk_state"])),
+                 "gs_blend_fwd")
+
     def _enqueue_step(self):
         """The whole step on the current stream, guarded; nothing here allocates or synchronises."""
         L, b, m, opt = nat.lib(), self.buf, self.model, self.opt
@@ -437,27 +520,14 @@ class TrainStepGraph:
         nat.check(L.gs_guard_set(_p(b["info"]), self.cap, self.cap_tile), "gs_guard_set")
         self._stage_no = 0
         try:
-            self._project()
-            self._count()
-            if self.binning == "bins":
-                self._ck(L.gs_bins_lists(st, 1, N, self.tw, self.th, self.bin_shift, _p(b["bbox"]), _p(b["ws"]), self.ws_bytes,
-                                          _p(b["coarse_keys"]), self.cap_coarse, _p(b["cum_tiles"]), _p(b["isect_offsets"]),
-                                          None, _p(b["flatten_ids"]), _p(b["slots"]), _p(b["info"])), "gs_bins_lists")
-            else:
-                self._ck(L.gs_bin_emit_sort(st, 1, N, self.tw, self.th, _p(b["bbox"]), _p(b["depths"]), _p(b["ws"]), self.ws_bytes,
-                                             _p(b["isect_offsets"]), self.cap, self.cap_tile, _p(b["keys_tmp"]), _p(b["slot_gid"]),
-                                             _p(b["cum_tiles"]), None, _p(b["flatten_ids"]), _p(b["slots"])), "gs_bin_emit_sort")
-            self._ck(L.gs_blend_fwd(st, 1, W, H, _p(b["rec"]), _p(b["bg"]), _p(b["isect_offsets"]), _p(b["bucket_offsets"]),
-                                     _p(b["tile_order"]), _p(b["flatten_ids"]), _p(b["slots"]), self.cap, _p(b["render_colors"]),
-                                     _p(b["render_alphas"]), _p(b["ckpt"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["qmask"]),
-                                     _p(b["unit_counter"]), _p(b["unit_desc"])), "gs_blend_fwd")
+            self._enqueue_forward()
             lam = float(self.lc.lambda_ssim)
             self._ck(L.gs_l1_ssim_fwd_slots(st, H, W, lam, _p(b["render_colors"]), _p(b["img_slots"]), int(self.has_mask), 1, _p(b["loss_ws"]),
                                              _p(b["loss3"])), "gs_l1_ssim_fwd_slots")
             self._ck(L.gs_l1_ssim_bwd_slots(st, H, W, lam, _p(b["render_colors"]), _p(b["img_slots"]), 1, _p(b["loss_ws"]),
                                              _p(b["one"]), _p(b["v_render"])), "gs_l1_ssim_bwd_slots")
-            self._ck(L.gs_blend_bwd(st, 1, W, H, _p(b["rec"]), _p(b["isect_offsets"]), _p(b["bucket_offsets"]), self.cap_buckets,
-                                     _p(b["qlist"]), _p(b["qcnt"]), _p(b["unit_counter"]), _p(b["unit_desc"]), _p(b["ckpt"]),
+            self._ck(L.gs_blend_bwd(st, 1, W, H, _p(b["rec"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["unit_desc"]), self.cap_units,
+                                     _p(b["ckpt"]), _p(b["qmask"]), _p(b["row_base"]), _p(b["walk_state"]),
                                      _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"])),
                       "gs_blend_bwd")
             b1, b2 = opt.defaults["betas"]
@@ -466,7 +536,7 @@ class TrainStepGraph:
                 self._ck(L.gs_project_bwd_adam(st, N, self.K, int(m.active_sh_degree), _p(opt.flat_param), _p(opt.exp_avg),
                                                _p(opt.exp_avg_sq), offs, _p(b["viewmats"]), _p(b["Ks"]), W, H, 0.3, 0.01, 1e10,
                                                _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]),
-                                               _p(b["rows"]), _p(b["qmask"]), _p(b["v_abs"]), float(b1), float(b2),
+                                               _p(b["rows"]), _p(b["row_base"]), _p(b["v_abs"]), float(b1), float(b2),
                                                float(opt.defaults["eps"]), _p(b["hyper"]), _p(b["applied"]), _p(m.max_radii),
                                                _p(m.grad_norm_accum), _p(m.collecting_counts), _p(b["sh_jac"])), "gs_project_bwd_adam")
             else:
@@ -474,7 +544,7 @@ class TrainStepGraph:
                 self._ck(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
                                           _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0, _p(b["viewmats"]), _p(b["Ks"]), W, H,
                                           0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]),
-                                          _p(b["cum_tiles"]), _p(b["rows"]), _p(b["qmask"]), _p(g["means"]), _p(g["quats"]),
+                                          _p(b["cum_tiles"]), _p(b["rows"]), _p(b["row_base"]), _p(g["means"]), _p(g["quats"]),
                                           _p(g["log_scales"]), _p(g["logit_opacities"]), _p(g["sh_0"]), _p(g["sh_rest"]), _p(b["v_abs"]),
                                           None, None, None, None, _p(m.logit_opacities), 1, _p(b["sh_jac"]), None, None, None), "gs_project_bwd")
                 self._ck(L.gs_update_statistics(st, N, float(max(H, W)), _p(b["radii"]), _p(b["v_abs"]), _p(m.max_radii),
@@ -487,7 +557,7 @@ class TrainStepGraph:
                                             ends, lens, gptr, float(b1), float(b2), float(opt.defaults["eps"]), 1.0, _p(b["hyper"]),
                                             _p(b["applied"])), "gs_adam_step_dev")
             self._ck(L.gs_step_status(st, _p(b["info"]), _p(b["applied"]), self.status.data_ptr(), _p(b["loss3"]), _p(b["loss_ring"]),
-                                      self.LOSS_RING), "gs_step_status")
+                                      self.LOSS_RING, _p(b["walk_state"])), "gs_step_status")
         except TrainStepGraph._Stop:
             pass
         finally:
@@ -583,15 +653,23 @@ class TrainStepGraph:
             # compounds margin on margin, and every kernel whose grid is sized by the capacity pays for the empty workgroups
             n_new = self.model.means.shape[0]
             growth = max(1.0, n_new / max(self.N, 1))
-            self.cap_floor = 0 if size_changed else min(int(self.seen_isects * growth * self.margin), (1 << 29) - 1)
+            self.cap_floor = 0 if size_changed else min(int(self.seen_isects * growth * self.margin), (1 << 31) - (1 << 20))
+            self.walk_floor = (0, 0) if size_changed else (int(self.seen_units * growth), int(self.seen_rows * growth))
             # ... and when that history exists (same frame size, per-tile binning, a model that grew by less than 2 x) the
             # re-build needs no probe at all: the host never reads the device between the refinement and the next replay
             # (bench.py `real_loop`: a probing re-build cost 5.5 ms + a throw-away warm-up step per refinement, more than the
             # 100 captured steps in between had saved against the eager loop)
+            # (an opacity reset changes how deep the blend walks -- nothing saturates any more -- though not the lists: the walk
+            #  capacities then come from a fresh probe, the list capacities keep their floor)
+            reset = getattr(self.model, "opacity_resets", 0) != self._opacity_resets
+            if reset:
+                self.walk_floor = (0, 0)
+                self._walk_history_void = True
             projected = carried = None
-            if (not size_changed and self.binning == "tiles" and self.seen_isects > 0 and growth <= 2.0 and self.project_rebuilds
+            if (not size_changed and not reset and self.binning == "tiles" and self.seen_isects > 0 and growth <= 2.0 and self.project_rebuilds
                     and self._key is not None and self._state_key(W, H)[5:] == self._key[5:]):
-                projected = (min(int(self.seen_isects * growth), (1 << 29) // 2), max(int(self.seen_tile * min(growth, 1.25)), 64))
+                projected = (min(int(self.seen_isects * growth), 1 << 30), max(int(self.seen_tile * min(growth, 1.25)), 64),
+                             int(self.seen_units * growth), int(self.seen_rows * growth))
                 # ... but only into a tile-sort class this runner has already run EAGERLY: a class used for the first time is
                 # another kernel / another LDS size, whose attributes `ensure_lds` would raise -- and which would launch for the
                 # first time -- inside the stream capture (gs_binning.hip: the warm-up exists to avoid exactly that)
@@ -599,10 +677,11 @@ class TrainStepGraph:
                 if (self.binning, cls) not in self._warm:
                     # (the probing re-build still takes the projection as a floor: its probe sees ONE view, the history all)
                     carried, projected = projected, None
-            self.seen_isects = self.seen_tile = 0
-            self.cap = 0
+            self.seen_isects = self.seen_tile = self.seen_units = self.seen_rows = 0
+            self.cap = self.cap_units = self.cap_rows = 0
             if projected is None and carried is not None:
-                self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None, min_cap=carried[0], min_cap_tile=carried[1])
+                self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None, min_cap=carried[0], min_cap_tile=carried[1],
+                            min_walk=carried[2:4])
             else:
                 self._build({"w2c": cur[0], "K": cur[1]}, cur[2], cur[3] if self.has_mask else None, projected=projected)
         b = self.buf
@@ -633,17 +712,18 @@ class TrainStepGraph:
         """Reads the device-written status words (plain host memory) and retires the steps known to be applied."""
         if block:
             self.stream.synchronize()
-        n_isects, _, max_tile, flags, applied = (int(v) for v in self.status[:5].tolist())
+        n_isects, _, max_tile, flags, applied, units, rows = (int(v) for v in self.status[:7].tolist())
         self.seen_isects = max(self.seen_isects, n_isects)
         self.seen_tile = max(self.seen_tile, max_tile)
+        self.seen_units, self.seen_rows = max(self.seen_units, units), max(self.seen_rows, rows)
         done = min(self.confirmed_at_build + applied - self.confirmed, len(self.pending))
         for _ in range(max(done, 0)):
             self.pending.popleft()
         self.confirmed += max(done, 0)
         if flags != 0:
-            self._recover(n_isects, max_tile)
+            self._recover(n_isects, max_tile, (units, rows) if flags & 48 else (0, 0))
 
-    def _recover(self, n_isects: int, max_tile: int):
+    def _recover(self, n_isects: int, max_tile: int, walk=(0, 0)):
         """A step did not fit: everything issued after the last applied step was skipped on the device.  Grow, re-capture,
         replay the skipped steps in order."""
         self.stream.synchronize()
@@ -657,9 +737,13 @@ class TrainStepGraph:
         self.issued -= len(redo)
         self.stats["overflows"] += 1
         self.stats["replayed_steps"] += len(redo)
+        # (what did not fit, and into what: flags 1 = listed intersections, 2 = longest tile list, 4 / 8 = coarse bins, 16 = work units, 32 = rows)
+        self.stats.setdefault("overflow_log", []).append({
+            "step": self.confirmed + 1, "flags": int(self.status[3]), "isects": n_isects, "longest_list": max_tile, "work_units": walk[0], "rows": walk[1],
+            "capacities": [self.cap, self.cap_tile, self.cap_units, self.cap_rows]})
         first = redo[0]
         # (min_cap >= 1 forces a fresh probe even when only a coarse-bin capacity was exceeded and the list sizes read 0)
-        self._build({"w2c": first[2], "K": first[3]}, first[4], first[5], min_cap=max(n_isects, 1), min_cap_tile=max_tile)
+        self._build({"w2c": first[2], "K": first[3]}, first[4], first[5], min_cap=max(n_isects, 1), min_cap_tile=max_tile, min_walk=walk)
         for e in redo:
             self._issue(e)
 
@@ -681,5 +765,7 @@ class TrainStepGraph:
 
     def report(self) -> Dict[str, Any]:
         return dict(self.stats, binning=self.binning, probed_isects=self.probed[0], probed_longest_list=self.probed[1],
-                    capacity_isects=self.cap, capacity_tile_list=self.cap_tile, steps=self.confirmed,
+                    capacity_isects=self.cap, capacity_tile_list=self.cap_tile, capacity_work_units=self.cap_units,
+                    capacity_rows=self.cap_rows, probed_work_units=self.probed_walk[0], probed_rows=self.probed_walk[1],
+                    seen_work_units=self.seen_units, seen_rows=self.seen_rows, steps=self.confirmed,
                     graph=self.graph is not None)

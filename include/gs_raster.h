@@ -39,6 +39,24 @@ extern "C" {
 #define GS_ROW_FLOATS 12     /* per-intersection gradient row written by gs_blend_bwd */
 #endif
 
+/* Walk state of a training forward (gs_blend_fwd -> gs_blend_bwd): int32 words, followed by the chunk counts of the row-base scan.
+ * gs_walk_state_ints(n_isects) = GS_WALK_WORDS + n_isects / 8192 + 1 words; 8-byte aligned; cleared by gs_blend_fwd itself. */
+#define GS_WALK_UNITS 0      /* work units published (descriptors written) */
+#define GS_WALK_STORAGE 1    /* storage units needed = GS_WALK_RANGES x the fullest range's count: what cap_units has to hold */
+#define GS_WALK_ROWS 3       /* gradient rows = (intersection, quadrant) pairs some pixel took: what cap_rows has to hold */
+#define GS_WALK_FLAGS 4      /* GS_FLAG_UNITS / GS_FLAG_ROWS of this call */
+#define GS_WALK_SKIP 5       /* 1: the step guard was tripped when the call started -- its kernels did nothing */
+#define GS_WALK_RANGES 32    /* the storage units are handed out from 32 counters, each over its own 1/32 of [0, cap_units) and in */
+#define GS_WALK_RANGE0 32    /* a cache line of its own: word GS_WALK_RANGE0 + 32 * r (one counter took 30 k same-address atomics per frame) */
+#define GS_WALK_WORDS (GS_WALK_RANGE0 + 32 * GS_WALK_RANGES)
+/* Flag bits of an info block (info_dev[3], gs_guard_set) */
+#define GS_FLAG_ISECTS 1     /* I > cap_isects */
+#define GS_FLAG_TILE 2       /* a tile list longer than cap_tile */
+#define GS_FLAG_COARSE 4     /* two-level binning: coarse entries > coarse_cap */
+#define GS_FLAG_COARSE_LIST 8 /* two-level binning: a bin list longer than coarse_list_cap */
+#define GS_FLAG_UNITS 16     /* training forward: the walk opened more work units than cap_units */
+#define GS_FLAG_ROWS 32      /* training forward: more gradient rows than cap_rows */
+
 #define GS_OK 0
 #define GS_ERR_ARG (-1)
 #define GS_ERR_HIP (-2)
@@ -46,6 +64,7 @@ extern "C" {
 
 /* Library identity / diagnostics. */
 int gs_version(void);
+const char* gs_build_flags(void); /* preprocessor flags beyond the product build's ("" = the product library; a diagnostic variant names its own) */
 const char* gs_last_error(void);
 const char* gs_arch(void); /* "gfx950" */
 
@@ -55,10 +74,12 @@ const char* gs_arch(void); /* "gfx950" */
  * cap_isects/64 + C*tiles + 1 buckets), launches the sort classes for lists of up to cap_tile entries
  * (gs_bin_emit_sort's max_tile_count = cap_tile) and zeroes info_dev[3] once.  While the guard is set (per host
  * thread; pass NULL to clear), gs_bin_count ORs into info_dev[3]: 1 if I > cap_isects, 2 if a tile list exceeds
- * cap_tile; and gs_bin_emit_sort, gs_blend_fwd, gs_blend_bwd, gs_project_bwd, gs_update_statistics and
+ * cap_tile; a training gs_blend_fwd ORs 16 if its walk opens more work units than its cap_units and 32 if it leaves more
+ * gradient rows than its cap_rows; and gs_bin_emit_sort, gs_blend_fwd, gs_blend_bwd, gs_project_bwd, gs_update_statistics and
  * gs_adam_step[_dev] return at once on the device when info_dev[3] != 0: a step that does not fit -- and every
  * step enqueued behind it -- is a no-op the host can detect later (read info_dev), re-size for, clear and replay.
- * n_isects / n_buckets / max_tile_count arguments of those entry points may then be the capacities. */
+ * n_isects / max_tile_count arguments of those entry points may then be the capacities (the passes over the slots -- the clear
+ * of the quadrant masks, the row-base scan -- stop at the I the tile scan left in info_dev[0]). */
 int gs_guard_set(const int64_t* info_dev, int64_t cap_isects, int64_t cap_tile);
 /* The same guard for ONE call (the eager seam: every rasterization() enqueues its list stages and blend speculatively under it):
  * the flags are not sticky across calls -- the call's first flag writer (gs_bins_count's bin scan, else gs_bin_count's tile scan)
@@ -71,28 +92,37 @@ int gs_guard_set_call(const int64_t* info_dev, int64_t cap_isects, int64_t cap_t
  * reads the list sizes and flags from plain memory -- no device-to-host copy (a 4 us transfer kernel and the idle gap behind
  * it) on the stream.  The blocking `info_host` argument of those calls is independent of this. */
 int gs_info_mirror_set(int64_t* info_host_mapped);
+/* The same for the walk record of a training gs_blend_fwd (per host thread; NULL clears it): int64[4] of page-locked, device-
+ * addressable host memory; the call's last kernel writes {work units, storage units taken, gradient rows, GS_FLAG_UNITS |
+ * GS_FLAG_ROWS} there, followed by a system-scope fence -- the eager seam's backward learns whether the walk fitted its
+ * capacities (and what it needed) from plain memory. */
+int gs_walk_mirror_set(int64_t* walk_host_mapped);
 
 /* Publishes a guarded step's outcome without a copy or an event: one tiny launch writes
- * status[0..3] = info_dev[0..3] ({I, n_buckets, max tile, flags}) and status[4] = applied_dev[0] (may be NULL).
+ * status[0..3] = info_dev[0..3] ({I, n_buckets, max tile, flags}), status[4] = applied_dev[0] (may be NULL) and -- walk_state
+ * (gs_blend_fwd's, may be NULL) -- status[5] = storage units taken, status[6] = gradient rows: what the walk needed.
  * `status` may be page-locked HOST memory (hipHostMalloc'ed, device-accessible): the host then polls plain memory
  * -- the flags are sticky and the applied-step counter monotonic, so a torn read is harmless.
  * loss_ring_dev (optional, with loss3_dev = gs_l1_ssim_fwd's out3): a device ring of ring_len x 3 floats; an APPLIED step
  * n (counted from 1) logs its {l1, 1-ssim, total} in slot (n-1) mod ring_len, a skipped step logs nothing. */
 int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied_dev, int64_t* status,
-                   const float* loss3_dev, float* loss_ring_dev, int ring_len);
+                   const float* loss3_dev, float* loss_ring_dev, int ring_len, const int32_t* walk_state);
 
 /* Persistent workspace of the eager seam (SURVEY.md section 8b "Ownership" / "Sync"; replaces the ~25 per-call allocations a
  * binding would otherwise make and lets the list stages be enqueued BEFORE the list sizes have reached the host).
  * gs_workspace_query: layout of every intermediate of one rasterization() call that does not escape to the caller, for a call
  * shape and a CAPACITY of intersections.  offsets[GS_WS_SLOTS]: byte offset of each buffer inside its arena (-1: not needed for
- * these flags); slots below GS_WS_LIST_FIRST live in the fixed arena (sized by C, N, image), the others in the list arena (sized
- * by cap_isects / coarse_cap); arena_bytes[2] = bytes of the two arenas.  Every offset is 256-byte aligned.
- * gs_workspace_bind: validates two caller-owned device arenas against a layout and zeroes the control words (info block, work-unit
- * counter) on `stream`; needed once per (arena pair, layout) -- calls made under gs_guard_set_call leave nothing behind that the
- * next call could trip over.  The caller keeps one (fixed, list) pair per call in flight on a (device, stream) and hands the sub-pointers
- * to the stage entry points below; a call whose lists outgrow the capacity (info flags, see gs_guard_set) replaces the list arena
- * only and repeats gs_bin_count .. gs_blend_fwd. */
-#define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, work-unit counter} */
+ * these flags); slots below GS_WS_LIST_FIRST live in the fixed arena (sized by C, N, image), those below GS_WS_WALK_FIRST in the
+ * list arena (sized by cap_isects / coarse_cap: what is LISTED), the others in the walk arena (sized by cap_units / cap_rows:
+ * what a training forward WALKS -- checkpoints, quadrant sublists, work units, gradient rows); arena_bytes[3] = bytes of the
+ * three arenas.  Every offset is 256-byte aligned.
+ * gs_workspace_bind: validates three caller-owned device arenas against a layout and zeroes the info block on `stream`; needed
+ * once per (arena triple, layout) -- calls made under gs_guard_set_call leave nothing behind that the next call could trip over.
+ * The caller keeps one triple per call in flight on a (device, stream) and hands the sub-pointers to the stage entry points
+ * below; a call whose lists outgrow the capacity (info flags, see gs_guard_set) replaces the list arena only and repeats
+ * gs_bin_count .. gs_blend_fwd; a training call whose walk outgrows cap_units / cap_rows replaces the walk arena only and repeats
+ * gs_blend_fwd. */
+#define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, -} */
 #define GS_WS_REC 1             /* f32 [C*N][12] */
 #define GS_WS_BBOX 2            /* u32 [C*N][4] */
 #define GS_WS_TILES_PER_GAUSS 3 /* i32 [C*N] */
@@ -102,29 +132,31 @@ int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied
 #define GS_WS_BUCKET_OFFSETS 7  /* i32 [C*tiles+1] */
 #define GS_WS_TILE_ORDER 8      /* i32 [C*tiles] */
 #define GS_WS_QCNT 9            /* i32 [C*tiles*4]              (training) */
-#define GS_WS_UNIT_COUNTER 10   /* i32 [1]                      (training; the last word of the info block) */
-#define GS_WS_SH_JAC 11         /* f32 [C*N*9]                  (training: gs_project_fwd -> gs_project_bwd) */
-#define GS_WS_LIST_FIRST 12     /* ---- list arena ---- */
-#define GS_WS_BIN 12            /* gs_bin_workspace_bytes / gs_bins_workspace_bytes */
-#define GS_WS_COARSE_KEYS 13    /* u64 [coarse_cap]             (two-level binning) */
-#define GS_WS_KEYS_TMP 14       /* u64 [cap]                    (per-tile pipeline) */
-#define GS_WS_SLOT_GID 15       /* i32 [cap]                    (per-tile pipeline, training) */
-#define GS_WS_FLATTEN_IDS 16    /* i32 [cap] */
-#define GS_WS_SLOTS_BUF 17      /* i32 [cap]                    (training) */
-#define GS_WS_ISECT_IDS_BUF 18  /* i64 [cap]                    (GS_WS_ISECT_IDS) */
-#define GS_WS_CKPT 19           /* f32 [8*cap_buckets][64][4]   (training; cap_buckets = cap/64 + C*tiles + 1) */
-#define GS_WS_QLIST 20          /* i32 [4*cap][2]               (training) */
-#define GS_WS_QMASK 21          /* u8  [cap]                    (training) */
-#define GS_WS_UNIT_DESC 22      /* i32 [8*cap_buckets][4]       (training) */
-#define GS_WS_ROWS 23           /* f32 [4*cap][12]              (training: gs_blend_bwd -> gs_project_bwd) */
-#define GS_WS_SLOTS 24
+#define GS_WS_SH_JAC 10         /* f32 [C*N*9]                  (training: gs_project_fwd -> gs_project_bwd) */
+#define GS_WS_LIST_FIRST 11     /* ---- list arena ---- */
+#define GS_WS_BIN 11            /* gs_bin_workspace_bytes / gs_bins_workspace_bytes */
+#define GS_WS_COARSE_KEYS 12    /* u64 [coarse_cap]             (two-level binning) */
+#define GS_WS_KEYS_TMP 13       /* u64 [cap]                    (per-tile pipeline) */
+#define GS_WS_SLOT_GID 14       /* i32 [cap]                    (per-tile pipeline, training) */
+#define GS_WS_FLATTEN_IDS 15    /* i32 [cap] */
+#define GS_WS_SLOTS_BUF 16      /* i32 [cap]                    (training) */
+#define GS_WS_ISECT_IDS_BUF 17  /* i64 [cap]                    (GS_WS_ISECT_IDS) */
+#define GS_WS_QMASK 18          /* u8  [cap]                    (training) */
+#define GS_WS_ROW_BASE 19       /* i32 [cap + 1]                (training) */
+#define GS_WS_WALK_STATE 20     /* i32 [gs_walk_state_ints(cap)] (training: counters of the walk + scan descriptors) */
+#define GS_WS_WALK_FIRST 21     /* ---- walk arena (training) ---- */
+#define GS_WS_CKPT 21           /* f32 [cap_units][64][4] */
+#define GS_WS_QLIST 22          /* i32 [cap_units][32][2] */
+#define GS_WS_UNIT_DESC 23      /* i32 [cap_units][4] */
+#define GS_WS_ROWS 24           /* f32 [cap_rows][12]           (gs_blend_bwd -> gs_project_bwd) */
+#define GS_WS_SLOTS 25
 #define GS_WS_TRAIN 1           /* flags: the backward's lists, checkpoints and rows */
 #define GS_WS_TWO_LEVEL 2       /*        two-level binning (coarse_cap, bin_shift) instead of the per-tile pipeline */
 #define GS_WS_ISECT_IDS 4       /*        gsplat's isect_ids written eagerly */
-int gs_workspace_query(int C, int64_t N, int width, int height, int64_t cap_isects, int64_t coarse_cap, int bin_shift, int flags,
-                       int64_t* offsets, int64_t* arena_bytes);
+int gs_workspace_query(int C, int64_t N, int width, int height, int64_t cap_isects, int64_t coarse_cap, int64_t cap_units,
+                       int64_t cap_rows, int bin_shift, int flags, int64_t* offsets, int64_t* arena_bytes);
 int gs_workspace_bind(void* stream, void* fixed_base, int64_t fixed_bytes, void* list_base, int64_t list_bytes,
-                      const int64_t* offsets, const int64_t* arena_bytes);
+                      void* walk_base, int64_t walk_bytes, const int64_t* offsets, const int64_t* arena_bytes);
 
 /* Number of Gaussian groups per camera used by the binning kernels, and the bytes of scratch
  * `workspace` gs_bin_count / gs_bin_emit_sort need for (C, N, tiles). */
@@ -222,44 +254,51 @@ int gs_bins_lists(void* stream, int C, int64_t N, int tile_w, int tile_h, int bi
 /* B-fwd (replaces gsplat rasterize_to_pixels forward).  backgrounds[C,3] may be NULL.
  * Outputs render_colors[C,H,W,3], render_alphas[C,H,W,1].  One wavefront per 16x16 tile, each
  * lane owning one pixel of each 8x8 quadrant.  Inference: pass ckpt = NULL (and NULL for every
- * list output).  Training (ckpt != NULL) additionally emits what gs_blend_bwd consumes:
- *   qlist[4*I*2] i32    per tile four compacted, depth-ordered quadrant sublists of (flatten id,
- *                       gradient-row slot) pairs (sublist k of tile t starts at pair 4*lo_t + k*len_t)
- *   qcnt[C*tiles*4]     sublist lengths
- *   ckpt[8*n_buckets*64*4] f32  per GS_UNIT-entry work unit of a quadrant sublist: the quadrant's 64 pixel
- *                       states in front of it (T -- negative once saturated / outside the image -- and accumulated rgb)
- *   qmask[I] u8         by gradient-row slot: which quadrant rows of an intersection exist.  Cleared by this call (one
- *                       streaming pass over n_isects bytes), then only the non-zero masks are stored: a scattered one-byte
+ * list output).  Training (ckpt != NULL) additionally emits what gs_blend_bwd consumes -- sized by what the forward WALKS (a
+ * saturated tile abandons the rest of its list), not by what is listed:
+ *   qcnt[C*tiles*4]     lengths of the four compacted, depth-ordered quadrant sublists of every tile
+ *   unit_desc[cap_units*4] i32   one work unit per GS_UNIT entries of a sublist: (tile*4+quadrant, position of the unit in its
+ *                       sublist, storage unit, 0), dense in [0, walk_state[GS_WALK_UNITS])
+ *   ckpt[cap_units*64*4] f32     row `storage unit`: the quadrant's 64 pixel states in front of the unit (T -- negative once
+ *                       saturated / outside the image -- and accumulated rgb)
+ *   qlist[cap_units*32*2] i32    block `storage unit`: the unit's (flatten id, gradient-row slot) pairs
+ *   qmask[n_isects] u8  by gradient-row slot: which quadrant rows of an intersection exist.  Cleared by this call (one
+ *                       streaming pass), then only the non-zero masks are stored: a scattered one-byte
  *                       store leaves L2 as a 32-byte partial write (profiles/r03_traffic_calibration.json)
- *   unit_counter[1], unit_desc[8*n_buckets*4] i32   work units (tile*4+quadrant, entries in the unit | 0x100 for the first
- *                       unit of its sublist -- its checkpoint is "T = 1 inside the image", not read --, index of its first
- *                       qlist pair, checkpoint row)
+ *   row_base[n_isects+1] i32     exclusive scan of popcount(qmask) over the slots (three small launches behind the
+ *                       blend): the gradient rows of slot s are rows [row_base[s], row_base[s+1]), in quadrant order --
+ *                       the rows of a Gaussian (contiguous slots) and of consecutive Gaussians are contiguous
+ *   walk_state[gs_walk_state_ints(n_isects)] i32   counters (GS_WALK_*) and the scan's chunk counts; cleared by this call.
+ * Storage units are taken in chunks of 8 per tile from GS_WALK_RANGES counters (a tile's launch slot picks one), each over its
+ * own 1/32 of [0, cap_units).  When a range runs out -- the walk needs more than cap_units units, give or take the imbalance -- or
+ * leaves more than cap_rows rows, the call is void: GS_FLAG_UNITS / GS_FLAG_ROWS are ORed into walk_state[GS_WALK_FLAGS] and
+ * into the step guard's flag word (gs_guard_set), and walk_state[GS_WALK_STORAGE] / [GS_WALK_ROWS] hold what was needed
+ * (render_colors / render_alphas are complete either way).  qmask / row_base 16-byte aligned; cap_units >= 256.
  * Inside the forward a pixel's state is one float: T in (1e-4, 1] = live; a finished pixel (stop rule fired / outside the image)
  * carries its final transmittance scaled by 2^64 (exact in fp32; "live" is T <= 1).  Checkpoints do NOT store that form: a live
  * pixel's checkpoint holds T, a finished one holds -1 (gs_blend_bwd looks at the sign only; the final T of a finished pixel comes
  * from render_alphas). */
+size_t gs_walk_state_ints(int64_t n_isects);
 int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
-                 const float* backgrounds, const int32_t* isect_offsets,
-                 const int32_t* bucket_offsets, const int32_t* tile_order, const int32_t* flatten_ids, const int32_t* slots,
-                 int64_t n_isects, float* render_colors, float* render_alphas, float* ckpt,
-                 int32_t* qlist, int32_t* qcnt, uint8_t* qmask, int32_t* unit_counter,
-                 int32_t* unit_desc);
+                 const float* backgrounds, const int32_t* isect_offsets, const int32_t* tile_order,
+                 const int32_t* flatten_ids, const int32_t* slots, int64_t n_isects, float* render_colors,
+                 float* render_alphas, float* ckpt, int32_t* qlist, int32_t* qcnt, uint8_t* qmask,
+                 int32_t* unit_desc, int64_t cap_units, int32_t* row_base, int64_t cap_rows, int32_t* walk_state);
 
 /* B-bwd (replaces rasterize_to_pixels backward incl. absgrad).  Gaussian-parallel: eight 8-lane
  * systolic pipelines per wavefront, one GS_UNIT-entry work unit each; no atomics.  Writes one
- * 12-float row per (intersection, quadrant) at rows[(slots[i]*4 + quadrant)*12]:
- * (v_mx, v_my, |v_mx|, |v_my|, v_A, v_B, v_C, v_opacity, v_r, v_g, v_b, 0); rows[I*4*12].
- * v_render_alphas may be NULL. */
+ * 12-float row per (intersection, quadrant) some pixel took, at rows[(row_base[slot] + rank of the quadrant among the slot's
+ * rows)*12]: (v_mx, v_my, |v_mx|, |v_my|, v_A, v_B, v_C, v_opacity, v_r, v_g, v_b, 0); rows[cap_rows*12].
+ * The launch covers cap_units work units (pipelines past walk_state[GS_WALK_UNITS] return at once).  v_render_alphas may be NULL. */
 int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
-                 const int32_t* isect_offsets, const int32_t* bucket_offsets, int64_t n_buckets,
-                 const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_counter,
-                 const int32_t* unit_desc, const float* ckpt, const float* render_colors,
-                 const float* render_alphas, const float* v_render_colors,
+                 const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_desc, int64_t cap_units,
+                 const float* ckpt, const uint8_t* qmask, const int32_t* row_base, const int32_t* walk_state,
+                 const float* render_colors, const float* render_alphas, const float* v_render_colors,
                  const float* v_render_alphas, float* rows);
 
 /* Row reduction + SH-bwd + P-bwd fused (replaces the atomics of the blend backward,
  * spherical_harmonics backward and fully_fused_projection backward).  Sums each Gaussian's rows
- * (slots [cum_tiles[f], cum_tiles[f]+tiles_per_gauss[f]), the quadrant rows qmask marks) and
+ * (slots [cum_tiles[f], cum_tiles[f]+tiles_per_gauss[f]) = rows [row_base[first slot], row_base[last slot + 1])) and
  * pushes the result through the colour and projection VJPs.  Outputs (all fully written):
  * v_means[N,3], v_quats[N,4], v_scales[N,3], v_opacities[N], v_colors: v_shs[N,K,3]
  * (sh_degree>=0; with the split layout v_colors is v_sh_0[N,1,3] and v_sh_rest[N,K-1,3]) or
@@ -275,7 +314,7 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
  * v_scales / v_opacities are gradients w.r.t. those raw parameters.  0 = gsplat's contract.
  * sh_jac (optional, may be NULL): gs_project_fwd's direction Jacobian of the same inputs; with it colors_in / sh_rest are not
  * read (same gradients to rounding: the direction term of v_means is then summed as J^T v_pre instead of per coefficient).
- * row_sums[C*N][12] (optional, may be NULL): the row sums gs_row_sums left -- rows / qmask are then not read (may be NULL);
+ * row_sums[C*N][12] (optional, may be NULL): the row sums gs_row_sums left -- rows / row_base are then not read (may be NULL);
  * same results bit for bit.  stat_grad_norm[N] / stat_count[N] (optional, both or neither; C = 1): this view's two additive
  * statistics of /root/reference/model/gaussian.py:188-197, WRITTEN not accumulated -- |absgrad|_2 * max(width, height) and 1 for
  * visible Gaussians, 0 for culled ones (the segments of the view-parallel step's SUM all-reduce, see gs_pack_view_step). */
@@ -284,7 +323,7 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    const float* sh_rest, int colors_per_camera, const float* viewmats,
                    const float* Ks, int width, int height, float eps2d, float near_plane, float far_plane,
                    const int32_t* radii, const float* colors_post, const int32_t* tiles_per_gauss,
-                   const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
+                   const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities,
                    float* v_colors, float* v_sh_rest, float* v_means2d_abs, float* v_means2d,
                    float* v_conics, float* v_colors_post, float* v_colors_pre,
@@ -299,7 +338,7 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
  * copy of viewmats[0].  With v_colors_pre / radii_norm / cam_out pointing into one buffer [3N | N | 16] this launch fills a
  * rank's whole all-gather payload of the view-parallel step (gs_sh_adam_views).  Honours the step guard. */
 int gs_row_sums(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
-                const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
+                const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
                 float* row_sums, float* v_colors_pre, float* radii_norm, float max_hw, const float* viewmats, float* cam_out);
 
 /* Row e (view sharding): dense SH-parameter gradients of R views rebuilt from the per-view
@@ -433,7 +472,7 @@ int gs_refine_apply(void* stream, int64_t n_old, int num_splits, int K, const in
 int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree, float* params, float* exp_avg, float* exp_avg_sq,
                         const int64_t* offsets_host, const float* viewmats, const float* Ks, int width, int height, float eps2d,
                         float near_plane, float far_plane, const int32_t* radii, const float* colors_post,
-                        const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const uint8_t* qmask,
+                        const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
                         float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev, int64_t* applied_dev,
                         float* max_radii, float* grad_norm_accum, float* counts, const float* sh_jac);
 

@@ -175,48 +175,53 @@ def test_binning_choice_host_logic(monkeypatch):
 
 def test_workspace_layout_query(native):
     """gs_workspace_query (SURVEY.md 8b "Ownership"): every buffer 256-byte aligned, no two buffers of an arena overlap,
-    training-only buffers absent from an inference layout, list arena scales with the capacity while the fixed one does
-    not, argument errors reported through the error channel.  (Host logic only: no GPU.)"""
+    training-only buffers absent from an inference layout, the list arena scales with the capacity of LISTED intersections
+    (13-25 bytes each), the walk arena with the capacities of work units and gradient rows (what a training forward WALKS), the
+    fixed one with neither; argument errors reported through the error channel.  (Host logic only: no GPU.)"""
     import ctypes as ct
     from easy_gaussian_splatting_amd import workspace as WS
     lib = native.lib()
 
     def sizes(layout):
         """(arena, offset) of every present slot, sorted by offset inside each arena"""
-        out = {0: [], 1: []}
+        out = {0: [], 1: [], 2: []}
         for slot, off in enumerate(layout.offsets):
             if off >= 0:
-                if slot == WS.UNIT_COUNTER:   # the work-unit counter is the last word of the info block (one memset clears both)
-                    assert off == layout.offsets[WS.INFO] + 56
-                    continue
                 assert off % 256 == 0, (slot, off)
-                out[0 if slot < WS.LIST_FIRST else 1].append((off, slot))
+                out[0 if slot < WS.LIST_FIRST else (1 if slot < WS.WALK_FIRST else 2)].append((off, slot))
         return {a: sorted(v) for a, v in out.items()}
 
-    tr = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 0, 0, WS.F_TRAIN)
+    tr = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 0, 0, WS.F_TRAIN, 200_000, 6_000_000)
     inf = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 0, 0, 0)
-    big = WS.Layout(1, 1_000_000, 1920, 1080, 8_000_000, 0, 0, WS.F_TRAIN)
-    two = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 3_000_000, 2, WS.F_TRAIN | WS.F_TWO_LEVEL | WS.F_ISECT_IDS)
-    for lay in (tr, inf, big, two):
+    big = WS.Layout(1, 1_000_000, 1920, 1080, 8_000_000, 0, 0, WS.F_TRAIN, 200_000, 6_000_000)
+    walked = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 0, 0, WS.F_TRAIN, 400_000, 12_000_000)
+    two = WS.Layout(1, 1_000_000, 1920, 1080, 4_000_000, 3_000_000, 2, WS.F_TRAIN | WS.F_TWO_LEVEL | WS.F_ISECT_IDS, 200_000, 6_000_000)
+    for lay in (tr, inf, big, walked, two):
         for arena, lst in sizes(lay).items():
-            offs = [o for o, _ in lst]
-            assert len(set(offs)) == len(offs) and offs[0] == 0 and offs[-1] < lay.arena_bytes[arena]
-    # known sizes: rec = 48 B per Gaussian right after the 64-byte info block; rows = 192 B per capacity entry
+            if lst:
+                offs = [o for o, _ in lst]
+                assert len(set(offs)) == len(offs) and offs[0] == 0 and offs[-1] < lay.arena_bytes[arena]
+    # known sizes: rec = 48 B per Gaussian right after the 64-byte info block; rows = 48 B per row of the capacity, last in
+    # the walk arena; a work unit holds a 1 KB checkpoint, 256 B of sublist pairs and a 16-byte descriptor
     assert tr.offsets[WS.REC] == 256 and tr.offsets[WS.BBOX] - tr.offsets[WS.REC] == 48_000_000
-    nxt = min(o for o in tr.offsets[WS.LIST_FIRST:] if o > tr.offsets[WS.ROWS]) if any(o > tr.offsets[WS.ROWS] for o in tr.offsets[WS.LIST_FIRST:]) else tr.arena_bytes[1]
-    assert nxt - tr.offsets[WS.ROWS] >= 4 * 4_000_000 * 48
-    for slot in (WS.CKPT, WS.QLIST, WS.QMASK, WS.UNIT_DESC, WS.ROWS, WS.SLOTS, WS.SLOT_GID, WS.QCNT, WS.UNIT_COUNTER):
+    assert tr.arena_bytes[2] - tr.offsets[WS.ROWS] >= 6_000_000 * 48
+    assert tr.offsets[WS.QLIST] - tr.offsets[WS.CKPT] == 200_000 * 1024 and tr.offsets[WS.UNIT_DESC] - tr.offsets[WS.QLIST] == 200_000 * 256
+    for slot in (WS.CKPT, WS.QLIST, WS.QMASK, WS.ROW_BASE, WS.WALK_STATE, WS.UNIT_DESC, WS.ROWS, WS.SLOTS, WS.SLOT_GID, WS.QCNT):
         assert tr.offsets[slot] >= 0 and inf.offsets[slot] == -1, slot
-    assert inf.offsets[WS.KEYS_TMP] >= 0 and inf.offsets[WS.FLATTEN_IDS] >= 0
+    assert inf.offsets[WS.KEYS_TMP] >= 0 and inf.offsets[WS.FLATTEN_IDS] >= 0 and inf.arena_bytes[2] == 256
     assert two.offsets[WS.COARSE_KEYS] >= 0 and two.offsets[WS.KEYS_TMP] == -1 and two.offsets[WS.ISECT_IDS] >= 0
-    assert big.arena_bytes[0] == tr.arena_bytes[0] and big.arena_bytes[1] > 1.9 * tr.arena_bytes[1] - 2**27
-    assert inf.arena_bytes[1] < tr.arena_bytes[1] / 10
+    # twice the LISTED capacity: twice the list arena, the same walk arena; twice the walk capacities: the other way round
+    assert big.arena_bytes[0] == tr.arena_bytes[0] and big.arena_bytes[1] > 1.9 * tr.arena_bytes[1] and big.arena_bytes[2] == tr.arena_bytes[2]
+    assert walked.arena_bytes[1] == tr.arena_bytes[1] and walked.arena_bytes[2] > 1.9 * tr.arena_bytes[2]
+    # a listed intersection costs a training call 25 bytes (round 5: 355 + 24); an inference call 12
+    assert tr.arena_bytes[1] <= 25 * 4_000_000 + 2**24 and inf.arena_bytes[1] <= 12 * 4_000_000 + 2**24   # (+ the binning scratch)
     # errors: through the status code + gs_last_error, never a crash
-    offs, ab = (ct.c_int64 * WS.N_SLOTS)(), (ct.c_int64 * 2)()
-    assert lib.gs_workspace_query(0, 10, 64, 64, 100, 0, 0, 0, offs, ab) == -1 and b"C>=1" in lib.gs_last_error()
-    assert lib.gs_workspace_query(1, 10, 64, 64, 1 << 30, 0, 0, WS.F_TRAIN, offs, ab) == -1 and b"2^29" in lib.gs_last_error()
-    assert lib.gs_workspace_query(1, 10, 64, 64, 100, 10, 7, WS.F_TWO_LEVEL, offs, ab) == -1
-    assert lib.gs_workspace_bind(None, None, 0, None, 0, offs, ab) == -1
+    offs, ab = (ct.c_int64 * WS.N_SLOTS)(), (ct.c_int64 * 3)()
+    assert lib.gs_workspace_query(0, 10, 64, 64, 100, 0, 8, 0, 0, 0, offs, ab) == -1 and b"C>=1" in lib.gs_last_error()
+    assert lib.gs_workspace_query(1, 10, 64, 64, 1 << 31, 0, 8, 0, 0, WS.F_TRAIN, offs, ab) == -1 and b"int32" in lib.gs_last_error()
+    assert lib.gs_workspace_query(1, 10, 64, 64, 100, 0, 4, 0, 0, WS.F_TRAIN, offs, ab) == -1 and b"cap_units" in lib.gs_last_error()
+    assert lib.gs_workspace_query(1, 10, 64, 64, 100, 10, 8, 0, 7, WS.F_TWO_LEVEL, offs, ab) == -1
+    assert lib.gs_workspace_bind(None, None, 0, None, 0, None, 0, offs, ab) == -1
 
 
 def test_workspace_pool_leases(native, monkeypatch):
@@ -243,6 +248,10 @@ def test_workspace_pool_leases(native, monkeypatch):
     assert c.fixed.data_ptr() == fixed_ptr and c.lists.numel() == list_bytes
     c.grow_lists(WS.Layout(1, 1000, 64, 64, 50000, 0, 0, WS.F_TRAIN), 0)  # capacity exceeded: the list arena alone grows
     assert c.fixed.data_ptr() == fixed_ptr and c.lists.numel() > list_bytes and c.cap == 50000
+    list_ptr, walk_bytes = c.lists.data_ptr(), c.walk.numel()
+    c.grow_walk(WS.Layout(1, 1000, 64, 64, 50000, 0, 0, WS.F_TRAIN, 4096, 100_000))   # the walk outgrew its capacities: the walk arena alone
+    assert c.fixed.data_ptr() == fixed_ptr and c.lists.data_ptr() == list_ptr and c.walk.numel() > walk_bytes
+    assert c.layout.cap_units == 4096 and c.layout.cap_rows == 100_000 and c.ptr(WS.ROWS) == c.walk.data_ptr() + c.layout.offsets[WS.ROWS]
     assert c.ptr(WS.REC) == c.fixed.data_ptr() + 256 and c.ptr(WS.COARSE_KEYS) is None
     assert c.view(WS.FLATTEN_IDS, 10).dtype == torch.int32 and c.view(WS.INFO, 8).dtype == torch.int64
     d = WS.pool.acquire(cpu, 999)                 # another stream: another pool

@@ -17,7 +17,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-CHK_LIB = os.path.join(ROOT, "easy_gaussian_splatting_amd", "libgsraster_chk.so")
+CHK_LIB = os.path.join(ROOT, "build", "variants", "libgsraster_chk.so")
 
 
 def test_backward_rederives_the_forwards_contributor_set_bit_for_bit():
@@ -25,7 +25,7 @@ def test_backward_rederives_the_forwards_contributor_set_bit_for_bit():
     #  symbols newer sources export, and the package refuses to bind a library that does not hold every symbol of the header)
     from easy_gaussian_splatting_amd import _native
     assert _native.build_variant("chk", "-DGS_BWD_CHECK") == CHK_LIB and os.path.exists(CHK_LIB)
-    env = dict(os.environ, GS_LIB_PATH=CHK_LIB)
+    env = dict(os.environ, GS_LIB_PATH=CHK_LIB, GS_ALLOW_VARIANT="1")   # (the binding refuses a variant library unless told so)
     proc = subprocess.run([sys.executable, os.path.join(HERE, "contrib_child.py")], env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stderr[-3000:]
     rows = [json.loads(l) for l in proc.stdout.splitlines() if l.startswith("{")]

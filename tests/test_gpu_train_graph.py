@@ -365,15 +365,29 @@ def test_projected_rebuild_never_enters_a_sort_class_for_the_first_time_under_ca
     runner.finish()
     assert runner.report().get("projected_rebuilds", 0) == before, "the re-build entered an unwarmed sort class without a warm-up"
     _assert_same(ma, oa, mb, ob, "after the probing re-build")
-    # ... while a projection that stays inside a warmed class needs no probe
+    # ... while a projection that stays inside a warmed class needs no probe (a refinement that only prunes: ten Gaussians faded out)
     for m in (ma, mb):
-        m.reset_opacities()
+        m.DENSIFY_GRAD_THRESH = 1e9
+        with torch.no_grad():
+            m.logit_opacities[:10] = -20.0
+        m.densify_and_prune(generator=torch.Generator(device=dev).manual_seed(6))
+    assert ma.nbr_gaussians == mb.nbr_gaussians and runner._state_key() != runner._key
     runner.seen_tile = min(runner.seen_tile, 200)
     for it in range(2):
         _eager_step(ma, oa, lc, datas[it], gts[it]); runner.step(datas[it], gts[it])
     runner.finish()
     assert runner.report().get("projected_rebuilds", 0) == before + 1
     _assert_same(ma, oa, mb, ob, "after the projected re-build")
+    # ... and an opacity reset voids the history of the WALK (nothing saturates any more: how deep the blend goes into its lists
+    # has nothing to do with the steps before): that re-build probes, whatever the projection says
+    for m in (ma, mb):
+        m.reset_opacities()
+    for it in range(2):
+        _eager_step(ma, oa, lc, datas[it], gts[it]); runner.step(datas[it], gts[it])
+    runner.finish()
+    rep = runner.report()
+    assert rep.get("projected_rebuilds", 0) == before + 1 and rep["overflows"] == 0 and rep["probed_work_units"] > 0
+    _assert_same(ma, oa, mb, ob, "after the re-build behind an opacity reset")
 
 
 def test_lazy_outputs_fence_on_every_way_of_reading_them():

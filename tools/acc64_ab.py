@@ -64,7 +64,7 @@ def child(scale, case):
 
 
 def run_child(lib, scale, case):
-    env = dict(os.environ, GS_LIB_PATH=lib)
+    env = dict(os.environ, GS_LIB_PATH=lib, GS_ALLOW_VARIANT="1")
     p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(scale), str(case)], env=env, capture_output=True, text=True, timeout=1200)
     for line in p.stdout.splitlines():
         if line.startswith("RESULT "):
@@ -79,8 +79,8 @@ def main():
     rows = []
     for scale, case in cases:
         a = run_child(os.path.join(pkg, "libgsraster.so"), scale, case)
-        b = run_child(os.path.join(pkg, "libgsraster_acc64.so"), scale, case)
-        c = run_child(os.path.join(pkg, "libgsraster_exact.so"), scale, case)
+        b = run_child(os.path.join(nat.VARIANT_DIR, "libgsraster_acc64.so"), scale, case)
+        c = run_child(os.path.join(nat.VARIANT_DIR, "libgsraster_exact.so"), scale, case)
         rec = {"scale": scale, "case": case, "n_gaussians": a["n"], "razor_fraction": round(a["razor"], 4), "tensors": {}}
         for name in NAMES:
             ta, tb, tc = a["tensors"][name], b["tensors"][name], c["tensors"][name]

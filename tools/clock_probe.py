@@ -2,7 +2,7 @@
 """Sustained shader clock under the blend kernels themselves.
 
 Run on the GPU box with the -DGS_CLOCK_PROBE variant of the library (tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE"):
-    GS_LIB_PATH=easy_gaussian_splatting_amd/libgsraster_clk.so python tools/clock_probe.py [out.json]
+    GS_ALLOW_VARIANT=1 GS_LIB_PATH=build/variants/libgsraster_clk.so python tools/clock_probe.py [out.json]
 Every wave of blend_fwd / blend_bwd adds d(s_memtime) and d(s_memrealtime) to device words; the ratio x the wall-clock rate is
 the shader clock those waves ran at.  Steady state: 30 eager train steps at the bench workload before the counters are read.
 Also samples `rocm-smi --showclocks` from a side thread while the loop runs (what the driver reports), if it is readable."""

@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out; mkdir -p $out
 $root/tools/micro/clock_probe > $out/${tag}_clock_micro.jsonl 2>&1
 khz=$(python3 -c "import json,sys; print(json.loads(open('$out/${tag}_clock_micro.jsonl').readline())['wall_clock_rate_kHz'])")
-GS_WALL_CLOCK_KHZ=$khz GS_LIB_PATH=$root/easy_gaussian_splatting_amd/libgsraster_clk.so python3 $root/tools/clock_probe.py $out/${tag}_clock_kernels.json > /dev/null 2> $out/${tag}_clock_kernels.err
+GS_WALL_CLOCK_KHZ=$khz GS_ALLOW_VARIANT=1 GS_LIB_PATH=$root/build/variants/libgsraster_clk.so python3 $root/tools/clock_probe.py $out/${tag}_clock_kernels.json > /dev/null 2> $out/${tag}_clock_kernels.err
 python3 - <<PY
 import json
 micro = [json.loads(l) for l in open("$out/${tag}_clock_micro.jsonl") if l.startswith("{")]

@@ -12,7 +12,7 @@ mkdir -p gpurun_out
 # sources export, and the package refuses to bind such a library: the tools that load one would fail silently)
 if [ "$GS_SKIP_VARIANT_BUILD" != 1 ]; then
   bash tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE" "acc64:-DGS_BWD_ACC64" "exact:-DGS_BWD_ACC64 -DGS_EXACT_MATH" "halfq100:-DGS_EXP_HALFQ=100" "halfq155:-DGS_EXP_HALFQ=155" > gpurun_out/${tag}_variants.log 2>&1
-  [ -x tools/micro/clock_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/clock_probe tools/micro/clock_probe.hip
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/clock_probe tools/micro/clock_probe.hip
 fi
 # shader clock under load first (bench.py's roofline_compute reads profiles/<tag>_clock.json)
 timeout 300 bash tools/clock_probe.sh $tag > gpurun_out/${tag}_clock_stdout.txt 2>&1
@@ -50,8 +50,8 @@ for cfg in S3 S5 heavy1M; do
 done
 # the loss kernels alone (cold inputs, with and without a mask), the issue cost per operand kind, the loss forward's memory side alone
 (timeout 120 python tools/loss_time.py; GS_LOSS_MASK=0 timeout 120 python tools/loss_time.py) 2>/dev/null > gpurun_out/${tag}_loss_time.txt
-[ -x tools/micro/valu_enc ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/valu_enc tools/micro/valu_enc.hip
-[ -x tools/micro/tile_stream ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/tile_stream tools/micro/tile_stream.hip
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/valu_enc tools/micro/valu_enc.hip
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/tile_stream tools/micro/tile_stream.hip
 timeout 60 tools/micro/valu_enc > gpurun_out/${tag}_valu_enc.txt 2>/dev/null
 timeout 60 tools/micro/tile_stream > gpurun_out/${tag}_tile_stream.txt 2>/dev/null
 # half-quadrant work units for blend_bwd, bounded (timing builds, numerically wrong on purpose)

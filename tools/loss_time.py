@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times gs_l1_ssim_fwd / gs_l1_ssim_bwd alone (HIP events, the bench resolution) for the product library and any variants:
-   tools/loss_time.py [H W] -- lib names after `--` are libgsraster_<name>.so files next to the product build.
+   tools/loss_time.py [H W] -- lib names after `--` are libgsraster_<name>.so files in build/variants/ (GS_ALLOW_VARIANT=1).
 Each variant's outputs are compared with the first library's (largest absolute difference of loss3 / maps-derived gradient)."""
 import ctypes as ct, json, os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
@@ -25,7 +25,7 @@ one = torch.ones((1,), device=dev)
 mask = (torch.rand((H, W), device=dev, generator=g) < 0.05).float() if os.environ.get("GS_LOSS_MASK", "1") == "1" else None
 mp = None if mask is None else mask.data_ptr()
 def load(name):
-    path = nat.LIB_PATH if name == "product" else os.path.join(os.path.dirname(nat.LIB_PATH), f"libgsraster_{name}.so")
+    path = nat.LIB_PATH if name == "product" else os.path.join(nat.VARIANT_DIR, f"libgsraster_{name}.so")
     L = ct.CDLL(path)
     for fn in ("gs_loss_workspace_floats", "gs_l1_ssim_fwd", "gs_l1_ssim_bwd"):
         f = getattr(L, fn); f.restype, f.argtypes = nat.SIGNATURES[fn]

@@ -8,16 +8,16 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 if [ "$mode" = build ]; then
   for v in "$@"; do
     name=${v%%:*}; flags=${v#*:}
-    d=/tmp/gsvar_$name; rm -rf $d; mkdir -p $d
-    cp $root/easy_gaussian_splatting_amd/csrc/*.hip $root/easy_gaussian_splatting_amd/csrc/*.h $root/easy_gaussian_splatting_amd/csrc/*.inc $root/easy_gaussian_splatting_amd/csrc/Makefile $d/
+    d=/tmp/gsvar_$name; rm -rf $d; mkdir -p $d $root/build/variants
+    cp $root/easy_gaussian_splatting_amd/csrc/*.hip $root/easy_gaussian_splatting_amd/csrc/*.h $root/easy_gaussian_splatting_amd/csrc/Makefile $d/
     sed -i "s|../../include/gs_raster.h|$root/include/gs_raster.h|g" $d/Makefile $d/*.h
-    make -C $d -j4 EXTRA="$flags" LIB=$root/easy_gaussian_splatting_amd/libgsraster_$name.so 2>&1 | grep -E "error|Error" | head -3
-    ls -la $root/easy_gaussian_splatting_amd/libgsraster_$name.so | awk '{print $5, $9}'
+    make -C $d -j4 EXTRA="$flags" LIB=$root/build/variants/libgsraster_$name.so 2>&1 | grep -E "error|Error" | head -3
+    ls -la $root/build/variants/libgsraster_$name.so | awk '{print $5, $9}'
   done
 else
   for name in base "$@"; do
-    lib=$root/easy_gaussian_splatting_amd/libgsraster_$name.so; [ $name = base ] && lib=$root/easy_gaussian_splatting_amd/libgsraster.so
-    GS_LIB_PATH=$lib timeout 200 python $root/bench.py --no-cpu-baseline --no-extras --steps 100 --warmup 20 2>/dev/null | python3 -c "
+    lib=$root/build/variants/libgsraster_$name.so; [ $name = base ] && lib=$root/easy_gaussian_splatting_amd/libgsraster.so
+    GS_ALLOW_VARIANT=1 GS_LIB_PATH=$lib timeout 200 python $root/bench.py --no-cpu-baseline --no-extras --steps 100 --warmup 20 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$name', d['value'], d['step_ms']['median'], d['forward_fps'], {k[3:]:round(v,3) for k,v in d['stage_ms'].items()})"
   done
