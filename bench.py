@@ -802,14 +802,16 @@ def run_rank(args) -> int:
 
     if world == 1 and not args.no_extras and graph_step is not None and not args.no_configs:
         # captured (hipGraph) train step on the real-capture-shaped workloads: heavy-tailed long lists, S3, S5
-        from easy_gaussian_splatting_amd.synthetic import config_heavy, config_long_lists, config_s3, config_s5
+        from easy_gaussian_splatting_amd.synthetic import config_heavy, config_heavy_5m_4k, config_long_lists, config_s3, config_s5
         from easy_gaussian_splatting_amd.train_graph import TrainStepGraph
         figs = {}
         for name, make, n_steps in (("long_lists_200k_1080p", lambda: config_long_lists(n=200_000, width=1920, height=1080), 30),
                                     ("S3_2M_1080p", lambda: config_s3(), 30), ("S5_5M_4K", lambda: config_s5(), 10),
                                     # the metric's N on a realistic footprint: gsplat's lists hold ~29 entries per Gaussian
                                     ("heavy_1M_1080p", lambda: config_heavy(n=1_000_000), 20),
-                                    ("heavy_2M_1080p", lambda: config_heavy(n=2_000_000), 20)):
+                                    ("heavy_2M_1080p", lambda: config_heavy(n=2_000_000), 20),
+                                    # configs[4] on a realistic footprint: ~28 entries per Gaussian at 4K, I ~ 140 M
+                                    ("heavy_5M_4K", lambda: config_heavy_5m_4k(), 10)):
             try:
                 t_build = time.perf_counter()
                 scx = make()
@@ -822,16 +824,25 @@ def run_rank(args) -> int:
                 outs = {}
                 for mode in ("gsplat_eager", "tight"):   # (gsplat's own lists walked by the captured step / the short lists)
                     mx.tile_culling = mode
+                    rendering.reset_hints()   # (the eager seam's idle workspaces of the configuration before: not this runner's memory)
+                    torch.cuda.empty_cache()
+                    torch.cuda.synchronize()
+                    held = torch.cuda.memory_allocated(device)   # model, optimizer state, target: not the runner's either
                     torch.cuda.reset_peak_memory_stats(device)
                     runner = TrainStepGraph(mx, ox, LossComputer(lambda_ssim=0.2, clamp_input=True), dx, gx, None)
                     ex, _, sx, _ = timed_loop(runner.step, n_steps, 5, finish=runner.finish, ev_stream=runner.stream)
                     rep = runner.report()
                     torch.cuda.synchronize()
+                    peak, listed = torch.cuda.max_memory_allocated(device), max(1, rep["probed_isects"])
                     outs[mode] = {"train_iters_per_s": round(n_steps / ex, 2), "train_ms": _percentiles(sx),
                                   "n_isects": rep["probed_isects"], "isects_per_gaussian": round(rep["probed_isects"] / max(1, scx["means"].shape[0]), 1),
                                   "longest_list": rep["probed_longest_list"], "binning": rep["binning"],
                                   "overflows": rep["overflows"], "captures": rep["captures"],
-                                  "peak_GiB": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)}
+                                  "walked_work_units": rep["seen_work_units"], "gradient_rows": rep["seen_rows"],
+                                  # peak of the process while the runner was built and stepped; of which the runner's own
+                                  # workspace (everything beyond model + optimizer state + target), in bytes per LISTED intersection
+                                  "peak_GiB": round(peak / 2 ** 30, 2), "runner_GiB": round((peak - held) / 2 ** 30, 2),
+                                  "runner_bytes_per_listed_isect": round((peak - held) / listed, 1)}
                     del runner
                 # roofline of the dominant kernel on THIS workload, priced on the entries the kernel actually walked (VERDICT r4
                 # missing #4): a saturated tile abandons the rest of its list, so bytes per LISTED entry over the launch time would

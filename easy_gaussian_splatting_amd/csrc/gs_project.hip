@@ -642,41 +642,77 @@ __device__ __forceinline__ void row_sum_wave(const A& a, int nr, int r0, RowSum&
             d.cx = c[0]; d.cy = c[1]; d.cz = c[2];
         }
     };
+    auto add = [](RowSum& p, const Row& d) {
+        p.v[0] += d.a.x; p.v[1] += d.a.y; p.v[2] += d.a.z; p.v[3] += d.a.w;
+        p.v[4] += d.b.x; p.v[5] += d.b.y; p.v[6] += d.b.z; p.v[7] += d.b.w;
+        p.v[8] += d.cx; p.v[9] += d.cy; p.v[10] += d.cz;
+    };
+    // the wave-wide sums of `p` go to lane `owner`
+    auto close = [&](RowSum& p, int owner) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const float t = wave_reduce_add_dpp(p.v[i]);
+            if (lane == owner) s.v[i] += t;
+        }
+    };
     Row cur, nxt;
     fetch(cur, 0);
-    RowSum p;   // partial sums of a run of items that belong to one Gaussian
-#pragma unroll
-    for (int i = 0; i < 12; ++i) p.v[i] = 0.f;
-    for (int it = 0; it < n_items; ++it) {
+    int it = 0;
+    while (it < n_items) {
         if (it + 1 < n_items) fetch(nxt, it + 1);
         const int jb = 64 * it;
         const int lo = max(o, jb) - jb, hi = min(o + nr, jb + 64) - jb;   // this Gaussian's rows inside the item
         const unsigned long long whole = __ballot(nr > 0 && lo == 0 && hi == 64);
-        if (whole) {   // wave-uniform: the item lies inside one Gaussian's range
-            p.v[0] += cur.a.x; p.v[1] += cur.a.y; p.v[2] += cur.a.z; p.v[3] += cur.a.w;
-            p.v[4] += cur.b.x; p.v[5] += cur.b.y; p.v[6] += cur.b.z; p.v[7] += cur.b.w;
-            p.v[8] += cur.cx; p.v[9] += cur.cy; p.v[10] += cur.cz;
+        if (whole) {   // wave-uniform: the item lies inside ONE Gaussian's range -- and so do the items up to `last`
             const int owner = __builtin_ctzll(whole);
-            if (__shfl(o + nr, owner, 64) < jb + 128) {   // the next item is not all this Gaussian's: close the run
+            const int last = (__shfl(o + nr, owner, 64) >> 6) - 1;   // the last item that is all this Gaussian's
+            RowSum p;
 #pragma unroll
-                for (int i = 0; i < 11; ++i) {
-                    const float t = wave_reduce_add_dpp(p.v[i]);
-                    if (lane == owner) s.v[i] += t;
-                    p.v[i] = 0.f;
-                }
+            for (int i = 0; i < 12; ++i) p.v[i] = 0.f;
+            add(p, cur);
+            int k = it + 1;
+            if (k <= last) { add(p, nxt); ++k; }
+            // four items in flight at a time: a wave that holds a splat over the whole image walks 10^4 .. 10^5 rows on its own, and
+            // one item per round trip made it the kernel's tail (round 6: 0.29 ms on the heavy-tailed 1 M scene, 0.21 before)
+            for (; k + 3 <= last; k += 4) {
+                Row b0, b1, b2, b3;
+                fetch(b0, k); fetch(b1, k + 1); fetch(b2, k + 2); fetch(b3, k + 3);
+                add(p, b0); add(p, b1); add(p, b2); add(p, b3);
             }
-        } else {
+            for (; k <= last; ++k) { Row b0; fetch(b0, k); add(p, b0); }
+            close(p, owner);
+            it = last + 1;
+            if (it < n_items) fetch(cur, it);   // (when the run was one item long this is `nxt` again: rare, and cached)
+            continue;
+        }
+        // segments of 16 rows and more: one masked wave reduction each (an owner that adds its rows one by one holds the other
+        // 63 lanes for as many LDS round trips); the shorter ones: every owner walks its own rows in LDS
+        unsigned long long longs = __ballot(nr > 0 && hi - lo >= 16);
+        for (; longs; longs &= longs - 1ull) {
+            const int owner = __builtin_ctzll(longs);
+            const int slo = __shfl(lo, owner, 64), shi = __shfl(hi, owner, 64);
+            const bool in = lane >= slo && lane < shi;
+            RowSum p;
+            p.v[0] = in ? cur.a.x : 0.f; p.v[1] = in ? cur.a.y : 0.f; p.v[2] = in ? cur.a.z : 0.f; p.v[3] = in ? cur.a.w : 0.f;
+            p.v[4] = in ? cur.b.x : 0.f; p.v[5] = in ? cur.b.y : 0.f; p.v[6] = in ? cur.b.z : 0.f; p.v[7] = in ? cur.b.w : 0.f;
+            p.v[8] = in ? cur.cx : 0.f; p.v[9] = in ? cur.cy : 0.f; p.v[10] = in ? cur.cz : 0.f;
+            close(p, owner);
+        }
+        if (__any(nr > 0 && hi > lo && hi - lo < 16)) {   // wave-uniform
             item[3 * lane] = cur.a; item[3 * lane + 1] = cur.b; item[3 * lane + 2] = make_float4(cur.cx, cur.cy, cur.cz, 0.f);
             __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in issue order)
-            for (int r = lo; r < hi; ++r) {
-                const float4 ix = item[3 * r], iy = item[3 * r + 1], iz = item[3 * r + 2];
-                s.v[0] += ix.x; s.v[1] += ix.y; s.v[2] += ix.z; s.v[3] += ix.w;
-                s.v[4] += iy.x; s.v[5] += iy.y; s.v[6] += iy.z; s.v[7] += iy.w;
-                s.v[8] += iz.x; s.v[9] += iz.y; s.v[10] += iz.z;
+            if (hi - lo < 16) {
+                for (int r = lo; r < hi; ++r) {
+                    const float4 ix = item[3 * r], iy = item[3 * r + 1], iz = item[3 * r + 2];
+                    s.v[0] += ix.x; s.v[1] += ix.y; s.v[2] += ix.z; s.v[3] += ix.w;
+                    s.v[4] += iy.x; s.v[5] += iy.y; s.v[6] += iy.z; s.v[7] += iy.w;
+                    s.v[8] += iz.x; s.v[9] += iz.y; s.v[10] += iz.z;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
         cur = nxt;
+        ++it;
     }
 }
 

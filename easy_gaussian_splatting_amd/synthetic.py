@@ -107,16 +107,24 @@ def config_long_lists(seed=1, n=45_000, width=640, height=368):
     return make_scene(n, width, height, sh_degree=3, seed=seed, extent=(4, 2.25, 4), scale_range=scale, dist=8.0, white_bg=False)
 
 
-def config_heavy(seed=42, n=1_000_000, n_views=1, width=1920, height=1080):
+def config_heavy(seed=42, n=1_000_000, n_views=1, width=1920, height=1080, median=0.015):
     """The metric's N on a REALISTIC footprint (VERDICT r4 missing #2): the 1 M / 1080p generator of SURVEY.md 8d covers ~3-5
     tiles per Gaussian, a trained Truck (/root/reference/configs/tandt_db.yaml, README.md:5-9) tens.  Same means, rotations,
     opacities, colours and cameras as `config_bench_1m` / `config_s3`; scales heavy-tailed: a log-normal size per Gaussian
     (median 0.015 = 3 px at the scene's depth, sigma 1.0) times a log-normal anisotropy per axis (sigma 0.5), clipped to
     [0.002, 0.5] -- gsplat's 3-sigma lists then hold ~29 entries per Gaussian (median 9 tiles, 1 % of the splats beyond ~480 tiles,
-    the largest the whole image): I ~ 29 M at 1 M, ~ 58 M at 2 M."""
+    the largest the whole image): I ~ 29 M at 1 M, ~ 58 M at 2 M.  `median`: the size in scene units -- `config_heavy_5m_4k` halves it,
+    so that a splat covers the same number of 4K pixels as the default does at 1080p."""
     sc = make_scene(n, width, height, sh_degree=3, n_views=n_views, seed=seed, extent=(4, 2.25, 4), scale_range=(0.003, 0.03),
                     dist=8.0, white_bg=False)
     rng = np.random.default_rng(seed + 1000)
-    base = np.exp(rng.normal(math.log(0.015), 1.0, (n, 1)))
+    base = np.exp(rng.normal(math.log(median), 1.0, (n, 1)))
     sc["scales"] = np.ascontiguousarray(np.clip(base * np.exp(rng.normal(0.0, 0.5, (n, 3))), 0.002, 0.5), dtype=np.float32)
     return sc
+
+
+def config_heavy_5m_4k(seed=42, n=5_000_000):
+    """configs[4] on a realistic footprint: 5 M Gaussians at 3840x2160 with `config_heavy`'s heavy-tailed
+    sizes at the same size IN PIXELS as its 1080p form (median 3 px: half the scene-space median) -- gsplat's lists hold ~28
+    entries per Gaussian, I ~ 140 M."""
+    return config_heavy(seed=seed, n=n, width=3840, height=2160, median=0.0075)

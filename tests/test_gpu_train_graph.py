@@ -117,6 +117,40 @@ def test_overflow_is_skipped_on_device_detected_lazily_and_replayed(binning, mon
     assert hist.shape == (min(3, int(runner.buf["applied"].item())), 3) and torch.equal(hist[-1], ref_losses[-1])
 
 
+def test_walk_overflow_is_skipped_on_device_detected_lazily_and_replayed():
+    """The capacities of what the forward WALKS (work units, gradient rows: flags 16 / 32) are guarded like the list capacity:
+    a step whose walk outgrows them -- and every step queued behind it -- must be a device-side no-op, found lazily, and
+    replayed onto exactly the eager trajectory.  (The shortage is staged: the runner is re-captured on walk capacities a
+    fraction of what its own probe measured -- as a projection that did not hold would leave it; the lists keep theirs.)"""
+    dev, make, datas, gts = _setup(n=30000, n_views=3, dist=4.0)
+    (ma, oa), (mb, ob) = make(), make()
+    lc = LossComputer(0.2, clamp_input=True)
+    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], check_every=4)
+    rep0 = runner.report()
+    assert rep0["probed_work_units"] > 2000 and rep0["probed_rows"] > 50_000
+    for it in range(3):
+        _eager_step(ma, oa, lc, datas[it % 3], gts[it % 3]); runner.step(datas[it % 3], gts[it % 3])
+    runner.finish()
+    assert runner.report()["overflows"] == 0
+    for cut in ("units", "rows"):
+        runner.cap_units, runner.cap_rows = (512, rep0["capacity_rows"]) if cut == "units" else (rep0["capacity_work_units"], 4096)
+        with torch.cuda.device(dev):
+            runner._alloc_walk()
+            runner.buf["applied"].zero_()   # (as a re-build leaves it: applied steps are counted from the capture)
+            runner._capture(warm_up=False)
+        ov = runner.report()["overflows"]
+        for it in range(6):   # no finish() in between: the host keeps enqueueing behind the overflow
+            _eager_step(ma, oa, lc, datas[it % 3], gts[it % 3]); runner.step(datas[it % 3], gts[it % 3])
+        runner.finish()
+        rep = runner.report()
+        assert rep["overflows"] == ov + 1 and rep["replayed_steps"] >= 1, (cut, rep)
+        last = rep["overflow_log"][-1]
+        assert last["flags"] == (16 if cut == "units" else 32) and last["work_units"] > 2000 and last["rows"] > 50_000, last
+        assert rep["capacity_work_units"] > 2000 and rep["capacity_rows"] > 50_000 and rep["capacity_isects"] <= 1.1 * rep0["capacity_isects"]   # (re-probed on another view)
+        _assert_same(ma, oa, mb, ob, f"after a walk overflow ({cut})")
+    assert runner.report()["steps"] == 15
+
+
 def test_refinement_between_graph_steps_rebuilds_the_workspace():
     """densify_and_prune changes N (up to 3x per call in the reference, model/gaussian.py:259), reset_opacities
     swaps the parameter storage, up_sh_degree changes the kernels' template: the runner must notice and re-capture."""

@@ -89,6 +89,60 @@ def test_capacity_overflow_is_repeated_transparently():
     assert rendering.stats["overflow_reruns"] == reruns
 
 
+def test_walk_capacity_overflow_is_repaired_by_the_backward():
+    """What a training forward WALKS (work units with their checkpoints and sublists, gradient rows) has capacities of its own,
+    learnt from the walk records of earlier calls.  A call whose walk outgrows them leaves a complete image and a void walk; its
+    backward reads the record (page-locked memory, no stream synchronisation), replaces the walk arena, repeats the blend and
+    must hand back exactly the gradients of a call that never ran short.  (The shortage is staged: the capacity hints of the call
+    shape are cut to a fraction of what the same call needed a moment ago -- once the work units, once the rows, once both.)"""
+    sc, t = _scene(n=30000)
+    rendering.reset_hints()
+    ref = _run(t, sc, 0, culling="tight")
+    for _ in range(2):
+        _run(t, sc, 0, culling="tight")
+    rec = ref[0].grad_fn.state["walk"].host.tolist()
+    assert rec[3] == 0 and rec[1] > 2000 and rec[2] > 50_000, rec   # (flags clear; storage units, rows)
+    keys = [k for k in rendering._hints if k[4]]   # (device, C, W, H, training, list mode): the one training shape since reset_hints()
+    assert len(keys) == 1, list(rendering._hints)
+    for cut in ("cap_units", "cap_rows", "both"):
+        with rendering._state_lock:
+            h = rendering._hints[keys[0]]
+            if cut in ("cap_units", "both"):
+                h["cap_units"] = 512
+            if cut in ("cap_rows", "both"):
+                h["cap_rows"] = 4096
+        reruns, grows = rendering.stats["walk_reruns"], WS.stats["walk_grows"]
+        got = _run(t, sc, 0, culling="tight")
+        assert rendering.stats["walk_reruns"] == reruns + 1 and WS.stats["walk_grows"] == grows + 1, cut
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), cut
+        for a, b in zip(got[3], ref[3]):
+            assert torch.equal(a, b), cut
+        assert torch.equal(got[2]["means2d"].absgrad, ref[2]["means2d"].absgrad), cut
+        # the capacities follow: the same call again does not run short
+        again = _run(t, sc, 0, culling="tight")
+        assert rendering.stats["walk_reruns"] == reruns + 1, cut
+        for a, b in zip(again[3], ref[3]):
+            assert torch.equal(a, b), cut
+
+
+def test_walk_arena_scales_with_what_is_walked_not_with_what_is_listed():
+    """heavy-tailed footprints (long lists, every pixel saturating after a few dozen entries) -- the list
+    arena holds at most 25 bytes per listed intersection, and the walk arena is a fraction of what 355 bytes per listed entry
+    (rounds 1-5) would be."""
+    from scenes import config_long_lists
+    sc = config_long_lists(seed=1, n=45_000, width=640, height=368)
+    t = {k: torch.from_numpy(v).to("cuda:0") for k, v in sc.items() if isinstance(v, np.ndarray)}
+    rendering.reset_hints()
+    for _ in range(3):
+        out = _run(t, sc, 0, culling="gsplat_eager")
+    listed = out[2]["flatten_ids"].numel()
+    lay = out[0].grad_fn.state["lease"].layout
+    dbg_rows = int(out[0].grad_fn.state["walk"].host[2])
+    assert listed > 1_500_000 and dbg_rows < 0.2 * 4 * listed
+    assert lay.arena_bytes[1] <= 26 * lay.key[4] + (1 << 22)
+    assert lay.arena_bytes[2] < 0.1 * 355 * listed, (lay.arena_bytes, listed)
+
+
 @pytest.mark.parametrize("culling", ["gsplat", "tight"])
 def test_two_forwards_in_flight_hold_two_leases(culling):
     """Several views accumulated into one loss: forward A, forward B, then one backward through both.  Each forward keeps
