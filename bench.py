@@ -705,6 +705,23 @@ def run_rank(args) -> int:
         except Exception as e:   # a secondary timing must never cost the bench line
             extras["real_loop"] = {"error": repr(e)[:300]}
 
+        # ---- e2e: the reference's acceptance test on a dataset that can be made here (tools/e2e_train.py): nerf_synthetic layout
+        # on disk -> Scene -> generate_pointcloud -> from_pointcloud -> nerf_synthetic.yaml's schedule scaled to 3000 steps ->
+        # held-out PSNR; the whole run's it/s (re-captures, refinements, resets included), captured and eager
+        try:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import e2e_train
+            e2 = e2e_train.run(3000, ("captured", "eager"))
+            extras["e2e"] = {"dataset": e2["dataset"], **{m: {k: r[k] for k in ("train_iters_per_s", "wall_s", "psnr", "ssim", "eval_fps", "n_gaussians_initial",
+                                                                                "n_gaussians_final", "active_sh_degree", "schedule", "runner")}
+                                                         for m, r in e2["runs"].items()},
+                             "what": "scene.Scene(blender) -> from_pointcloud(100 k random points) -> 3000 steps of /root/reference/configs/nerf_synthetic.yaml's "
+                                     "schedule (densify every 100 in (100, 1500], reset every 1000, SH degree + 1 every 500, means-LR) -> PSNR on 8 held-out views"}
+            rendering.reset_hints()
+            torch.cuda.empty_cache()
+        except Exception as e:   # a secondary timing must never cost the bench line
+            extras["e2e"] = {"error": repr(e)[:300]}
+
         # ---- drop_in: the reference's own loop body behind the one-line import change (DropInLoop above)
         try:
             di = DropInLoop(sc, device, lrs)

@@ -58,7 +58,7 @@ def _p(t: Optional[Tensor]):
 class TrainStepGraph:
     def __init__(self, model, optimizer: FusedAdam, loss_computer, data: Dict[str, Any], gt_img: Tensor,
                  mask: Optional[Tensor] = None, margin: float = 1.3, use_graph: bool = True, check_every: int = 16,
-                 fuse_adam: bool = True, handback: str = "eager"):
+                 fuse_adam: bool = True, handback: str = "eager", copy_targets: bool = False):
         """`handback`: when the caller's stream is ordered behind a step.
         "eager" (default): on return from every `step()` -- whatever the caller enqueues next (a read of the outputs, an eval
         render that reads the parameters, `densify_and_prune`) sees the finished step, no thought required.
@@ -70,6 +70,11 @@ class TrainStepGraph:
         if handback not in ("eager", "lazy"):
             raise ValueError("handback: 'eager' or 'lazy'")
         self.handback = handback
+        # copy_targets: every step takes a private copy of its target image (and mask) instead of reading the caller's tensors in
+        # place -- for loaders that recycle ONE device staging buffer (`gt_buf.copy_(next)`): a target is read until its step is
+        # RETIRED (the loss forward and backward of the replay, and again if an overflow recovery replays the step up to
+        # `check_every` steps later), not only until `step()` returns.  Costs the copy the in-place read saved (25 MB at 1080p).
+        self.copy_targets = bool(copy_targets)
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("TrainStepGraph drives optim.FusedAdam (flat parameter / moment buffers)")
         if not getattr(loss_computer, "clamp_input", False) or not getattr(loss_computer, "fused", True):
@@ -607,7 +612,8 @@ class TrainStepGraph:
 
     # ------------------------------------------------------------------------------------------ stepping
     def _issue(self, entry):
-        t, lrs, w2c, K, gt, mask, ready = entry
+        t, lrs, w2c, K, gt, mask, ready = entry[:7]
+        conv = entry[7] if len(entry) > 7 else None
         # The step waits for the caller's stream on entry: that orders it behind pending WRITERS of the inputs handed in and
         # behind pending READERS of what the replay overwrites -- the static outputs the previous `step()` returned, the
         # parameters and moments (fused Adam), the statistics.  (Round 3 skipped the wait for steps that take no input from
@@ -616,6 +622,11 @@ class TrainStepGraph:
         # stream holds neither -- skips it.  The wait is free when the caller's stream is idle, i.e. with handback="lazy" in a
         # loop that reads nothing between steps; behind an eager hand-back it costs two cross-queue signal hops.
         with torch.cuda.device(self.dev), self._on_stream(wait_outer=not ready, hand_back=self.handback == "eager"):
+            if conv is not None:
+                # the runner's OWN conversion / copy of a target was enqueued on the caller's stream (`step`): the promise
+                # `inputs_ready=True` covers the caller's writers, not this one
+                self.stream.wait_event(conv)
+                entry[7] = None
             entry[4], entry[5] = self._stage_inputs(t, lrs, w2c, K, gt, mask)   # (the tensors the step reads: kept by the entry)
             if self.graph is not None:
                 self.graph.replay()
@@ -632,7 +643,11 @@ class TrainStepGraph:
         enqueued on the caller's stream before that call are ordered in front of the replay that overwrites them).
         `inputs_ready=True` is the caller's promise that no work still pending on its stream (a) writes the tensors handed
         in, (b) reads the outputs of an earlier step, the model's parameters or its statistics: the step then does not wait
-        for the caller's stream (see `_issue`).  Without the promise every step does."""
+        for the caller's stream (see `_issue`).  Without the promise every step does.
+        LIFETIME of the inputs: the target image and the mask are read IN PLACE, by the loss kernels of the replay and -- after a
+        capacity overflow -- again by the replay of the skipped step, up to `check_every` steps later: a tensor handed in must
+        not be written (nor its storage recycled by the loader) until the step is retired, i.e. until `finish()` or
+        `check_every` further steps.  A loader that refills one staging buffer builds the runner with `copy_targets=True`."""
         W, H = (self.W, self.H) if data is None else (int(data["width"]), int(data["height"]))
         if self._state_key(W, H) != self._key:
             self.finish()
@@ -689,11 +704,21 @@ class TrainStepGraph:
         K = b["Ks"][0] if data is None else data["K"]
         gt = self._last_inputs[2] if gt_img is None else gt_img   # (the previous step's own tensors, by reference)
         mk = (self._last_inputs[3] if mask is None else mask) if self.has_mask else None
+        gt_in, mk_in = gt, mk
         gt = self._image(gt, (self.H, self.W, 3))   # (validated / converted BEFORE the step is counted)
         if self.has_mask:
             if mk is None:
                 raise ValueError("this runner was built with a mask; pass one every step")
             mk = self._image(mk, (self.H, self.W))
+        if self.copy_targets and gt_img is not None:   # (a step that re-uses the previous step's tensors re-uses its private copies)
+            gt = gt.clone() if gt is gt_in else gt
+            mk = (mk.clone() if mk is mk_in else mk) if mk is not None else None
+        conv = None
+        if gt is not gt_in or mk is not mk_in:
+            # a conversion (dtype / device / layout) or a private copy ran on the CALLER's stream just now: the runner's stream
+            # waits for exactly that, whatever `inputs_ready` promises about the caller's own work
+            conv = torch.cuda.Event()
+            conv.record(torch.cuda.current_stream(self.dev))
         self._last_inputs = (w2c, K, gt, mk)
         opt = self.opt
         opt._step += 1
@@ -702,7 +727,7 @@ class TrainStepGraph:
         # target and the mask are not even copied: the step reads them where they lie (`_stage_inputs`).  Entries that alias the
         # runner's OWN static camera buffers (data=None steps) are snapshotted right before a later step overwrites those
         # buffers (`_protect_pending`), so a skipped step is always replayed with its own inputs.
-        self._issue([opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk, bool(inputs_ready)])
+        self._issue([opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk, bool(inputs_ready), conv])
         if self.issued % self.check_every == 0:
             self._poll(block=False)
         return TrainStepGraph._StepOutputs(self, {"render_img": b["render_colors"][0], "loss3": b["loss3"], "batch_radii": b["radii"],

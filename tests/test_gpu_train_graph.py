@@ -482,3 +482,28 @@ def test_targets_are_read_in_place_through_pointer_slots():
     with pytest.raises(ValueError):
         runner.step(datas[0], torch.rand((H + 1, W, 3), device=dev), mask)
     assert ob._step == t0                                                # refused before the step was counted
+
+
+def test_copy_targets_lets_a_loader_recycle_one_staging_buffer():
+    """targets are read in place until their step is RETIRED, so a loader that refills one device buffer
+    (`buf.copy_(next)`) races the loss pass of the step before -- unless the runner is built with `copy_targets=True`, which takes
+    a private copy per step (on the caller's stream; the runner's stream waits for exactly that copy, also under
+    `inputs_ready=True`).  A target that needs converting (float64 here) goes the same way.  Both must follow the eager loop."""
+    dev, make, datas, gts = _setup()
+    (ma, oa), (mb, ob) = make(), make()
+    lc = LossComputer(0.2, clamp_input=True)
+    runner = TrainStepGraph(mb, ob, lc, datas[0], gts[0], None, handback="lazy", copy_targets=True, check_every=4)
+    buf = torch.empty_like(gts[0])
+    for it in range(9):   # no finish() in between: up to four steps in flight read four different contents of `buf`
+        _eager_step(ma, oa, lc, datas[it % 3], gts[(2 * it) % 3])
+        buf.copy_(gts[(2 * it) % 3])
+        runner.step(datas[it % 3], buf)
+    runner.finish()
+    _assert_same(ma, oa, mb, ob, "recycled staging buffer, copy_targets=True")
+    plain = TrainStepGraph(mb, ob, lc, datas[0], gts[0], None, handback="lazy")
+    for it in range(4):
+        _eager_step(ma, oa, lc, datas[it % 3], gts[it % 3])
+        torch.cuda.current_stream().synchronize()   # (the caller's own work is done: the promise below holds)
+        plain.step(datas[it % 3], gts[it % 3].double(), inputs_ready=True)   # converted by the runner, on the caller's stream
+    plain.finish()
+    _assert_same(ma, oa, mb, ob, "converted target under inputs_ready=True")
