@@ -622,6 +622,48 @@ def run_rank(args) -> int:
         lazy_handback = {"train_iters_per_s": round(args.steps / e_l, 2), "train_ms": _percentiles(s_l),
                          "note": "the headline loop with TrainStepGraph(handback='lazy') -- opt-in: the caller's stream is ordered behind a step only "
                                  "when the caller touches the returned outputs or calls fence(); rounds 4's headline mode"}
+    # ---- host_fed: the loop the way the reference FEEDS it (train.py:36-43 DataLoader(pin_memory=True), :97 data_to_device): camera,
+    # target image and mask of every step come from page-locked host memory -- 33 MB per step at 1080p -- uploaded on a copy
+    # stream into two recycled device slots, event-ordered in front of the replay (train_graph.HostFeed); with float32 targets
+    # (what the reference's loader pins) and with uint8 targets (a third of the bytes, converted on the device with the loader's
+    # own `/ 255`).  The headline above has the 8 targets resident in HBM, as the contract asks.
+    host_fed = None
+    if graph_step is not None and not args.no_extras:
+        try:
+            from easy_gaussian_splatting_amd.train_graph import HostFeed
+            pin = lambda t: t.detach().cpu().contiguous().pin_memory()
+            hm = pin(mask)
+            host_fed = {}
+            # what the link gives: one 64 MB pinned -> device copy on an otherwise idle GPU, best of 5 (HIP events)
+            probe_h, probe_d = torch.empty((64 << 20,), dtype=torch.uint8).pin_memory(), torch.empty((64 << 20,), dtype=torch.uint8, device=device)
+            best = 1e9
+            for _ in range(6):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); probe_d.copy_(probe_h, non_blocking=True); e1.record(); e1.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            h2d_peak = (64 << 20) / (best * 1e-3) / 1e9
+            del probe_h, probe_d
+            for kind in ("float32", "uint8"):
+                imgs = [pin(t) if kind == "float32" else pin((t * 255.0).round().clamp(0, 255).to(torch.uint8)) for t in targets]
+                batches = [{"w2c": pin(d["w2c"]), "K": pin(d["K"]), "width": W, "height": H, "image": imgs[v], "mask": hm} for v, d in enumerate(datas)]
+                feed = HostFeed(graph_step, n_slots=2)
+
+                def fed_step():
+                    feed.step(batches[sched.next()])
+                    model.update_learning_rate(sched.step)
+
+                e_h, _, s_h, _ = timed_loop(fed_step, args.steps, 10, finish=graph_step.finish, ev_stream=g_stream)
+                graph_step.fence()
+                nbytes = sum(int(b["image"].numel() * b["image"].element_size() + b["mask"].numel() * 4 + 100) for b in batches) / len(batches)
+                host_fed[kind] = {"train_iters_per_s": round(args.steps / e_h, 2), "train_ms": _percentiles(s_h),
+                                  "host_bytes_per_step": int(nbytes), "h2d_GBps": round(nbytes * args.steps / e_h / 1e9, 2),
+                                  "h2d_GBps_at_headline_rate": round(nbytes * (args.steps / elapsed) / 1e9, 2), "h2d_link_GBps_measured": round(h2d_peak, 2),
+                                  "vs_headline": round((args.steps / e_h) / (args.steps / elapsed), 4)}
+                del feed, batches, imgs
+            host_fed["note"] = ("every step's camera, target image and mask uploaded from pinned host memory on a copy stream, double-buffered, "
+                                "event-ordered in front of the hipGraph replay (train_graph.HostFeed); same runner, same schedule as the headline")
+        except Exception as e:   # a secondary timing must never cost the bench line
+            host_fed = {"error": repr(e)[:300]}
     # the round-1..3 headline, kept for comparison: ONE static camera and target, no LR change
     static_view = None
     if world == 1 and not force_dist:
@@ -1060,6 +1102,8 @@ def run_rank(args) -> int:
             result["static_view"] = static_view
         if lazy_handback is not None:
             result["lazy_handback"] = lazy_handback
+        if host_fed is not None:
+            result["host_fed"] = host_fed
         if graph_report is not None:
             result["host"]["graph"] = graph_report
             if graph_report["overflows"]:

@@ -614,6 +614,7 @@ class TrainStepGraph:
     def _issue(self, entry):
         t, lrs, w2c, K, gt, mask, ready = entry[:7]
         conv = entry[7] if len(entry) > 7 else None
+        after = entry[8] if len(entry) > 8 else None
         # The step waits for the caller's stream on entry: that orders it behind pending WRITERS of the inputs handed in and
         # behind pending READERS of what the replay overwrites -- the static outputs the previous `step()` returned, the
         # parameters and moments (fused Adam), the statistics.  (Round 3 skipped the wait for steps that take no input from
@@ -627,6 +628,9 @@ class TrainStepGraph:
                 # `inputs_ready=True` covers the caller's writers, not this one
                 self.stream.wait_event(conv)
                 entry[7] = None
+            if after is not None:   # (`step(ready_event=...)`: the upload of this step's inputs on the caller's copy stream)
+                self.stream.wait_event(after)
+                entry[8] = None
             entry[4], entry[5] = self._stage_inputs(t, lrs, w2c, K, gt, mask)   # (the tensors the step reads: kept by the entry)
             if self.graph is not None:
                 self.graph.replay()
@@ -636,7 +640,7 @@ class TrainStepGraph:
         self.issued += 1
 
     def step(self, data: Optional[Dict[str, Any]] = None, gt_img: Optional[Tensor] = None, mask: Optional[Tensor] = None,
-             inputs_ready: bool = False):
+             inputs_ready: bool = False, ready_event: Optional["torch.cuda.Event"] = None, host_src=None):
         """One training iteration.  `data` / `gt_img` / `mask` default to the previous step's (the camera's static buffers are
         re-used as they are; the target image and the mask are the previous step's own tensors, read in place).  Returns the
         runner's static output tensors (valid until the next `step()` is CALLED: reads
@@ -647,7 +651,11 @@ class TrainStepGraph:
         LIFETIME of the inputs: the target image and the mask are read IN PLACE, by the loss kernels of the replay and -- after a
         capacity overflow -- again by the replay of the skipped step, up to `check_every` steps later: a tensor handed in must
         not be written (nor its storage recycled by the loader) until the step is retired, i.e. until `finish()` or
-        `check_every` further steps.  A loader that refills one staging buffer builds the runner with `copy_targets=True`."""
+        `check_every` further steps.  A loader that refills one staging buffer builds the runner with `copy_targets=True`.
+        `ready_event`: an event the step's stream waits for before it reads anything (the upload of the inputs on a copy stream:
+        `HostFeed`).  `host_src = {"w2c", "K", "image"[, "mask"]}` host tensors the device inputs were uploaded from: a feeder that
+        recycles its device slots hands them in, and an overflow recovery replays the step from a FRESH upload of those instead
+        of from slots that have been refilled since."""
         W, H = (self.W, self.H) if data is None else (int(data["width"]), int(data["height"]))
         if self._state_key(W, H) != self._key:
             self.finish()
@@ -727,7 +735,7 @@ class TrainStepGraph:
         # target and the mask are not even copied: the step reads them where they lie (`_stage_inputs`).  Entries that alias the
         # runner's OWN static camera buffers (data=None steps) are snapshotted right before a later step overwrites those
         # buffers (`_protect_pending`), so a skipped step is always replayed with its own inputs.
-        self._issue([opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk, bool(inputs_ready), conv])
+        self._issue([opt._step, [float(grp["lr"]) for grp, _ in opt._plist], w2c, K, gt, mk, bool(inputs_ready), conv, ready_event, host_src])
         if self.issued % self.check_every == 0:
             self._poll(block=False)
         return TrainStepGraph._StepOutputs(self, {"render_img": b["render_colors"][0], "loss3": b["loss3"], "batch_radii": b["radii"],
@@ -766,6 +774,12 @@ class TrainStepGraph:
         self.stats.setdefault("overflow_log", []).append({
             "step": self.confirmed + 1, "flags": int(self.status[3]), "isects": n_isects, "longest_list": max_tile, "work_units": walk[0], "rows": walk[1],
             "capacities": [self.cap, self.cap_tile, self.cap_units, self.cap_rows]})
+        for e in redo:   # steps fed from recycled device slots (HostFeed): upload their own inputs again
+            src = e[9] if len(e) > 9 else None
+            if src is not None:
+                e[2], e[3] = src["w2c"].to(self.dev, torch.float32), src["K"].to(self.dev, torch.float32)
+                e[4] = HostFeed.to_target(src["image"], self.dev)
+                e[5] = src["mask"].to(self.dev, torch.float32) if (self.has_mask and src.get("mask") is not None) else e[5]
         first = redo[0]
         # (min_cap >= 1 forces a fresh probe even when only a coarse-bin capacity was exceeded and the list sizes read 0)
         self._build({"w2c": first[2], "K": first[3]}, first[4], first[5], min_cap=max(n_isects, 1), min_cap_tile=max_tile, min_walk=walk)
@@ -794,3 +808,74 @@ class TrainStepGraph:
                     capacity_rows=self.cap_rows, probed_work_units=self.probed_walk[0], probed_rows=self.probed_walk[1],
                     seen_work_units=self.seen_units, seen_rows=self.seen_rows, steps=self.confirmed,
                     graph=self.graph is not None)
+
+
+class HostFeed:
+    """The loop the way the reference feeds it (/root/reference/train.py:36-43 `DataLoader(pin_memory=True)`, :97
+    `data_to_device`, scene/data_class.py:158-162): every step's camera, target image and mask come from PAGE-LOCKED HOST
+    memory -- 33 MB per step at 1080p, 23 GB/s at 700 it/s.  The reference uploads them on the compute stream in front of the
+    forward; here they cross PCIe on a copy stream into one of `n_slots` device slots while the previous step computes, and the
+    step waits for exactly that upload (an event), not for the caller's stream:
+
+        feed = HostFeed(runner)                      # runner: TrainStepGraph
+        for batch in loader:                         # batch: {"w2c", "K", "width", "height", "image"[, "mask"]} pinned host tensors
+            feed.step(batch)
+
+    A slot is refilled once the step that read it last has run (an event on the runner's stream).  A step the device SKIPPED
+    behind a capacity overflow is replayed from a fresh upload of its own host tensors (`step(host_src=...)`), so recycling
+    the slots never feeds a replay another step's image; the host tensors themselves must stay untouched until the step is
+    retired (a DataLoader's pinned batches are: each is a new allocation).
+    `image` may be uint8 [H, W, 3] (8 MB instead of 25 MB across PCIe): it is converted on the copy stream with the
+    reference's own arithmetic, `float32(x) / 255` (a true division: bit-identical to `Frame.to_data`'s numpy expression)."""
+
+    def __init__(self, runner: "TrainStepGraph", n_slots: int = 2):
+        self.r, self.n = runner, max(2, int(n_slots))
+        dev = runner.dev
+        self.copy_stream = torch.cuda.Stream(dev)
+        H, W = runner.H, runner.W
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.gt = [torch.empty((H, W, 3), **f32) for _ in range(self.n)]
+        self.u8 = [None] * self.n
+        self.mask = [torch.empty((H, W), **f32) if runner.has_mask else None for _ in range(self.n)]
+        self.w2c = [torch.empty((4, 4), **f32) for _ in range(self.n)]
+        self.K = [torch.empty((3, 3), **f32) for _ in range(self.n)]
+        self.done = [None] * self.n
+        self._t255 = torch.full((), 255.0, **f32)
+        self.i = 0
+
+    @staticmethod
+    def to_target(image: Tensor, dev) -> Tensor:
+        """A host image as the loss kernels read it: float32 [H, W, 3] on the device (uint8: / 255 as the reference's loader)."""
+        x = image.to(dev, non_blocking=False)
+        if x.dtype == torch.uint8:
+            return torch.div(x.to(torch.float32), torch.full((), 255.0, dtype=torch.float32, device=dev))
+        return x.to(torch.float32)
+
+    def step(self, batch: Dict[str, Any]):
+        r, j = self.r, self.i % self.n
+        self.i += 1
+        if (int(batch["width"]), int(batch["height"])) != (r.W, r.H):
+            raise ValueError("HostFeed: one frame size per feed (build another for another size)")
+        cs = self.copy_stream
+        if self.done[j] is not None:
+            cs.wait_event(self.done[j])   # the step that read this slot last has run
+        img = batch["image"]
+        with torch.cuda.device(r.dev), torch.cuda.stream(cs):
+            self.w2c[j].copy_(batch["w2c"], non_blocking=True)
+            self.K[j].copy_(batch["K"], non_blocking=True)
+            if img.dtype == torch.uint8:
+                if self.u8[j] is None:
+                    self.u8[j] = torch.empty(tuple(img.shape), dtype=torch.uint8, device=r.dev)
+                self.u8[j].copy_(img, non_blocking=True)
+                torch.div(self.u8[j].to(torch.float32), self._t255, out=self.gt[j])
+            else:
+                self.gt[j].copy_(img, non_blocking=True)
+            if r.has_mask:
+                self.mask[j].copy_(batch["mask"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        out = r.step({"w2c": self.w2c[j], "K": self.K[j], "width": r.W, "height": r.H}, self.gt[j], self.mask[j] if r.has_mask else None,
+                     inputs_ready=True, ready_event=ev, host_src=batch)
+        self.done[j] = torch.cuda.Event()
+        self.done[j].record(r.stream)
+        return out
