@@ -656,6 +656,7 @@ def run_rank(args) -> int:
                 graph_step.fence()
                 nbytes = sum(int(b["image"].numel() * b["image"].element_size() + b["mask"].numel() * 4 + 100) for b in batches) / len(batches)
                 host_fed[kind] = {"train_iters_per_s": round(args.steps / e_h, 2), "train_ms": _percentiles(s_h),
+                                  "slowest_steps_ms": [round(float(x), 3) for x in sorted(s_h)[-5:]],
                                   "host_bytes_per_step": int(nbytes), "h2d_GBps": round(nbytes * args.steps / e_h / 1e9, 2),
                                   "h2d_GBps_at_headline_rate": round(nbytes * (args.steps / elapsed) / 1e9, 2), "h2d_link_GBps_measured": round(h2d_peak, 2),
                                   "vs_headline": round((args.steps / e_h) / (args.steps / elapsed), 4)}

@@ -628,8 +628,9 @@ class TrainStepGraph:
                 # `inputs_ready=True` covers the caller's writers, not this one
                 self.stream.wait_event(conv)
                 entry[7] = None
-            if after is not None:   # (`step(ready_event=...)`: the upload of this step's inputs on the caller's copy stream)
-                self.stream.wait_event(after)
+            if after is not None:   # (`step(ready_event=...)`: the upload of this step's inputs on the caller's copy stream(s))
+                for ev in (after if isinstance(after, (list, tuple)) else (after,)):
+                    self.stream.wait_event(ev)
                 entry[8] = None
             entry[4], entry[5] = self._stage_inputs(t, lrs, w2c, K, gt, mask)   # (the tensors the step reads: kept by the entry)
             if self.graph is not None:
@@ -821,15 +822,25 @@ class HostFeed:
         for batch in loader:                         # batch: {"w2c", "K", "width", "height", "image"[, "mask"]} pinned host tensors
             feed.step(batch)
 
-    A slot is refilled once the step that read it last has run (an event on the runner's stream).  A step the device SKIPPED
-    behind a capacity overflow is replayed from a fresh upload of its own host tensors (`step(host_src=...)`), so recycling
-    the slots never feeds a replay another step's image; the host tensors themselves must stay untouched until the step is
-    retired (a DataLoader's pinned batches are: each is a new allocation).
-    `image` may be uint8 [H, W, 3] (8 MB instead of 25 MB across PCIe): it is converted on the copy stream with the
-    reference's own arithmetic, `float32(x) / 255` (a true division: bit-identical to `Frame.to_data`'s numpy expression)."""
+    A slot is refilled once the step that read it last has run -- the copy stream waits for that (an event on the runner's
+    stream), and so does the HOST: a feeder is never more than `n_slots` steps ahead of the device, a DataLoader's prefetch depth.
+    (Unthrottled, the enqueueing thread ran hundreds of uploads ahead and stalled for 8-15 ms at a time inside the runtime's copy
+    path: 645 it/s instead of 695 at the bench workload.)  A step the device SKIPPED behind a capacity overflow is replayed from
+    a fresh upload of its own host tensors (`step(host_src=...)`), so recycling the slots never feeds a replay another step's
+    image; the host tensors themselves must stay untouched until the step is retired (a DataLoader's pinned batches are: each is
+    a new allocation).
+    `image` may be uint8 [H, W, 3] (8 MB instead of 25 MB across the link): it is widened on the copy stream with the
+    reference's own arithmetic, `float32(x) / 255` (a true division: bit-identical to `Frame.to_data`'s numpy expression).
+    Measured and not kept (round 6, tools/host_feed_probe.py; 33 MB per step, the link 55 GB/s on an idle GPU): the batch pulled
+    across by a KERNEL of 8 / 32 / 128 workgroups instead of the DMA engine -- 17-19 GB/s whatever its size, 1.70 / 1.94 / 2.00 ms
+    per step; the image split over 2 / 4 / 8 copy streams -- 656 / 637 / 602 it/s against 680 on one.  A concurrent GEMM slows the
+    same DMA batch from 0.64 to 7.1 ms: how fast the link is under load is the platform's business."""
 
-    def __init__(self, runner: "TrainStepGraph", n_slots: int = 2):
+    def __init__(self, runner: "TrainStepGraph", n_slots: int = 2, inputs_ready: bool = False):
+        """`inputs_ready`: the caller's promise of `TrainStepGraph.step` (its stream holds no pending reader of the outputs, the
+        parameters or the statistics) -- the uploads themselves are ordered by events either way."""
         self.r, self.n = runner, max(2, int(n_slots))
+        self.inputs_ready = bool(inputs_ready)
         dev = runner.dev
         self.copy_stream = torch.cuda.Stream(dev)
         H, W = runner.H, runner.W
@@ -858,6 +869,7 @@ class HostFeed:
             raise ValueError("HostFeed: one frame size per feed (build another for another size)")
         cs = self.copy_stream
         if self.done[j] is not None:
+            self.done[j].synchronize()    # (the host: never more than n_slots steps ahead)
             cs.wait_event(self.done[j])   # the step that read this slot last has run
         img = batch["image"]
         with torch.cuda.device(r.dev), torch.cuda.stream(cs):
@@ -875,7 +887,7 @@ class HostFeed:
             ev = torch.cuda.Event()
             ev.record(cs)
         out = r.step({"w2c": self.w2c[j], "K": self.K[j], "width": r.W, "height": r.H}, self.gt[j], self.mask[j] if r.has_mask else None,
-                     inputs_ready=True, ready_event=ev, host_src=batch)
+                     inputs_ready=self.inputs_ready, ready_event=ev, host_src=batch)
         self.done[j] = torch.cuda.Event()
         self.done[j].record(r.stream)
         return out
