@@ -674,6 +674,23 @@ def run_rank(args) -> int:
         e_s, _, s_s, _ = timed_loop(sfn, args.steps, 10, finish=None if graph_step is None else graph_step.finish, ev_stream=g_stream)
         static_view = {"train_iters_per_s": round(args.steps / e_s, 2), "train_ms": _percentiles(s_s),
                        "note": "the same step replayed on one static camera and target (rounds 1-3's headline)"}
+    per_rank = None
+    if world > 1 or force_dist:
+        # every rank's own clock and step-time distribution, so that ONE multi-GPU run can be read without a second one:
+        # [wall seconds of the timed loop, median / p10 / p90 / max step ms (HIP events on the rank's stream)], gathered to all ranks;
+        # and the world size as the collective library itself sees it (an all-reduce of ones over the group)
+        sm = np.asarray(step_ms, dtype=np.float64)
+        mine = torch.tensor([elapsed, float(np.median(sm)), float(np.percentile(sm, 10)), float(np.percentile(sm, 90)), float(sm.max())],
+                            device=device, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ones = torch.ones((1,), device=device)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rows_pr = [[round(float(x), 4) for x in t.tolist()] for t in allr]
+        ms_pr = [1e3 * r[0] / args.steps for r in rows_pr]
+        per_rank = {"columns": ["wall_s", "step_ms_median", "step_ms_p10", "step_ms_p90", "step_ms_max"], "ranks": rows_pr,
+                    "ms_per_step_min": round(min(ms_pr), 4), "ms_per_step_median": round(float(np.median(ms_pr)), 4), "ms_per_step_max": round(max(ms_pr), 4),
+                    "world_size_seen_by_collective": int(round(float(ones.item()))), "backend": dist.get_backend()}
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -1105,6 +1122,8 @@ def run_rank(args) -> int:
             result["lazy_handback"] = lazy_handback
         if host_fed is not None:
             result["host_fed"] = host_fed
+        if per_rank is not None:
+            result["per_rank"] = per_rank
         if graph_report is not None:
             result["host"]["graph"] = graph_report
             if graph_report["overflows"]:
@@ -1112,6 +1131,21 @@ def run_rank(args) -> int:
         result.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sc, args.cpu_sample, args.cpu_reps)
+        # the figures a reader of the LAST 1500 characters of this line needs (a record that keeps only the tail of stdout)
+        def _g(d, *ks):
+            for k in ks:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        cfgs = result.get("captured_step_configs", {})
+        result["summary"] = {
+            "train_iters_per_s": result["value"], "forward_fps": result.get("forward_fps"), "lazy_handback_it_s": _g(result, "lazy_handback", "train_iters_per_s"),
+            "host_fed_it_s": {k: _g(result, "host_fed", k, "train_iters_per_s") for k in ("float32", "uint8")},
+            "real_loop_it_s": {k: _g(result, "real_loop", k, "train_iters_per_s") for k in ("captured", "eager")},
+            "e2e": {"psnr": _g(result, "e2e", "captured", "psnr"), "it_s": _g(result, "e2e", "captured", "train_iters_per_s"), "n_final": _g(result, "e2e", "captured", "n_gaussians_final")},
+            "configs_it_s_gsplat_lists_tight": {k: [_g(v, "gsplat_eager", "train_iters_per_s"), _g(v, "tight", "train_iters_per_s")] for k, v in cfgs.items() if isinstance(v, dict)},
+            "configs_peak_GiB": {k: _g(v, "gsplat_eager", "peak_GiB") for k, v in cfgs.items() if isinstance(v, dict)},
+            "configs_runner_bytes_per_listed_isect": {k: _g(v, "gsplat_eager", "runner_bytes_per_listed_isect") for k, v in cfgs.items() if isinstance(v, dict)},
+            "roofline_frac": _g(result, "roofline", "frac"), "cpu_baseline_it_s": _g(result, "cpu_baseline", "value")}
         print(json.dumps(result), flush=True)
     if world > 1 or force_dist:
         dist.barrier()

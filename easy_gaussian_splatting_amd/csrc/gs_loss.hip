@@ -30,7 +30,7 @@ constexpr int kHP = kLT + 1;          // row stride of the horizontal-pass buffe
 static_assert(kLT * (kLT / 4) == 256 && kLR * 6 <= 256 && kLR % 6 == 0, "thread mapping of the staging and the separable passes");
 static_assert(kLR % 2 == 0 && kLR * 3 <= 128, "backward staging: two 128-thread halves, one staged row each");
 constexpr int64_t kLossMaxPixels = (int64_t)1 << 28;   // 12 bytes per pixel and plane under 2^32
-constexpr int kLossMaxWidth = 1 << 20;                 // a row's 12 W bytes and every row index under 2^24 (24-bit multiplies)
+constexpr int kLossMaxWidth = 1 << 20;                 // a row's 12 W bytes under 2^24; the row INDEX is held under 2^24 by the entry points (24-bit multiplies)
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 // The window as compile-time constants: every tap is a LITERAL operand of its FMA.  From __constant__ memory the taps sat in
@@ -457,7 +457,8 @@ extern "C" size_t gs_loss_workspace_floats(int height, int width) {
 static int loss_fwd_launch(void* stream, int height, int width, float lambda_ssim, const float* render, const float* gt,
                            const float* mask, const float* const* slots, bool has_mask, int clamp_input, float* workspace, float* out3) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
-    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels && width <= kLossMaxWidth, "image too large for the loss kernels' 32-bit byte offsets");
+    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels && width <= kLossMaxWidth && height <= (1 << 24),
+               "image too large for the loss kernels' 32-bit byte offsets (H * W <= 2^28, W <= 2^20, H <= 2^24: row indices go through 24-bit multiplies)");
     GS_REQUIRE(render && (gt || slots) && workspace && out3, "null pointer");
     LossArgs a;
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask; a.slots = slots;
@@ -478,7 +479,8 @@ static int loss_bwd_launch(void* stream, int height, int width, float lambda_ssi
                            const float* mask, const float* const* slots, int clamp_input, const float* workspace,
                            const float* v_total, float* v_render) {
     GS_REQUIRE(height > 2 * kHalo && width > 2 * kHalo, "image must be larger than the 11x11 window");
-    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels && width <= kLossMaxWidth, "image too large for the loss kernels' 32-bit byte offsets");
+    GS_REQUIRE((int64_t)height * width <= kLossMaxPixels && width <= kLossMaxWidth && height <= (1 << 24),
+               "image too large for the loss kernels' 32-bit byte offsets (H * W <= 2^28, W <= 2^20, H <= 2^24: row indices go through 24-bit multiplies)");
     GS_REQUIRE(render && (gt || slots) && workspace && v_total && v_render, "null pointer");
     LossArgs a;
     a.H = height; a.W = width; a.lambda_ssim = lambda_ssim; a.render = render; a.gt = gt; a.mask = mask; a.slots = slots;

@@ -271,33 +271,30 @@ def load_frames(path: Path, use_masks: bool, mask_expand_pixels: int, white_back
 
 
 def generate_pointcloud(frames: List[Frame], num_points: int = 100000) -> Pointcloud:
-    """Uniform random points in the middle third of the cameras' bounding range, grey (blender data has no SfM cloud)."""
-    camera_positions = np.stack([np.linalg.inv(frame.w2c)[:3, 3] for frame in frames])
-    max_val, min_val = camera_positions.max(), camera_positions.min()
-    center_val = (max_val + min_val) / 2.0
-    min_val = center_val - (center_val - min_val) / 3
-    max_val = center_val + (max_val - center_val) / 3
-    xyzs = np.random.rand(num_points, 3) * (max_val - min_val) + min_val
-    rgbs = np.floor(np.ones((num_points, 3)) * 127.0).astype(np.uint8)
-    return Pointcloud(xyzs, rgbs)
+    """The start cloud of a dataset without SfM points (/root/reference/scene/blender_loader.py:55-71): `num_points` grey
+    points, uniform in a cube -- ONE scalar interval for all three axes: the middle third of [smallest, largest] coordinate of
+    any camera centre.  Draws `num_points x 3` numbers from numpy's GLOBAL generator in one call, like the reference (a run
+    seeded the same way starts from the same cloud)."""
+    centres = np.stack([-(f.w2c[:3, :3].T @ f.w2c[:3, 3]) for f in frames])   # camera centre = -R^T t of the world-to-camera pose
+    lo, hi = float(centres.min()), float(centres.max())
+    mid, half = 0.5 * (lo + hi), (hi - lo) / 6.0
+    xyzs = (mid - half) + np.random.rand(num_points, 3) * (2.0 * half)
+    return Pointcloud(xyzs, np.full((num_points, 3), 127, dtype=np.uint8))
 
 
 def load_blender_data(path: str, use_masks: bool, mask_expand_pixels: int, eval: bool, eval_in_val: bool, eval_in_test: bool,
                       white_background: bool) -> Tuple[List[Frame], Pointcloud, List[int], List[int]]:
+    """nerf_synthetic layout (/root/reference/scene/blender_loader.py:74-114): the held-out frames (val and / or test, as asked)
+    come FIRST in the frame list, the training split behind them; with `eval` off every frame trains.  The start cloud is
+    generated from the cameras that train."""
     root = Path(path)
-    train_frames = load_frames(root / "transforms_train.json", use_masks, mask_expand_pixels, white_background)
-    eval_frames: List[Frame] = []
-    if eval_in_val:
-        eval_frames += load_frames(root / "transforms_val.json", use_masks, mask_expand_pixels, white_background)
-    if eval_in_test:
-        eval_frames += load_frames(root / "transforms_test.json", use_masks, mask_expand_pixels, white_background)
-    frames = eval_frames + train_frames
-    split_point = len(eval_frames)
-    indexes = list(range(len(frames)))
-    eval_indexes = indexes[:split_point]
-    train_indexes = indexes[split_point:] if eval else indexes
-    pc = generate_pointcloud(frames[split_point:] if eval else frames)
-    return frames, pc, train_indexes, eval_indexes
+    read = lambda split: load_frames(root / f"transforms_{split}.json", use_masks, mask_expand_pixels, white_background)   # noqa: E731
+    held_out = [fr for split, wanted in (("val", eval_in_val), ("test", eval_in_test)) if wanted for fr in read(split)]
+    frames = held_out + read("train")
+    n_held = len(held_out)
+    eval_indexes = list(range(n_held))
+    train_indexes = list(range(n_held if eval else 0, len(frames)))
+    return frames, generate_pointcloud([frames[i] for i in train_indexes]), train_indexes, eval_indexes
 
 
 # ------------------------------------------------------------------------------------------------ Scene

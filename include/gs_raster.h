@@ -372,7 +372,7 @@ int gs_sh_adam_views(void* stream, int R, int64_t N, int K, int sh_degree, const
  * v_total: device scalar d(loss)/d(out3[2]);  v_render[H,W,3] is fully written.
  * clamp_input != 0: `render` is the rasterizer's un-clamped image; torch.clamp(render, 0, 1) of
  * GaussianModel.forward (/root/reference/model/gaussian.py:368) and its backward are applied inside.
- * Sizes: height, width > 10 (the window), height * width <= 2^28 and width <= 2^20 (32-bit byte offsets inside the kernels);
+ * Sizes: height, width > 10 (the window), height * width <= 2^28, width <= 2^20 and height <= 2^24 (32-bit byte offsets, 24-bit row multiplies);
  * anything else is refused with GS_ERR_ARG before a launch. */
 size_t gs_loss_workspace_floats(int height, int width);
 int gs_l1_ssim_fwd(void* stream, int height, int width, float lambda_ssim, const float* render,

@@ -39,6 +39,7 @@ def dump(path: str) -> None:
                 "n_backward_checks", "n_row_criterion_fp32_oracle_uses"):
         tot[key] = sum(int(r.get(key, 0)) for r in RECORDS.values())
     tot["max_razor_fraction"] = max((r.get("razor_fraction", 0.0) for r in RECORDS.values()), default=0.0)
+    tot["max_flip_tile_frac"] = max((r.get("flip_tile_frac", 0.0) for r in RECORDS.values()), default=0.0)
     tot["max_forward_err_strict"] = max((r.get("max_forward_err_strict", 0.0) for r in RECORDS.values()), default=0.0)
     worst = {}
     for r in RECORDS.values():
@@ -57,5 +58,5 @@ def dump(path: str) -> None:
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         json.dump({"summary": tot, "tolerances": {"forward_abs": 1e-4, "grad_rel": 1e-3, "grad_rel_l2": 1e-4, "row_bad_frac": 5e-3, "row_bad_rows_abs": 3, "row_bad_frac_hard_cap_and_fp32_oracle_fallback": 1e-2,
-                                                  "unmasked_l2": 5e-4, "unmasked_max": 1e-2, "means2d_ulps": 1.0, "conics_rel": 2.4e-7,
+                                                  "unmasked_l2": 4e-4, "unmasked_max": 6e-3, "means2d_ulps": 1.0, "conics_rel": 2.4e-7,
                                                   "depths_rel": 2.4e-7}, "tests": RECORDS}, f, indent=1)

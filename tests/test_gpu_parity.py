@@ -246,6 +246,7 @@ def forward_report(meta, fw, lists=True, geom_slack=1.0, max_flip_tile_frac=0.02
     razor = razor_mask(fw)
     H, W = razor.shape[1:]
     loose = razor | np.repeat(np.repeat(tmask, tile, axis=1), tile, axis=2)[:, :H, :W]
+    parity_log.record(flip_tile_frac=float(tmask.mean()), max_flip_tile_frac_allowed=float(max_flip_tile_frac))
     parity_log.record(n_radius_flips=int(mism.sum()), n_rectangle_flips=n_edge, razor_fraction=float(razor.mean()),
                       loose_fraction=float(loose.mean()), max_means2d_err_ulps=e_mu, max_conics_rel_err=e_con, max_depths_rel_err=e_dep,
                       n_gaussians=int(mism.size), n_isects=int(fw["n_isects"]))
@@ -304,8 +305,8 @@ ROW_BAD_HARD = 1e-2        # ... and, beyond that, at most what an INDEPENDENT f
                            # the fp32 build of the oracle has 89 on the same scenes, 10 where the HIP path has its worst 8 (of 1187,
                            # v_opacities): it is the fp32 rounding of the per-pixel terms themselves (exp2, alpha, the T chain), shared by
                            # any fp32 evaluation -- not a defect of the s_vs / v_op path.  Suite scenes measure <= 5.5e-4.
-UNMASKED_L2_RTOL = 5e-4    # unmasked upstream gradient against the fp32 oracle: isolated threshold flips, bounded
-UNMASKED_MAX_RTOL = 1e-2
+UNMASKED_L2_RTOL = 4e-4    # unmasked upstream gradient against the fp32 oracle: isolated threshold flips, bounded
+UNMASKED_MAX_RTOL = 6e-3   # (round 6: 5e-4 / 1e-2 before -- measured 3.6e-4 / 5.0e-3, tightened so that a regression shows)
 
 
 def _grad_metrics(g, ref, rtol, relax=None):
