@@ -30,12 +30,8 @@
 
 namespace gs {
 
-#ifndef GS_BIN_PER_GROUP
 #define GS_BIN_PER_GROUP 4096     // Gaussians per binning block (histogram / emit)
-#endif
-#ifndef GS_BIN_MAX_GROUPS
 #define GS_BIN_MAX_GROUPS 256     // (bin_colscan_kernel takes up to kColChunks * 16 groups in its batched path)
-#endif
 constexpr int kBinThreads = 1024;
 constexpr int kCoopTiles = 32;  // footprints above this are spread over the whole wave
 
@@ -460,9 +456,6 @@ __global__ void tile_sort_kernel(const SortArgs a) {
 // Equal depths must come out in slot order (the stable-sort contract of the reference, A.3) but
 // arrive in arbitrary order: a tile in which an equal-depth pair is out of order -- practically
 // never -- is re-sorted on the full 64-bit key by the bitonic network.
-#ifndef GS_SORT_MATCH_SELECT
-#define GS_SORT_MATCH_SELECT 0
-#endif
 template <int T>
 __device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vblock) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
@@ -536,15 +529,6 @@ __device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vbl
                 const bool valid = i < w_hi;
                 const unsigned long long k = valid ? src[i] : 0ull;
                 const int d = (int)((k >> shift) & 255ull);
-#if GS_SORT_MATCH_SELECT
-                unsigned long long peers = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const bool bit = (d >> b) & 1;
-                    const unsigned long long bm = __ballot(bit);
-                    peers &= bit ? bm : ~bm;
-                }
-#else
                 // lanes whose digit differs from this lane's in bit b: ballot ^ (-bit) -- one sign-extending bit-field
                 // extract, one compare, two xor and two or per bit (the select form costs two cndmask + two and + a not more)
                 uint32_t mlo = 0u, mhi = 0u;
@@ -556,7 +540,6 @@ __device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vbl
                     mhi |= (uint32_t)(bm >> 32) ^ (uint32_t)e;
                 }
                 const unsigned long long peers = __ballot(valid) & ~(((unsigned long long)mhi << 32) | (unsigned long long)mlo);
-#endif
                 if (valid) {
                     const int rank = __popcll(peers & lt_mask);
                     const uint32_t off = cnt[wave * 256 + d];
@@ -1159,12 +1142,8 @@ static int ensure_lds(const void* fn, size_t bytes) {
     return GS_OK;
 }
 
-#ifndef GS_SORT1K_THREADS
 #define GS_SORT1K_THREADS 256
-#endif
-#ifndef GS_SORT4K_THREADS
 #define GS_SORT4K_THREADS 256
-#endif
 // Size classes of the per-list sort (max_count: the longest list, known to the host, or an upper bound):
 //   <= 1024 keys: one block per list, 256 threads, 24 KB of LDS
 //   (1024, 4096] 72 KB | (4096, 8192] 768 threads, 152 KB | (8192, 65536] 8192-key segments + rank merge: over compacted

@@ -70,10 +70,7 @@ constexpr int kUnit = GS_UNIT;
 // leaves unused of its last chunk costs memory only -- the work-unit descriptors are published densely, see unit log).
 // Round 6, same box, blend_fwd stage at 1 M / 1080p: ONE counter for all tiles, chunks of 8 / 32 / 64: 0.47 / 0.395 / 0.398 ms
 // (30 k / 10 k / 8 k same-address device-scope atomics per frame) -- hence GS_WALK_RANGES counters, a cache line each.
-#ifndef GS_EXP_CHUNK
-#define GS_EXP_CHUNK 8
-#endif
-constexpr int kChunk = GS_EXP_CHUNK;
+constexpr int kChunk = 8;
 // Work units a tile-wave has opened and not yet published, in LDS: (storage unit, position in the sublist * 4 + quadrant).
 // Published -- one atomic for the lot, descriptors dense in launch order -- when the log fills up and at the end of the tile.
 constexpr int kUnitLog = 128;

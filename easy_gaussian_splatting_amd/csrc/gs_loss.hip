@@ -39,9 +39,6 @@ constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 #define GS_WIN_TAPS {1.0283800845e-03f, 7.5987581352e-03f, 3.6000772128e-02f, 1.0936068951e-01f, 2.1300553771e-01f, \
                      2.6601172486e-01f, 2.1300553771e-01f, 1.0936068951e-01f, 3.6000772128e-02f, 7.5987581352e-03f, 1.0283800845e-03f}
 
-#ifndef GS_SSIM_IEEE_DIV
-#define GS_SSIM_IEEE_DIV 0
-#endif
 struct LossArgs {
     int H, W;
     int clamp_input;                   // render is the un-clamped image: clamp to [0,1] on load, mask the gradient
@@ -104,7 +101,7 @@ constexpr int kHOut = 6, kHWin = kHOut + 10;
 // Measured at 1080p with a mask on inputs that are cold in every cache, as in the train step (tools/loss_time.py; the
 // forward entry including its one-block reduction): round 4's three-channel block with 71 KB of LDS 68 us; a block per
 // (tile, channel) with 4-byte accesses at a 12-byte stride 58-64; this form with five moment maps 51, with four 44-48.
-// Timing builds (-DGS_LOSS_EXP=1 no stores, =2 synthetic pixels instead of loads, =3 both; wrong on purpose): 52 -> 47 / 42 /
+// Round 5's timing builds (no stores / synthetic pixels instead of loads / both; since removed from the sources): 52 -> 47 / 42 /
 // 39 us without a mask, and the memory side alone (tools/micro/tile_stream.hip: the same loads and stores, no arithmetic)
 // 23 us: the kernel is bound by its ~900 VALU instructions per tile and channel, with the memory side two thirds hidden.
 template <bool MASK>
@@ -137,11 +134,7 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
         for (int i = 0; i < kPer; ++i) {
             const unsigned cy = (unsigned)clampi(ytop + 6 * i, 0, a.H - 1);
             const unsigned o = __umul24(cy, row_bytes) + 12u * (unsigned)cx;
-#if GS_LOSS_EXP & 2
-            const F3 g3 = F3{(float)(o & 255u) * 0.003f, (float)(o & 127u) * 0.006f, 0.5f}, r3 = F3{(float)(o & 63u) * 0.01f, 0.25f, (float)(o & 31u) * 0.03f};
-#else
             const F3 g3 = ld3_off(gt_img, o), r3 = ld3_off(a.render, o);
-#endif
             gv[i][0] = g3.x; gv[i][1] = g3.y; gv[i][2] = g3.z;
             rv[i][0] = r3.x; rv[i][1] = r3.y; rv[i][2] = r3.z;
             if (MASK) mv[i] = ld_off(mask_img, __umul24(cy, 4u * (unsigned)a.W) + 4u * (unsigned)cx);
@@ -231,14 +224,6 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
                         const float mm = mu_x * mu_x + mu_y * mu_y, sxy = exy - mu_x * mu_y;
                         const float n1 = 2.f * mu_x * mu_y + kC1, n2 = 2.f * sxy + kC2;
                         const float d1 = mm + kC1, d2 = (ess - mm) + kC2;
-#if GS_SSIM_IEEE_DIV
-                        const float inv = 1.f / (d1 * d2);
-                        const float sv = n1 * n2 * inv;
-                        ssim_sum += sv;
-                        dxx = -sv / d2;
-                        dxy = 2.f * n1 * inv;
-                        dmu = 2.f * mu_y * (n2 - n1) * inv - 2.f * mu_x * sv / d1 + 2.f * mu_x * sv / d2;
-#else
                         // two hardware reciprocals (1 ulp) instead of four IEEE divisions (~10 instructions each on gfx950):
                         // d1, d2 >= C1, C2 > 0 are far from any range the refinement steps guard
                         const float i1 = __builtin_amdgcn_rcpf(d1), i2 = __builtin_amdgcn_rcpf(d2), inv = i1 * i2;
@@ -247,14 +232,9 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(const LossArgs a) {
                         dxx = -sv * i2;
                         dxy = 2.f * n1 * inv;
                         dmu = 2.f * mu_y * (n2 - n1) * inv + 2.f * mu_x * sv * (i2 - i1);
-#endif
                     }
                     // [ch][H][W][dmu, dxx, dxy]: one 12-byte store per pixel, a tile row one contiguous run
-#if GS_LOSS_EXP & 1
-                    if (dmu == 123.f) st3_off(maps_c, __umul24((unsigned)gy, row_bytes) + 12u * (unsigned)gx, dmu, dxx, dxy);
-#else
                     st3_off(maps_c, __umul24((unsigned)gy, row_bytes) + 12u * (unsigned)gx, dmu, dxx, dxy);
-#endif
                 }
             }
         }

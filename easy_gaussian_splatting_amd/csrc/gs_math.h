@@ -68,10 +68,7 @@ GS_HD void alpha_extent(float opacity, float cxx, float cyy, float& ex, float& e
 // radius and the tile rectangle).  fp64 by default: CDNA4 issues vector fp64 at half the fp32 rate, the chain is
 // ~10^3 flops per Gaussian against ~10^5 per Gaussian in the blend, and its inverse (det = ac - b^2 of a 60:1 needle
 // loses 3 digits, twice in the VJP) is the one badly conditioned step of the whole path.  Inputs and outputs stay fp32.
-#ifndef GS_PROJ_REAL
-#define GS_PROJ_REAL double
-#endif
-typedef GS_PROJ_REAL preal;
+typedef double preal;
 
 GS_HD float r_sqrt(float x) { return sqrtf(x); }
 GS_HD double r_sqrt(double x) { return sqrt(x); }

@@ -11,9 +11,7 @@
 
 namespace gs {
 
-#ifndef GS_PROJ_THREADS
 #define GS_PROJ_THREADS 256
-#endif
 constexpr int kProjThreads = GS_PROJ_THREADS;
 
 struct ProjFwdArgs {
@@ -475,9 +473,7 @@ __device__ __forceinline__ void write_sh_tile(const float* tile, int rows, int K
     else write_sh_tile_k<0>(tile, rows, K, n0, v_colors, v_sh_rest, accumulate);
 }
 
-#ifndef GS_ADAM_BATCH
 #define GS_ADAM_BATCH 3
-#endif
 // The same walk over one block's SH-gradient tile, but as an in-place Adam update of sh_0 / sh_rest (split layout)
 // and their moments: the 48 SH gradients per Gaussian (81 % of all gradient bytes at SH3) are never written to HBM
 // nor read back by a separate optimizer pass.  (The block staged its own SH rows into LDS before the barrier in
@@ -553,9 +549,6 @@ __device__ __forceinline__ void adam_sh_tile(const float* tile, int rows, int Kr
     }
 }
 
-#ifndef GS_GEO_ADAM_SCALAR
-#define GS_GEO_ADAM_SCALAR 0
-#endif
 // In-place Adam of one block's slice of the four geometry tensors (groups 0 means[N,3], 1 log_scales[N,3], 2 quats[N,4],
 // 5 logit_opacities[N]) from gradients staged in LDS in element order: tile + {0, 3, 6, 10} * kProjThreads.
 __device__ __forceinline__ void adam_geo_tile(const float* tile, int rows, int64_t n0, const ProjBwdArgs& a) {
@@ -837,12 +830,9 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         const float scale[3] = {act_scale(p_scales[3 * n], a.activations), act_scale(p_scales[3 * n + 1], a.activations),
                                 act_scale(p_scales[3 * n + 2], a.activations)};
         if (a.activations) { sc_fac[0] = scale[0]; sc_fac[1] = scale[1]; sc_fac[2] = scale[2]; }
-#ifndef GS_BWD_REAL   // (diagnostic builds: -DGS_BWD_REAL=float prices the fp64 chain of the backward)
-#define GS_BWD_REAL preal
-#endif
-        ProjChainT<GS_BWD_REAL> p;
-        if (project_chain<GS_BWD_REAL>(mean, quat, scale, cam, a.eps2d, a.near_p, a.far_p, p))
-            project_vjp<GS_BWD_REAL>(scale, cam, p, s.v[0], s.v[1], s.v[4], s.v[5], s.v[6], 0.f, v_mean, v_quat, v_scale);
+        ProjChainT<preal> p;
+        if (project_chain<preal>(mean, quat, scale, cam, a.eps2d, a.near_p, a.far_p, p))
+            project_vjp<preal>(scale, cam, p, s.v[0], s.v[1], s.v[4], s.v[5], s.v[6], 0.f, v_mean, v_quat, v_scale);
     }
     float geo_op = 0.f;
     if (in_range) {
@@ -851,21 +841,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         const float v_op = s.v[7] * op_fac;
         float* vm = a.v_means + 3 * n; float* vq = a.v_quats + 4 * n; float* vs = a.v_scales + 3 * n;
         if (ADAM) {
-#if GS_GEO_ADAM_SCALAR
-            const float isbc2 = a.ad_hyper[0];
-            auto upd = [&](int t, int64_t idx, float g) {
-                float p = adam_p(a, t)[idx], m = adam_m(a, t)[idx], v = adam_v(a, t)[idx];
-                adam1(p, g, m, v, a.ad_b1, a.ad_b2, a.ad_eps, isbc2, a.ad_hyper[1 + t]);
-                adam_p(a, t)[idx] = p; adam_m(a, t)[idx] = m; adam_v(a, t)[idx] = v;
-            };
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { upd(0, 3 * n + k, v_mean[k]); upd(1, 3 * n + k, v_scale[k]); }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) upd(2, 4 * n + k, v_quat[k]);
-            upd(5, n, v_op);
-#else
             geo_op = v_op;   // (applied block-wide below: adam_geo_tile)
-#endif
             if (a.st_max_radii != nullptr && vis) {   // same arithmetic as update_statistics_kernel
                 a.st_max_radii[n] = fmaxf(a.st_max_radii[n], (float)a.radii[f] * (1.f / a.st_max_hw));
                 a.st_grad_norm[n] += sqrtf(s.v[2] * s.v[2] + s.v[3] * s.v[3]) * a.st_max_hw;
@@ -891,7 +867,6 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         if (a.v_conics) { a.v_conics[3 * f] = s.v[4]; a.v_conics[3 * f + 1] = s.v[5]; a.v_conics[3 * f + 2] = s.v[6]; }
         if (a.v_colors_post) { a.v_colors_post[3 * f] = v_rgb[0]; a.v_colors_post[3 * f + 1] = v_rgb[1]; a.v_colors_post[3 * f + 2] = v_rgb[2]; }
     }
-#if !GS_GEO_ADAM_SCALAR
     if (DEG >= 0 && ADAM) {
         // Geometry Adam, block-wide: the 11 gradients of every Gaussian of the block go through LDS into element order, and
         // means / log-scales / quaternions / logit-opacities (+ their moments) are updated with 16-byte accesses, every load
@@ -911,7 +886,6 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         __syncthreads();
         adam_geo_tile(tile, (int)min((int64_t)kProjThreads, a.N - n0), n0, a);
     }
-#endif
 }
 
 static size_t proj_lds_bytes(int K, int degree);

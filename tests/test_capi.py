@@ -257,3 +257,35 @@ def test_workspace_pool_leases(native, monkeypatch):
     d = WS.pool.acquire(cpu, 999)                 # another stream: another pool
     assert d is not b and d is not c
     WS.pool.clear()
+
+
+def test_the_loaded_library_is_the_product_build(native, monkeypatch):
+    """every build names the preprocessor flags it was made with (`gs_build_flags`); the product's are empty,
+    the binding refuses a diagnostic variant unless GS_ALLOW_VARIANT=1 says so, variants live in build/variants/ -- never in the
+    package directory -- and the shipped sources carry no experiment switch beyond the four diagnostic ones tests and tools use."""
+    import glob
+    import re
+    assert native.build_flags() == "" and native.lib().gs_version() >= 300
+    pkg = os.path.dirname(native.LIB_PATH)
+    assert sorted(os.path.basename(f) for f in glob.glob(os.path.join(pkg, "*.so"))) == ["libgsraster.so"]
+    assert os.path.realpath(native.VARIANT_DIR).startswith(os.path.realpath(os.path.join(ROOT, "build")))
+    switches = set()
+    for f in glob.glob(os.path.join(native.CSRC_DIR, "*.hip")) + glob.glob(os.path.join(native.CSRC_DIR, "*.h")):
+        switches |= set(re.findall(r"^#\s*if(?:n?def)?\s+(?:defined\()?\s*!?(GS_\w+)", open(f).read(), flags=re.M))
+    assert switches <= {"GS_BWD_CHECK", "GS_BWD_ACC64", "GS_EXACT_MATH", "GS_CLOCK_PROBE", "GS_BUILD_FLAGS"}, switches
+    n_if_blend = len(re.findall(r"^#\s*if", open(os.path.join(native.CSRC_DIR, "gs_blend.hip")).read(), flags=re.M))
+    assert n_if_blend <= 10, n_if_blend
+    # a variant is refused ... (a fake one: the loader only looks at what the library says about itself)
+    class Fake:
+        def __getattr__(self, name):
+            f = lambda *a: b"-DGS_BWD_CHECK" if name == "gs_build_flags" else 0
+            return f
+    import ctypes as ct
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(ct, "CDLL", lambda path: Fake())
+    monkeypatch.delenv("GS_ALLOW_VARIANT", raising=False)
+    with pytest.raises(native.NativeLibraryError, match="diagnostic variant"):
+        native.lib()
+    monkeypatch.setenv("GS_ALLOW_VARIANT", "1")   # ... unless asked for
+    assert native.lib().gs_build_flags() == b"-DGS_BWD_CHECK"
+    monkeypatch.setattr(native, "_lib", None)
