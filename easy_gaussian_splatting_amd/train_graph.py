@@ -492,6 +492,7 @@ class TrainStepGraph:
                 self.cap_coarse = int(int(info[4]) * self.margin) + 4096
             self.cap_coarse = int(int(info[4]) * self.margin) + 4096
             self.cap_coarse_list = int(int(info[5]) * 1.5) + 64
+            self.probed_coarse = (int(info[4]), int(info[5]))   # coarse-bin entries I', longest bin list
             n_isects, max_tile = int(info[0]), int(info[2])
         b["info"].zero_()
         return n_isects, max_tile
@@ -805,6 +806,7 @@ class TrainStepGraph:
 
     def report(self) -> Dict[str, Any]:
         return dict(self.stats, binning=self.binning, probed_isects=self.probed[0], probed_longest_list=self.probed[1],
+                    probed_coarse_entries=getattr(self, "probed_coarse", (0, 0))[0] if self.binning == "bins" else 0,
                     capacity_isects=self.cap, capacity_tile_list=self.cap_tile, capacity_work_units=self.cap_units,
                     capacity_rows=self.cap_rows, probed_work_units=self.probed_walk[0], probed_rows=self.probed_walk[1],
                     seen_work_units=self.seen_units, seen_rows=self.seen_rows, steps=self.confirmed,

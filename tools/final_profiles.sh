@@ -1,17 +1,16 @@
 #!/bin/bash
-# One GPU-box call that regenerates everything under profiles/ for a round:  tools/final_profiles.sh r05
+# One GPU-box call that regenerates everything under profiles/ for a round:  tools/final_profiles.sh r06
 # (build the diagnostic variants in the container first:
-#    tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE" "acc64:-DGS_BWD_ACC64" "exact:-DGS_BWD_ACC64 -DGS_EXACT_MATH" \
-#                                 "halfq100:-DGS_EXP_HALFQ=100" "halfq155:-DGS_EXP_HALFQ=155"
+#    tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE" "acc64:-DGS_BWD_ACC64" "exact:-DGS_BWD_ACC64 -DGS_EXACT_MATH"
 #    hipcc -O3 --offload-arch=gfx950 -o tools/micro/clock_probe tools/micro/clock_probe.hip)
 # (SQ counters and HBM traffic first: bench.py quotes them in its roofline objects)
-tag=${1:-r05}
+tag=${1:-r06}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 # the diagnostic variants, re-made on the box unless GS_SKIP_VARIANT_BUILD=1 (a variant older than the sources lacks the symbols newer
 # sources export, and the package refuses to bind such a library: the tools that load one would fail silently)
 if [ "$GS_SKIP_VARIANT_BUILD" != 1 ]; then
-  bash tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE" "acc64:-DGS_BWD_ACC64" "exact:-DGS_BWD_ACC64 -DGS_EXACT_MATH" "halfq100:-DGS_EXP_HALFQ=100" "halfq155:-DGS_EXP_HALFQ=155" > gpurun_out/${tag}_variants.log 2>&1
+  bash tools/tune_variants.sh build "clk:-DGS_CLOCK_PROBE" "acc64:-DGS_BWD_ACC64" "exact:-DGS_BWD_ACC64 -DGS_EXACT_MATH" > gpurun_out/${tag}_variants.log 2>&1
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/clock_probe tools/micro/clock_probe.hip
 fi
 # shader clock under load first (bench.py's roofline_compute reads profiles/<tag>_clock.json)
@@ -42,7 +41,7 @@ timeout 900 python tools/config_table.py > gpurun_out/${tag}_configs.md 2> gpuru
 timeout 200 python tools/binning_sweep.py 2>/dev/null > gpurun_out/${tag}_binning_sweep.txt
 timeout 200 python tools/blend_time.py 2>/dev/null > gpurun_out/${tag}_blend_time.txt
 # the workloads beside the headline: kernel trace + FETCH / WRITE traffic of eager train steps (tools/config_run.py)
-for cfg in S3 S5 heavy1M; do
+for cfg in S3 S5 heavy1M heavy2M; do
   lc=$(echo $cfg | tr A-Z a-z)
   timeout 600 bash tools/prof_cmd.sh ${tag}_${lc} tools/config_run.py $cfg 6 > /dev/null 2>&1
   grep "^{" /tmp/${tag}_${lc}.log | tail -1 > gpurun_out/${tag}_${lc}_run.json
@@ -54,8 +53,11 @@ done
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/micro/tile_stream tools/micro/tile_stream.hip
 timeout 60 tools/micro/valu_enc > gpurun_out/${tag}_valu_enc.txt 2>/dev/null
 timeout 60 tools/micro/tile_stream > gpurun_out/${tag}_tile_stream.txt 2>/dev/null
-# half-quadrant work units for blend_bwd, bounded (timing builds, numerically wrong on purpose)
-for v in "" _halfq100 _halfq155; do GS_LIB_PATH=$PWD/easy_gaussian_splatting_amd/libgsraster$v.so timeout 200 python tools/blend_time.py 2>/dev/null; done > gpurun_out/${tag}_halfq_bound.txt
+# where the captured step's memory goes (bytes per listed intersection), the host-fed loop, the end-to-end run, the lazy-binning bound
+for c in "bench1M tight" "heavy2M gsplat_eager" "heavy2M tight" "S5 tight"; do timeout 300 python tools/mem_report.py $c 2>/dev/null; done > gpurun_out/${tag}_mem_report.jsonl
+for a in "2 eager" "3 eager" "2 lazy"; do timeout 200 python tools/host_feed_probe.py $a 2>/dev/null; done > gpurun_out/${tag}_host_feed_probe.jsonl
+timeout 300 python tools/e2e_train.py 3000 both gpurun_out/${tag}_e2e.json > /dev/null 2>&1
+for c in "heavy2M tight" "heavy2M gsplat_eager" "heavy1M tight"; do timeout 300 python tools/lazy_bin_bound.py $c 2>/dev/null; done > gpurun_out/${tag}_lazy_bin_bound.jsonl
 # per-Gaussian criterion: fp32 sums / fp64 sums / fp64 sums + exact exp2 and division / fp32 oracle
 timeout 900 python tools/acc64_ab.py gpurun_out/${tag}_acc64_ab.json > gpurun_out/${tag}_acc64_ab.log 2>&1
 head -c 600 gpurun_out/${tag}_bench_line.json; echo; tail -3 gpurun_out/${tag}_bench.err
