@@ -56,8 +56,8 @@ SIGNATURES = {
     "gs_blend_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_project_bwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F,
-                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
-    "gs_row_sums": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+                            _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "gs_row_sums": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "gs_sh_adam_views": (_I, [_P, _I, _L, _I, _I, _P, _P, _L, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _L, _F, _P]),
     "gs_sh_grad_views": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P]),
     "gs_loss_workspace_floats": (_Z, [_I, _I]),
@@ -80,7 +80,7 @@ SIGNATURES = {
     "gs_scan_rows_i32": (_I, [_P, _I, _L, _P, _P, _P]),
     "gs_refine_flags": (_I, [_P, _L, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
     "gs_refine_apply": (_I, [_P, _L, _I, _I, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gs_project_bwd_adam": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P,
+    "gs_project_bwd_adam": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P,
                                   _P, _P, _P, _P]),
     "gs_workspace_query": (_I, [_I, _L, _I, _I, _L, _L, _L, _L, _I, _I, _P, _P]),
     "gs_workspace_bind": (_I, [_P, _P, _L, _P, _L, _P, _L, _P, _P]),

@@ -404,9 +404,10 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------
-// row_base[s] = number of gradient rows in front of slot s = exclusive scan of popcount(qmask), s = 0 .. n (n + 1 entries: the
-// last one is the total).  Three small launches over chunks of 8192 slots: per-chunk counts, a one-block scan of the counts
-// (which also publishes the total, checks it against cap_rows and writes the call's walk record), per-chunk scan + offset.
+// row_base[g] = number of gradient rows in front of slot 16 g = exclusive scan of popcount(qmask) sampled every 16 slots, g = 0 ..
+// n / 16 (readers add the popcounts inside the group: rows_before, gs_common.h).  Three small launches over chunks of 8192 slots:
+// per-chunk counts, a one-block scan of the counts (which also publishes the total, checks it against cap_rows and writes the
+// call's walk record), per-chunk scan + offset.
 // (A chained single-pass scan with decoupled look-back was measured first: one thread walking back over the descriptors of
 //  400 co-resident blocks cost 0.25 ms at 3.3 M slots and 3.7 ms at 57 M -- every hop an uncached device-scope load.)
 struct RowScanArgs {
@@ -500,23 +501,13 @@ __global__ __launch_bounds__(kScanThreads) void row_base_kernel(const RowScanArg
     uint32_t w[8];
     const int32_t tot = row_counts32(a.qmask, i0, n, w);
     int32_t block_tot;
-    int32_t run = block_excl_scan_add<int32_t>(tot, scratch, &block_tot) + a.walk[GS_WALK_WORDS + blockIdx.x];
-    int32_t o[kScanPerThread];
+    const int32_t run = block_excl_scan_add<int32_t>(tot, scratch, &block_tot) + a.walk[GS_WALK_WORDS + blockIdx.x];
+    // this thread's 32 slots are two groups of 16: the base of the first, and of the second behind the first's 16 masks
+    int32_t first16 = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t ex = w[j] * 0x01010100u;   // exclusive prefix of the four byte counts (sums stay below 256)
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) o[4 * j + bb] = run + (int32_t)((ex >> (8 * bb)) & 0xffu);
-        run += (int32_t)((w[j] * 0x01010101u) >> 24);
-    }
-    if (i0 + kScanPerThread <= n + 1) {
-        int4* dst = reinterpret_cast<int4*>(a.row_base + i0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = make_int4(o[4 * j], o[4 * j + 1], o[4 * j + 2], o[4 * j + 3]);
-    } else {
-        for (int j = 0; j < kScanPerThread; ++j)
-            if (i0 + j <= n) a.row_base[i0 + j] = o[j];
-    }
+    for (int j = 0; j < 4; ++j) first16 += (int32_t)((w[j] * 0x01010101u) >> 24);
+    if (i0 <= n) a.row_base[i0 >> 4] = run;
+    if (i0 + 16 <= n) a.row_base[(i0 >> 4) + 1] = run + first16;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -657,18 +648,14 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         l_va[i] = vap[o];
         l_ck[i] = ckp[p];
     }
-    // batch 2: the entries' packed records, their slots' row bases and quadrant masks (addresses from batch 1), in flight
-    // while the pixels are staged
+    // batch 2: the entries' packed records (addresses from batch 1), in flight while the pixels are staged
     const int n_in = min(kUnit, n_sub - ud.y * kUnit);   // entries of the sublist that fall into this unit
     float4 rq[kPerLane][3];
-    int rbase[kPerLane], rmask[kPerLane];
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
         const bool has = kPerLane * r + i < n_in;
         const float4* rp = a.rec + 3 * (size_t)(has ? gs[i].x : 0);
         rq[i][0] = rp[0]; rq[i][1] = rp[1]; rq[i][2] = rp[2];
-        const int sl = has ? gs[i].y : 0;
-        rbase[i] = a.row_base[sl]; rmask[i] = (int)a.qmask[sl];
     }
 #pragma unroll
     for (int i = 0; i < kPix; ++i) {
@@ -687,13 +674,12 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
     }
 
     EntryState e[kPerLane];
-    int row[kPerLane];
+    int slot[kPerLane];
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
         const int en = kPerLane * r + i;
         e[i].has = en < n_in;
-        // the row of (slot, quadrant): the slot's first row + the number of its existing rows in front of this quadrant
-        row[i] = rbase[i] + __popc((unsigned)rmask[i] & ((1u << q) - 1u));
+        slot[i] = e[i].has ? gs[i].y : 0;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 q0 = e[i].has ? rq[i][0] : z4, q1 = e[i].has ? rq[i][1] : z4, q2 = e[i].has ? rq[i][2] : z4;
         e[i].mx = q0.x; e[i].my = q0.y; e[i].hA = q0.z; e[i].Bc = q0.w; e[i].hC = q1.x; e[i].op = q1.y;
@@ -730,6 +716,16 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         T_out = T; P_out = P;
     }
 
+    // the row of (slot, quadrant): the slot's first row (rows_before: a base per 16 slots + the masks of its predecessors in the
+    // group) + the number of its existing rows in front of this quadrant.  Looked up HERE, not in the prologue: four 16-byte mask
+    // loads in flight next to the records and the pixels cost the kernel its third wave per SIMD (178 VGPRs).
+    int row[kPerLane];
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) {
+        int m;
+        row[i] = rows_before(a.row_base, a.qmask, slot[i], &m);
+        row[i] += __popc((unsigned)m & ((1u << q) - 1u));
+    }
 #pragma unroll
     for (int i = 0; i < kPerLane; ++i) {
         if (e[i].has) {
@@ -781,6 +777,7 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     GS_REQUIRE(!train || (cap_units >= kChunk * GS_WALK_RANGES && cap_units < (1ll << 26) && cap_rows >= 0 && cap_rows < (1ll << 31)),
                "training mode: 256 <= cap_units < 2^26 work units, cap_rows < 2^31 gradient rows");
     GS_REQUIRE(!train || n_isects < (1ll << 31) - kScanChunk, "training mode: the slots of a call are indexed by int32");
+    static_assert(kScanPerThread == 32, "row_base_kernel writes two groups of 16 slots per thread");
     GS_REQUIRE(!train || (((uintptr_t)qmask & 15) == 0 && ((uintptr_t)row_base & 15) == 0 && ((uintptr_t)walk_state & 7) == 0),
                "training mode: qmask / row_base 16-byte aligned, walk_state 8-byte aligned");
     BlendFwdArgs a;

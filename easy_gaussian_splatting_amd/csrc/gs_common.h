@@ -58,6 +58,25 @@ int64_t* current_info_mirror();
 int64_t* current_walk_mirror();
 __device__ __forceinline__ bool guard_tripped(const int64_t* info) { return info != nullptr && info[3] != 0; }
 
+// Gradient rows in front of slot s (training: gs_blend_fwd's row-base scan).  The scan leaves ONE base per 16 slots -- a base per
+// slot was 4 bytes written per LISTED intersection for the 2 % a saturated scene walks (65 us at 57 M) --; the reader adds the
+// popcounts of the slot's predecessors inside its group: one aligned 16-byte load of their 4-bit quadrant masks.  *slot_mask (if
+// asked for) = the slot's own mask.  s may be the slot one past the end (its group exists; bytes at or beyond s are not looked at).
+__device__ __forceinline__ int rows_before(const int32_t* __restrict__ row_base16, const uint8_t* __restrict__ qmask, int s, int* slot_mask = nullptr) {
+    const int g = s >> 4, k = s & 15;
+    const uint4 q = reinterpret_cast<const uint4*>(qmask)[g];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    int n = row_base16[g];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = min(max(k - 4 * j, 0), 4);                        // bytes of word j in front of the slot
+        const uint32_t m = b >= 4 ? 0xffffffffu : ((1u << (8 * b)) - 1u);
+        n += __popc(w[j] & m & 0x0f0f0f0fu);
+    }
+    if (slot_mask) *slot_mask = (int)((w[k >> 2] >> (8 * (k & 3))) & 0xfu);
+    return n;
+}
+
 // Workspace layout of the binning stage (all offsets in bytes, 256-B aligned).
 struct BinLayout {
     int groups;          // Gaussian groups per camera

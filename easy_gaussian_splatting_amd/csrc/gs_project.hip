@@ -369,7 +369,8 @@ struct ProjBwdArgs {
     const float *means, *quats, *scales, *colors_in, *sh_rest, *viewmats, *Ks, *colors_post;
     const int32_t *radii, *tiles_per_gauss, *cum_tiles;
     const float4* rows;      // [I*4][3]: one row per (intersection slot, tile quadrant)
-    const int32_t* row_base; // [I+1] by slot: gradient rows in front of the slot (gs_blend_fwd's scan of the quadrant masks)
+    const int32_t* row_base; // [I/16+1]: gradient rows in front of every 16th slot (gs_blend_fwd's scan of the quadrant masks)
+    const uint8_t* qmask;    // [I] by slot: which of the four quadrant rows exist (the readers' share of the scan: rows_before)
     const float4* sh_jac;    // optional, from gs_project_fwd ([C*N][8] + [C*N]): the SH rows are then not read at all
     float *v_means, *v_quats, *v_scales, *v_opacities, *v_colors, *v_sh_rest, *v_means2d_abs, *v_means2d,
         *v_conics, *v_colors_post, *v_colors_pre;
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
     const int cnt = vis ? a.tiles_per_gauss[f] : 0;
     const int base = vis ? a.cum_tiles[f] : 0;
     int r0 = 0, nr = 0;   // this Gaussian's gradient rows: [r0, r0 + nr)
-    if (!SUMS && cnt > 0) { r0 = a.row_base[base]; nr = a.row_base[base + cnt] - r0; }
+    if (!SUMS && cnt > 0) { r0 = rows_before(a.row_base, a.qmask, base); nr = rows_before(a.row_base, a.qmask, base + cnt) - r0; }
 
     // ---- 1. sum this Gaussian's gradient rows (contiguous and compact, written once each by blend_bwd) -- or take the sums gs_row_sums
     //         left (a.row_sums: the view-parallel step forms them early, for the colour-gradient exchange)
@@ -1000,6 +1001,7 @@ struct RowSumsArgs {
     const float* colors_post;
     const float4* rows;
     const int32_t* row_base;
+    const uint8_t* qmask;
     float4* row_sums;
     float *v_colors_pre, *radii_norm, *cam_out;
     const float* viewmats;
@@ -1016,7 +1018,7 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const RowSumsArgs a) {
     const bool vis = radius > 0;
     const int cnt = vis ? a.tiles_per_gauss[f] : 0, base = vis ? a.cum_tiles[f] : 0;
     int r0 = 0, nr = 0;
-    if (cnt > 0) { r0 = a.row_base[base]; nr = a.row_base[base + cnt] - r0; }
+    if (cnt > 0) { r0 = rows_before(a.row_base, a.qmask, base); nr = rows_before(a.row_base, a.qmask, base + cnt) - r0; }
     float rgb[3] = {0.f, 0.f, 0.f};
     if (vis) { rgb[0] = a.colors_post[3 * f]; rgb[1] = a.colors_post[3 * f + 1]; rgb[2] = a.colors_post[3 * f + 2]; }
     if (a.cam_out && blockIdx.x == 0 && threadIdx.x < 16) a.cam_out[threadIdx.x] = a.viewmats[threadIdx.x];
@@ -1098,18 +1100,18 @@ extern "C" int gs_sh_adam_views(void* stream, int R, int64_t N, int K, int sh_de
 }
 
 extern "C" int gs_row_sums(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
-                           const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
+                           const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base, const uint8_t* qmask,
                            float* row_sums, float* v_colors_pre, float* radii_norm, float max_hw, const float* viewmats,
                            float* cam_out) {
     GS_REQUIRE(C >= 1 && N >= 0, "C>=1, N>=0");
     if (N == 0) return GS_OK;
-    GS_REQUIRE(radii && colors_post && tiles_per_gauss && cum_tiles && rows && row_base && row_sums && v_colors_pre, "null pointer");
+    GS_REQUIRE(radii && colors_post && tiles_per_gauss && cum_tiles && rows && row_base && qmask && row_sums && v_colors_pre, "null pointer");
     GS_REQUIRE(((uintptr_t)row_sums & 15) == 0, "row_sums must be 16-byte aligned");
     GS_REQUIRE(!radii_norm || max_hw > 0.f, "radii_norm needs a positive image extent");
     GS_REQUIRE(!cam_out || (viewmats && C == 1), "cam_out: the single camera's view matrix");
     RowSumsArgs a;
     a.total = (int64_t)C * N; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss; a.cum_tiles = cum_tiles;
-    a.colors_post = colors_post; a.rows = reinterpret_cast<const float4*>(rows); a.row_base = row_base;
+    a.colors_post = colors_post; a.rows = reinterpret_cast<const float4*>(rows); a.row_base = row_base; a.qmask = qmask;
     a.row_sums = reinterpret_cast<float4*>(row_sums); a.v_colors_pre = v_colors_pre; a.radii_norm = radii_norm;
     a.cam_out = cam_out; a.viewmats = viewmats; a.max_hw = max_hw;
     a.guard = current_guard().info;
@@ -1172,7 +1174,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
                               int height, float eps2d, float near_plane, float far_plane,
                               const int32_t* radii, const float* colors_post,
                               const int32_t* tiles_per_gauss, const int32_t* cum_tiles,
-                              const float* rows, const int32_t* row_base, float* v_means, float* v_quats, float* v_scales,
+                              const float* rows, const int32_t* row_base, const uint8_t* qmask, float* v_means, float* v_quats, float* v_scales,
                               float* v_opacities, float* v_colors, float* v_sh_rest, float* v_means2d_abs,
                               float* v_means2d, float* v_conics, float* v_colors_post, float* v_colors_pre,
                               const float* opacities, int activations, const float* sh_jac, const float* row_sums,
@@ -1184,7 +1186,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     GS_REQUIRE(sh_degree < 0 || (K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16), "K must hold (sh_degree+1)^2 coefficients and be <= 16");
     if (N == 0) return GS_OK;
     GS_REQUIRE(means && quats && scales && colors_in && viewmats && Ks && radii && colors_post && tiles_per_gauss && cum_tiles, "null input pointer");
-    GS_REQUIRE(row_sums || (rows && row_base), "the gradient rows (rows + row_base) or their sums (row_sums, from gs_row_sums)");
+    GS_REQUIRE(row_sums || (rows && row_base && qmask), "the gradient rows (rows + row_base + qmask) or their sums (row_sums, from gs_row_sums)");
     GS_REQUIRE(v_means && v_quats && v_scales && v_opacities && v_means2d_abs, "null output pointer");
     GS_REQUIRE(v_colors || sh_degree >= 0, "v_colors may be NULL only with SH colours (gradients rebuilt by gs_sh_grad_views)");
     ProjBwdArgs a;
@@ -1193,7 +1195,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.means = means; a.quats = quats; a.scales = scales; a.colors_in = colors_in; a.viewmats = viewmats;
     a.sh_rest = sh_degree >= 0 ? sh_rest : nullptr; a.v_sh_rest = a.sh_rest ? v_sh_rest : nullptr;
     a.Ks = Ks; a.colors_post = colors_post; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss;
-    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.row_base = row_base;
+    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.row_base = row_base; a.qmask = qmask;
     a.v_means = v_means; a.v_quats = v_quats; a.v_scales = v_scales; a.v_opacities = v_opacities;
     a.v_colors = v_colors; a.v_means2d_abs = v_means2d_abs; a.v_means2d = v_means2d;
     a.v_conics = v_conics; a.v_colors_post = v_colors_post; a.v_colors_pre = sh_degree >= 0 ? v_colors_pre : nullptr;
@@ -1239,7 +1241,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
 extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree, float* params, float* exp_avg, float* exp_avg_sq,
                                    const int64_t* offsets_host, const float* viewmats, const float* Ks, int width, int height,
                                    float eps2d, float near_plane, float far_plane, const int32_t* radii, const float* colors_post,
-                                   const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
+                                   const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base, const uint8_t* qmask,
                                    float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev,
                                    int64_t* applied_dev, float* max_radii, float* grad_norm_accum, float* counts,
                                    const float* sh_jac) {
@@ -1247,7 +1249,7 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     GS_REQUIRE(sh_degree >= 0 && sh_degree <= 3 && K >= (sh_degree + 1) * (sh_degree + 1) && K <= 16, "SH colours: 0 <= degree <= 3, (degree+1)^2 <= K <= 16");
     if (N == 0) return GS_OK;
     GS_REQUIRE(params && exp_avg && exp_avg_sq && offsets_host && viewmats && Ks && radii && colors_post && tiles_per_gauss &&
-               cum_tiles && rows && row_base && v_means2d_abs && hyper_dev, "null pointer");
+               cum_tiles && rows && row_base && qmask && v_means2d_abs && hyper_dev, "null pointer");
     ProjBwdArgs a;
     a.C = 1; a.N = N; a.K = K; a.colors_per_camera = 0; a.W = width; a.H = height;
     a.eps2d = eps2d; a.near_p = near_plane; a.far_p = far_plane;
@@ -1256,7 +1258,7 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     a.opacities = params + offsets_host[5]; a.activations = 1;
     GS_REQUIRE(((uintptr_t)a.quats & 15) == 0, "the quaternion tensor must be 16-byte aligned");
     a.viewmats = viewmats; a.Ks = Ks; a.colors_post = colors_post; a.radii = radii; a.tiles_per_gauss = tiles_per_gauss;
-    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.row_base = row_base;
+    a.cum_tiles = cum_tiles; a.rows = reinterpret_cast<const float4*>(rows); a.row_base = row_base; a.qmask = qmask;
     a.v_means = a.v_quats = a.v_scales = a.v_opacities = a.v_colors = a.v_sh_rest = nullptr;
     a.v_means2d_abs = v_means2d_abs; a.v_means2d = a.v_conics = a.v_colors_post = a.v_colors_pre = nullptr;
     a.sh_jac = reinterpret_cast<const float4*>(sh_jac);

@@ -56,7 +56,7 @@ extern "C" int gs_workspace_query(int C, int64_t N, int width, int height, int64
     if (train) {
         size[GS_WS_SLOTS_BUF] = cap * 4;
         size[GS_WS_QMASK] = cap + 16;
-        size[GS_WS_ROW_BASE] = (cap + 1) * 4;
+        size[GS_WS_ROW_BASE] = (cap / 16 + 2) * 4;
         size[GS_WS_WALK_STATE] = (int64_t)gs_walk_state_ints(cap) * 4;
         size[GS_WS_CKPT] = cap_units * 64 * 16;
         size[GS_WS_QLIST] = cap_units * GS_UNIT * 8;

@@ -810,7 +810,7 @@ class _Rasterize(torch.autograd.Function):
             else:
                 v_pre, rad_out, cam_out = torch.empty((C, N, 3), **f32), None, None
             _stage("gs_row_sums", dev, lambda: nat.check(L.gs_row_sums(
-                st, C, N, _ptr(s["radii"]), P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES), P(WS.ROWS), P(WS.ROW_BASE),
+                st, C, N, _ptr(s["radii"]), P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES), P(WS.ROWS), P(WS.ROW_BASE), P(WS.QMASK),
                 _ptr(row_sums), _ptr(v_pre), _ptr(rad_out), float(max(W, H)), _ptr(viewmats), _ptr(cam_out)), "gs_row_sums"))
             if holder.means2d_ref is not None and holder.means2d_ref() is not None:
                 holder.means2d_ref().colors_pre_grad = v_pre
@@ -829,7 +829,7 @@ class _Rasterize(torch.autograd.Function):
                                    _ptr(colors_rest), s["per_cam"], _ptr(viewmats), _ptr(Ks), W, H, cfg["eps2d"],
                                    cfg["near_plane"], cfg["far_plane"], _ptr(s["radii"]),
                                    P(WS.COLORS_POST), P(WS.TILES_PER_GAUSS), P(WS.CUM_TILES),
-                                   P(WS.ROWS), P(WS.ROW_BASE), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
+                                   P(WS.ROWS), P(WS.ROW_BASE), P(WS.QMASK), _ptr(v_means), _ptr(v_quats), _ptr(v_scales), _ptr(v_opac),
                                    _ptr(v_colors), _ptr(v_rest), _ptr(v_abs), _ptr(v_m2), _ptr(v_cn), _ptr(v_cp), None,
                                    _ptr(opacities), cfg.get("activations", 0), P(WS.SH_JAC) if s.get("sh_jac") else None,
                                    _ptr(row_sums), _ptr(go.get("grad_norm")), _ptr(go.get("count"))), "gs_project_bwd"))

@@ -274,7 +274,7 @@ class TrainStepGraph:
         b["flatten_ids"] = self._take("flatten_ids", (cap,), torch.int32)
         b["slots"] = self._take("slots", (cap,), torch.int32)
         b["qmask"] = self._take("qmask", (cap + 16,), torch.uint8)
-        b["row_base"] = self._take("row_base", (cap + 4,), torch.int32)
+        b["row_base"] = self._take("row_base", (cap // 16 + 4,), torch.int32)
         b["walk_state"] = self._take("walk_state", (int(nat.lib().gs_walk_state_ints(cap)),), torch.int32)
 
     def _alloc_walk(self):
@@ -542,7 +542,7 @@ class TrainStepGraph:
                 self._ck(L.gs_project_bwd_adam(st, N, self.K, int(m.active_sh_degree), _p(opt.flat_param), _p(opt.exp_avg),
                                                _p(opt.exp_avg_sq), offs, _p(b["viewmats"]), _p(b["Ks"]), W, H, 0.3, 0.01, 1e10,
                                                _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]),
-                                               _p(b["rows"]), _p(b["row_base"]), _p(b["v_abs"]), float(b1), float(b2),
+                                               _p(b["rows"]), _p(b["row_base"]), _p(b["qmask"]), _p(b["v_abs"]), float(b1), float(b2),
                                                float(opt.defaults["eps"]), _p(b["hyper"]), _p(b["applied"]), _p(m.max_radii),
                                                _p(m.grad_norm_accum), _p(m.collecting_counts), _p(b["sh_jac"])), "gs_project_bwd_adam")
             else:
@@ -550,7 +550,7 @@ class TrainStepGraph:
                 self._ck(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
                                           _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0, _p(b["viewmats"]), _p(b["Ks"]), W, H,
                                           0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]),
-                                          _p(b["cum_tiles"]), _p(b["rows"]), _p(b["row_base"]), _p(g["means"]), _p(g["quats"]),
+                                          _p(b["cum_tiles"]), _p(b["rows"]), _p(b["row_base"]), _p(b["qmask"]), _p(g["means"]), _p(g["quats"]),
                                           _p(g["log_scales"]), _p(g["logit_opacities"]), _p(g["sh_0"]), _p(g["sh_rest"]), _p(b["v_abs"]),
                                           None, None, None, None, _p(m.logit_opacities), 1, _p(b["sh_jac"]), None, None, None), "gs_project_bwd")
                 self._ck(L.gs_update_statistics(st, N, float(max(H, W)), _p(b["radii"]), _p(b["v_abs"]), _p(m.max_radii),

@@ -142,7 +142,7 @@ int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied
 #define GS_WS_SLOTS_BUF 16      /* i32 [cap]                    (training) */
 #define GS_WS_ISECT_IDS_BUF 17  /* i64 [cap]                    (GS_WS_ISECT_IDS) */
 #define GS_WS_QMASK 18          /* u8  [cap]                    (training) */
-#define GS_WS_ROW_BASE 19       /* i32 [cap + 1]                (training) */
+#define GS_WS_ROW_BASE 19       /* i32 [cap / 16 + 2]           (training) */
 #define GS_WS_WALK_STATE 20     /* i32 [gs_walk_state_ints(cap)] (training: counters of the walk + scan descriptors) */
 #define GS_WS_WALK_FIRST 21     /* ---- walk arena (training) ---- */
 #define GS_WS_CKPT 21           /* f32 [cap_units][64][4] */
@@ -265,9 +265,10 @@ int gs_bins_lists(void* stream, int C, int64_t N, int tile_w, int tile_h, int bi
  *   qmask[n_isects] u8  by gradient-row slot: which quadrant rows of an intersection exist.  Cleared by this call (one
  *                       streaming pass), then only the non-zero masks are stored: a scattered one-byte
  *                       store leaves L2 as a 32-byte partial write (profiles/r03_traffic_calibration.json)
- *   row_base[n_isects+1] i32     exclusive scan of popcount(qmask) over the slots (three small launches behind the
- *                       blend): the gradient rows of slot s are rows [row_base[s], row_base[s+1]), in quadrant order --
- *                       the rows of a Gaussian (contiguous slots) and of consecutive Gaussians are contiguous
+ *   row_base[n_isects/16+2] i32  exclusive scan of popcount(qmask) over the slots, sampled every 16 slots (three small launches
+ *                       behind the blend): rows_before(s) = row_base[s / 16] + popcount of the masks of slots [16 (s / 16), s);
+ *                       the gradient rows of slot s are rows [rows_before(s), rows_before(s + 1)), in quadrant order -- the
+ *                       rows of a Gaussian (contiguous slots) and of consecutive Gaussians are contiguous
  *   walk_state[gs_walk_state_ints(n_isects)] i32   counters (GS_WALK_*) and the scan's chunk counts; cleared by this call.
  * Storage units are taken in chunks of 8 per tile from GS_WALK_RANGES counters (a tile's launch slot picks one), each over its
  * own 1/32 of [0, cap_units).  When a range runs out -- the walk needs more than cap_units units, give or take the imbalance -- or
@@ -298,7 +299,7 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
 
 /* Row reduction + SH-bwd + P-bwd fused (replaces the atomics of the blend backward,
  * spherical_harmonics backward and fully_fused_projection backward).  Sums each Gaussian's rows
- * (slots [cum_tiles[f], cum_tiles[f]+tiles_per_gauss[f]) = rows [row_base[first slot], row_base[last slot + 1])) and
+ * (slots [cum_tiles[f], cum_tiles[f]+tiles_per_gauss[f]) = rows [rows_before(first slot), rows_before(last slot + 1)): row_base + qmask) and
  * pushes the result through the colour and projection VJPs.  Outputs (all fully written):
  * v_means[N,3], v_quats[N,4], v_scales[N,3], v_opacities[N], v_colors: v_shs[N,K,3]
  * (sh_degree>=0; with the split layout v_colors is v_sh_0[N,1,3] and v_sh_rest[N,K-1,3]) or
@@ -314,7 +315,7 @@ int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
  * v_scales / v_opacities are gradients w.r.t. those raw parameters.  0 = gsplat's contract.
  * sh_jac (optional, may be NULL): gs_project_fwd's direction Jacobian of the same inputs; with it colors_in / sh_rest are not
  * read (same gradients to rounding: the direction term of v_means is then summed as J^T v_pre instead of per coefficient).
- * row_sums[C*N][12] (optional, may be NULL): the row sums gs_row_sums left -- rows / row_base are then not read (may be NULL);
+ * row_sums[C*N][12] (optional, may be NULL): the row sums gs_row_sums left -- rows / row_base / qmask are then not read (may be NULL);
  * same results bit for bit.  stat_grad_norm[N] / stat_count[N] (optional, both or neither; C = 1): this view's two additive
  * statistics of /root/reference/model/gaussian.py:188-197, WRITTEN not accumulated -- |absgrad|_2 * max(width, height) and 1 for
  * visible Gaussians, 0 for culled ones (the segments of the view-parallel step's SUM all-reduce, see gs_pack_view_step). */
@@ -323,7 +324,7 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
                    const float* sh_rest, int colors_per_camera, const float* viewmats,
                    const float* Ks, int width, int height, float eps2d, float near_plane, float far_plane,
                    const int32_t* radii, const float* colors_post, const int32_t* tiles_per_gauss,
-                   const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
+                   const int32_t* cum_tiles, const float* rows, const int32_t* row_base, const uint8_t* qmask,
                    float* v_means, float* v_quats, float* v_scales, float* v_opacities,
                    float* v_colors, float* v_sh_rest, float* v_means2d_abs, float* v_means2d,
                    float* v_conics, float* v_colors_post, float* v_colors_pre,
@@ -338,7 +339,7 @@ int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degree, const f
  * copy of viewmats[0].  With v_colors_pre / radii_norm / cam_out pointing into one buffer [3N | N | 16] this launch fills a
  * rank's whole all-gather payload of the view-parallel step (gs_sh_adam_views).  Honours the step guard. */
 int gs_row_sums(void* stream, int C, int64_t N, const int32_t* radii, const float* colors_post,
-                const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
+                const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base, const uint8_t* qmask,
                 float* row_sums, float* v_colors_pre, float* radii_norm, float max_hw, const float* viewmats, float* cam_out);
 
 /* Row e (view sharding): dense SH-parameter gradients of R views rebuilt from the per-view
@@ -472,7 +473,7 @@ int gs_refine_apply(void* stream, int64_t n_old, int num_splits, int K, const in
 int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree, float* params, float* exp_avg, float* exp_avg_sq,
                         const int64_t* offsets_host, const float* viewmats, const float* Ks, int width, int height, float eps2d,
                         float near_plane, float far_plane, const int32_t* radii, const float* colors_post,
-                        const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base,
+                        const int32_t* tiles_per_gauss, const int32_t* cum_tiles, const float* rows, const int32_t* row_base, const uint8_t* qmask,
                         float* v_means2d_abs, float beta1, float beta2, float eps, const float* hyper_dev, int64_t* applied_dev,
                         float* max_radii, float* grad_norm_accum, float* counts, const float* sh_jac);
 

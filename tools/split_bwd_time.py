@@ -36,10 +36,10 @@ main = torch.cuda.Stream(dev); side = torch.cuda.Stream(dev)
 def fused(st):
     nat.check(L.gs_project_bwd_adam(st, N, K, int(m.active_sh_degree), _p(opt.flat_param), _p(opt.exp_avg), _p(opt.exp_avg_sq), offs,
               _p(b["viewmats"]), _p(b["Ks"]), W, H, 0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]),
-              _p(b["rows"]), _p(b["row_base"]), _p(b["v_abs"]), float(b1), float(b2), eps, _p(b["hyper"]), _p(b["applied"]), _p(m.max_radii),
+              _p(b["rows"]), _p(b["row_base"]), _p(b["qmask"]), _p(b["v_abs"]), float(b1), float(b2), eps, _p(b["hyper"]), _p(b["applied"]), _p(m.max_radii),
               _p(m.grad_norm_accum), _p(m.collecting_counts), _p(b["sh_jac"])), "fused")
 def rowsums(st):
-    nat.check(L.gs_row_sums(st, 1, N, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]), _p(b["rows"]), _p(b["row_base"]),
+    nat.check(L.gs_row_sums(st, 1, N, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]), _p(b["rows"]), _p(b["row_base"]), _p(b["qmask"]),
               _p(row_sums), _p(pay[:3 * N]), _p(pay[3 * N:4 * N]), float(max(W, H)), _p(b["viewmats"]), _p(pay[4 * N:])), "row_sums")
 def geo(st):
     nat.check(L.gs_project_bwd(st, 1, N, K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales), _p(m.sh_0), _p(m.sh_rest), 0,
