@@ -76,11 +76,12 @@ def main():
     out_path = sys.argv[1]
     cases = [tuple(int(x) for x in a.split(":")) for a in sys.argv[2:]] or [(2, 176), (2, 1444), (2, 104), (1, 730), (1, 113), (1, 444), (1, 254)]
     pkg = os.path.join(ROOT, "easy_gaussian_splatting_amd")
+    variants = os.path.join(ROOT, "build", "variants")   # (_native.VARIANT_DIR; this parent process never loads the library)
     rows = []
     for scale, case in cases:
         a = run_child(os.path.join(pkg, "libgsraster.so"), scale, case)
-        b = run_child(os.path.join(nat.VARIANT_DIR, "libgsraster_acc64.so"), scale, case)
-        c = run_child(os.path.join(nat.VARIANT_DIR, "libgsraster_exact.so"), scale, case)
+        b = run_child(os.path.join(variants, "libgsraster_acc64.so"), scale, case)
+        c = run_child(os.path.join(variants, "libgsraster_exact.so"), scale, case)
         rec = {"scale": scale, "case": case, "n_gaussians": a["n"], "razor_fraction": round(a["razor"], 4), "tensors": {}}
         for name in NAMES:
             ta, tb, tc = a["tensors"][name], b["tensors"][name], c["tensors"][name]
