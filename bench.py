@@ -514,7 +514,10 @@ def run_rank(args) -> int:
     # N > 1: factorised exchange (all-gather of colour gradients + all-reduce of the geometry
     # gradients, distributed.ViewParallelStep); GS_DP_EXCHANGE=allreduce selects the plain all-reduce
     exchange = "none" if (world == 1 and not force_dist) else os.environ.get("GS_DP_EXCHANGE", "factorised")
-    vp = ViewParallelStep(model, optimizer, force_exchange=force_dist) if (exchange == "factorised" and bucket is None) else None
+    # GS_VP_CAPTURE=1 (opt-in): the view-parallel step with everything in front of its first collective as one hipGraph
+    # (train_graph.ViewParallelGraphStep); default: the step enqueued eagerly around its two collectives
+    vp_capture = os.environ.get("GS_VP_CAPTURE") == "1"
+    vp = ViewParallelStep(model, optimizer, force_exchange=force_dist, guard_words=vp_capture) if (exchange == "factorised" and bucket is None) else None
     if (world > 1 or force_dist) and vp is None:
         exchange = "allreduce"
 
@@ -557,6 +560,10 @@ def run_rank(args) -> int:
                                         handback=os.environ.get("GS_TG_HANDBACK", "eager"))
         except ImportError:
             graph_step = None
+    elif vp is not None and vp_capture and vp.native and not args.no_graph:
+        from easy_gaussian_splatting_amd.train_graph import ViewParallelGraphStep
+        graph_step = ViewParallelGraphStep(model, optimizer, loss_computer, data, gt_img, mask, vp=vp, margin=float(os.environ.get('GS_TG_MARGIN', '1.3')),
+                                           handback=os.environ.get("GS_TG_HANDBACK", "eager"))
 
     def loop_step():
         """One iteration of the reference's loop: the next shuffled view (camera + target), the step, the means-LR
@@ -614,7 +621,7 @@ def run_rank(args) -> int:
     trace("timed loop done")
     graph_report = None if graph_step is None else graph_step.report()   # (of the headline run: the extras re-capture the runner)
     lazy_handback = None
-    if graph_step is not None and graph_step.handback == "eager" and not args.no_extras:
+    if graph_step is not None and graph_step.handback == "eager" and not args.no_extras and world == 1 and not force_dist:
         graph_step.handback = "lazy"   # (read per step: no re-build)
         e_l, _, s_l, _ = timed_loop(step_fn, args.steps, 10, finish=graph_step.finish, ev_stream=g_stream)
         graph_step.fence()
@@ -628,7 +635,7 @@ def run_rank(args) -> int:
     # (what the reference's loader pins) and with uint8 targets (a third of the bytes, converted on the device with the loader's
     # own `/ 255`).  The headline above has the 8 targets resident in HBM, as the contract asks.
     host_fed = None
-    if graph_step is not None and not args.no_extras:
+    if graph_step is not None and not args.no_extras and world == 1 and not force_dist:
         try:
             from easy_gaussian_splatting_amd.train_graph import HostFeed
             pin = lambda t: t.detach().cpu().contiguous().pin_memory()
@@ -1114,7 +1121,7 @@ def run_rank(args) -> int:
                        "parallelism": f"view-dp{world}", "exchange": exchange,
                        "dist_backend": dist.get_backend() if (world > 1 or force_dist) else None,
                        "dist_world_size": dist.get_world_size() if (world > 1 or force_dist) else 1,
-                       "step_launch": "hipGraph replay" if graph_step is not None else "eager",
+                       "step_launch": ("hipGraph replay" if (world == 1 and not force_dist) else "hipGraph replay up to the first collective + 4 launches") if graph_step is not None else "eager",
                        "exchange_bytes_per_rank": None if (world == 1 and not force_dist) else (
                            {"all_gather_view_record": 16 * args.gaussians + 64, "all_reduce_geometry_stats": 4 * 13 * args.gaussians,
                             "collectives_per_step": 2} if vp is not None else

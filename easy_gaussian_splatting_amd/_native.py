@@ -73,6 +73,9 @@ SIGNATURES = {
     "gs_info_mirror_set": (_I, [_P]),
     "gs_walk_mirror_set": (_I, [_P]),
     "gs_step_status": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "gs_guard_flag_out": (_I, [_P, _P, _P, _P]),
+    "gs_guard_merge": (_I, [_P, _P, _P, _I, _L]),
+    "gs_step_applied": (_I, [_P, _P, _P]),
     "gs_adam_hyper": (_I, [_P, _I, _P, _F, _F, _L, _P]),
     "gs_step_inputs": (_I, [_P, _I, _P, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gs_adam_step_dev": (_I, [_P, _L, _P, _P, _P, _I, _P, _P, _P, _F, _F, _F, _F, _P, _P]),

@@ -77,6 +77,47 @@ extern "C" int gs_step_status(void* stream, const int64_t* info_dev, const int64
     return GS_OK;
 }
 
+// ---- the step guard across ranks (view-parallel captured step: one view per rank, two collectives per step).  A rank whose
+// lists or walk outgrew its capacities must not be the only one that skips the step: its flag travels inside both
+// collectives (gs_guard_flag_out writes it where the record / the bucket carry it), and every rank ORs what arrives into
+// its own guard (gs_guard_merge) in front of the kernels that apply the step -- all replicas skip, or none.
+namespace gs {
+__global__ void guard_flag_out_kernel(const int64_t* __restrict__ info, float* __restrict__ dst0, float* __restrict__ dst1) {
+    const float f = info[3] != 0 ? 1.f : 0.f;
+    if (dst0) dst0[0] = f;
+    if (dst1) dst1[0] = f;
+}
+__global__ void guard_merge_kernel(int64_t* __restrict__ info, const float* __restrict__ src, int n, int64_t stride) {
+    bool any = false;
+    for (int i = threadIdx.x; i < n; i += 64) any |= src[(int64_t)i * stride] != 0.f;
+    if (__ballot(any) != 0ull && threadIdx.x == 0) info[3] |= GS_FLAG_PEER;
+}
+__global__ void step_applied_kernel(const int64_t* __restrict__ info, int64_t* __restrict__ applied) {
+    if (info[3] == 0) applied[0] += 1;
+}
+}  // namespace gs
+
+extern "C" int gs_guard_flag_out(void* stream, const int64_t* info_dev, float* dst0, float* dst1) {
+    if (!info_dev || (!dst0 && !dst1)) { gs::set_error("invalid argument: null pointer"); return GS_ERR_ARG; }
+    hipLaunchKernelGGL(gs::guard_flag_out_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, info_dev, dst0, dst1);
+    GS_LAUNCH_CHECK("guard_flag_out_kernel");
+    return GS_OK;
+}
+
+extern "C" int gs_guard_merge(void* stream, int64_t* info_dev, const float* flags, int n, int64_t stride) {
+    if (!info_dev || !flags || n < 1) { gs::set_error("invalid argument: null pointer / n < 1"); return GS_ERR_ARG; }
+    hipLaunchKernelGGL(gs::guard_merge_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info_dev, flags, n, stride);
+    GS_LAUNCH_CHECK("guard_merge_kernel");
+    return GS_OK;
+}
+
+extern "C" int gs_step_applied(void* stream, const int64_t* info_dev, int64_t* applied_dev) {
+    if (!info_dev || !applied_dev) { gs::set_error("invalid argument: null pointer"); return GS_ERR_ARG; }
+    hipLaunchKernelGGL(gs::step_applied_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, info_dev, applied_dev);
+    GS_LAUNCH_CHECK("step_applied_kernel");
+    return GS_OK;
+}
+
 extern "C" int gs_version(void) { return 300; }
 // The preprocessor flags beyond the Makefile's own this library was built with ("" = the product build): a -DGS_BWD_CHECK,
 // -DGS_BWD_ACC64, -DGS_EXACT_MATH or -DGS_CLOCK_PROBE diagnostic variant names itself, and the Python binding refuses to load

@@ -111,8 +111,12 @@ class ViewParallelStep:
     SH = ("sh_0", "sh_rest")
     GEOMETRY = ("means", "log_scales", "quats", "logit_opacities")
 
-    def __init__(self, model, optimizer, group=None, sh_grad_fn=None, force_exchange: bool = False):
+    def __init__(self, model, optimizer, group=None, sh_grad_fn=None, force_exchange: bool = False, guard_words: bool = False):
+        """`guard_words`: the all-gather record and the all-reduce bucket each carry one more word (16 bytes with its pad) -- the
+        rank's step-guard flag, for the captured form of the step (train_graph.ViewParallelGraphStep): a rank that skips a step on
+        the device must take every replica with it."""
         self.model, self.opt, self.group = model, optimizer, group
+        self.guard_words = bool(guard_words)
         self.world = dist.get_world_size(group) if group_ready() else 1
         if force_exchange and not group_ready():
             raise RuntimeError("ViewParallelStep(force_exchange=True) needs an initialised process group")
@@ -149,7 +153,8 @@ class ViewParallelStep:
         for n_el in sizes:
             offs.append(off)
             off = (off + n_el + 3) // 4 * 4
-        return N, offs, off
+        self._flag_off = off   # (guard_words: the bucket's last 4 floats; [0] = the sum of the ranks' guard flags)
+        return N, offs, off + (4 if self.guard_words else 0)
 
     def _bucket(self):
         m = self.model
@@ -160,13 +165,17 @@ class ViewParallelStep:
         return N, offs, self._flat
 
     def _records(self):
-        """(send [P], recv [world * P]), P = 4 N + 16: one view's record of the all-gather (re-made when N changed)."""
+        """(send [P], recv [world * P]), P = 4 N + 16 (+ 4 with guard_words: [4 N + 16] = this rank's guard flag): one view's record
+        of the all-gather (re-made when N changed)."""
         m = self.model
-        P = 4 * m.means.shape[0] + 16
+        P = self.record_len()
         if self._send is None or self._send.numel() != P or self._send.device != m.means.device or self._send.dtype != m.means.dtype:
             self._send = torch.zeros(P, dtype=m.means.dtype, device=m.means.device)
             self._recv = torch.empty(self.world * P, dtype=m.means.dtype, device=m.means.device)
         return self._send, self._recv
+
+    def record_len(self) -> int:
+        return 4 * self.model.means.shape[0] + 16 + (4 if self.guard_words else 0)
 
     def _raw_parameters(self) -> bool:
         """The model hands its RAW parameters to the rasterizer (exp / sigmoid inside the kernels): only then are the
@@ -247,7 +256,7 @@ class ViewParallelStep:
             return
         world, group = self.world, self.group
         N = m.means.shape[0]
-        P = 4 * N + 16
+        P = self.record_len()
         xys = out["batch_xys"]
         dt = m.means.dtype   # float32 in the product; the CPU tests drive this class in float64
         max_hw = float(max(data["height"], data["width"]))

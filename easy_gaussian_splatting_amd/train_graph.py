@@ -569,6 +569,9 @@ class TrainStepGraph:
         finally:
             L.gs_guard_set(None, 0, 0)
 
+    def _tail(self, t: int, lrs):
+        """What a step enqueues behind its graph (nothing: the single-GPU step is the graph)."""
+
     def _hyper(self, t: int, lrs):
         L, opt = nat.lib(), self.opt
         ns = len(opt._plist)
@@ -638,6 +641,7 @@ class TrainStepGraph:
                 self.graph.replay()
             else:
                 self._enqueue_step()
+            self._tail(t, lrs)   # (ViewParallelGraphStep: the collectives and what applies the step; nothing here)
         self.pending.append(entry)
         self.issued += 1
 
@@ -811,6 +815,118 @@ class TrainStepGraph:
                     capacity_rows=self.cap_rows, probed_work_units=self.probed_walk[0], probed_rows=self.probed_walk[1],
                     seen_work_units=self.seen_units, seen_rows=self.seen_rows, steps=self.confirmed,
                     graph=self.graph is not None)
+
+
+class ViewParallelGraphStep(TrainStepGraph):
+    """The view-parallel step (one view per rank, `distributed.ViewParallelStep`'s two collectives) with everything in front of
+    the first collective as ONE replayable hipGraph:
+
+        [graph: projection .. blend forward .. loss .. blend backward .. row sums + this rank's all-gather record + guard words]
+        -> all-gather (async) || projection backward from the sums, gradients + statistics into the bucket
+        -> all-reduce (async) || SH half of Adam from the gathered records  ->  geometry half of Adam + statistics  ->  status
+
+    The four launches behind the graph and the two collectives are enqueued per step (they take the step's learning rates and
+    step count as launch arguments).  Capacities, step guard and overflow recovery are `TrainStepGraph`'s -- with one addition:
+    a rank that skips a step on the device must take every replica with it, and every replica must notice at the same step.
+    So each rank's guard flag travels inside both collectives (`gs_guard_flag_out` -> one word of the record, one of the
+    bucket) and is ORed into every rank's guard in front of the kernels that apply the step (`gs_guard_merge`); and the status
+    words are polled BLOCKING every `check_every` steps, so that all ranks re-size, re-capture and replay the same steps in
+    the same order (a rank that found the flag sixteen steps before its peers would issue other collectives than they).
+    `vp`: a `ViewParallelStep(model, optimizer, force_exchange=..., guard_words=True)`; the model must hand raw parameters to the
+    rasterizer (`fuse_activations`, the default)."""
+
+    def __init__(self, model, optimizer, loss_computer, data, gt_img, mask=None, vp=None, **kw):
+        if vp is None or not vp.exchange or not vp.native or not vp.guard_words:
+            raise ValueError("ViewParallelGraphStep needs a native ViewParallelStep(..., guard_words=True) with the exchange on")
+        if not vp._raw_parameters():
+            raise ValueError("ViewParallelGraphStep: the model must pass its raw parameters (fuse_activations)")
+        self.vp = vp
+        kw["fuse_adam"] = False
+        super().__init__(model, optimizer, loss_computer, data, gt_img, mask, **kw)
+
+    def _alloc_lists(self):
+        super()._alloc_lists()
+        self.buf["row_sums"] = self._take("row_sums", (self.N, 12), torch.float32)
+        self.vp._records(); self.vp._bucket()   # (the record and the bucket the graph writes into: made before the capture)
+
+    def _enqueue_step(self):
+        """The captured part: everything up to this rank's all-gather record."""
+        L, b, m, vp = nat.lib(), self.buf, self.model, self.vp
+        st = self._st()
+        N, W, H = self.N, self.W, self.H
+        send, _ = vp._records()
+        _, offs, flat = vp._bucket()
+        nat.check(L.gs_guard_set(_p(b["info"]), self.cap, self.cap_tile), "gs_guard_set")
+        self._stage_no = 0
+        try:
+            self._enqueue_forward()
+            lam = float(self.lc.lambda_ssim)
+            self._ck(L.gs_l1_ssim_fwd_slots(st, H, W, lam, _p(b["render_colors"]), _p(b["img_slots"]), int(self.has_mask), 1, _p(b["loss_ws"]),
+                                             _p(b["loss3"])), "gs_l1_ssim_fwd_slots")
+            self._ck(L.gs_l1_ssim_bwd_slots(st, H, W, lam, _p(b["render_colors"]), _p(b["img_slots"]), 1, _p(b["loss_ws"]),
+                                             _p(b["one"]), _p(b["v_render"])), "gs_l1_ssim_bwd_slots")
+            self._ck(L.gs_blend_bwd(st, 1, W, H, _p(b["rec"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["unit_desc"]), self.cap_units,
+                                     _p(b["ckpt"]), _p(b["qmask"]), _p(b["row_base"]), _p(b["walk_state"]),
+                                     _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"])), "gs_blend_bwd")
+            sp = send.data_ptr()
+            self._ck(L.gs_row_sums(st, 1, N, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]), _p(b["rows"]),
+                                    _p(b["row_base"]), _p(b["qmask"]), _p(b["row_sums"]), sp, sp + 4 * 3 * N, float(max(H, W)), _p(b["viewmats"]),
+                                    sp + 4 * 4 * N), "gs_row_sums")
+            # this rank's guard flag: into its record and into the bucket (both collectives carry it)
+            self._ck(L.gs_guard_flag_out(st, _p(b["info"]), sp + 4 * (4 * N + 16), flat.data_ptr() + 4 * vp._flag_off), "gs_guard_flag_out")
+        except TrainStepGraph._Stop:
+            pass
+        finally:
+            L.gs_guard_set(None, 0, 0)
+
+    def _tail(self, t: int, lrs):
+        """Behind the graph: the two collectives and the four launches that apply the step (on the runner's stream)."""
+        import torch.distributed as dist
+        L, b, m, vp, opt = nat.lib(), self.buf, self.model, self.vp, self.opt
+        st = self._st()
+        N, W, H, world = self.N, self.W, self.H, vp.world
+        P = vp.record_len()
+        send, recv = vp._records()
+        _, offs, flat = vp._bucket()
+        seg = lambda i, n: flat.data_ptr() + 4 * offs[i]   # noqa: E731
+        w_gather = dist.all_gather_into_tensor(recv, send, group=vp.group, async_op=True)
+        vp.collectives += 1
+        nat.check(L.gs_guard_set(_p(b["info"]), self.cap, self.cap_tile), "gs_guard_set")
+        try:
+            nat.check(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales), _p(m.sh_0),
+                                       _p(m.sh_rest) if self.K > 1 else None, 0, _p(b["viewmats"]), _p(b["Ks"]), W, H, 0.3, 0.01, 1e10, _p(b["radii"]),
+                                       _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]), _p(b["rows"]), _p(b["row_base"]), _p(b["qmask"]),
+                                       seg(0, 3 * N), seg(2, 4 * N), seg(1, 3 * N), seg(3, N), None, None, _p(b["v_abs"]), None, None, None, None,
+                                       _p(m.logit_opacities), 1, _p(b["sh_jac"]), _p(b["row_sums"]), seg(4, N), seg(5, N)), "gs_project_bwd")
+            w_sum = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=vp.group, async_op=True)
+            vp.collectives += 1
+            w_gather.wait()
+            nat.check(L.gs_guard_merge(st, _p(b["info"]), recv.data_ptr() + 4 * (4 * N + 16), world, P), "gs_guard_merge")
+            lr = dict(zip([g["name"] for g, _ in opt._plist], lrs))
+            m0, v0 = opt.moments_of(m.sh_0)
+            mr, vr = opt.moments_of(m.sh_rest) if self.K > 1 else (None, None)
+            b1, b2 = opt.defaults["betas"]
+            nat.check(L.gs_sh_adam_views(st, world, N, self.K, int(m.active_sh_degree), _p(m.means), recv.data_ptr(), P, _p(m.sh_0), _p(m0), _p(v0),
+                                         _p(m.sh_rest) if self.K > 1 else None, _p(mr), _p(vr), float(lr["sh_0"]), float(lr["sh_rest"]), float(b1),
+                                         float(b2), float(opt.defaults["eps"]), int(t), 1.0 / world, _p(m.max_radii)), "gs_sh_adam_views")
+            w_sum.wait()
+            nat.check(L.gs_guard_merge(st, _p(b["info"]), flat.data_ptr() + 4 * vp._flag_off, 1, 0), "gs_guard_merge")
+            ns = len(opt._plist)
+            grads = {"means": seg(0, 3 * N), "log_scales": seg(1, 3 * N), "quats": seg(2, 4 * N), "logit_opacities": seg(3, N)}
+            gptr = (ct.c_void_p * ns)(*[grads.get(g["name"]) for g, _ in opt._plist])
+            nat.check(L.gs_adam_step_stats(st, opt.flat_param.numel(), _p(opt.flat_param), _p(opt.exp_avg), _p(opt.exp_avg_sq), ns,
+                                           (ct.c_int64 * ns)(*opt._ends), (ct.c_int64 * ns)(*opt._lens), gptr, (ct.c_float * ns)(*lrs), float(b1),
+                                           float(b2), float(opt.defaults["eps"]), int(t), 1.0 / world, N, seg(4, N), seg(5, N),
+                                           _p(m.grad_norm_accum), _p(m.collecting_counts)), "gs_adam_step_stats")
+            nat.check(L.gs_step_applied(st, _p(b["info"]), _p(b["applied"])), "gs_step_applied")
+            nat.check(L.gs_step_status(st, _p(b["info"]), _p(b["applied"]), self.status.data_ptr(), _p(b["loss3"]), _p(b["loss_ring"]),
+                                       self.LOSS_RING, _p(b["walk_state"])), "gs_step_status")
+        finally:
+            L.gs_guard_set(None, 0, 0)
+
+    def _poll(self, block: bool):
+        # every rank must find an overflow at the SAME step: the status words are read behind a synchronisation, never early
+        super()._poll(block=True)
 
 
 class HostFeed:

@@ -56,6 +56,7 @@ extern "C" {
 #define GS_FLAG_COARSE_LIST 8 /* two-level binning: a bin list longer than coarse_list_cap */
 #define GS_FLAG_UNITS 16     /* training forward: the walk opened more work units than cap_units */
 #define GS_FLAG_ROWS 32      /* training forward: more gradient rows than cap_rows */
+#define GS_FLAG_PEER 128     /* view-parallel step: another rank's guard was tripped (gs_guard_merge) */
 
 #define GS_OK 0
 #define GS_ERR_ARG (-1)
@@ -97,6 +98,17 @@ int gs_info_mirror_set(int64_t* info_host_mapped);
  * GS_FLAG_ROWS} there, followed by a system-scope fence -- the eager seam's backward learns whether the walk fitted its
  * capacities (and what it needed) from plain memory. */
 int gs_walk_mirror_set(int64_t* walk_host_mapped);
+
+/* The step guard across ranks (row e: one view per rank, the captured view-parallel step).  A rank whose lists or walk outgrew its
+ * capacities must not be the only replica that skips the step.  gs_guard_flag_out writes 1.0f / 0.0f (info_dev[3] != 0) to dst0
+ * and dst1 (either may be NULL): the word of this rank's all-gather record and the word of the SUM all-reduce bucket that carry
+ * it.  gs_guard_merge ORs GS_FLAG_PEER into info_dev[3] when any of the n floats flags[i * stride] is non-zero (the gathered
+ * records' words; the reduced bucket's word): in front of the kernels that apply the step, on every rank -- all replicas skip,
+ * or none.  gs_step_applied: applied_dev[0] += 1 unless the guard is tripped (the applied-step count of gs_step_status, for a
+ * step whose update is not one of the fused kernels that count themselves). */
+int gs_guard_flag_out(void* stream, const int64_t* info_dev, float* dst0, float* dst1);
+int gs_guard_merge(void* stream, int64_t* info_dev, const float* flags, int n, int64_t stride);
+int gs_step_applied(void* stream, const int64_t* info_dev, int64_t* applied_dev);
 
 /* Publishes a guarded step's outcome without a copy or an event: one tiny launch writes
  * status[0..3] = info_dev[0..3] ({I, n_buckets, max tile, flags}), status[4] = applied_dev[0] (may be NULL) and -- walk_state

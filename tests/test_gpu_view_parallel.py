@@ -242,6 +242,79 @@ def test_two_ranks_equal_one_process_on_both_views(tmp_path, variant):
     np.testing.assert_array_equal(r0["rad"], ref["rad"])
 
 
+def _worker_captured(rank, world, port, out_dir):
+    """Both forms of the view-parallel step in one process, one after the other (the ranks issue the same collectives in the same
+    order): the eager exchange on model A, `ViewParallelGraphStep` on model B -- with a capacity shortage staged on RANK 1 ONLY."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from easy_gaussian_splatting_amd.distributed import ViewParallelStep
+    from easy_gaussian_splatting_amd.loss import LossComputer
+    from easy_gaussian_splatting_amd.train_graph import ViewParallelGraphStep
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    n_steps = 9
+    # (a) eager
+    model, opt, datas, targets = _make(dev, "plain")
+    vp = ViewParallelStep(model, opt)
+    lc = LossComputer(0.2, clamp_input=True)
+    for it in range(n_steps):
+        vp.begin_step(datas[rank])
+        out = model(datas[rank], clamp=False)
+        vp.after_forward(datas[rank], out)
+        lc.get_loss_dict(out["render_img"], targets[rank])["total"].backward()
+        vp.step(datas[rank], out)
+        model.update_learning_rate(it + 1)
+    torch.cuda.synchronize()
+    eager = _snapshot(model)
+    eager.update({"m_" + k: opt.moments_of(getattr(model, k))[0].cpu().numpy() for k in model.param_names})
+    # (b) captured
+    model, opt, datas, targets = _make(dev, "plain")
+    vp = ViewParallelStep(model, opt, guard_words=True)
+    runner = ViewParallelGraphStep(model, opt, LossComputer(0.2, clamp_input=True), datas[rank], targets[rank], None, vp=vp, check_every=4)
+    for it in range(n_steps):
+        if it == 3 and rank == 1:
+            # rank 1 alone runs short of work units from here on: BOTH ranks must skip these steps on the device, find it at the
+            # same poll, re-capture and replay -- or the replicas (and the collectives) part ways
+            runner.finish()
+            runner.cap_units = 512
+            with torch.cuda.device(dev):
+                runner._alloc_walk()
+                runner.buf["applied"].zero_()
+                runner._capture(warm_up=False)
+        elif it == 3:
+            runner.finish()   # (rank 0 drains too: `finish` polls, and polls are collective in effect)
+        runner.step(datas[rank], targets[rank])
+        model.update_learning_rate(it + 1)
+    runner.finish()
+    torch.cuda.synchronize()
+    rep = runner.report()
+    cap = _snapshot(model)
+    cap.update({"m_" + k: opt.moments_of(getattr(model, k))[0].cpu().numpy() for k in model.param_names})
+    np.savez(os.path.join(out_dir, f"c{rank}.npz"), overflows=rep["overflows"], replayed=rep["replayed_steps"], steps=rep["steps"],
+             collectives=vp.collectives, **{"e_" + k: v for k, v in eager.items()}, **{"c_" + k: v for k, v in cap.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_captured_view_parallel_step_equals_the_eager_exchange(tmp_path):
+    """everything in front of the first collective as one hipGraph (`train_graph.ViewParallelGraphStep`), two
+    ranks over gloo on the one device.  Nine steps, bitwise the eager exchange on every rank -- parameters, Adam moments,
+    statistics -- although rank 1 alone is made to run out of work-unit storage at step 3: its guard flag travels inside both
+    collectives, rank 0 skips the same steps, both find out at the same (blocking) poll, re-size, re-capture and replay."""
+    mp.spawn(_worker_captured, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(os.path.join(tmp_path, f"c{k}.npz")) for k in range(2)]
+    for k in range(2):
+        assert int(r[k]["steps"]) == 9 and int(r[k]["overflows"]) >= 1 and int(r[k]["replayed"]) >= 1, {f: r[k][f] for f in ("steps", "overflows", "replayed")}
+        for f in r[k].files:
+            if f.startswith("e_"):
+                np.testing.assert_array_equal(r[k]["c_" + f[2:]], r[k][f], err_msg=f"rank {k}: captured != eager in {f[2:]}")
+    assert int(r[0]["overflows"]) == int(r[1]["overflows"]) and int(r[0]["collectives"]) == int(r[1]["collectives"])
+    for f in r[0].files:
+        if f.startswith("c_"):
+            np.testing.assert_array_equal(r[0][f], r[1][f], err_msg=f"replicas diverged in {f[2:]}")
+
+
 def test_row_sums_pass_on_gaussians_of_hundreds_of_slots():
     """`gs_row_sums` on a heavy-tailed scene (synthetic.config_long_lists: splats of several hundred tiles, most list tails
     abandoned by saturated tiles): the slot-per-lane path with its empty-item skip AND the whole-wave path of the > 128-slot
