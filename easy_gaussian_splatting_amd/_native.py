@@ -27,6 +27,7 @@ GS_BUCKET = 64
 GS_UNIT = 32
 GS_REC_FLOATS = 12
 GS_ROW_FLOATS = 12
+GS_ROUND_BASE, GS_ROUND_SPLIT, GS_ROUND_LIVE, GS_ROUND_FRONT_N, GS_ROUND_WORDS = 0, 1, 2, 3, 8   # words of a depth-rounds block
 
 _lib: Optional[ct.CDLL] = None
 _lock = threading.Lock()
@@ -72,6 +73,9 @@ SIGNATURES = {
     "gs_guard_set_call": (_I, [_P, _L, _L]),
     "gs_info_mirror_set": (_I, [_P]),
     "gs_walk_mirror_set": (_I, [_P]),
+    "gs_rounds_set": (_I, [_P, _P, _P, _P, _I]),
+    "gs_round_split": (_I, [_P, _L, _P, _P, _F, _P, _P]),
+    "gs_round_footprints": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),
     "gs_step_status": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "gs_guard_flag_out": (_I, [_P, _P, _P, _P]),
     "gs_guard_merge": (_I, [_P, _P, _P, _I, _L]),

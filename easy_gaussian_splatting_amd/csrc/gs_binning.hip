@@ -63,8 +63,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_hist_kernel(int64_t N, int tw
                                                                int64_t per_group,
                                                                const uint4* __restrict__ bbox,
                                                                uint32_t* __restrict__ hist_mat,
-                                                               uint32_t* __restrict__ grp_tot) {
+                                                               uint32_t* __restrict__ grp_tot, const int64_t* __restrict__ rblk, int phase) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (round_idle(rblk, phase)) return;
     uint32_t* hist = lds;               // [tiles]
     uint32_t* scratch = lds + tiles;    // [32]
     const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
@@ -167,9 +168,13 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
     const uint32_t* __restrict__ grp_tot, int32_t* __restrict__ isect_offsets,
     int32_t* __restrict__ bucket_offsets, uint32_t* __restrict__ grp_base,
     int64_t* __restrict__ info, int32_t* __restrict__ tile_order, int64_t cap_isects, int64_t cap_tile,
-    int64_t keep_mask, int32_t* __restrict__ sort_counts, int64_t* __restrict__ info_mirror, int per_call) {
+    int64_t keep_mask, int32_t* __restrict__ sort_counts, int64_t* __restrict__ info_mirror, int per_call,
+    int64_t* __restrict__ rblk, int phase) {
     __shared__ unsigned long long scratch[17];
     const int chunk = kBinThreads * kScanItems;
+    // depth rounds: the back round's lists (and slots) continue behind the front round's; a back round with no live tile
+    // leaves everything as the front round left it (info[0] = its total)
+    if (round_idle(rblk, phase)) return;
     if (blockIdx.x == 2) {   // group bases (few thousand values at most): serial chunks of kBinThreads
         if (sort_counts && threadIdx.x < 64) sort_counts[threadIdx.x] = 0;   // work-list counters of the sort that follows
         unsigned long long gcarry = 0;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
             if (first + k < n_tiles_total) tile_order[atomicAdd(&cls_cnt[cls_of(v[k])][wv], 1u)] = first + k;
         return;
     }
-    unsigned long long carry_i = 0, carry_b = 0;
+    unsigned long long carry_i = phase == 2 ? (unsigned long long)rblk[GS_ROUND_BASE] : 0ull, carry_b = 0;
     uint32_t max_cnt = 0;
     for (int base = 0; base < n_tiles_total; base += chunk) {
         const int first = base + threadIdx.x * kScanItems;
@@ -267,6 +272,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
         for (int i = 0; i < kBinThreads / 64; ++i) mm = max(mm, smax[i]);
         isect_offsets[n_tiles_total] = (int32_t)carry_i;
         bucket_offsets[n_tiles_total] = (int32_t)carry_b;
+        if (phase == 1) rblk[GS_ROUND_BASE] = (int64_t)carry_i;
+        if (phase == 2) mm = max(mm, (uint32_t)info[2]);   // (the longest list of either round)
         info[0] = (int64_t)carry_i; info[1] = (int64_t)carry_b; info[2] = (int64_t)mm;
         if (cap_isects > 0) {
             // guarded step (gs_guard_set): flags are sticky -- once a step does not fit, this and every later
@@ -291,9 +298,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
     const float* __restrict__ depths, const uint32_t* __restrict__ hist_mat,
     const int32_t* __restrict__ isect_offsets, const uint32_t* __restrict__ grp_base,
     unsigned long long* __restrict__ keys, int32_t* __restrict__ slot_gid,
-    int32_t* __restrict__ cum_tiles, const int64_t* __restrict__ guard) {
+    int32_t* __restrict__ cum_tiles, const int64_t* __restrict__ guard, const int64_t* __restrict__ rblk, int phase) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    if (guard_tripped(guard)) return;
+    if (guard_tripped(guard) || round_idle(rblk, phase)) return;
     uint32_t* cursor = lds;                                    // [tiles]
     uint32_t* scratch = lds + tiles;                           // [32]
     const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
@@ -314,7 +321,8 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
         }
     }
     __syncthreads();
-    uint32_t running = grp_base[c * G + grp];
+    // (depth rounds: the back round's gradient-row slots continue behind the front round's)
+    uint32_t running = grp_base[c * G + grp] + (phase == 2 ? (uint32_t)rblk[GS_ROUND_BASE] : 0u);
     const int64_t g0 = grp * per_group, g1 = min(N, g0 + per_group);
     // the next round's footprint and depth are requested before this round's scatter
     uint4 fp_next = make_uint4(0u, 0u, 0u, 0u);
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(kBinThreads) void bin_emit_kernel(
         // (after the scan: its barriers drain the vector-memory counter)
         fp_next = make_uint4(0u, 0u, 0u, 0u);
         if (n + blockDim.x < g1) { fp_next = bbox[f + blockDim.x]; d_next = depths[f + blockDim.x]; }
-        if (n < g1) cum_tiles[f] = (int32_t)slot0;
+        if (n < g1 && (phase != 2 || cnt > 0)) cum_tiles[f] = (int32_t)slot0;   // (a Gaussian of the front round keeps its slots)
         const uint32_t dbits = cnt > 0 ? __float_as_uint(dcur) : 0u;
         if (rect <= kCoopTiles) {
             uint32_t k = 0;
@@ -406,7 +414,10 @@ struct SortArgs {
     int coarse;   // two-level binning: the lists are coarse-bin lists of (depth bits << 32 | flatten id) keys, sorted in place
     int seg;      // > 0: segment mode -- block b sorts segment b % kSegMax (kSegLen keys) of list b / kSegMax, in place
     unsigned long long* merged;   // segment mode, coarse lists: where seg_merge_kernel leaves the merged list
+    const int64_t* rblk;          // depth rounds (gs_rounds_set): a back round with no live tile sorts nothing
+    int phase;
 };
+__device__ __forceinline__ bool sort_off(const SortArgs& a) { return guard_tripped(a.guard) || round_idle(a.rblk, a.phase); }
 
 constexpr int kSegLen = 8192;   // the largest LDS radix class
 constexpr int kSegMax = 8;      // lists of up to 65536 keys: sorted segment by segment, then rank-merged
@@ -415,7 +426,7 @@ template <bool IN_LDS>
 __global__ void tile_sort_kernel(const SortArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     const int t = blockIdx.x;
-    if (guard_tripped(a.guard)) return;
+    if (sort_off(a)) return;
     const int lo = a.isect_offsets[t], hi = a.isect_offsets[t + 1];
     const int n = hi - lo;
     if (n <= a.lo_excl || n > a.hi_incl) return;
@@ -584,7 +595,7 @@ __device__ __forceinline__ void radix_sort_list(const SortArgs& a, const int vbl
 
 template <int T>
 __global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
-    if (guard_tripped(a.guard)) return;
+    if (sort_off(a)) return;
     radix_sort_list<T>(a, blockIdx.x);
 }
 
@@ -594,7 +605,7 @@ __global__ __launch_bounds__(T) void tile_radix_sort_kernel(const SortArgs a) {
 template <int T>
 __global__ __launch_bounds__(T) void tile_radix_sort_items_kernel(const SortArgs a, const int32_t* __restrict__ items,
                                                                   const int32_t* __restrict__ n_items) {
-    if (guard_tripped(a.guard)) return;
+    if (sort_off(a)) return;
     const int n = *n_items;
     for (int it = blockIdx.x; it < n; it += gridDim.x) {
         radix_sort_list<T>(a, items[it]);
@@ -606,8 +617,8 @@ __global__ __launch_bounds__(T) void tile_radix_sort_items_kernel(const SortArgs
 // (list * kSegMax + segment) pairs of the lists of (8192, 65536].  counts[3] zeroed by the caller.
 __global__ __launch_bounds__(256) void class_items_kernel(int n_lists, const int32_t* __restrict__ offsets,
                                                           int32_t* __restrict__ items, int32_t* __restrict__ counts,
-                                                          const int64_t* __restrict__ guard) {
-    if (guard_tripped(guard)) return;
+                                                          const int64_t* __restrict__ guard, const int64_t* __restrict__ rblk, int phase) {
+    if (guard_tripped(guard) || round_idle(rblk, phase)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_lists) return;
     const int n = offsets[i + 1] - offsets[i];
@@ -708,8 +719,9 @@ __device__ __forceinline__ void coarse_rect(uint4 fp, int shift, int& cx0, int& 
 __global__ __launch_bounds__(kBinThreads) void bins_hist_kernel(int64_t N, int shift, int bw, int nbins, int64_t per_group,
                                                                 const uint4* __restrict__ bbox,
                                                                 uint32_t* __restrict__ hist_mat,
-                                                                uint32_t* __restrict__ grp_tot) {
+                                                                uint32_t* __restrict__ grp_tot, const int64_t* __restrict__ rblk, int phase) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    if (round_idle(rblk, phase)) return;
     uint32_t* hist = lds;               // [nbins]
     uint32_t* scratch = lds + nbins;    // [32]
     const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
@@ -783,9 +795,11 @@ __global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total
                                                                 int4* __restrict__ chunk_desc, int64_t max_chunks,
                                                                 int chunk_shift, uint32_t* __restrict__ grp_base,
                                                                 int64_t* __restrict__ info, int64_t coarse_cap, int64_t list_cap,
-                                                                int guarded, int32_t* __restrict__ sort_counts) {
+                                                                int guarded, int32_t* __restrict__ sort_counts,
+                                                                const int64_t* __restrict__ rblk, int phase) {
     __shared__ unsigned long long scratch[17];
     __shared__ uint32_t smax[16];
+    if (round_idle(rblk, phase)) return;
     if (blockIdx.x == 1) {   // second block of the launch: group bases, beside the bin scan
         if (threadIdx.x < 64) sort_counts[threadIdx.x] = 0;   // work-list counters of the coarse sort
         unsigned long long gcarry = 0;
@@ -847,7 +861,11 @@ __global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total
         for (int i = 0; i < kBinThreads / 64; ++i) mm = max(mm, smax[i]);
         coff[n_bins_total] = (int32_t)min(carry, (unsigned long long)0x7fffffff);
         choff[n_bins_total] = (int32_t)ccarry;
-        info[4] = (int64_t)carry; info[5] = (int64_t)mm; info[6] = (int64_t)ccarry;
+        if (phase == 2) {   // (depth rounds: the status words show what the larger of the two rounds needed)
+            info[4] = max(info[4], (int64_t)carry); info[5] = max(info[5], (int64_t)mm); info[6] = (int64_t)ccarry;
+        } else {
+            info[4] = (int64_t)carry; info[5] = (int64_t)mm; info[6] = (int64_t)ccarry;
+        }
         const int64_t f = ((int64_t)carry > coarse_cap ? 4 : 0) | ((int64_t)mm > list_cap ? 8 : 0);
         if (guarded) { if (f) info[3] |= f; }
         else info[3] = f;
@@ -858,9 +876,9 @@ __global__ __launch_bounds__(kBinThreads) void bins_emit_kernel(
     int64_t N, int shift, int bw, int nbins, int64_t per_group, const uint4* __restrict__ bbox,
     const float* __restrict__ depths, const uint32_t* __restrict__ hist_mat, const int32_t* __restrict__ coff,
     const uint32_t* __restrict__ grp_base, unsigned long long* __restrict__ keys, int32_t* __restrict__ cum_tiles,
-    uint4* __restrict__ rec, const int64_t* __restrict__ info) {
+    uint4* __restrict__ rec, const int64_t* __restrict__ info, const int64_t* __restrict__ rblk, int phase) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    if (info[3] != 0) return;
+    if (info[3] != 0 || round_idle(rblk, phase)) return;
     uint32_t* cursor = lds;             // [nbins]
     uint32_t* scratch = lds + nbins;    // [32]
     const int grp = blockIdx.x, c = blockIdx.y, G = gridDim.x;
@@ -880,7 +898,7 @@ __global__ __launch_bounds__(kBinThreads) void bins_emit_kernel(
         }
     }
     __syncthreads();
-    uint32_t running = grp_base[c * G + grp];
+    uint32_t running = grp_base[c * G + grp] + (phase == 2 ? (uint32_t)rblk[GS_ROUND_BASE] : 0u);   // (the back round's slots continue)
     const int64_t g0 = grp * per_group, g1 = min(N, g0 + per_group);
     uint4 fp_next = make_uint4(0u, 0u, 0u, 0u);
     float d_next = 0.f;
@@ -898,7 +916,7 @@ __global__ __launch_bounds__(kBinThreads) void bins_emit_kernel(
         fp_next = make_uint4(0u, 0u, 0u, 0u);
         if (n + blockDim.x < g1) { fp_next = bbox[f + blockDim.x]; d_next = depths[f + blockDim.x]; }
         if (n < g1) {
-            cum_tiles[f] = (int32_t)slot0;
+            if (phase != 2 || fp.w != 0u) cum_tiles[f] = (int32_t)slot0;   // (a Gaussian of the front round keeps its slots)
             rec[f] = make_uint4(fp.x, fp.y, fp.z, slot0);
         }
         const unsigned long long key = ((unsigned long long)__float_as_uint(dcur) << 32) | (unsigned long long)(uint32_t)f;
@@ -936,6 +954,8 @@ struct RefineArgs {
     int32_t* flatten_ids;
     int32_t* slots;
     const int64_t* info;
+    const int64_t* rblk;   // depth rounds (gs_rounds_set)
+    int phase;
 };
 
 // One block per CHUNK (64 << 2*SHIFT consecutive entries of one bin's sorted list), one wave per tile of the bin.  The
@@ -955,7 +975,7 @@ __global__ __launch_bounds__(64 << (2 * SHIFT)) void bins_refine_kernel(const Re
     const int64_t flags = a.info[3];
     const int n_chunks = a.choff[a.n_bins_total];
     const int4 desc = a.chunk_desc[chunk];
-    if (flags != 0 || chunk >= n_chunks) return;
+    if (flags != 0 || chunk >= n_chunks || round_idle(a.rblk, a.phase)) return;
     const int bin = desc.x, base = desc.y, m = desc.z;
     const int cam = bin / a.nbins, b = bin - cam * a.nbins;
     const int by = b / a.bw, bx = b - by * a.bw;
@@ -1035,7 +1055,7 @@ __global__ __launch_bounds__(256) void bins_chunkscan_kernel(const RefineArgs a,
     constexpr int B = 1 << SHIFT;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * a.tiles) return;
-    if (a.info[3] != 0) return;
+    if (a.info[3] != 0 || round_idle(a.rblk, a.phase)) return;
     const int cam = i / a.tiles, t = i - cam * a.tiles;
     const int ty = t / a.tw, tx = t - ty * a.tw;
     const int bin = cam * a.nbins + (ty >> SHIFT) * a.bw + (tx >> SHIFT);
@@ -1063,7 +1083,7 @@ __global__ __launch_bounds__(256) void bins_chunkscan_kernel(const RefineArgs a,
 // them back.  (The bitonic network this replaces moved every key ~100 times through LDS: 229 us for 9 k-key bins.)
 __global__ __launch_bounds__(1024) void seg_merge_kernel(const SortArgs a, const int32_t* __restrict__ items,
                                                          const int32_t* __restrict__ n_items) {
-    if (guard_tripped(a.guard)) return;
+    if (sort_off(a)) return;
     const int n_it = *n_items;
     for (int it = blockIdx.x; it < n_it; it += gridDim.x) {
     const int vblock = items[it];
@@ -1101,7 +1121,7 @@ __global__ __launch_bounds__(1024) void seg_merge_kernel(const SortArgs a, const
 
 __global__ __launch_bounds__(1024) void seg_copy_kernel(const SortArgs a, const int32_t* __restrict__ items,
                                                         const int32_t* __restrict__ n_items) {
-    if (guard_tripped(a.guard)) return;
+    if (sort_off(a)) return;
     const int n_it = *n_items;
     for (int it = blockIdx.x; it < n_it; it += gridDim.x) {
         const int vblock = items[it];
@@ -1119,6 +1139,14 @@ constexpr int kSortLarge = kSegLen * kSegMax;   // beyond: bitonic network in pl
 using namespace gs;
 
 extern "C" int gs_bin_groups(int64_t N) { return bin_layout(1, N, 1).groups; }
+
+// the depth round the list stages work for (gs_rounds_set): 1 front, 2 back, 0 none
+static int list_round(int64_t*& rblk) {
+    const Rounds R = current_rounds();
+    const int phase = (R.phase == 1 || R.phase == 2) ? R.phase : 0;
+    rblk = phase ? R.blk : nullptr;
+    return phase;
+}
 
 extern "C" size_t gs_bin_workspace_bytes(int C, int64_t N, int tile_w, int tile_h) {
     return bin_layout(C, N, tile_w * tile_h).total;
@@ -1162,7 +1190,7 @@ static int launch_list_sorts(hipStream_t st, SortArgs& a, unsigned grid, int64_t
     }
     if (max_tile_count <= 1024) return GS_OK;
     // (counts were zeroed by the scan kernel of the count stage: bin_tilescan_kernel block 2 / bins_scan_kernel block 1)
-    hipLaunchKernelGGL(class_items_kernel, dim3((grid + 255) / 256), dim3(256), 0, st, (int)grid, a.isect_offsets, items, counts, a.guard);
+    hipLaunchKernelGGL(class_items_kernel, dim3((grid + 255) / 256), dim3(256), 0, st, (int)grid, a.isect_offsets, items, counts, a.guard, a.rblk, a.phase);
     GS_LAUNCH_CHECK("class_items_kernel");
     {   // (1024, 4096]: 72 KB -> two blocks per CU
         a.lo_excl = 1024; a.hi_incl = 4096;
@@ -1216,6 +1244,9 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
     GS_REQUIRE(workspace && workspace_bytes >= L.total, "workspace too small (see gs_bin_workspace_bytes)");
     GS_REQUIRE(isect_offsets && bucket_offsets && info_dev, "null output pointer");
     GS_REQUIRE(N == 0 || bbox, "null bbox");
+    int64_t* rblk;
+    const int phase = list_round(rblk);
+    GS_REQUIRE(phase == 0 || C == 1, "depth rounds: one camera per call");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     uint32_t* hist = (uint32_t*)(ws + L.hist_off);
@@ -1225,7 +1256,7 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
     const size_t lds = sizeof(uint32_t) * ((size_t)tiles + 32);
     if (int rc = ensure_lds((const void*)bin_hist_kernel, lds)) return rc;
     hipLaunchKernelGGL(bin_hist_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, tile_w, tiles,
-                       L.per_group, (const uint4*)bbox, hist, grp_tot);
+                       L.per_group, (const uint4*)bbox, hist, grp_tot, (const int64_t*)rblk, phase);
     GS_LAUNCH_CHECK("bin_hist_kernel");
     const int64_t ct = (int64_t)C * tiles;
     hipLaunchKernelGGL(bin_colscan_kernel, dim3((unsigned)((ct + kColTiles - 1) / kColTiles)), dim3(kColTiles * kColChunks), 0, st, C, L.groups,
@@ -1235,7 +1266,7 @@ extern "C" int gs_bin_count(void* stream, int C, int64_t N, int tile_w, int tile
     GS_REQUIRE(gd.info == nullptr || gd.info == info_dev, "the guard set by gs_guard_set must be this call's info_dev");
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(3), dim3(kBinThreads), 0, st, (int)ct, C * L.groups, tile_cnt,
                        grp_tot, isect_offsets, bucket_offsets, grp_base, info_dev, tile_order, gd.cap_isects, gd.cap_tile,
-                       (int64_t)0, (int32_t*)(ws + L.items_off), current_info_mirror(), gd.per_call);
+                       (int64_t)0, (int32_t*)(ws + L.items_off), current_info_mirror(), gd.per_call, rblk, phase);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
     if (info_host) {
         GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
@@ -1258,6 +1289,9 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     GS_REQUIRE(bbox && depths && isect_offsets && cum_tiles, "null pointer");
     GS_REQUIRE(n_isects == 0 || (keys_tmp && flatten_ids), "null intersection buffer");
     GS_REQUIRE((slot_gid == nullptr) == (slots == nullptr), "slot_gid and slots: both (training lists) or neither (inference lists)");
+    int64_t* rblk;
+    const int phase = list_round(rblk);
+    GS_REQUIRE(phase == 0 || C == 1, "depth rounds: one camera per call");
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     const uint32_t* hist = (const uint32_t*)(ws + L.hist_off);
@@ -1266,7 +1300,7 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     if (int rc = ensure_lds((const void*)bin_emit_kernel, lds)) return rc;
     hipLaunchKernelGGL(bin_emit_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, tile_w, tiles,
                        L.per_group, (const uint4*)bbox, depths, hist, isect_offsets, grp_base,
-                       (unsigned long long*)keys_tmp, slot_gid, cum_tiles, current_guard().info);
+                       (unsigned long long*)keys_tmp, slot_gid, cum_tiles, current_guard().info, (const int64_t*)rblk, phase);
     GS_LAUNCH_CHECK("bin_emit_kernel");
     if (n_isects == 0) return GS_OK;
     SortArgs a;
@@ -1277,7 +1311,7 @@ extern "C" int gs_bin_emit_sort(void* stream, int C, int64_t N, int tile_w, int 
     a.isect_offsets = isect_offsets; a.keys = (unsigned long long*)keys_tmp; a.slot_gid = slot_gid;
     a.isect_ids = isect_ids; a.flatten_ids = flatten_ids; a.slots = slots;
     a.guard = current_guard().info;
-    a.coarse = 0; a.seg = 0; a.merged = nullptr;
+    a.coarse = 0; a.seg = 0; a.merged = nullptr; a.rblk = rblk; a.phase = phase;
     static_assert(2 + kSegMax == 10, "bin_layout sizes the work lists for kSegMax == 8");
     return launch_list_sorts(st, a, (unsigned)(C * tiles), max_tile_count, (int32_t*)(ws + L.items_off));
 }
@@ -1313,6 +1347,9 @@ static void fill_refine_args(RefineArgs& r, const BinsLayout& L, int C, int tile
     r.tile_cnt = (uint32_t*)(ws + L.tile_cnt_off);
     r.isect_offsets = nullptr; r.isect_ids = nullptr; r.flatten_ids = nullptr; r.slots = nullptr;
     r.info = info_dev;
+    int64_t* rblk;
+    r.phase = list_round(rblk);
+    r.rblk = rblk;
 }
 
 extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int tile_h, int bin_shift, const uint32_t* bbox,
@@ -1340,6 +1377,9 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     uint32_t* tile_cnt = (uint32_t*)(ws + L.tile_cnt_off);
     const Guard gd = current_guard();
     GS_REQUIRE(gd.info == nullptr || gd.info == info_dev, "the guard set by gs_guard_set must be this call's info_dev");
+    int64_t* rblk;
+    const int phase = list_round(rblk);
+    GS_REQUIRE(phase == 0 || C == 1, "depth rounds: one camera per call");
     // sort classes launched: up to the one that holds coarse_list_cap (<= 0: all of them); a longer bin list raises
     // flags bit 8 and nothing is emitted
     int64_t list_cap = 0x7fffffff;
@@ -1348,7 +1388,7 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     const size_t lds = sizeof(uint32_t) * ((size_t)L.nbins + 32);
     if (int rc = ensure_lds((const void*)bins_hist_kernel, lds)) return rc;
     hipLaunchKernelGGL(bins_hist_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, L.shift, L.bw, L.nbins, L.per_group,
-                       (const uint4*)bbox, hist, grp_tot);
+                       (const uint4*)bbox, hist, grp_tot, (const int64_t*)rblk, phase);
     GS_LAUNCH_CHECK("bins_hist_kernel");
     const int64_t cb = (int64_t)C * L.nbins;
     hipLaunchKernelGGL(bins_colscan_kernel, dim3((unsigned)((cb + 3) / 4)), dim3(256), 0, st, C, L.groups, L.nbins, hist, bin_cnt);
@@ -1356,19 +1396,19 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     hipLaunchKernelGGL(bins_scan_kernel, dim3(2), dim3(kBinThreads), 0, st, (int)cb, C * L.groups, bin_cnt, grp_tot, coff,
                        (int32_t*)(ws + L.choff_off), (int4*)(ws + L.chunk_bin_off), L.max_chunks, L.chunk_shift, grp_base,
                        info_dev, coarse_cap, list_cap,
-                       (gd.info != nullptr && !gd.per_call) ? 1 : 0, (int32_t*)(ws + L.items_off));   // (per-call guard: overwrite)
+                       (gd.info != nullptr && !gd.per_call) ? 1 : 0, (int32_t*)(ws + L.items_off), (const int64_t*)rblk, phase);   // (per-call guard: overwrite)
     GS_LAUNCH_CHECK("bins_scan_kernel");
     if (N > 0) {
         if (int rc = ensure_lds((const void*)bins_emit_kernel, lds)) return rc;
         hipLaunchKernelGGL(bins_emit_kernel, dim3(L.groups, C), dim3(kBinThreads), lds, st, N, L.shift, L.bw, L.nbins, L.per_group,
                            (const uint4*)bbox, depths, hist, coff, grp_base, (unsigned long long*)coarse_keys, cum_tiles,
-                           (uint4*)(ws + L.rec_off), (const int64_t*)info_dev);
+                           (uint4*)(ws + L.rec_off), (const int64_t*)info_dev, (const int64_t*)rblk, phase);
         GS_LAUNCH_CHECK("bins_emit_kernel");
         SortArgs a;
         a.tiles = L.nbins; a.tile_bits = 0;
         a.isect_offsets = coff; a.keys = (unsigned long long*)coarse_keys; a.slot_gid = nullptr;
         a.isect_ids = nullptr; a.flatten_ids = nullptr; a.slots = nullptr;
-        a.guard = info_dev; a.coarse = 1; a.seg = 0;
+        a.guard = info_dev; a.coarse = 1; a.seg = 0; a.rblk = rblk; a.phase = phase;
         a.merged = (unsigned long long*)(ws + L.staged_off);   // (free until the refinement's first pass fills it)
         // (the longest bin list is not known to the host here: every class is launched, the blocks of the classes a
         //  list does not belong to return at once; a list can never be longer than the key buffer)
@@ -1385,7 +1425,7 @@ extern "C" int gs_bins_count(void* stream, int C, int64_t N, int tile_w, int til
     }
     hipLaunchKernelGGL(bin_tilescan_kernel, dim3(2), dim3(kBinThreads), 0, st, C * tiles, 0, tile_cnt, (const uint32_t*)nullptr,
                        isect_offsets, bucket_offsets, (uint32_t*)nullptr, info_dev, tile_order, gd.cap_isects,
-                       (int64_t)0x7fffffffffffffffll, (int64_t)12, (int32_t*)nullptr, current_info_mirror(), gd.per_call);
+                       (int64_t)0x7fffffffffffffffll, (int64_t)12, (int32_t*)nullptr, current_info_mirror(), gd.per_call, rblk, phase);
     GS_LAUNCH_CHECK("bin_tilescan_kernel");
     if (info_host) {
         GS_HIP_CHECK(hipMemcpyAsync(info_host, info_dev, 8 * sizeof(int64_t), hipMemcpyDeviceToHost, st));

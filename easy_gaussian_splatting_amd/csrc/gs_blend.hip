@@ -96,6 +96,11 @@ struct BlendFwdArgs {
     int cap_units;
     unsigned long long* flags;   // the guard's flag word (overflow bits are ORed in) or nullptr
     const int64_t* guard;  // step guard (gs_guard_set) or nullptr
+    // depth rounds (gs_rounds_set; blend_fwd_kernel's ROUND 1 / 2)
+    int64_t* rblk;
+    uint8_t* live;         // [tiles]
+    float4* tstate;        // [tiles][4][64]
+    int4* trec;            // [tiles][2]  {sublist lengths}, {part-filled work units' storage}
     GS_IF_CHECK(BwdCheck chk;)
 };
 
@@ -177,16 +182,22 @@ __device__ __forceinline__ int64_t slots_in_use(int64_t n, const int64_t* guard)
 // Streaming clear of the quadrant masks (16-byte stores; `n` bytes from an arbitrarily aligned pointer) + of the walk state
 // (counters; the chunk counts of the row-base scan are written before they are read).
 __global__ __launch_bounds__(256) void qmask_clear_kernel(uint8_t* __restrict__ q, int64_t n_cap, int32_t* __restrict__ walk, int walk_ints,
-                                                          const int64_t* __restrict__ guard) {
+                                                          const int64_t* __restrict__ guard, const int64_t* __restrict__ rblk, int phase) {
     // The step guard as it stands when the CALL starts decides for all three of its kernels (walk[kWalkSkip]): the overflow flags
     // this call's own blend raises must not stop its later tiles (the image stays complete) nor its scan (which reports what
-    // the walk needed).
-    const bool skip = guard_tripped(guard);
+    // the walk needed).  Depth rounds: the two calls of a frame are one walk -- the back round goes on unless the front round
+    // was skipped or the list stages of the back round overflowed (the front round's own blend does not touch the guard).
+    bool skip = guard_tripped(guard);
+    if (phase == 2) skip = skip || walk[kWalkSkip] != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) walk[kWalkSkip] = skip ? 1 : 0;
     if (skip) return;
-    const int64_t n = slots_in_use(n_cap, guard);
-    for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < walk_ints; i += (int)gridDim.x * 256)
-        if (i != kWalkSkip) walk[i] = 0;
+    // the slots this call's lists own: all of them, or (back round) those behind the front round's
+    const int64_t first = phase == 2 ? min(rblk[GS_ROUND_BASE], slots_in_use(n_cap, guard)) : 0;
+    const int64_t n = slots_in_use(n_cap, guard) - first;
+    q += first;
+    if (phase != 2)
+        for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < walk_ints; i += (int)gridDim.x * 256)
+            if (i != kWalkSkip) walk[i] = 0;
     const int64_t head = min(n, (int64_t)((16 - ((uintptr_t)q & 15)) & 15));
     const int64_t n16 = (n - head) >> 4;
     uint4* q16 = reinterpret_cast<uint4*>(q + head);
@@ -198,7 +209,10 @@ __global__ __launch_bounds__(256) void qmask_clear_kernel(uint8_t* __restrict__ 
     }
 }
 
-template <bool CKPT, int WAVES>
+// ROUND (depth rounds, include/gs_raster.h): 0 = the frame's one list per tile; 1 = front round: a tile that still has live pixels
+// behind its list leaves them (and, training, where its quadrant sublists stand) for the back round; 2 = back round: only such
+// tiles, from those states -- the same walk as over one list, cut in two.
+template <bool CKPT, int WAVES, int ROUND>
 __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const BlendFwdArgs a) {
     __shared__ float4 srec_all[WAVES][GS_BUCKET * 3];
     __shared__ int2 ulog_all[CKPT ? WAVES : 1][CKPT ? kUnitLog : 1];
@@ -207,6 +221,7 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
     const int ti = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
     if (ti >= a.C * a.tiles) return;   // wave-uniform
     if (CKPT ? a.walk[kWalkSkip] != 0 : guard_tripped(a.guard)) return;   // (training: the guard at the start of the call, qmask_clear_kernel)
+    if (ROUND == 2 && a.rblk[GS_ROUND_LIVE] == 0) return;   // the front round finished every tile
     GS_CLOCK_PROBE_SCOPE(0);
     const int t = a.tile_order ? a.tile_order[ti] : ti;   // launch slot -> tile (longest lists first)
     const int cam = t / a.tiles, tt = t - cam * a.tiles;
@@ -219,6 +234,8 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
     const int len = hi - lo;
     const int nb = (len + GS_BUCKET - 1) / GS_BUCKET;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // back round: a tile the front round finished, or one with nothing behind the split, keeps what the front round wrote
+    if (ROUND == 2 && (len == 0 || a.live[t] == 0)) return;   // wave-uniform
 
     float T[4], cr[4], cg[4], cb[4];   // T <= 1: live; T > 2^32: finished, T * 2^-64 final (blend_pair)
     int cnt[4] = {0, 0, 0, 0};   // wave-uniform sublist lengths
@@ -235,6 +252,20 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
     for (int k = 0; k < 4; ++k) {
         cr[k] = cg[k] = cb[k] = 0.f;
         T[k] = ((px0 + 8 * (k & 1)) < a.W && (py0 + 8 * (k >> 1)) < a.H) ? 1.f : kDoneScale;
+    }
+    if (ROUND == 2) {   // the states the front round left, in its lanes' own layout
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 s4 = a.tstate[((size_t)t * 4 + k) * 64 + lane];
+            T[k] = s4.x; cr[k] = s4.y; cg[k] = s4.z; cb[k] = s4.w;
+        }
+        if (CKPT) {
+            const int4 rc = a.trec[2 * (size_t)t], ru = a.trec[2 * (size_t)t + 1];
+            cnt[0] = __builtin_amdgcn_readfirstlane(rc.x); cnt[1] = __builtin_amdgcn_readfirstlane(rc.y);
+            cnt[2] = __builtin_amdgcn_readfirstlane(rc.z); cnt[3] = __builtin_amdgcn_readfirstlane(rc.w);
+            us[0][0] = __builtin_amdgcn_readfirstlane(ru.x); us[1][0] = __builtin_amdgcn_readfirstlane(ru.y);
+            us[2][0] = __builtin_amdgcn_readfirstlane(ru.z); us[3][0] = __builtin_amdgcn_readfirstlane(ru.w);
+        }
     }
     // pixel-centre bounds of the four quadrants
     const float qxlo[2] = {(float)x0 + 0.5f, (float)x0 + 8.5f}, qxhi[2] = {(float)x0 + 7.5f, (float)x0 + 15.5f};
@@ -333,9 +364,11 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
                                     // out of storage: the call is void (flag; every kernel behind it is a no-op under the step guard,
                                     // the caller re-sizes from the counters, which keep counting) -- its stores land in the range's
                                     // first chunk
+                                    // (front round: the step guard learns of it behind the back round -- row_chunk_scan_kernel --, whose
+                                    //  list stages run under the same guard and must not find it tripped by the walk in between)
                                     if (lane == 0) {
                                         atomicOr(a.walk + kWalkFlags, GS_FLAG_UNITS);
-                                        if (a.flags) atomicOr(a.flags, (unsigned long long)GS_FLAG_UNITS);
+                                        if (ROUND != 1 && a.flags) atomicOr(a.flags, (unsigned long long)GS_FLAG_UNITS);
                                     }
                                     base = 0;
                                 }
@@ -385,6 +418,21 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
         // publish the sublist lengths and the work units still in the log
         if (lane < 4) a.qcnt[4 * t + lane] = lane == 0 ? cnt[0] : (lane == 1 ? cnt[1] : (lane == 2 ? cnt[2] : cnt[3]));
         publish();
+    }
+    if (ROUND == 1) {
+        const bool lv = __builtin_amdgcn_ballot_w64(px_live(T[0]) || px_live(T[1]) || px_live(T[2]) || px_live(T[3])) != 0ull;
+        if (lane == 0) {
+            a.live[t] = lv ? 1 : 0;
+            if (lv) atomicAdd(reinterpret_cast<unsigned long long*>(a.rblk + GS_ROUND_LIVE), 1ull);
+        }
+        if (lv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.tstate[((size_t)t * 4 + k) * 64 + lane] = make_float4(T[k], cr[k], cg[k], cb[k]);
+            if (CKPT && lane == 0) {
+                a.trec[2 * (size_t)t] = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
+                a.trec[2 * (size_t)t + 1] = make_int4(us[0][0], us[1][0], us[2][0], us[3][0]);
+            }
+        }
     }
     float bgr = 0.f, bgg = 0.f, bgb = 0.f;
     if (a.bg) { bgr = a.bg[3 * cam]; bgg = a.bg[3 * cam + 1]; bgb = a.bg[3 * cam + 2]; }
@@ -479,6 +527,7 @@ __global__ __launch_bounds__(1024) void row_chunk_scan_kernel(const RowScanArgs 
         a.walk[kWalkStorage] = GS_WALK_RANGES * fullest;
         a.walk[kWalkRows] = total;
         int fl = a.walk[kWalkFlags];   // (the blend's tiles have all finished: its flag is final)
+        if (a.flags && (fl & GS_FLAG_UNITS)) atomicOr(a.flags, (unsigned long long)GS_FLAG_UNITS);   // (depth rounds: the front round's, see blend_fwd_kernel)
         if ((int64_t)total > a.cap_rows) {
             fl |= GS_FLAG_ROWS;
             a.walk[kWalkFlags] = fl;
@@ -792,6 +841,11 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     a.tile_order = tile_order;
     a.guard = current_guard().info;
     a.flags = a.guard ? reinterpret_cast<unsigned long long*>(const_cast<int64_t*>(a.guard) + 3) : nullptr;
+    const Rounds R = current_rounds();
+    const int phase = (R.phase == 1 || R.phase == 2) ? R.phase : 0;
+    GS_REQUIRE(phase == 0 || C == 1, "depth rounds: one camera per call");
+    GS_REQUIRE(phase == 0 || !train || R.tile_rec, "depth rounds, training mode: gs_rounds_set needs tile_rec");
+    a.rblk = R.blk; a.live = R.live; a.tstate = R.state; a.trec = reinterpret_cast<int4*>(R.tile_rec);
     GS_IF_CHECK(a.chk = g_bwd_check;)
     const unsigned n_tiles = (unsigned)(C * a.tiles);
     hipStream_t st = (hipStream_t)stream;
@@ -805,10 +859,14 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
         // takes, and the tails of lists a saturated tile abandons, then need no store at all
         const int walk_ints = (int)gs_walk_state_ints(n_isects);
         const unsigned cg = (unsigned)std::min<int64_t>(1024, std::max<int64_t>(1, (n_isects / 16 + 255) / 256));
-        hipLaunchKernelGGL(qmask_clear_kernel, dim3(cg), dim3(256), 0, st, qmask, n_isects, walk_state, walk_ints, a.guard);
+        hipLaunchKernelGGL(qmask_clear_kernel, dim3(cg), dim3(256), 0, st, qmask, n_isects, walk_state, walk_ints, a.guard,
+                           (const int64_t*)R.blk, phase);
         GS_LAUNCH_CHECK("qmask_clear_kernel");
-        hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves>), grid, block, 0, st, a);
+        if (phase == 1) hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves, 1>), grid, block, 0, st, a);
+        else if (phase == 2) hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves, 0>), grid, block, 0, st, a);
         GS_LAUNCH_CHECK("blend_fwd_kernel");
+        if (phase == 1) return GS_OK;   // (the row bases are scanned once, behind the back round)
         RowScanArgs s;
         s.qmask = qmask; s.row_base = row_base; s.walk = walk_state; s.n_cap = n_isects; s.cap_rows = cap_rows;
         s.flags = a.flags; s.guard = a.guard; s.mirror = current_walk_mirror();
@@ -818,7 +876,9 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
         hipLaunchKernelGGL(row_base_kernel, dim3(chunks), dim3(kScanThreads), 0, st, s);
         GS_LAUNCH_CHECK("row_base_kernel");
     } else {
-        hipLaunchKernelGGL((blend_fwd_kernel<false, kFwdWaves>), grid, block, 0, st, a);
+        if (phase == 1) hipLaunchKernelGGL((blend_fwd_kernel<false, kFwdWaves, 1>), grid, block, 0, st, a);
+        else if (phase == 2) hipLaunchKernelGGL((blend_fwd_kernel<false, kFwdWaves, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((blend_fwd_kernel<false, kFwdWaves, 0>), grid, block, 0, st, a);
         GS_LAUNCH_CHECK("blend_fwd_kernel");
     }
     return GS_OK;

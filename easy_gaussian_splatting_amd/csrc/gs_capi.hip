@@ -18,7 +18,26 @@ static thread_local int64_t* g_info_mirror = nullptr;
 int64_t* current_info_mirror() { return g_info_mirror; }
 static thread_local int64_t* g_walk_mirror = nullptr;
 int64_t* current_walk_mirror() { return g_walk_mirror; }
+static thread_local Rounds g_rounds = {nullptr, nullptr, nullptr, nullptr, 0};
+Rounds current_rounds() { return g_rounds; }
 }  // namespace gs
+
+extern "C" int gs_rounds_set(int64_t* rounds_dev, uint8_t* tile_live, float* tile_state, int32_t* tile_rec, int phase) {
+    if (phase < 0 || phase > 3 || (phase != 0 && !rounds_dev) || ((phase == 1 || phase == 2) && (!tile_live || !tile_state))) {
+        gs::set_error("invalid argument: phase 0 (off), 1 (front round), 2 (back round) or 3 (behind both); a round needs its buffers");
+        return GS_ERR_ARG;
+    }
+    if ((((uintptr_t)tile_state) & 15) != 0 || (((uintptr_t)tile_rec) & 15) != 0) {
+        gs::set_error("invalid argument: tile_state / tile_rec 16-byte aligned");
+        return GS_ERR_ARG;
+    }
+    gs::g_rounds.blk = phase ? rounds_dev : nullptr;
+    gs::g_rounds.live = phase ? tile_live : nullptr;
+    gs::g_rounds.state = phase ? reinterpret_cast<float4*>(tile_state) : nullptr;
+    gs::g_rounds.tile_rec = phase ? tile_rec : nullptr;
+    gs::g_rounds.phase = phase;
+    return GS_OK;
+}
 
 extern "C" int gs_info_mirror_set(int64_t* info_host_mapped) {
     gs::g_info_mirror = info_host_mapped;

@@ -58,6 +58,20 @@ int64_t* current_info_mirror();
 int64_t* current_walk_mirror();
 __device__ __forceinline__ bool guard_tripped(const int64_t* info) { return info != nullptr && info[3] != 0; }
 
+// Depth rounds (gs_rounds_set, include/gs_raster.h): the list stages, the blend forward and the row gather of the backward run
+// the frame's Gaussians in TWO rounds -- the front slab by depth first, the rest only into tiles the front slab has not
+// finished.  `phase` 0: off; 1: front round; 2: back round; 3: behind both (the backward: rows of the two rounds are two ranges).
+struct Rounds {
+    int64_t* blk;        // device int64[GS_ROUND_WORDS]
+    uint8_t* live;       // [tiles]  1: the front round left the tile with live pixels
+    float4* state;       // [tiles][4][64]  pixel states of the live tiles, the front round's lanes' own
+    int32_t* tile_rec;   // [tiles][8]  training: the quadrant sublists' lengths and part-filled work units
+    int phase;
+};
+Rounds current_rounds();
+// the back round has nothing to do: the front round left no live tile (its kernels return at once)
+__device__ __forceinline__ bool round_idle(const int64_t* blk, int phase) { return phase == 2 && blk[GS_ROUND_LIVE] == 0; }
+
 // Gradient rows in front of slot s (training: gs_blend_fwd's row-base scan).  The scan leaves ONE base per 16 slots -- a base per
 // slot was 4 bytes written per LISTED intersection for the 2 % a saturated scene walks (65 us at 57 M) --; the reader adds the
 // popcounts of the slot's predecessors inside its group: one aligned 16-byte load of their 4-bit quadrant masks.  *slot_mask (if

@@ -397,6 +397,7 @@ struct ProjBwdArgs {
     // |absgrad|_2 * max_hw and the visibility flag, 0 for culled Gaussians (st_max_hw as above)
     const float* row_sums;            // optional [C*N][12]
     float *st_gn_out, *st_cnt_out;    // optional [N] each (single camera)
+    const int64_t* rblk;              // depth rounds (gs_rounds_set phase 3): the rows are two ranges, split at slot rblk[GS_ROUND_BASE]
 };
 
 __device__ __forceinline__ float* adam_p(const ProjBwdArgs& a, int t) { return a.ad_pbase + a.ad_off[t]; }
@@ -612,16 +613,32 @@ __device__ __forceinline__ void adam_geo_tile(const float* tile, int rows, int64
 // same bits from project_bwd_kernel and row_sums_kernel.
 constexpr int kRowWaveFloats = 64 * 12;   // LDS of one wave: an item's 64 rows
 
+// Depth rounds (a.rblk: gs_rounds_set phase 3): the wave's rows are TWO such ranges -- the slots of the front round's Gaussians lie
+// in front of slot GS_ROUND_BASE, those of the back round's behind it, and the Gaussians of one round follow one another inside
+// their range.  The walk below runs over the two ranges laid end to end: row j of the wave is row R0 + j of the front range for
+// j < Ta and row R0b + (j - Ta) of the back range behind (an item may straddle the seam: every lane forms its own address).
 template <class A>
-__device__ __forceinline__ void row_sum_wave(const A& a, int nr, int r0, RowSum& s, float* wl) {
+__device__ __forceinline__ void row_sum_wave(const A& a, int nr, int r0, int base, RowSum& s, float* wl) {
     const int lane = lane_id();
 #pragma unroll
     for (int i = 0; i < 12; ++i) s.v[i] = 0.f;
-    const int incl = wave_incl_scan_add(nr);
-    const int o = incl - nr;
-    const int T = __shfl(incl, 63, 64);
+    const bool two = a.rblk != nullptr;   // (kernel argument: uniform)
+    const bool back = two && (int64_t)base >= a.rblk[GS_ROUND_BASE];
+    const int incl = wave_incl_scan_add(back ? 0 : nr);
+    int o = incl - nr;
+    const int Ta = __builtin_amdgcn_readlane(incl, 63);
+    int T = Ta;
+    int64_t R0b = 0;
+    if (two) {
+        const int inb = wave_incl_scan_add(back ? nr : 0);
+        if (back) o = Ta + inb - nr;
+        T += __builtin_amdgcn_readlane(inb, 63);
+        const unsigned long long bb = __ballot(back && nr > 0);
+        if (bb) R0b = __shfl(r0, __builtin_ctzll(bb), 64);
+    }
     if (T == 0) return;   // wave-uniform
-    const int64_t R0 = __shfl(r0, __builtin_ctzll(__ballot(nr > 0)), 64);
+    const unsigned long long fb = __ballot(!back && nr > 0);
+    const int64_t R0 = fb ? __shfl(r0, __builtin_ctzll(fb), 64) : 0;
     float4* item = reinterpret_cast<float4*>(wl);
     const int n_items = (T + 63) >> 6;
     // (the third quad of a row holds three live floats: loaded as 12 bytes)
@@ -630,7 +647,7 @@ __device__ __forceinline__ void row_sum_wave(const A& a, int nr, int r0, RowSum&
         const int j = 64 * it + lane;
         d.a = d.b = make_float4(0.f, 0.f, 0.f, 0.f); d.cx = d.cy = d.cz = 0.f;
         if (j < T) {
-            const float4* rp = a.rows + kRow4 * (R0 + j);
+            const float4* rp = a.rows + kRow4 * (j < Ta ? R0 + j : R0b + (j - Ta));
             d.a = rp[0]; d.b = rp[1];
             const float* c = reinterpret_cast<const float*>(rp + 2);
             d.cx = c[0]; d.cy = c[1]; d.cz = c[2];
@@ -744,7 +761,7 @@ __global__ __launch_bounds__(kProjThreads) void project_bwd_kernel(const ProjBwd
         s.v[0] = x.x; s.v[1] = x.y; s.v[2] = x.z; s.v[3] = x.w; s.v[4] = y.x; s.v[5] = y.y; s.v[6] = y.z; s.v[7] = y.w;
         s.v[8] = z.x; s.v[9] = z.y; s.v[10] = z.z; s.v[11] = 0.f;
     } else {
-        row_sum_wave(a, nr, r0, s, tile + (threadIdx.x >> 6) * kRowWaveFloats);
+        row_sum_wave(a, nr, r0, base, s, tile + (threadIdx.x >> 6) * kRowWaveFloats);
     }
 
     // ---- 2. colour path
@@ -1007,6 +1024,7 @@ struct RowSumsArgs {
     const float* viewmats;
     float max_hw;
     const int64_t* guard;
+    const int64_t* rblk;   // depth rounds (see ProjBwdArgs)
 };
 
 __global__ __launch_bounds__(256) void row_sums_kernel(const RowSumsArgs a) {
@@ -1023,7 +1041,7 @@ __global__ __launch_bounds__(256) void row_sums_kernel(const RowSumsArgs a) {
     if (vis) { rgb[0] = a.colors_post[3 * f]; rgb[1] = a.colors_post[3 * f + 1]; rgb[2] = a.colors_post[3 * f + 2]; }
     if (a.cam_out && blockIdx.x == 0 && threadIdx.x < 16) a.cam_out[threadIdx.x] = a.viewmats[threadIdx.x];
     RowSum s;
-    row_sum_wave(a, nr, r0, s, wl_all[threadIdx.x >> 6]);
+    row_sum_wave(a, nr, r0, base, s, wl_all[threadIdx.x >> 6]);
     if (!in_range) return;
     if (vis) {   // (culled Gaussians: gs_project_bwd does not read their sums)
         float4* rs = a.row_sums + 3 * f;
@@ -1115,6 +1133,7 @@ extern "C" int gs_row_sums(void* stream, int C, int64_t N, const int32_t* radii,
     a.row_sums = reinterpret_cast<float4*>(row_sums); a.v_colors_pre = v_colors_pre; a.radii_norm = radii_norm;
     a.cam_out = cam_out; a.viewmats = viewmats; a.max_hw = max_hw;
     a.guard = current_guard().info;
+    a.rblk = current_rounds().phase == 3 ? current_rounds().blk : nullptr;   // (depth rounds: the rows are two ranges)
     hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)((a.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("row_sums_kernel");
     return GS_OK;
@@ -1203,6 +1222,7 @@ extern "C" int gs_project_bwd(void* stream, int C, int64_t N, int K, int sh_degr
     a.opacities = opacities; a.activations = activations != 0;
     a.sh_jac = sh_degree >= 0 ? reinterpret_cast<const float4*>(sh_jac) : nullptr;
     a.guard = current_guard().info;
+    a.rblk = current_rounds().phase == 3 ? current_rounds().blk : nullptr;   // (depth rounds: the rows are two ranges)
     a.adam = 0; a.ad_hyper = nullptr; a.ad_applied = nullptr; a.ad_b1 = a.ad_b2 = a.ad_eps = 0.f;
     a.st_max_radii = a.st_grad_norm = a.st_counts = nullptr; a.st_max_hw = (float)(width > height ? width : height);
     a.row_sums = row_sums; a.st_gn_out = stat_grad_norm; a.st_cnt_out = stat_count;
@@ -1263,6 +1283,7 @@ extern "C" int gs_project_bwd_adam(void* stream, int64_t N, int K, int sh_degree
     a.v_means2d_abs = v_means2d_abs; a.v_means2d = a.v_conics = a.v_colors_post = a.v_colors_pre = nullptr;
     a.sh_jac = reinterpret_cast<const float4*>(sh_jac);
     a.guard = current_guard().info;
+    a.rblk = current_rounds().phase == 3 ? current_rounds().blk : nullptr;   // (depth rounds: the rows are two ranges)
     a.adam = 1; a.ad_hyper = hyper_dev; a.ad_applied = applied_dev; a.ad_b1 = beta1; a.ad_b2 = beta2; a.ad_eps = eps;
     GS_REQUIRE((max_radii == nullptr) == (grad_norm_accum == nullptr) && (max_radii == nullptr) == (counts == nullptr),
                "the three statistics buffers come together or not at all");

@@ -58,7 +58,8 @@ def _p(t: Optional[Tensor]):
 class TrainStepGraph:
     def __init__(self, model, optimizer: FusedAdam, loss_computer, data: Dict[str, Any], gt_img: Tensor,
                  mask: Optional[Tensor] = None, margin: float = 1.3, use_graph: bool = True, check_every: int = 16,
-                 fuse_adam: bool = True, handback: str = "eager", copy_targets: bool = False):
+                 fuse_adam: bool = True, handback: str = "eager", copy_targets: bool = False, rounds: str = "auto",
+                 round_fraction: float = 0.125):
         """`handback`: when the caller's stream is ordered behind a step.
         "eager" (default): on return from every `step()` -- whatever the caller enqueues next (a read of the outputs, an eval
         render that reads the parameters, `densify_and_prune`) sees the finished step, no thought required.
@@ -70,6 +71,17 @@ class TrainStepGraph:
         if handback not in ("eager", "lazy"):
             raise ValueError("handback: 'eager' or 'lazy'")
         self.handback = handback
+        # rounds: depth rounds of the list stages (include/gs_raster.h "Depth rounds": the front slab of the frame is listed, sorted
+        # and blended first, the rest only into tiles it has not finished; same images, sublists and gradient rows bit for bit).
+        # "auto" (default): on when the build-time probe finds that the frame lists several times what its blend walks
+        # (realistic footprints: 20-50 x) -- the two-round pipeline costs ~0.1 ms of extra launches, which a scene that walks most
+        # of what it lists never earns back; "on" / "off" force it.  round_fraction: the share of the listed intersections in
+        # front of the depth split.
+        rounds = __import__("os").environ.get("GS_TG_ROUNDS", rounds)
+        if rounds not in ("auto", "on", "off"):
+            raise ValueError("rounds: 'auto', 'on' or 'off'")
+        self.rounds_mode, self.round_fraction = rounds, float(__import__("os").environ.get("GS_TG_ROUND_FRACTION", round_fraction))
+        self.rounds_on = rounds == "on"
         # copy_targets: every step takes a private copy of its target image (and mask) instead of reading the caller's tensors in
         # place -- for loaders that recycle ONE device staging buffer (`gt_buf.copy_(next)`): a target is read until its step is
         # RETIRED (the loss forward and backward of the replay, and again if an overflow recovery replays the step up to
@@ -202,6 +214,7 @@ class TrainStepGraph:
             probe_walk = True
         self._alloc_binning()
         self._alloc_lists()
+        self._alloc_rounds()
         if probe_walk:
             # what the forward WALKS on this view: one guarded forward on first-guess capacities, repeated with what it reports
             floor = (max(min_walk[0], self.walk_floor[0]), max(min_walk[1], self.walk_floor[1]))
@@ -224,7 +237,11 @@ class TrainStepGraph:
             self.cap_units = max(int(max(units * scale, floor[0]) * wm) + 512, 256)
             self.cap_rows = max(int(max(rows * scale, floor[1]) * wm) + 4096, 4096)
             self._walk_history_void = False
+            if self.rounds_mode == "auto":
+                # listed against walked: a gradient row is one (intersection, quadrant) pair some pixel took, 1.5 per walked entry
+                self.rounds_on = n_isects >= self.ROUNDS_MIN_LISTED and n_isects >= self.ROUNDS_MIN_RATIO * max(rows, 1)
         self._alloc_walk()
+        self._alloc_rounds()
         self._key = self._state_key()
         self._opacity_resets = getattr(m, "opacity_resets", 0)
         # eager warm-up of the guarded pipeline (raises every kernel attribute; also a functional check before capture)
@@ -287,6 +304,34 @@ class TrainStepGraph:
         b["unit_desc"] = self._take("unit_desc", (cu, 4), torch.int32, shrink=True)
         b["rows"] = self._take("rows", (cr, nat.GS_ROW_FLOATS), torch.float32, shrink=True)
 
+    ROUNDS_MIN_LISTED = 4_000_000   # "auto": below this the list stages are too short for a second round to pay
+    ROUNDS_MIN_RATIO = 4.0          # ... and so they are when the frame lists less than this many entries per gradient row
+
+    def _alloc_rounds(self):
+        """Depth rounds: the round block, the tiles' liveness / pixel states / sublist records between the rounds, the footprints
+        and per-Gaussian counts of the round at hand."""
+        b, tiles = self.buf, self.tw * self.th
+        if not self.rounds_on:
+            return
+        b["rounds"] = torch.zeros((nat.GS_ROUND_WORDS,), dtype=torch.int64, device=self.dev)
+        b["depth_hist"] = torch.zeros((4096,), dtype=torch.int32, device=self.dev)
+        b["tile_live"] = torch.zeros((tiles,), dtype=torch.uint8, device=self.dev)
+        b["tile_state"] = self._take("tile_state", (tiles, 4, 64, 4), torch.float32)
+        b["tile_rec"] = self._take("tile_rec", (tiles, 8), torch.int32)
+        b["bbox_round"] = self._take("bbox_round", (self.N, 4), torch.int32)
+        b["tpg_round"] = self._take("tpg_round", (1, self.N), torch.int32)
+
+    def _rounds_phase(self, phase: int):
+        L, b = nat.lib(), self.buf
+        if phase == 0:
+            nat.check(L.gs_rounds_set(None, None, None, None, 0), "gs_rounds_set")
+        else:
+            nat.check(L.gs_rounds_set(_p(b["rounds"]), _p(b["tile_live"]), _p(b["tile_state"]), _p(b["tile_rec"]), phase), "gs_rounds_set")
+
+    def _tpg(self):
+        """The per-Gaussian intersection counts the backward reads: the projection's, or (depth rounds) each Gaussian's in its round."""
+        return _p(self.buf["tpg_round"] if self.rounds_on else self.buf["tiles_per_gauss"])
+
     def _probe_walk(self):
         """One guarded forward (projection .. blend) on the current capacities; returns (storage units, gradient rows, flags) of
         its walk -- the counters keep counting past the capacities.  Build time only (blocking)."""
@@ -300,6 +345,7 @@ class TrainStepGraph:
                 pass
             finally:
                 nat.lib().gs_guard_set(None, 0, 0)
+                nat.lib().gs_rounds_set(None, None, None, None, 0)
         self.stream.synchronize()
         info = b["info"].tolist()
         w = b["walk_state"][:8].tolist()
@@ -445,15 +491,15 @@ class TrainStepGraph:
                                    _p(b["radii"]), _p(b["means2d"]), _p(b["depths"]), _p(b["conics"]), _p(b["colors_post"]),
                                    _p(b["rec"]), _p(b["bbox"]), _p(b["tiles_per_gauss"]), None, _p(b["sh_jac"])), "gs_project_fwd")
 
-    def _count(self):
+    def _count(self, bbox: str = "bbox"):
         L, b = nat.lib(), self.buf
         if self.binning == "bins":
-            self._ck(L.gs_bins_count(self._st(), 1, self.N, self.tw, self.th, self.bin_shift, _p(b["bbox"]), _p(b["depths"]), _p(b["ws"]),
+            self._ck(L.gs_bins_count(self._st(), 1, self.N, self.tw, self.th, self.bin_shift, _p(b[bbox]), _p(b["depths"]), _p(b["ws"]),
                                       self.ws_bytes, _p(b["coarse_keys"]), self.cap_coarse, self.cap_coarse_list, _p(b["cum_tiles"]),
                                       _p(b["isect_offsets"]), _p(b["bucket_offsets"]), _p(b["tile_order"]), _p(b["info"]), None),
                      "gs_bins_count")
         else:
-            self._ck(L.gs_bin_count(self._st(), 1, self.N, self.tw, self.th, _p(b["bbox"]), _p(b["ws"]), self.ws_bytes,
+            self._ck(L.gs_bin_count(self._st(), 1, self.N, self.tw, self.th, _p(b[bbox]), _p(b["ws"]), self.ws_bytes,
                                      _p(b["isect_offsets"]), _p(b["bucket_offsets"]), _p(b["tile_order"]), _p(b["info"]), None),
                      "gs_bin_count")
 
@@ -498,18 +544,34 @@ class TrainStepGraph:
         return n_isects, max_tile
 
     def _enqueue_forward(self):
-        """Projection, tile lists and the training blend on the current stream (the caller holds the step guard)."""
+        """Projection, tile lists and the training blend on the current stream (the caller holds the step guard).  With depth
+        rounds: the list stages and the blend twice, on the footprints of the front and of the back round; the rounds context is
+        left at "behind both" for the backward (the caller clears it)."""
+        L, b = nat.lib(), self.buf
+        self._project()
+        if not self.rounds_on:
+            self._lists_and_blend("bbox")
+            return
+        self._ck(L.gs_round_split(self._st(), self.N, _p(b["depths"]), _p(b["tiles_per_gauss"]), self.round_fraction, _p(b["depth_hist"]),
+                                   _p(b["rounds"])), "gs_round_split")
+        for phase in (1, 2):
+            self._rounds_phase(phase)
+            self._ck(L.gs_round_footprints(self._st(), self.N, self.tw, self.th, _p(b["bbox"]), _p(b["depths"]), _p(b["bbox_round"]),
+                                            _p(b["tpg_round"])), "gs_round_footprints")
+            self._lists_and_blend("bbox_round")
+        self._rounds_phase(3)
+
+    def _lists_and_blend(self, bbox: str):
         L, b = nat.lib(), self.buf
         st = self._st()
         N, W, H = self.N, self.W, self.H
-        self._project()
-        self._count()
+        self._count(bbox)
         if self.binning == "bins":
-            self._ck(L.gs_bins_lists(st, 1, N, self.tw, self.th, self.bin_shift, _p(b["bbox"]), _p(b["ws"]), self.ws_bytes,
+            self._ck(L.gs_bins_lists(st, 1, N, self.tw, self.th, self.bin_shift, _p(b[bbox]), _p(b["ws"]), self.ws_bytes,
                                       _p(b["coarse_keys"]), self.cap_coarse, _p(b["cum_tiles"]), _p(b["isect_offsets"]),
                                       None, _p(b["flatten_ids"]), _p(b["slots"]), _p(b["info"])), "gs_bins_lists")
         else:
-            self._ck(L.gs_bin_emit_sort(st, 1, N, self.tw, self.th, _p(b["bbox"]), _p(b["depths"]), _p(b["ws"]), self.ws_bytes,
+            self._ck(L.gs_bin_emit_sort(st, 1, N, self.tw, self.th, _p(b[bbox]), _p(b["depths"]), _p(b["ws"]), self.ws_bytes,
                                          _p(b["isect_offsets"]), self.cap, self.cap_tile, _p(b["keys_tmp"]), _p(b["slot_gid"]),
                                          _p(b["cum_tiles"]), None, _p(b["flatten_ids"]), _p(b["slots"])), "gs_bin_emit_sort")
         self._ck(L.gs_blend_fwd(st, 1, W, H, _p(b["rec"]), _p(b["bg"]), _p(b["isect_offsets"]),
@@ -541,7 +603,7 @@ class TrainStepGraph:
                 offs = (ct.c_int64 * 6)(*opt._offs)
                 self._ck(L.gs_project_bwd_adam(st, N, self.K, int(m.active_sh_degree), _p(opt.flat_param), _p(opt.exp_avg),
                                                _p(opt.exp_avg_sq), offs, _p(b["viewmats"]), _p(b["Ks"]), W, H, 0.3, 0.01, 1e10,
-                                               _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]),
+                                               _p(b["radii"]), _p(b["colors_post"]), self._tpg(), _p(b["cum_tiles"]),
                                                _p(b["rows"]), _p(b["row_base"]), _p(b["qmask"]), _p(b["v_abs"]), float(b1), float(b2),
                                                float(opt.defaults["eps"]), _p(b["hyper"]), _p(b["applied"]), _p(m.max_radii),
                                                _p(m.grad_norm_accum), _p(m.collecting_counts), _p(b["sh_jac"])), "gs_project_bwd_adam")
@@ -549,7 +611,7 @@ class TrainStepGraph:
                 g = self.grads
                 self._ck(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales),
                                           _p(m.sh_0), _p(m.sh_rest) if self.K > 1 else None, 0, _p(b["viewmats"]), _p(b["Ks"]), W, H,
-                                          0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]),
+                                          0.3, 0.01, 1e10, _p(b["radii"]), _p(b["colors_post"]), self._tpg(),
                                           _p(b["cum_tiles"]), _p(b["rows"]), _p(b["row_base"]), _p(b["qmask"]), _p(g["means"]), _p(g["quats"]),
                                           _p(g["log_scales"]), _p(g["logit_opacities"]), _p(g["sh_0"]), _p(g["sh_rest"]), _p(b["v_abs"]),
                                           None, None, None, None, _p(m.logit_opacities), 1, _p(b["sh_jac"]), None, None, None), "gs_project_bwd")
@@ -568,6 +630,7 @@ class TrainStepGraph:
             pass
         finally:
             L.gs_guard_set(None, 0, 0)
+            L.gs_rounds_set(None, None, None, None, 0)
 
     def _tail(self, t: int, lrs):
         """What a step enqueues behind its graph (nothing: the single-GPU step is the graph)."""
@@ -814,7 +877,7 @@ class TrainStepGraph:
                     capacity_isects=self.cap, capacity_tile_list=self.cap_tile, capacity_work_units=self.cap_units,
                     capacity_rows=self.cap_rows, probed_work_units=self.probed_walk[0], probed_rows=self.probed_walk[1],
                     seen_work_units=self.seen_units, seen_rows=self.seen_rows, steps=self.confirmed,
-                    graph=self.graph is not None)
+                    graph=self.graph is not None, rounds=bool(self.rounds_on), round_fraction=self.round_fraction if self.rounds_on else None)
 
 
 class ViewParallelGraphStep(TrainStepGraph):
@@ -869,7 +932,7 @@ class ViewParallelGraphStep(TrainStepGraph):
                                      _p(b["ckpt"]), _p(b["qmask"]), _p(b["row_base"]), _p(b["walk_state"]),
                                      _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"])), "gs_blend_bwd")
             sp = send.data_ptr()
-            self._ck(L.gs_row_sums(st, 1, N, _p(b["radii"]), _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]), _p(b["rows"]),
+            self._ck(L.gs_row_sums(st, 1, N, _p(b["radii"]), _p(b["colors_post"]), self._tpg(), _p(b["cum_tiles"]), _p(b["rows"]),
                                     _p(b["row_base"]), _p(b["qmask"]), _p(b["row_sums"]), sp, sp + 4 * 3 * N, float(max(H, W)), _p(b["viewmats"]),
                                     sp + 4 * 4 * N), "gs_row_sums")
             # this rank's guard flag: into its record and into the bucket (both collectives carry it)
@@ -878,6 +941,7 @@ class ViewParallelGraphStep(TrainStepGraph):
             pass
         finally:
             L.gs_guard_set(None, 0, 0)
+            L.gs_rounds_set(None, None, None, None, 0)
 
     def _tail(self, t: int, lrs):
         """Behind the graph: the two collectives and the four launches that apply the step (on the runner's stream)."""
@@ -895,7 +959,7 @@ class ViewParallelGraphStep(TrainStepGraph):
         try:
             nat.check(L.gs_project_bwd(st, 1, N, self.K, int(m.active_sh_degree), _p(m.means), _p(m.quats), _p(m.log_scales), _p(m.sh_0),
                                        _p(m.sh_rest) if self.K > 1 else None, 0, _p(b["viewmats"]), _p(b["Ks"]), W, H, 0.3, 0.01, 1e10, _p(b["radii"]),
-                                       _p(b["colors_post"]), _p(b["tiles_per_gauss"]), _p(b["cum_tiles"]), _p(b["rows"]), _p(b["row_base"]), _p(b["qmask"]),
+                                       _p(b["colors_post"]), self._tpg(), _p(b["cum_tiles"]), _p(b["rows"]), _p(b["row_base"]), _p(b["qmask"]),
                                        seg(0, 3 * N), seg(2, 4 * N), seg(1, 3 * N), seg(3, N), None, None, _p(b["v_abs"]), None, None, None, None,
                                        _p(m.logit_opacities), 1, _p(b["sh_jac"]), _p(b["row_sums"]), seg(4, N), seg(5, N)), "gs_project_bwd")
             w_sum = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=vp.group, async_op=True)
@@ -923,6 +987,7 @@ class ViewParallelGraphStep(TrainStepGraph):
                                        self.LOSS_RING, _p(b["walk_state"])), "gs_step_status")
         finally:
             L.gs_guard_set(None, 0, 0)
+            L.gs_rounds_set(None, None, None, None, 0)
 
     def _poll(self, block: bool):
         # every rank must find an overflow at the SAME step: the status words are read behind a synchronisation, never early

@@ -110,6 +110,50 @@ int gs_guard_flag_out(void* stream, const int64_t* info_dev, float* dst0, float*
 int gs_guard_merge(void* stream, int64_t* info_dev, const float* flags, int n, int64_t stride);
 int gs_step_applied(void* stream, const int64_t* info_dev, int64_t* applied_dev);
 
+/* Depth rounds: refine-on-demand list stages (a per-tile order equal to the stable global sort is
+ * contract-equivalent).  On realistic footprints 97-98 % of what the list stages count, emit and sort is never read: a tile
+ * saturates a few hundred entries into a list of thousands.  With rounds the frame's Gaussians are split at a depth quantile
+ * (gs_round_split): the FRONT round lists, sorts and blends the nearest slab only; the BACK round lists the rest only into the
+ * tiles the front round left with live pixels (gs_round_footprints windows every footprint to them) and resumes those tiles'
+ * blend from their saved pixel states.  Every depth of the front slab is smaller than every depth behind it, so a tile walks
+ * the same entries in the same order as over one list: images, sublists, checkpoints and gradient rows are bit for bit those
+ * of the one-round pipeline; only lists nobody reads are never built.  A Gaussian lives in exactly one round; the back round's
+ * list entries and gradient-row slots continue behind the front round's (isect_offsets, flatten_ids, slots, qmask, row_base,
+ * unit_desc, ckpt, qlist are ONE set of buffers for both), gs_blend_bwd needs no change and the row gather of gs_project_bwd* /
+ * gs_row_sums reads a wave's rows as two ranges.
+ * gs_rounds_set (per host thread, like gs_guard_set; phase 0 clears it) tells the entry points which round they work for:
+ *   phase 1 (front round)  gs_round_footprints, gs_bin_count / gs_bin_emit_sort or gs_bins_count / gs_bins_lists, gs_blend_fwd
+ *   phase 2 (back round)   the same calls again, on the same buffers
+ *   phase 3 (behind both)  gs_project_bwd, gs_project_bwd_adam, gs_row_sums
+ * Per round the caller passes the footprints gs_round_footprints wrote (bbox_round) to the list stages, and to the backward the
+ * tiles_per_gauss it wrote (a Gaussian's count in ITS round).  Under phase 1 / 2 the list entry points require C == 1.
+ *   rounds_dev[GS_ROUND_WORDS] i64   device block: see GS_ROUND_*; written by gs_round_split and the list stages
+ *   tile_live[tiles] u8             1: the front round left the tile with live pixels
+ *   tile_state[tiles*4*64*4] f32    pixel states (T, r, g, b) of the live tiles
+ *   tile_rec[tiles*8] i32           training: lengths of the quadrant sublists and their part-filled work units (NULL: inference)
+ * gs_blend_fwd in phase 1 clears the quadrant masks and the walk state and leaves the row-base scan to phase 2; render_colors /
+ * render_alphas are complete after phase 2 (phase 1 writes every tile, phase 2 re-writes the tiles it resumes).  When the
+ * front round leaves no live tile (rounds_dev[GS_ROUND_LIVE] == 0) the kernels of the back round return at once. */
+#define GS_ROUND_BASE 0      /* list entries (= gradient-row slots) of the front round: the back round continues here */
+#define GS_ROUND_SPLIT 1     /* depth split as float bits: a Gaussian is in the front round when its depth bits are below */
+#define GS_ROUND_LIVE 2      /* tiles the front round left with live pixels */
+#define GS_ROUND_FRONT_N 3   /* visible Gaussians in the front round (diagnostic) */
+#define GS_ROUND_WORDS 8
+int gs_rounds_set(int64_t* rounds_dev, uint8_t* tile_live, float* tile_state, int32_t* tile_rec, int phase);
+/* Depth split of a frame (C == 1): the smallest depth bin edge d such that the Gaussians nearer than d hold at least `fraction`
+ * of the frame's listed intersections (histogram over the float bits >> 19: 16 bins per octave; weights tiles_per_gauss).
+ * Writes rounds_dev[GS_ROUND_SPLIT] and zeroes GS_ROUND_BASE / GS_ROUND_LIVE.  hist_ws: 4096 u32 of scratch, ZERO on first use
+ * (the call leaves it zero).  fraction >= 1: everything is front. */
+int gs_round_split(void* stream, int64_t N, const float* depths, const int32_t* tiles_per_gauss, float fraction,
+                   uint32_t* hist_ws, int64_t* rounds_dev);
+/* Footprints of the current round (gs_rounds_set phase 1 or 2), in gs_project_fwd's bbox layout: phase 1 keeps the footprints
+ * of the front slab and empties the others; phase 2 keeps those of the Gaussians behind the split, windowed to the live tiles
+ * (footprints of <= 32 tiles: dead tiles leave the mask; larger ones shrink to the bounding rectangle of their live tiles, and
+ * get a mask when that holds <= 32 tiles).  tiles_per_gauss_round[N]: phase 1 writes every count (0 behind the split), phase 2
+ * only those of the Gaussians behind the split -- afterwards it holds every Gaussian's count in its own round. */
+int gs_round_footprints(void* stream, int64_t N, int tile_w, int tile_h, const uint32_t* bbox, const float* depths,
+                        uint32_t* bbox_round, int32_t* tiles_per_gauss_round);
+
 /* Publishes a guarded step's outcome without a copy or an event: one tiny launch writes
  * status[0..3] = info_dev[0..3] ({I, n_buckets, max tile, flags}), status[4] = applied_dev[0] (may be NULL) and -- walk_state
  * (gs_blend_fwd's, may be NULL) -- status[5] = storage units taken, status[6] = gradient rows: what the walk needed.

@@ -56,7 +56,7 @@ def test_forward_and_backward_round_alpha_and_transmittance_with_the_same_instru
     it re-derives who contributed from alpha and T' = fma(-alpha, T, T), which must therefore round exactly as in the forward.
     The source spells both alike, but the library is built with -ffp-contract=fast -- a compiler that fused one kernel's
     multiply-adds differently would show up only as scattered gradient noise.  So: compile gs_blend.hip to ISA with the
-    Makefile's flags and compare, across the three kernels, the expression tree under every v_exp_f32 (tests/isa_slices.py)."""
+    Makefile's flags and compare, across the seven kernels, the expression tree under every v_exp_f32 (tests/isa_slices.py)."""
     import subprocess
     import isa_slices as ISA
     csrc = native.CSRC_DIR
@@ -66,7 +66,8 @@ def test_forward_and_backward_round_alpha_and_transmittance_with_the_same_instru
     subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", os.path.join(csrc, "gs_blend.hip"), "-o", str(out)],
                    check=True, capture_output=True, cwd=csrc)
     ks = {k: v for k, v in ISA.kernels(out.read_text()).items() if "blend_" in k}
-    assert len(ks) == 3 and sum("blend_bwd" in k for k in ks) == 1 and sum("blend_fwd" in k for k in ks) == 2, list(ks)
+    # (the forward: training / inference x one list per tile, front round, back round of the depth rounds)
+    assert len(ks) == 7 and sum("blend_bwd" in k for k in ks) == 1 and sum("blend_fwd" in k for k in ks) == 6, list(ks)
     trees = set()
     for name, ins in ks.items():
         slices = ISA.sigma_alpha_slices(ins)
