@@ -926,8 +926,17 @@ def run_rank(args) -> int:
                                   # peak of the process while the runner was built and stepped; of which the runner's own
                                   # workspace (everything beyond model + optimizer state + target), in bytes per LISTED intersection
                                   "peak_GiB": round(peak / 2 ** 30, 2), "runner_GiB": round((peak - held) / 2 ** 30, 2),
-                                  "runner_bytes_per_listed_isect": round((peak - held) / listed, 1)}
+                                  "runner_bytes_per_listed_isect": round((peak - held) / listed, 1),
+                                  # depth rounds (TrainStepGraph rounds="auto"): on where the frame lists several times what its blend walks
+                                  "depth_rounds": bool(rep.get("rounds")), "round_fraction": rep.get("round_fraction"),
+                                  "listed_per_step": int(runner.buf["info"][0])}
                     del runner
+                    if outs[mode]["depth_rounds"]:   # ... and the same step with the list stages in ONE round, same box, same minute
+                        runner = TrainStepGraph(mx, ox, LossComputer(lambda_ssim=0.2, clamp_input=True), dx, gx, None, rounds="off")
+                        e1, _, s1, _ = timed_loop(runner.step, n_steps, 5, finish=runner.finish, ev_stream=runner.stream)
+                        outs[mode]["one_round"] = {"train_iters_per_s": round(n_steps / e1, 2), "train_ms": _percentiles(s1),
+                                                   "listed_per_step": int(runner.buf["info"][0])}
+                        del runner
                 # roofline of the dominant kernel on THIS workload, priced on the entries the kernel actually walked (VERDICT r4
                 # missing #4): a saturated tile abandons the rest of its list, so bytes per LISTED entry over the launch time would
                 # exceed the HBM peak on the long-list scenes.  Eager steps (model mirror + HIP loss + fused Adam), HIP events
@@ -1163,6 +1172,9 @@ def run_rank(args) -> int:
             "real_loop_it_s": {k: _g(result, "real_loop", k, "train_iters_per_s") for k in ("captured", "eager")},
             "e2e": {"psnr": _g(result, "e2e", "captured", "psnr"), "it_s": _g(result, "e2e", "captured", "train_iters_per_s"), "n_final": _g(result, "e2e", "captured", "n_gaussians_final")},
             "configs_it_s_gsplat_lists_tight": {k: [_g(v, "gsplat_eager", "train_iters_per_s"), _g(v, "tight", "train_iters_per_s")] for k, v in cfgs.items() if isinstance(v, dict)},
+            # [it/s with the list stages in one round, in two depth rounds] where TrainStepGraph's rounds="auto" turned them on (tight lists)
+            "configs_it_s_one_round_vs_depth_rounds": {k: [_g(v, "tight", "one_round", "train_iters_per_s"), _g(v, "tight", "train_iters_per_s")]
+                                                       for k, v in cfgs.items() if isinstance(v, dict) and _g(v, "tight", "depth_rounds")},
             "configs_peak_GiB": {k: _g(v, "gsplat_eager", "peak_GiB") for k, v in cfgs.items() if isinstance(v, dict)},
             "configs_runner_bytes_per_listed_isect": {k: _g(v, "gsplat_eager", "runner_bytes_per_listed_isect") for k, v in cfgs.items() if isinstance(v, dict)},
             "roofline_frac": _g(result, "roofline", "frac"), "cpu_baseline_it_s": _g(result, "cpu_baseline", "value")}
