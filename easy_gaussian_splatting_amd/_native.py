@@ -27,7 +27,7 @@ GS_BUCKET = 64
 GS_UNIT = 32
 GS_REC_FLOATS = 12
 GS_ROW_FLOATS = 12
-GS_ROUND_BASE, GS_ROUND_SPLIT, GS_ROUND_LIVE, GS_ROUND_FRONT_N, GS_ROUND_WORDS = 0, 1, 2, 3, 8   # words of a depth-rounds block
+GS_ROUND_BASE, GS_ROUND_SPLIT, GS_ROUND_LIVE, GS_ROUND_FRONT_N, GS_ROUND_LISTED_ALL, GS_ROUND_WORDS = 0, 1, 2, 3, 4, 8   # words of a depth-rounds block
 
 _lib: Optional[ct.CDLL] = None
 _lock = threading.Lock()

@@ -273,13 +273,15 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
         isect_offsets[n_tiles_total] = (int32_t)carry_i;
         bucket_offsets[n_tiles_total] = (int32_t)carry_b;
         if (phase == 1) rblk[GS_ROUND_BASE] = (int64_t)carry_i;
+        if (phase != 0) info[7] = rblk[GS_ROUND_LISTED_ALL];   // (what one round would have listed: the callers' footprint statistics)
         if (phase == 2) mm = max(mm, (uint32_t)info[2]);   // (the longest list of either round)
         info[0] = (int64_t)carry_i; info[1] = (int64_t)carry_b; info[2] = (int64_t)mm;
         if (cap_isects > 0) {
             // guarded step (gs_guard_set): flags are sticky -- once a step does not fit, this and every later
             // step is a no-op until the host has re-sized the buffers and cleared the word
             const int64_t f = ((int64_t)carry_i > cap_isects ? 1 : 0) | ((int64_t)mm > cap_tile ? 2 : 0);
-            if (per_call) info[3] = (info[3] & keep_mask) | f;   // (gs_guard_set_call: whatever an earlier call left is overwritten)
+            // (gs_guard_set_call: whatever an earlier CALL left is overwritten -- by the front round when there are two)
+            if (per_call && phase != 2) info[3] = (info[3] & keep_mask) | f;
             else if (f) info[3] |= f;
         } else {
             info[3] = keep_mask ? (info[3] & keep_mask) : 0;   // (two-level binning: the coarse stage's overflow bit survives)
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(kBinThreads) void bins_scan_kernel(int n_bins_total
             info[4] = (int64_t)carry; info[5] = (int64_t)mm; info[6] = (int64_t)ccarry;
         }
         const int64_t f = ((int64_t)carry > coarse_cap ? 4 : 0) | ((int64_t)mm > list_cap ? 8 : 0);
-        if (guarded) { if (f) info[3] |= f; }
+        if (guarded || phase == 2) { if (f) info[3] |= f; }   // (the back round of a call adds to the front round's flags)
         else info[3] = f;
     }
 }

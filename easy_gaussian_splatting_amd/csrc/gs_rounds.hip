@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kRoundThreads) void round_select_kernel(uint32_t* _
     if (threadIdx.x == 0) {
         const bool all = !(fraction < 1.f) || total == 0ull || s_bin >= kDepthBins - 1;
         blk[GS_ROUND_SPLIT] = all ? (int64_t)0x7f800000 : ((int64_t)(s_bin + 1) << kDepthShift);
-        blk[GS_ROUND_BASE] = 0; blk[GS_ROUND_LIVE] = 0; blk[GS_ROUND_FRONT_N] = 0;
+        blk[GS_ROUND_BASE] = 0; blk[GS_ROUND_LIVE] = 0; blk[GS_ROUND_FRONT_N] = 0; blk[GS_ROUND_LISTED_ALL] = (int64_t)total;
     }
 }
 

@@ -89,6 +89,7 @@ def reset_hints() -> None:
     with _state_lock:
         _hints.clear()
         _coarse_hint.clear()
+        _round_bufs.clear()
     WS.pool.clear()
 
 
@@ -142,7 +143,46 @@ def binning_choice(footprint, tiles: int = 0) -> str:
 
 # host-side diagnostics: time spent blocked on the list-size read-back (bench.py reports it; a wait
 # near zero means the host, not the GPU, paces the loop)
-stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0, "overflow_reruns": 0, "walk_reruns": 0, "deferred_calls": 0, "late_overflows": 0}
+stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0, "overflow_reruns": 0, "walk_reruns": 0, "deferred_calls": 0, "late_overflows": 0,
+         "round_calls": 0}
+
+
+# Depth rounds in the eager seam (include/gs_raster.h "Depth rounds"; the captured train step has its own switch,
+# TrainStepGraph(rounds=...)): INFERENCE calls with one camera whose lists are long enough for the two-level binning run the list
+# stages and the blend in two rounds -- the front slab by depth, then the rest only into tiles it has not finished.  Same image bit
+# for bit; the lists nobody reads are never built.  GS_ROUNDS: "auto" (default: on for a call shape whose first, one-round call
+# listed >= ROUNDS_MIN_LISTED entries through the two-level binning), "on", "off".  GS_ROUND_FRACTION: share of the listed
+# intersections in front of the depth split.
+ROUNDS_MIN_LISTED = 4_000_000
+ROUND_FRACTION = float(os.environ.get("GS_ROUND_FRACTION", "0.125"))
+_round_bufs: Dict[tuple, dict] = {}   # per (device, stream, N, tiles): what lives between the rounds of a call
+
+
+def rounds_mode() -> str:
+    mode = os.environ.get("GS_ROUNDS", "auto")
+    if mode not in ("auto", "on", "off"):
+        raise ValueError(f"GS_ROUNDS must be 'auto', 'on' or 'off', got {mode!r}")
+    return mode
+
+
+def _round_buffers(dev: torch.device, st: int, N: int, tiles: int) -> dict:
+    """The round block, the depth histogram (zero between calls), the tiles' liveness and pixel states, the footprints and
+    counts of the round at hand: one set per (device, stream) -- calls on one stream follow one another --, re-made when the
+    call shape changes."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), st)
+    with _state_lock:
+        b = _round_bufs.get(key)
+    if b is None or b["N"] != N or b["tiles"] != tiles:
+        b = {"N": N, "tiles": tiles,
+             "blk": torch.zeros((nat.GS_ROUND_WORDS,), dtype=torch.int64, device=dev),
+             "hist": torch.zeros((4096,), dtype=torch.int32, device=dev),
+             "live": torch.zeros((tiles,), dtype=torch.uint8, device=dev),
+             "state": torch.empty((tiles, 4, 64, 4), dtype=torch.float32, device=dev),
+             "bbox": torch.empty((N, 4), dtype=torch.int32, device=dev),
+             "tpg": torch.empty((N,), dtype=torch.int32, device=dev)}
+        with _state_lock:
+            _round_bufs[key] = b
+    return b
 
 
 def _quantize_up(x: int) -> int:
@@ -389,6 +429,45 @@ class _ReferenceLists:
         return out
 
 
+class _OneRoundLists:
+    """The list arrays of a call that rendered in two depth rounds, built when somebody reads them: the per-tile pipeline, in one
+    round, on the footprints and depths the projection left (blocking; the arrays a one-round call of the same mode hands out)."""
+
+    def __init__(self, lease, depths: Tensor, C: int, N: int, tw: int, th: int):
+        self.lease, self.depths, self.shape, self.out = lease, depths, (C, N, tw, th), None
+
+    def get(self, key: str) -> Tensor:
+        if self.out is None:
+            self.out = self._build()
+        return self.out[key]
+
+    def _build(self) -> Dict[str, Tensor]:
+        C, N, tw, th = self.shape
+        tiles = tw * th
+        if tiles > MAX_TILES_PER_TILE_PIPELINE:
+            raise NotImplementedError("list arrays of a two-round call at this image size: render with GS_ROUNDS=off to read them")
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("meta's list arrays of a two-round call are built on first access with a host read-back: read them "
+                               "before the capture starts, or render with GS_ROUNDS=off")
+        L, dev = nat.lib(), self.depths.device
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            i32 = dict(dtype=torch.int32, device=dev)
+            ws_bytes = int(L.gs_bin_workspace_bytes(C, N, tw, th))
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            offs, bko, info = torch.empty((C * tiles + 1,), **i32), torch.empty((C * tiles + 1,), **i32), torch.zeros((8,), dtype=torch.int64, device=dev)
+            host = torch.zeros((4,), dtype=torch.int64)
+            bbox = self.lease.ptr(WS.BBOX)
+            nat.check(L.gs_bin_count(st, C, N, tw, th, bbox, ws.data_ptr(), ws_bytes, offs.data_ptr(), bko.data_ptr(), None, info.data_ptr(),
+                                     host.data_ptr()), "gs_bin_count")
+            n_isects, max_tile = int(host[0]), int(host[2])
+            keys = torch.empty((max(n_isects, 1),), dtype=torch.int64, device=dev)
+            flat, cum = torch.empty((max(n_isects, 1),), **i32), torch.empty((C * N,), **i32)
+            nat.check(L.gs_bin_emit_sort(st, C, N, tw, th, bbox, self.depths.data_ptr(), ws.data_ptr(), ws_bytes, offs.data_ptr(), n_isects,
+                                         max(max_tile, 1), keys.data_ptr(), None, cum.data_ptr(), None, flat.data_ptr(), None), "gs_bin_emit_sort")
+        return {"flatten_ids": flat[:n_isects], "isect_offsets": offs[: C * tiles].view(C, th, tw)}
+
+
 def _sort_class(n: int) -> int:
     """Capacity of the smallest per-tile sort class that takes a list of n entries (gs_binning.hip: launch_list_sorts)."""
     for c in (1024, 4096, 8192, 16384):
@@ -442,6 +521,12 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         hint = dict(_hints.get(hint_key, {}))
     two_level = binning_choice(hint.get("footprint"), tiles) == "bins"
     shift = bin_shift_for(hint.get("footprint")) if two_level else 0
+    # depth rounds: inference, one camera, long lists (see ROUNDS_MIN_LISTED above); the decision of a call shape is taken from
+    # what its one-round calls listed and kept (a two-round call reports the short total of its two rounds)
+    rmode = cfg.get("rounds") or rounds_mode()
+    rounds = (not need_grad) and C == 1 and N > 0 and rmode != "off" and (rmode == "on" or (
+        two_level and int(hint.get("n", -1)) == N and int(hint.get("listed_one_round", 0)) >= ROUNDS_MIN_LISTED))
+    rb = _round_buffers(dev, st, N, tiles) if rounds else None
     eager_ids = os.environ.get("GS_EAGER_ISECT_IDS") == "1"   # (default: meta builds isect_ids on first access, _LazyMeta)
     factorised = cfg.get("sh_grads") == "colors_pre"
     flags = (WS.F_TRAIN if need_grad else 0) | (WS.F_TWO_LEVEL if two_level else 0) | (WS.F_ISECT_IDS if eager_ids else 0)
@@ -481,23 +566,26 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
             P(WS.COLORS_POST), P(WS.REC), P(WS.BBOX), P(WS.TILES_PER_GAUSS), _ptr(rect_ref),
             P(WS.SH_JAC) if use_jac else None), "gs_project_fwd"))
 
+    def bbox_ptr():   # the footprints the list stages read: the projection's, or (depth rounds) those of the round at hand
+        return rb["bbox"].data_ptr() if rounds else P(WS.BBOX)
+
     def count():
         if two_level:
-            nat.check(L.gs_bins_count(st, C, N, tw, th, shift, P(WS.BBOX), _ptr(depths), P(WS.BIN), bin_bytes(),
+            nat.check(L.gs_bins_count(st, C, N, tw, th, shift, bbox_ptr(), _ptr(depths), P(WS.BIN), bin_bytes(),
                                       P(WS.COARSE_KEYS), coarse_cap, coarse_list_cap, P(WS.CUM_TILES), P(WS.ISECT_OFFSETS),
                                       P(WS.BUCKET_OFFSETS), P(WS.TILE_ORDER), P(WS.INFO), None), "gs_bins_count")
         else:
-            nat.check(L.gs_bin_count(st, C, N, tw, th, P(WS.BBOX), P(WS.BIN), bin_bytes(), P(WS.ISECT_OFFSETS),
+            nat.check(L.gs_bin_count(st, C, N, tw, th, bbox_ptr(), P(WS.BIN), bin_bytes(), P(WS.ISECT_OFFSETS),
                                      P(WS.BUCKET_OFFSETS), P(WS.TILE_ORDER), P(WS.INFO), None), "gs_bin_count")
 
     def lists_and_blend():
         if two_level:
             _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bins_lists(
-                st, C, N, tw, th, shift, P(WS.BBOX), P(WS.BIN), bin_bytes(), P(WS.COARSE_KEYS), coarse_cap,
+                st, C, N, tw, th, shift, bbox_ptr(), P(WS.BIN), bin_bytes(), P(WS.COARSE_KEYS), coarse_cap,
                 P(WS.CUM_TILES), P(WS.ISECT_OFFSETS), P(WS.ISECT_IDS), P(WS.FLATTEN_IDS), P(WS.SLOTS), P(WS.INFO)), "gs_bins_lists"))
         else:
             _stage("gs_bin_emit_sort", dev, lambda: nat.check(L.gs_bin_emit_sort(
-                st, C, N, tw, th, P(WS.BBOX), _ptr(depths), P(WS.BIN), bin_bytes(), P(WS.ISECT_OFFSETS), cap,
+                st, C, N, tw, th, bbox_ptr(), _ptr(depths), P(WS.BIN), bin_bytes(), P(WS.ISECT_OFFSETS), cap,
                 min(cap_tile, cap), P(WS.KEYS_TMP), P(WS.SLOT_GID), P(WS.CUM_TILES), P(WS.ISECT_IDS), P(WS.FLATTEN_IDS),
                 P(WS.SLOTS)), "gs_bin_emit_sort"))
         if walk is not None:
@@ -529,6 +617,24 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         # (the tile scan writes the eight info words straight into the page-locked landing buffer: no copy on the stream)
         nat.check(L.gs_info_mirror_set(info_host.data_ptr()), "gs_info_mirror_set")
         try:
+            if rounds:
+                # depth split, then count .. blend per round on the round's footprints; the size record is the back round's (the
+                # total of both; a back round with no live tile leaves the front round's record standing)
+                if sizes["attempt"] == 0 and _SPLIT_PROJECT:
+                    project(2, "gs_project_fwd_color")
+                nat.check(L.gs_round_split(st, N, _ptr(depths), P(WS.TILES_PER_GAUSS), ROUND_FRACTION, rb["hist"].data_ptr(), rb["blk"].data_ptr()),
+                          "gs_round_split")
+                for phase in (1, 2):
+                    nat.check(L.gs_rounds_set(rb["blk"].data_ptr(), rb["live"].data_ptr(), rb["state"].data_ptr(), None, phase), "gs_rounds_set")
+                    _stage("gs_round_footprints", dev, lambda: nat.check(L.gs_round_footprints(
+                        st, N, tw, th, P(WS.BBOX), _ptr(depths), rb["bbox"].data_ptr(), rb["tpg"].data_ptr()), "gs_round_footprints"))
+                    _stage("gs_bin_count", dev, count)
+                    if phase == 2:
+                        nat.check(L.gs_info_mirror_set(None), "gs_info_mirror_set")
+                        ev = torch.cuda.Event()
+                        ev.record(tstream)
+                    lists_and_blend()
+                return ev
             _stage("gs_bin_count", dev, count)
             nat.check(L.gs_info_mirror_set(None), "gs_info_mirror_set")
             ev = torch.cuda.Event()
@@ -539,6 +645,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         finally:
             L.gs_guard_set(None, 0, 0)
             L.gs_info_mirror_set(None)
+            L.gs_rounds_set(None, None, None, None, 0)
         return ev
 
     def settle(ev, whole_stream: bool) -> bool:
@@ -585,11 +692,14 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         with _state_lock:
             stats["sync_wait_ns"] += sizes["waited"]
             stats["calls"] += 1
+            stats["round_calls"] += 1 if rounds else 0
             old = _hints.get(hint_key, {})
             # the capacity follows the largest recent frame (slow decay), so alternating views do not overflow every time
             new = dict(cap=max(n_isects + (n_isects >> 2) + 1024, int(old.get("cap", 0) * 0.995)),
                        cap_tile=max(_sort_class(max_tile + (max_tile >> 2)), int(old.get("cap_tile", 1024))), footprint=n_isects / max(1, C * N),
-                       mode="bins" if two_level else "tiles", n=N)
+                       mode="bins" if two_level else "tiles", n=N, listed_one_round=n_isects)
+            if rounds:   # (what one round would have listed, info[7]: the pipeline choice and the rounds decision follow the frame, not the rounds)
+                new["footprint"], new["listed_one_round"] = info[7] / max(1, C * N), info[7]
             if two_level:
                 new.update(entries=max(info[4] + (info[4] >> 2) + 1024, int(old.get("entries", 0) * 0.995)),
                            longest=max(info[5] + (info[5] >> 2) + 64, int(old.get("longest", 0) * 0.995)))
@@ -651,6 +761,13 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
                         "isect_ids": lazy(lambda: ref_lists.get("isect_ids")) if eager_ids else _LazyMeta.PENDING,
                         "flatten_ids": lazy(lambda: ref_lists.get("flatten_ids")),
                         "isect_offsets": lazy(lambda: ref_lists.get("isect_offsets"))}
+    elif rounds:
+        # a two-round call never builds the frame's one-round lists: a caller that reads them has them built then, from the
+        # footprints the projection left (blocking; same arrays as a one-round call's)
+        one = _OneRoundLists(lease, depths, C, N, tw, th)
+        list_entries = {"tiles_per_gauss": lazy(lambda: lease.view(WS.TILES_PER_GAUSS, C * N).clone().view(C, N)),
+                        "isect_ids": _LazyMeta.PENDING, "flatten_ids": lazy(lambda: one.get("flatten_ids")),
+                        "isect_offsets": lazy(lambda: one.get("isect_offsets"))}
     else:
         list_entries = {
             # list arrays: copied out of the workspace on first access (the lease is kept alive by this dict)
@@ -933,6 +1050,7 @@ def rasterization(
     _on_colors_pre=None,
     _activations: str = "none",
     _size_check: Optional[str] = None,
+    _rounds: Optional[str] = None,
     _grad_out: Optional[Dict[str, Tensor]] = None,
     _view_payload: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
@@ -978,6 +1096,12 @@ def rasterization(
     in ONE launch right after the blend backward, with this rank's record of the view-parallel all-gather: [3N pre-clamp colour
     gradients | N radii / max(W, H) (0 for culled Gaussians) | the 16 floats of the view matrix] (`gs_row_sums`;
     `meta["means2d"].colors_pre_grad` is then a view of its first segment).
+
+    `_rounds` ("auto" | "on" | "off"; default: env GS_ROUNDS or "auto"): depth rounds of the list stages for INFERENCE calls with
+    one camera -- the front slab by depth is listed, sorted and blended first, the rest only into tiles it has not finished
+    (include/gs_raster.h "Depth rounds"; same image bit for bit).  "auto": on for a call shape whose one-round call listed
+    >= 4 M intersections through the two-level binning.  With `_tile_culling="tight"` / `"gsplat_eager"` the list arrays in
+    `meta` of such a call are built (in one round, blocking) when they are first read.
 
     `_size_check` ("immediate" | "deferred"; default: env GS_SIZE_CHECK or "immediate"): when the host looks at the list sizes
     the count kernels reported.  "immediate": before the call returns (one host wait per forward, never a stream drain).
@@ -1037,6 +1161,8 @@ def rasterization(
     size_check = _size_check or os.environ.get("GS_SIZE_CHECK", "immediate")
     if size_check not in ("immediate", "deferred"):
         raise ValueError("_size_check: 'immediate' or 'deferred'")
+    if _rounds not in (None, "auto", "on", "off"):
+        raise ValueError("_rounds: 'auto', 'on' or 'off'")
     flush_size_checks()   # (size records of earlier deferred calls on this thread: looked at -- and repaired -- in order)
 
     def prep(t: Tensor) -> Tensor:
@@ -1055,7 +1181,7 @@ def rasterization(
                sh_degree=sh_degree, tile_culling={"gsplat": 1, "tight": 1, "gsplat_eager": 0}[_tile_culling],
                lazy_ref_lists=_tile_culling == "gsplat", sh_grads=_sh_grads,
                activations={"none": 0, "exp_sigmoid": 1}[_activations], grad_enabled=torch.is_grad_enabled(),
-               defer_size_check=size_check == "deferred")
+               defer_size_check=size_check == "deferred", rounds=_rounds)
     if _sh_grads not in ("dense", "colors_pre") or (_sh_grads == "colors_pre" and sh_degree is None):
         raise ValueError("_sh_grads: 'dense', or 'colors_pre' together with sh_degree")
     holder = _Holder(absgrad)

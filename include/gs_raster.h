@@ -138,6 +138,7 @@ int gs_step_applied(void* stream, const int64_t* info_dev, int64_t* applied_dev)
 #define GS_ROUND_SPLIT 1     /* depth split as float bits: a Gaussian is in the front round when its depth bits are below */
 #define GS_ROUND_LIVE 2      /* tiles the front round left with live pixels */
 #define GS_ROUND_FRONT_N 3   /* visible Gaussians in the front round (diagnostic) */
+#define GS_ROUND_LISTED_ALL 4 /* what the frame would list in ONE round (sum of tiles_per_gauss); the tile scans of both rounds copy it to info_dev[7] */
 #define GS_ROUND_WORDS 8
 int gs_rounds_set(int64_t* rounds_dev, uint8_t* tile_live, float* tile_state, int32_t* tile_rec, int phase);
 /* Depth split of a frame (C == 1): the smallest depth bin edge d such that the Gaussians nearer than d hold at least `fraction`
@@ -178,7 +179,7 @@ int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied
  * below; a call whose lists outgrow the capacity (info flags, see gs_guard_set) replaces the list arena only and repeats
  * gs_bin_count .. gs_blend_fwd; a training call whose walk outgrows cap_units / cap_rows replaces the walk arena only and repeats
  * gs_blend_fwd. */
-#define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, -} */
+#define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, one-round I of a call in depth rounds} */
 #define GS_WS_REC 1             /* f32 [C*N][12] */
 #define GS_WS_BBOX 2            /* u32 [C*N][4] */
 #define GS_WS_TILES_PER_GAUSS 3 /* i32 [C*N] */

@@ -3,8 +3,6 @@ rounds -- the front slab by depth, then the rest only into tiles the front slab 
 entries in the same order as over one list, so the contract is the strongest there is: images, loss, quadrant sublists and
 the SET of gradient rows bit for bit those of the one-round pipeline (which tests/test_gpu_parity.py holds against the oracle);
 the per-Gaussian gradient sums equal to the rounding of a different summation tree (a wave's rows are read as two ranges)."""
-import ctypes as ct
-
 import numpy as np
 import pytest
 import torch
@@ -232,3 +230,62 @@ def test_split_and_footprints_against_numpy(tw, th):
                 assert np.array_equal(tpg_r.cpu().numpy(), want_tpg)
     finally:
         L.gs_rounds_set(None, None, None, None, 0)
+
+
+# ---- the eager seam: inference calls in two rounds ---------------------------------------------------------------------------
+@pytest.mark.parametrize("culling", ["gsplat", "tight", "gsplat_eager"])
+@pytest.mark.parametrize("kind", ["sparse", "heavy"])
+def test_inference_in_two_rounds_is_the_one_round_image(kind, culling):
+    from easy_gaussian_splatting_amd import rendering
+    dev = torch.device("cuda:0")
+    sc = _scene(kind)
+    W, H = int(sc["width"]), int(sc["height"])
+    t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
+    args = (t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"][:1], t["Ks"][:1], W, H)
+    kw = dict(sh_degree=3, packed=False, backgrounds=t["backgrounds"][:1], _tile_culling=culling)
+    with torch.no_grad():
+        rendering.reset_hints()
+        n0 = rendering.stats["round_calls"]
+        for _ in range(2):   # (second call: capacities learnt from the first)
+            img_a, al_a, meta_a = rendering.rasterization(*args, _rounds="off", **kw)
+        assert rendering.stats["round_calls"] == n0
+        rendering.reset_hints()
+        for _ in range(3):
+            img_b, al_b, meta_b = rendering.rasterization(*args, _rounds="on", **kw)
+        assert rendering.stats["round_calls"] == n0 + 3
+        torch.cuda.synchronize()
+        assert torch.equal(img_a, img_b) and torch.equal(al_a, al_b)
+        for k in ("radii", "means2d", "depths", "conics", "tiles_per_gauss", "isect_offsets", "flatten_ids", "isect_ids"):
+            assert torch.equal(meta_a[k], meta_b[k]), k
+        # a call that needs gradients takes one round whatever is asked for
+        ins = [t[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "shs")]
+        with torch.enable_grad():
+            img_c, _, _ = rendering.rasterization(*ins, *args[5:], _rounds="on", **kw)
+            img_c.sum().backward()
+        assert rendering.stats["round_calls"] == n0 + 3 and torch.equal(img_c.detach(), img_a)
+    rendering.reset_hints()
+
+
+def test_inference_rounds_turn_themselves_on_for_long_lists():
+    """`_rounds="auto"` (the default): the first call of a shape lists in one round; from 4 M listed intersections through the
+    two-level binning upwards the following calls take two -- and keep doing so (their own short totals do not undo it)."""
+    from easy_gaussian_splatting_amd import rendering
+    dev = torch.device("cuda:0")
+    sc = config_heavy(seed=5, n=300_000, n_views=1)
+    W, H = int(sc["width"]), int(sc["height"])
+    t = {k: torch.from_numpy(v).to(dev) for k, v in sc.items() if isinstance(v, np.ndarray)}
+    args = (t["means"], t["quats"], t["scales"], t["opacities"], t["shs"], t["viewmats"], t["Ks"], W, H)
+    kw = dict(sh_degree=3, packed=False, backgrounds=t["backgrounds"])
+    with torch.no_grad():
+        rendering.reset_hints()
+        ref, _, meta = rendering.rasterization(*args, _rounds="off", **kw)
+        listed = int(meta["flatten_ids"].numel())
+        assert listed >= rendering.ROUNDS_MIN_LISTED, listed
+        rendering.reset_hints()
+        n0 = rendering.stats["round_calls"]
+        outs = [rendering.rasterization(*args, **kw)[0] for _ in range(5)]
+        torch.cuda.synchronize()
+        assert rendering.stats["round_calls"] - n0 >= 3 and rendering.last_binning(dev) == "bins"
+        for o in outs:
+            assert torch.equal(o, ref)
+    rendering.reset_hints()
