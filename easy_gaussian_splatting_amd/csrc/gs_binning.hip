@@ -273,7 +273,10 @@ __global__ __launch_bounds__(kBinThreads) void bin_tilescan_kernel(
         isect_offsets[n_tiles_total] = (int32_t)carry_i;
         bucket_offsets[n_tiles_total] = (int32_t)carry_b;
         if (phase == 1) rblk[GS_ROUND_BASE] = (int64_t)carry_i;
-        if (phase != 0) info[7] = rblk[GS_ROUND_LISTED_ALL];   // (what one round would have listed: the callers' footprint statistics)
+        if (phase != 0) {   // (depth rounds: what one round would have listed, and how many tiles the front round left live -- 0 when
+            info[7] = rblk[GS_ROUND_LISTED_ALL];   //  this record is the front round's and no back round's follows: it was idle)
+            info[6] = phase == 2 ? rblk[GS_ROUND_LIVE] : 0;
+        }
         if (phase == 2) mm = max(mm, (uint32_t)info[2]);   // (the longest list of either round)
         info[0] = (int64_t)carry_i; info[1] = (int64_t)carry_b; info[2] = (int64_t)mm;
         if (cap_isects > 0) {

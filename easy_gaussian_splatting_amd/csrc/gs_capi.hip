@@ -70,8 +70,10 @@ extern "C" int gs_guard_set_call(const int64_t* info_dev, int64_t cap_isects, in
 namespace gs {
 __global__ void step_status_kernel(const int64_t* __restrict__ info, const int64_t* __restrict__ applied,
                                    volatile int64_t* __restrict__ status, const float* __restrict__ loss3,
-                                   float* __restrict__ loss_ring, int ring_len, const int32_t* __restrict__ walk) {
+                                   float* __restrict__ loss_ring, int ring_len, const int32_t* __restrict__ walk,
+                                   const int64_t* __restrict__ rblk) {
     if (threadIdx.x < 4) status[threadIdx.x] = info[threadIdx.x];
+    if (threadIdx.x == 7) status[7] = rblk ? rblk[GS_ROUND_LIVE] : -1;   // depth rounds: tiles the front round left live (-1: one round)
     if (threadIdx.x == 4) status[4] = applied ? applied[0] : 0;
     // what the walk of this step needed (a step the guard skipped before its blend leaves the cleared words of the step before)
     if (threadIdx.x == 5) status[5] = walk ? walk[GS_WALK_STORAGE] : 0;
@@ -90,8 +92,9 @@ extern "C" int gs_step_status(void* stream, const int64_t* info_dev, const int64
         gs::set_error("invalid argument: null pointer / empty ring");
         return GS_ERR_ARG;
     }
+    const gs::Rounds R = gs::current_rounds();
     hipLaunchKernelGGL(gs::step_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info_dev, applied_dev, status, loss3_dev,
-                       loss_ring_dev, ring_len, walk_state);
+                       loss_ring_dev, ring_len, walk_state, (const int64_t*)(R.phase == 3 ? R.blk : nullptr));
     GS_LAUNCH_CHECK("step_status_kernel");
     return GS_OK;
 }

@@ -62,24 +62,27 @@ __device__ __forceinline__ bool live_at(const unsigned long long* __restrict__ b
     return (bits[y * W64 + (x >> 6)] >> (x & 63)) & 1ull;
 }
 
-// a footprint cut down to the live tiles (bits: a row of W64 words per tile row)
-__device__ __forceinline__ uint4 window_footprint(uint4 fp, const unsigned long long* __restrict__ bits, int W64) {
-    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
-    int x0 = fp.x & 0xffff, x1 = fp.x >> 16, y0 = fp.y & 0xffff, y1 = fp.y >> 16;
-    int w = x1 - x0, rect = w * (y1 - y0);
-    if (rect <= 32) {   // a bit per tile: dead tiles leave the mask, the rectangle stays (the bits are relative to it)
-        const float inv_w = 1.0f / (float)max(w, 1);
-        uint32_t m = 0u;
-        for (uint32_t mb = fp.z; mb; mb &= mb - 1) {
-            const int i = __ffs((int)mb) - 1, yy = div_by_width(i, inv_w);
-            if (live_at(bits, W64, x0 + (i - yy * w), y0 + yy)) m |= 1u << i;
-        }
-        return m ? make_uint4(fp.x, fp.y, m, (uint32_t)__popc(m)) : none;
+// Footprints of <= 32 tiles carry a bit per tile: dead tiles leave the mask, the rectangle stays (the bits are relative to it).
+__device__ __forceinline__ uint4 window_small(uint4 fp, const unsigned long long* __restrict__ bits, int W64) {
+    const int x0 = fp.x & 0xffff, x1 = fp.x >> 16, y0 = fp.y & 0xffff;
+    const int w = x1 - x0;
+    const float inv_w = 1.0f / (float)max(w, 1);
+    uint32_t m = 0u;
+    for (uint32_t mb = fp.z; mb; mb &= mb - 1) {
+        const int i = __ffs((int)mb) - 1, yy = div_by_width(i, inv_w);
+        if (live_at(bits, W64, x0 + (i - yy * w), y0 + yy)) m |= 1u << i;
     }
-    // larger: the bounding rectangle of the live tiles inside
-    int nx0 = 1 << 20, nx1 = -1, ny0 = 1 << 20, ny1 = -1;
+    return m ? make_uint4(fp.x, fp.y, m, (uint32_t)__popc(m)) : make_uint4(0u, 0u, 0u, 0u);
+}
+
+// Larger footprints shrink to the bounding rectangle of their live tiles.  The WAVE finds it: lane l looks at tile rows y0 + l,
+// y0 + l + 64, ... of the footprint and four min / max reductions close it -- a thread walking its own footprint's rows held its
+// 63 neighbours for up to th x W64 LDS reads (the first form: 70 us per frame at 2 M Gaussians with 38 % of the tiles live).
+__device__ __forceinline__ void live_bounds_wave(int x0, int x1, int y0, int y1, const unsigned long long* __restrict__ bits, int W64,
+                                                 int& nx0, int& nx1, int& ny0, int& ny1) {
+    nx0 = 1 << 20; nx1 = -1; ny0 = 1 << 20; ny1 = -1;
     const int j0 = x0 >> 6, j1 = (x1 - 1) >> 6;
-    for (int y = y0; y < y1; ++y) {
+    for (int y = y0 + lane_id(); y < y1; y += 64) {
         for (int j = j0; j <= j1; ++j) {
             const int lo = max(x0 - 64 * j, 0), hi = min(x1 - 64 * j, 64);
             const unsigned long long mask = (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
@@ -91,9 +94,18 @@ __device__ __forceinline__ uint4 window_footprint(uint4 fp, const unsigned long 
             }
         }
     }
-    if (ny1 < 0) return none;
-    x0 = nx0; x1 = nx1 + 1; y0 = ny0; y1 = ny1 + 1;
-    w = x1 - x0; rect = w * (y1 - y0);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        nx0 = min(nx0, __shfl_xor(nx0, d, 64)); ny0 = min(ny0, __shfl_xor(ny0, d, 64));
+        nx1 = max(nx1, __shfl_xor(nx1, d, 64)); ny1 = max(ny1, __shfl_xor(ny1, d, 64));
+    }
+}
+
+// the footprint of a bounding rectangle of live tiles [x0, x1] x [y0, y1] (inclusive): a mask when it holds <= 32 tiles
+__device__ __forceinline__ uint4 box_footprint(int x0, int x1, int y0, int y1, const unsigned long long* __restrict__ bits, int W64) {
+    if (y1 < 0) return make_uint4(0u, 0u, 0u, 0u);
+    ++x1; ++y1;
+    const int w = x1 - x0, rect = w * (y1 - y0);
     uint32_t m = 0xffffffffu, cnt = (uint32_t)rect;
     if (rect <= 32) {
         m = 0u;
@@ -123,17 +135,31 @@ __global__ __launch_bounds__(kRoundThreads) void round_footprints_kernel(int64_t
         __syncthreads();
     }
     uint32_t front_n = 0;
-    for (int64_t n = (int64_t)blockIdx.x * kRoundThreads + threadIdx.x; n < N; n += (int64_t)gridDim.x * kRoundThreads) {
-        const uint4 fp = bbox[n];
-        const bool behind = fp.w != 0u && __float_as_uint(depths[n]) >= split;
+    const int64_t stride = (int64_t)gridDim.x * kRoundThreads;
+    for (int64_t base = (int64_t)blockIdx.x * kRoundThreads; base < N; base += stride) {   // (block-uniform trip count: the waves cooperate)
+        const int64_t n = base + threadIdx.x;
+        const bool in = n < N;
+        const uint4 fp = in ? bbox[n] : make_uint4(0u, 0u, 0u, 0u);
+        const bool behind = in && fp.w != 0u && __float_as_uint(depths[n]) >= split;
         uint4 o = make_uint4(0u, 0u, 0u, 0u);
         if (phase == 1) {
             if (!behind) o = fp;
-            out[n] = o; tpg[n] = (int32_t)o.w;
+            if (in) { out[n] = o; tpg[n] = (int32_t)o.w; }
             front_n += o.w != 0u ? 1u : 0u;
         } else {
-            if (behind) { o = window_footprint(fp, bits, W64); tpg[n] = (int32_t)o.w; }
-            out[n] = o;
+            const int x0 = fp.x & 0xffff, x1 = fp.x >> 16, y0 = fp.y & 0xffff, y1 = fp.y >> 16;
+            const bool large = behind && (x1 - x0) * (y1 - y0) > 32;
+            if (behind && !large) o = window_small(fp, bits, W64);
+            int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
+            for (unsigned long long todo = __ballot(large); todo; todo &= todo - 1ull) {
+                const int src = (int)__builtin_ctzll(todo);
+                int a0, a1, c0, c1;
+                live_bounds_wave(__shfl(x0, src, 64), __shfl(x1, src, 64), __shfl(y0, src, 64), __shfl(y1, src, 64), bits, W64, a0, a1, c0, c1);
+                if (lane_id() == src) { bx0 = a0; bx1 = a1; by0 = c0; by1 = c1; }
+            }
+            if (large) o = box_footprint(bx0, bx1, by0, by1, bits, W64);
+            if (behind) tpg[n] = (int32_t)o.w;
+            if (in) out[n] = o;
         }
     }
     if (phase == 1) {   // (diagnostic count: one global atomic per block -- one per wave, 32 k on one address at 2 M Gaussians, cost 0.19 ms)

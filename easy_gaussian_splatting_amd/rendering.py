@@ -154,6 +154,7 @@ stats = {"sync_wait_ns": 0, "calls": 0, "coarse_retries": 0, "overflow_reruns": 
 # listed >= ROUNDS_MIN_LISTED entries through the two-level binning), "on", "off".  GS_ROUND_FRACTION: share of the listed
 # intersections in front of the depth split.
 ROUNDS_MIN_LISTED = 4_000_000
+ROUNDS_MAX_LIVE = 0.05   # "auto": share of the tiles the front round may leave live, three calls in a row, before rounds are given up
 ROUND_FRACTION = float(os.environ.get("GS_ROUND_FRACTION", "0.125"))
 _round_bufs: Dict[tuple, dict] = {}   # per (device, stream, N, tiles): what lives between the rounds of a call
 
@@ -525,7 +526,7 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
     # what its one-round calls listed and kept (a two-round call reports the short total of its two rounds)
     rmode = cfg.get("rounds") or rounds_mode()
     rounds = (not need_grad) and C == 1 and N > 0 and rmode != "off" and (rmode == "on" or (
-        two_level and int(hint.get("n", -1)) == N and int(hint.get("listed_one_round", 0)) >= ROUNDS_MIN_LISTED))
+        two_level and int(hint.get("n", -1)) == N and int(hint.get("listed_one_round", 0)) >= ROUNDS_MIN_LISTED and not hint.get("rounds_off")))
     rb = _round_buffers(dev, st, N, tiles) if rounds else None
     eager_ids = os.environ.get("GS_EAGER_ISECT_IDS") == "1"   # (default: meta builds isect_ids on first access, _LazyMeta)
     factorised = cfg.get("sh_grads") == "colors_pre"
@@ -700,6 +701,12 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
                        mode="bins" if two_level else "tiles", n=N, listed_one_round=n_isects)
             if rounds:   # (what one round would have listed, info[7]: the pipeline choice and the rounds decision follow the frame, not the rounds)
                 new["footprint"], new["listed_one_round"] = info[7] / max(1, C * N), info[7]
+                # ... and "auto" gives rounds up for a call shape whose front slab keeps leaving tiles to the back round (info[6]: a
+                # back round that has work pays the fixed costs of the list stages twice -- train_graph.TrainStepGraph.ROUNDS_MAX_LIVE)
+                strikes = int(old.get("live_strikes", 0)) + 1 if info[6] > ROUNDS_MAX_LIVE * C * tiles else 0
+                new["live_strikes"], new["rounds_off"] = strikes, strikes >= 3
+            elif old.get("rounds_off") and int(old.get("n", -1)) == N:
+                new["rounds_off"] = True
             if two_level:
                 new.update(entries=max(info[4] + (info[4] >> 2) + 1024, int(old.get("entries", 0) * 0.995)),
                            longest=max(info[5] + (info[5] >> 2) + 64, int(old.get("longest", 0) * 0.995)))

@@ -82,6 +82,7 @@ class TrainStepGraph:
             raise ValueError("rounds: 'auto', 'on' or 'off'")
         self.rounds_mode, self.round_fraction = rounds, float(__import__("os").environ.get("GS_TG_ROUND_FRACTION", round_fraction))
         self.rounds_on = rounds == "on"
+        self._live_sum = self._live_n = 0   # tiles the front round left live, summed over the polled steps since the last build
         # copy_targets: every step takes a private copy of its target image (and mask) instead of reading the caller's tensors in
         # place -- for loaders that recycle ONE device staging buffer (`gt_buf.copy_(next)`): a target is read until its step is
         # RETIRED (the loss forward and backward of the replay, and again if an overflow recovery replays the step up to
@@ -240,8 +241,20 @@ class TrainStepGraph:
             if self.rounds_mode == "auto":
                 # listed against walked: a gradient row is one (intersection, quadrant) pair some pixel took, 1.5 per walked entry
                 self.rounds_on = n_isects >= self.ROUNDS_MIN_LISTED and n_isects >= self.ROUNDS_MIN_RATIO * max(rows, 1)
+        elif self.rounds_mode == "auto" and self.rounds_on and self._live_n > 0 and self._live_sum > self.ROUNDS_MAX_LIVE * tiles * self._live_n:
+            self.rounds_on = False   # (a re-build without a probe: the steps since the last build left too many tiles to the back round)
         self._alloc_walk()
         self._alloc_rounds()
+        if probe_walk and self.rounds_mode == "auto" and self.rounds_on:
+            # ... and only where the front slab finishes (nearly) the whole frame: a back round that has work pays the passes over
+            # the footprints and the fixed costs of the list stages a second time -- with 38 % of the tiles still live the two-round
+            # step is 4-9 % SLOWER than one round (tools/rounds_time.py heavy2Mwin), with 7 % it breaks even
+            self._probe_walk()
+            live = int(b["rounds"][nat.GS_ROUND_LIVE])
+            self.stats["probed_live_tiles"] = live
+            if live > self.ROUNDS_MAX_LIVE * tiles:
+                self.rounds_on = False
+        self._live_sum = self._live_n = 0
         self._key = self._state_key()
         self._opacity_resets = getattr(m, "opacity_resets", 0)
         # eager warm-up of the guarded pipeline (raises every kernel attribute; also a functional check before capture)
@@ -306,6 +319,7 @@ class TrainStepGraph:
 
     ROUNDS_MIN_LISTED = 4_000_000   # "auto": below this the list stages are too short for a second round to pay
     ROUNDS_MIN_RATIO = 4.0          # ... and so they are when the frame lists less than this many entries per gradient row
+    ROUNDS_MAX_LIVE = 0.05          # ... and rounds stay off where the front slab leaves more than this share of the tiles live
 
     def _alloc_rounds(self):
         """Depth rounds: the round block, the tiles' liveness / pixel states / sublist records between the rounds, the footprints
@@ -814,7 +828,9 @@ class TrainStepGraph:
         """Reads the device-written status words (plain host memory) and retires the steps known to be applied."""
         if block:
             self.stream.synchronize()
-        n_isects, _, max_tile, flags, applied, units, rows = (int(v) for v in self.status[:7].tolist())
+        n_isects, _, max_tile, flags, applied, units, rows, live = (int(v) for v in self.status[:8].tolist())
+        if live >= 0 and applied > 0:
+            self._live_sum, self._live_n = self._live_sum + live, self._live_n + 1
         self.seen_isects = max(self.seen_isects, n_isects)
         self.seen_tile = max(self.seen_tile, max_tile)
         self.seen_units, self.seen_rows = max(self.seen_units, units), max(self.seen_rows, rows)

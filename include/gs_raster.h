@@ -157,7 +157,8 @@ int gs_round_footprints(void* stream, int64_t N, int tile_w, int tile_h, const u
 
 /* Publishes a guarded step's outcome without a copy or an event: one tiny launch writes
  * status[0..3] = info_dev[0..3] ({I, n_buckets, max tile, flags}), status[4] = applied_dev[0] (may be NULL) and -- walk_state
- * (gs_blend_fwd's, may be NULL) -- status[5] = storage units taken, status[6] = gradient rows: what the walk needed.
+ * (gs_blend_fwd's, may be NULL) -- status[5] = storage units taken, status[6] = gradient rows: what the walk needed; status[7] =
+ * tiles the front round of the step left live (under gs_rounds_set phase 3; -1 otherwise).
  * `status` may be page-locked HOST memory (hipHostMalloc'ed, device-accessible): the host then polls plain memory
  * -- the flags are sticky and the applied-step counter monotonic, so a torn read is harmless.
  * loss_ring_dev (optional, with loss3_dev = gs_l1_ssim_fwd's out3): a device ring of ring_len x 3 floats; an APPLIED step
@@ -179,7 +180,7 @@ int gs_step_status(void* stream, const int64_t* info_dev, const int64_t* applied
  * below; a call whose lists outgrow the capacity (info flags, see gs_guard_set) replaces the list arena only and repeats
  * gs_bin_count .. gs_blend_fwd; a training call whose walk outgrows cap_units / cap_rows replaces the walk arena only and repeats
  * gs_blend_fwd. */
-#define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks, one-round I of a call in depth rounds} */
+#define GS_WS_INFO 0            /* int64[8]   {I, n_buckets, longest tile list, flags, I', longest bin list, chunks (depth rounds: tiles the front round left live), one-round I of a call in depth rounds} */
 #define GS_WS_REC 1             /* f32 [C*N][12] */
 #define GS_WS_BBOX 2            /* u32 [C*N][4] */
 #define GS_WS_TILES_PER_GAUSS 3 /* i32 [C*N] */

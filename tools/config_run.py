@@ -18,6 +18,21 @@ MAKE = {"bench1M": SY.config_bench_1m, "S3": SY.config_s3, "S5": SY.config_s5, "
 LRS = (1.6e-4, 5e-3, 1e-3, 2.5e-3, 1.25e-4, 5e-2)
 
 
+def _heavy_window(n):
+    """config_heavy with nothing in front of depth 8 in the left 40 % of the image: the front slab of a depth split finishes
+    the right part of the frame and leaves the left part live -- a frame that needs BOTH depth rounds (tools/rounds_time.py)."""
+    sc = SY.config_heavy(n=n)
+    zc = sc["means"][:, 2] + 8.0
+    keep = ~((sc["means"][:, 0] / zc < -0.12) & (zc < 8.0))
+    for k in ("means", "quats", "scales", "opacities", "shs"):
+        sc[k] = np.ascontiguousarray(sc[k][keep])
+    return sc
+
+
+MAKE["heavy2Mwin"] = lambda: _heavy_window(2_000_000)
+MAKE["heavy1Mwin"] = lambda: _heavy_window(1_000_000)
+
+
 def model_from_scene(sc, dev):
     T = torch.from_numpy
     op = np.clip(sc["opacities"], 1e-4, 1 - 1e-4)
