@@ -289,3 +289,106 @@ def test_inference_rounds_turn_themselves_on_for_long_lists():
         for o in outs:
             assert torch.equal(o, ref)
     rendering.reset_hints()
+
+
+# ---- corners ---------------------------------------------------------------------------------------------------------------
+def _model_and_views(sc, dev, n_views):
+    T = torch.from_numpy
+    op = np.clip(sc["opacities"], 1e-3, 1 - 1e-3)
+    shs = T(sc["shs"])
+    W, H = int(sc["width"]), int(sc["height"])
+
+    def make():
+        m = GaussianModel(means=T(sc["means"]), log_scales=torch.log(T(sc["scales"])), quats=T(sc["quats"]),
+                          sh_0=shs[:, :1].contiguous(), sh_rest=shs[:, 1:].contiguous(),
+                          logit_opacities=T(np.log(op / (1 - op)).astype(np.float32)), sh_degree=3, white_background=False).to(dev)
+        return m, build_optimizers(m, *LRS, fused="hip")
+
+    datas = [{"w2c": T(sc["viewmats"][v]).to(dev), "K": T(sc["Ks"][v]).to(dev), "width": W, "height": H} for v in range(n_views)]
+    return make, datas
+
+
+@pytest.mark.parametrize("W,H", [(2100, 300), (333, 517)])
+def test_rounds_on_ragged_and_wide_tile_grids(W, H):
+    """Tile grids that are not a multiple of anything: 132 x 19 tiles (three 64-bit words per row of the live-tile bitmap) and
+    21 x 33 with ragged right / bottom tiles (pixels outside the image are finished from the start)."""
+    dev = torch.device("cuda:0")
+    sc = config_heavy(seed=9, n=30000, n_views=1, width=W, height=H, median=0.04)
+    make, datas = _model_and_views(sc, dev, 1)
+    gt = torch.rand((H, W, 3), generator=torch.Generator().manual_seed(2)).to(dev)
+    lc = LossComputer(0.2, clamp_input=True)
+    (ma, oa), (mb, ob) = make(), make()
+    ra = TrainStepGraph(ma, oa, lc, datas[0], gt, fuse_adam=False, rounds="off")
+    rb = TrainStepGraph(mb, ob, lc, datas[0], gt, fuse_adam=False, rounds="on", round_fraction=0.1)
+    oa_, ob_ = ra.step(), rb.step()
+    ra.finish(); rb.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(oa_["render_img"], ob_["render_img"]) and torch.equal(oa_["loss3"], ob_["loss3"])
+    assert torch.equal(ra.buf["qcnt"], rb.buf["qcnt"])
+    for k, ga in ra.grads.items():
+        if ga is not None:
+            _close(ga, rb.grads[k], 2e-5, k)
+
+
+def test_rounds_on_a_frame_that_lists_nothing():
+    """Every Gaussian behind the camera: no weight in the depth histogram, no entry in either round; the step must still apply
+    (Adam on zero gradients), exactly like the one-round step."""
+    dev = torch.device("cuda:0")
+    sc = _scene("sparse")
+    sc["means"] = sc["means"].copy()
+    sc["means"][:, 2] -= 100.0
+    make, datas = _model_and_views(sc, dev, 1)
+    W, H = int(sc["width"]), int(sc["height"])
+    gt = torch.rand((H, W, 3), generator=torch.Generator().manual_seed(2)).to(dev)
+    lc = LossComputer(0.2, clamp_input=True)
+    (ma, oa), (mb, ob) = make(), make()
+    ra = TrainStepGraph(ma, oa, lc, datas[0], gt, rounds="off")
+    rb = TrainStepGraph(mb, ob, lc, datas[0], gt, rounds="on")
+    for _ in range(2):
+        la, lb = ra.step()["loss3"].clone(), rb.step()["loss3"].clone()
+    ra.finish(); rb.finish()
+    assert torch.equal(la, lb) and int(rb.buf["info"][0]) == 0 and rb.report()["steps"] == 2
+    for k in ma.param_names:
+        assert torch.equal(getattr(ma, k).detach(), getattr(mb, k).detach()), k
+
+
+def test_rounds_through_refinement_and_an_opacity_reset():
+    """The loop shape of the reference with rounds forced on: 60 steps over three views, densify_and_prune every 15, one opacity
+    reset -- re-builds on projected capacities and behind a probe, with the round buffers re-made for the new N.  Against the
+    one-round runner on the same schedule: the same number of Gaussians to 0.2 % (a rounding-level difference in a gradient norm
+    can flip a densification decision), the loss to 1e-3, no overflow storm."""
+    dev = torch.device("cuda:0")
+    sc = config_heavy(seed=5, n=40000, n_views=3, width=480, height=272, median=0.05)
+    make, datas = _model_and_views(sc, dev, 3)
+    W, H = 480, 272
+    with torch.no_grad():
+        ref, _ = make()
+        gts = [ref(d)["render_img"].clone() for d in datas]
+    del ref
+
+    def run(rounds):
+        m, o = make()
+        with torch.no_grad():
+            m.means.add_(0.01 * torch.randn(m.means.shape, generator=torch.Generator().manual_seed(4)).to(dev))
+        gen = torch.Generator(device=dev).manual_seed(9)
+        r = TrainStepGraph(m, o, LossComputer(0.2, clamp_input=True), datas[0], gts[0], rounds=rounds)
+        ns = []
+        for it in range(1, 61):
+            r.step(datas[it % 3], gts[it % 3])
+            m.update_learning_rate(it)
+            if it % 15 == 0 and it < 60:
+                r.finish()
+                if it == 30:
+                    m.reset_opacities()
+                else:
+                    m.densify_and_prune(generator=gen)
+                ns.append(m.nbr_gaussians)
+        r.finish()
+        return ns, float(r.loss_history(10)[:, 2].mean()), r.report()
+
+    ns_a, la, rep_a = run("off")
+    ns_b, lb, rep_b = run("on")
+    assert rep_b["rounds"] and rep_b["steps"] == 60 and rep_b["overflows"] <= rep_a["overflows"] + 2, (rep_a, rep_b)
+    for a, b in zip(ns_a, ns_b):
+        assert abs(a - b) <= max(2, 0.002 * a), (ns_a, ns_b)
+    assert abs(la - lb) <= 1e-3 * max(abs(la), 1e-6) + 1e-5, (la, lb)

@@ -242,7 +242,7 @@ def test_two_ranks_equal_one_process_on_both_views(tmp_path, variant):
     np.testing.assert_array_equal(r0["rad"], ref["rad"])
 
 
-def _worker_captured(rank, world, port, out_dir):
+def _worker_captured(rank, world, port, out_dir, rounds="off"):
     """Both forms of the view-parallel step in one process, one after the other (the ranks issue the same collectives in the same
     order): the eager exchange on model A, `ViewParallelGraphStep` on model B -- with a capacity shortage staged on RANK 1 ONLY."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -271,7 +271,9 @@ def _worker_captured(rank, world, port, out_dir):
     # (b) captured
     model, opt, datas, targets = _make(dev, "plain")
     vp = ViewParallelStep(model, opt, guard_words=True)
-    runner = ViewParallelGraphStep(model, opt, LossComputer(0.2, clamp_input=True), datas[rank], targets[rank], None, vp=vp, check_every=4)
+    runner = ViewParallelGraphStep(model, opt, LossComputer(0.2, clamp_input=True), datas[rank], targets[rank], None, vp=vp, check_every=4,
+                                   rounds=rounds)
+    assert runner.report()["rounds"] == (rounds == "on")
     for it in range(n_steps):
         if it == 3 and rank == 1:
             # rank 1 alone runs short of work units from here on: BOTH ranks must skip these steps on the device, find it at the
@@ -310,6 +312,23 @@ def test_captured_view_parallel_step_equals_the_eager_exchange(tmp_path):
             if f.startswith("e_"):
                 np.testing.assert_array_equal(r[k]["c_" + f[2:]], r[k][f], err_msg=f"rank {k}: captured != eager in {f[2:]}")
     assert int(r[0]["overflows"]) == int(r[1]["overflows"]) and int(r[0]["collectives"]) == int(r[1]["collectives"])
+    for f in r[0].files:
+        if f.startswith("c_"):
+            np.testing.assert_array_equal(r[0][f], r[1][f], err_msg=f"replicas diverged in {f[2:]}")
+
+
+def test_captured_view_parallel_step_in_depth_rounds(tmp_path):
+    """The same nine steps with the list stages of the captured part in two depth rounds (`rounds="on"`: gs_row_sums reads a wave's
+    rows as two ranges): the replicas bitwise equal to each other, and on the eager exchange's trajectory to the rounding of
+    another summation order of the gradient rows."""
+    mp.spawn(_worker_captured, args=(2, _free_port(), str(tmp_path), "on"), nprocs=2, join=True)
+    r = [np.load(os.path.join(tmp_path, f"c{k}.npz")) for k in range(2)]
+    for k in range(2):
+        assert int(r[k]["steps"]) == 9 and int(r[k]["overflows"]) >= 1
+        for f in r[k].files:
+            if f.startswith("e_"):
+                a, b = r[k]["c_" + f[2:]].astype(np.float64), r[k][f].astype(np.float64)
+                assert np.abs(a - b).max() <= 2e-4 * max(np.abs(b).max(), 1e-30), (k, f[2:], np.abs(a - b).max(), np.abs(b).max())
     for f in r[0].files:
         if f.startswith("c_"):
             np.testing.assert_array_equal(r[0][f], r[1][f], err_msg=f"replicas diverged in {f[2:]}")
