@@ -76,6 +76,7 @@ SIGNATURES = {
     "gs_rounds_set": (_I, [_P, _P, _P, _P, _I]),
     "gs_round_split": (_I, [_P, _L, _P, _P, _F, _P, _P]),
     "gs_round_footprints": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),
+    "gs_round_status": (_I, [_P, _P, _P]),
     "gs_step_status": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "gs_guard_flag_out": (_I, [_P, _P, _P, _P]),
     "gs_guard_merge": (_I, [_P, _P, _P, _I, _L]),

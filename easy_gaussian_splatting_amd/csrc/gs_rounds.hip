@@ -192,6 +192,20 @@ extern "C" int gs_round_split(void* stream, int64_t N, const float* depths, cons
     return GS_OK;
 }
 
+namespace gs {
+__global__ void round_status_kernel(const int64_t* __restrict__ blk, volatile int64_t* __restrict__ host) {
+    if (threadIdx.x < GS_ROUND_WORDS) host[threadIdx.x] = blk[threadIdx.x];
+    __threadfence_system();
+}
+}  // namespace gs
+
+extern "C" int gs_round_status(void* stream, const int64_t* rounds_dev, int64_t* status_host_mapped) {
+    GS_REQUIRE(rounds_dev && status_host_mapped, "null pointer");
+    hipLaunchKernelGGL(round_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rounds_dev, status_host_mapped);
+    GS_LAUNCH_CHECK("round_status_kernel");
+    return GS_OK;
+}
+
 extern "C" int gs_round_footprints(void* stream, int64_t N, int tile_w, int tile_h, const uint32_t* bbox, const float* depths,
                                    uint32_t* bbox_round, int32_t* tiles_per_gauss_round) {
     const Rounds R = current_rounds();

@@ -180,7 +180,8 @@ def _round_buffers(dev: torch.device, st: int, N: int, tiles: int) -> dict:
              "live": torch.zeros((tiles,), dtype=torch.uint8, device=dev),
              "state": torch.empty((tiles, 4, 64, 4), dtype=torch.float32, device=dev),
              "bbox": torch.empty((N, 4), dtype=torch.int32, device=dev),
-             "tpg": torch.empty((N,), dtype=torch.int32, device=dev)}
+             "tpg": torch.empty((N,), dtype=torch.int32, device=dev),
+             "host": torch.zeros((nat.GS_ROUND_WORDS,), dtype=torch.int64, pin_memory=True)}
         with _state_lock:
             _round_bufs[key] = b
     return b
@@ -619,22 +620,36 @@ def _forward_stages(means, quats, scales, opacities, colors, colors_rest, viewma
         nat.check(L.gs_info_mirror_set(info_host.data_ptr()), "gs_info_mirror_set")
         try:
             if rounds:
-                # depth split, then count .. blend per round on the round's footprints; the size record is the back round's (the
-                # total of both; a back round with no live tile leaves the front round's record standing)
+                # depth split, then count .. blend per round on the round's footprints.  Immediate size check: the host waits for the
+                # front round anyway (its size record), so it also looks at how many tiles that round left live -- and does not
+                # enqueue the back round at all when there are none (18 launches that would return at once: 0.1 ms per frame).
+                # Deferred check: both rounds are enqueued, the size record is the back round's (the total of both; a back round
+                # with no live tile leaves the front round's record standing).
                 if sizes["attempt"] == 0 and _SPLIT_PROJECT:
                     project(2, "gs_project_fwd_color")
                 nat.check(L.gs_round_split(st, N, _ptr(depths), P(WS.TILES_PER_GAUSS), ROUND_FRACTION, rb["hist"].data_ptr(), rb["blk"].data_ptr()),
                           "gs_round_split")
+                ev = None
                 for phase in (1, 2):
                     nat.check(L.gs_rounds_set(rb["blk"].data_ptr(), rb["live"].data_ptr(), rb["state"].data_ptr(), None, phase), "gs_rounds_set")
+                    nat.check(L.gs_info_mirror_set(info_host.data_ptr()), "gs_info_mirror_set")
                     _stage("gs_round_footprints", dev, lambda: nat.check(L.gs_round_footprints(
                         st, N, tw, th, P(WS.BBOX), _ptr(depths), rb["bbox"].data_ptr(), rb["tpg"].data_ptr()), "gs_round_footprints"))
                     _stage("gs_bin_count", dev, count)
+                    nat.check(L.gs_info_mirror_set(None), "gs_info_mirror_set")
                     if phase == 2:
-                        nat.check(L.gs_info_mirror_set(None), "gs_info_mirror_set")
                         ev = torch.cuda.Event()
                         ev.record(tstream)
                     lists_and_blend()
+                    if phase == 1 and not deferred:
+                        nat.check(L.gs_round_status(st, rb["blk"].data_ptr(), rb["host"].data_ptr()), "gs_round_status")
+                        ev = torch.cuda.Event()
+                        ev.record(tstream)
+                        t_wait = time.perf_counter_ns()
+                        ev.synchronize()
+                        sizes["waited"] += time.perf_counter_ns() - t_wait
+                        if int(info_host[3]) != 0 or int(rb["host"][nat.GS_ROUND_LIVE]) == 0:
+                            break   # (the front round did not fit: `settle` re-sizes and the attempt is repeated; or it finished the frame)
                 return ev
             _stage("gs_bin_count", dev, count)
             nat.check(L.gs_info_mirror_set(None), "gs_info_mirror_set")

@@ -155,6 +155,12 @@ int gs_round_split(void* stream, int64_t N, const float* depths, const int32_t* 
 int gs_round_footprints(void* stream, int64_t N, int tile_w, int tile_h, const uint32_t* bbox, const float* depths,
                         uint32_t* bbox_round, int32_t* tiles_per_gauss_round);
 
+/* The round block into page-locked, device-addressable host memory (int64[GS_ROUND_WORDS]; one tiny launch + a system-scope fence,
+ * like gs_step_status): a host that waits for an event behind it -- behind the front round's gs_blend_fwd -- reads
+ * GS_ROUND_LIVE from plain memory and does not enqueue the back round at all when the front round left no tile live (the eager
+ * seam; a captured step cannot branch on the host and lets the back round's kernels return at once instead). */
+int gs_round_status(void* stream, const int64_t* rounds_dev, int64_t* status_host_mapped);
+
 /* Publishes a guarded step's outcome without a copy or an event: one tiny launch writes
  * status[0..3] = info_dev[0..3] ({I, n_buckets, max tile, flags}), status[4] = applied_dev[0] (may be NULL) and -- walk_state
  * (gs_blend_fwd's, may be NULL) -- status[5] = storage units taken, status[6] = gradient rows: what the walk needed; status[7] =
