@@ -1148,7 +1148,7 @@ extern "C" int gs_bin_groups(int64_t N) { return bin_layout(1, N, 1).groups; }
 // the depth round the list stages work for (gs_rounds_set): 1 front, 2 back, 0 none
 static int list_round(int64_t*& rblk) {
     const Rounds R = current_rounds();
-    const int phase = (R.phase == 1 || R.phase == 2) ? R.phase : 0;
+    const int phase = (R.phase == 1 || R.phase == 4) ? 1 : (R.phase == 2 ? 2 : 0);   // (4: the front round alone)
     rblk = phase ? R.blk : nullptr;
     return phase;
 }

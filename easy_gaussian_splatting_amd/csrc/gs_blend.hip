@@ -101,6 +101,7 @@ struct BlendFwdArgs {
     uint8_t* live;         // [tiles]
     float4* tstate;        // [tiles][4][64]
     int4* trec;            // [tiles][2]  {sublist lengths}, {part-filled work units' storage}
+    int solo;              // front round alone (gs_rounds_set phase 4): a tile left live voids the step instead of leaving its state
     GS_IF_CHECK(BwdCheck chk;)
 };
 
@@ -424,8 +425,9 @@ __global__ __launch_bounds__(64 * WAVES) GS_FWD_ATTR void blend_fwd_kernel(const
         if (lane == 0) {
             a.live[t] = lv ? 1 : 0;
             if (lv) atomicAdd(reinterpret_cast<unsigned long long*>(a.rblk + GS_ROUND_LIVE), 1ull);
+            if (lv && a.solo && a.flags) atomicOr(a.flags, (unsigned long long)GS_FLAG_BACK);   // nobody will come for this tile
         }
-        if (lv) {
+        if (lv && !a.solo) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) a.tstate[((size_t)t * 4 + k) * 64 + lane] = make_float4(T[k], cr[k], cg[k], cb[k]);
             if (CKPT && lane == 0) {
@@ -842,7 +844,9 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     a.guard = current_guard().info;
     a.flags = a.guard ? reinterpret_cast<unsigned long long*>(const_cast<int64_t*>(a.guard) + 3) : nullptr;
     const Rounds R = current_rounds();
-    const int phase = (R.phase == 1 || R.phase == 2) ? R.phase : 0;
+    const int phase = (R.phase == 1 || R.phase == 4) ? 1 : (R.phase == 2 ? 2 : 0);
+    a.solo = R.phase == 4 ? 1 : 0;
+    GS_REQUIRE(R.phase != 4 || a.flags != nullptr, "depth rounds, front round alone: needs a step guard (gs_guard_set)");
     GS_REQUIRE(phase == 0 || C == 1, "depth rounds: one camera per call");
     GS_REQUIRE(phase == 0 || !train || R.tile_rec, "depth rounds, training mode: gs_rounds_set needs tile_rec");
     a.rblk = R.blk; a.live = R.live; a.tstate = R.state; a.trec = reinterpret_cast<int4*>(R.tile_rec);
@@ -866,7 +870,7 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
         else if (phase == 2) hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves, 2>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((blend_fwd_kernel<true, kFwdWaves, 0>), grid, block, 0, st, a);
         GS_LAUNCH_CHECK("blend_fwd_kernel");
-        if (phase == 1) return GS_OK;   // (the row bases are scanned once, behind the back round)
+        if (phase == 1 && !a.solo) return GS_OK;   // (the row bases are scanned once, behind the back round)
         RowScanArgs s;
         s.qmask = qmask; s.row_base = row_base; s.walk = walk_state; s.n_cap = n_isects; s.cap_rows = cap_rows;
         s.flags = a.flags; s.guard = a.guard; s.mirror = current_walk_mirror();

@@ -23,8 +23,8 @@ Rounds current_rounds() { return g_rounds; }
 }  // namespace gs
 
 extern "C" int gs_rounds_set(int64_t* rounds_dev, uint8_t* tile_live, float* tile_state, int32_t* tile_rec, int phase) {
-    if (phase < 0 || phase > 3 || (phase != 0 && !rounds_dev) || ((phase == 1 || phase == 2) && (!tile_live || !tile_state))) {
-        gs::set_error("invalid argument: phase 0 (off), 1 (front round), 2 (back round) or 3 (behind both); a round needs its buffers");
+    if (phase < 0 || phase > 4 || (phase != 0 && !rounds_dev) || ((phase == 1 || phase == 2 || phase == 4) && (!tile_live || !tile_state))) {
+        gs::set_error("invalid argument: phase 0 (off), 1 (front round), 2 (back round), 3 (behind both) or 4 (front round alone); a round needs its buffers");
         return GS_ERR_ARG;
     }
     if ((((uintptr_t)tile_state) & 15) != 0 || (((uintptr_t)tile_rec) & 15) != 0) {

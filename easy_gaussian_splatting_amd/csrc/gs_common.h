@@ -60,7 +60,8 @@ __device__ __forceinline__ bool guard_tripped(const int64_t* info) { return info
 
 // Depth rounds (gs_rounds_set, include/gs_raster.h): the list stages, the blend forward and the row gather of the backward run
 // the frame's Gaussians in TWO rounds -- the front slab by depth first, the rest only into tiles the front slab has not
-// finished.  `phase` 0: off; 1: front round; 2: back round; 3: behind both (the backward: rows of the two rounds are two ranges).
+// finished.  `phase` 0: off; 1: front round; 2: back round; 3: behind both (the backward: rows of the two rounds are two ranges);
+// 4: the front round alone (a tile it leaves live voids the step: GS_FLAG_BACK) -- the list stages see it as 1.
 struct Rounds {
     int64_t* blk;        // device int64[GS_ROUND_WORDS]
     uint8_t* live;       // [tiles]  1: the front round left the tile with live pixels

@@ -209,7 +209,7 @@ extern "C" int gs_round_status(void* stream, const int64_t* rounds_dev, int64_t*
 extern "C" int gs_round_footprints(void* stream, int64_t N, int tile_w, int tile_h, const uint32_t* bbox, const float* depths,
                                    uint32_t* bbox_round, int32_t* tiles_per_gauss_round) {
     const Rounds R = current_rounds();
-    GS_REQUIRE(R.phase == 1 || R.phase == 2, "gs_round_footprints works for a round: gs_rounds_set phase 1 or 2 first");
+    GS_REQUIRE(R.phase == 1 || R.phase == 2 || R.phase == 4, "gs_round_footprints works for a round: gs_rounds_set phase 1, 2 or 4 first");
     GS_REQUIRE(N >= 0 && tile_w > 0 && tile_h > 0 && tile_w < 65536 && tile_h < 65536, "N>=0, tile grid within 16 bits");
     if (N == 0) return GS_OK;
     GS_REQUIRE(bbox && depths && bbox_round && tiles_per_gauss_round, "null pointer");
@@ -218,7 +218,7 @@ extern "C" int gs_round_footprints(void* stream, int64_t N, int tile_w, int tile
     GS_REQUIRE(lds <= 60 * 1024, "tile grid too large for the live-tile bitmap in LDS");
     const unsigned grid = (unsigned)std::min<int64_t>(1024, (N + kRoundThreads - 1) / kRoundThreads);
     hipLaunchKernelGGL(round_footprints_kernel, dim3(grid), dim3(kRoundThreads), lds, (hipStream_t)stream, N, tile_w, tile_h, W64,
-                       (const uint4*)bbox, depths, (const uint8_t*)R.live, R.blk, R.phase, (uint4*)bbox_round, tiles_per_gauss_round);
+                       (const uint4*)bbox, depths, (const uint8_t*)R.live, R.blk, R.phase == 4 ? 1 : R.phase, (uint4*)bbox_round, tiles_per_gauss_round);
     GS_LAUNCH_CHECK("round_footprints_kernel");
     return GS_OK;
 }

@@ -83,6 +83,11 @@ class TrainStepGraph:
         self.rounds_mode, self.round_fraction = rounds, float(__import__("os").environ.get("GS_TG_ROUND_FRACTION", round_fraction))
         self.rounds_on = rounds == "on"
         self._live_sum = self._live_n = 0   # tiles the front round left live, summed over the polled steps since the last build
+        # "auto" only: the captured step holds the FRONT round alone (gs_rounds_set phase 4), speculating that it finishes every
+        # frame -- a hipGraph cannot skip the ~18 launches of a back round that has nothing to do (0.09 ms).  A frame that does
+        # leave tiles live voids its step on the device (GS_FLAG_BACK) like a capacity overflow; the runner then re-builds with
+        # both rounds and replays.
+        self.front_only = False
         # copy_targets: every step takes a private copy of its target image (and mask) instead of reading the caller's tensors in
         # place -- for loaders that recycle ONE device staging buffer (`gt_buf.copy_(next)`): a target is read until its step is
         # RETIRED (the loss forward and backward of the replay, and again if an overflow recovery replays the step up to
@@ -199,6 +204,7 @@ class TrainStepGraph:
         b["hyper"] = torch.zeros((16,), **f32)
         self._stage_inputs(max(self.opt._step, 0) + 1, [float(grp["lr"]) for grp, _ in self.opt._plist], data["w2c"], data["K"], gt_img, mask)
         probe_walk = False
+        front_before, self.front_only = self.front_only, False   # (the probes below run both rounds)
         if projected is not None:
             n_isects, max_tile, units, rows = projected
             self.cap = int(n_isects * self.margin) + 4096
@@ -243,6 +249,7 @@ class TrainStepGraph:
                 self.rounds_on = n_isects >= self.ROUNDS_MIN_LISTED and n_isects >= self.ROUNDS_MIN_RATIO * max(rows, 1)
         elif self.rounds_mode == "auto" and self.rounds_on and self._live_n > 0 and self._live_sum > self.ROUNDS_MAX_LIVE * tiles * self._live_n:
             self.rounds_on = False   # (a re-build without a probe: the steps since the last build left too many tiles to the back round)
+        self.front_only = bool(front_before and not probe_walk and self.rounds_on and self.rounds_mode == "auto" and self._live_sum == 0)
         self._alloc_walk()
         self._alloc_rounds()
         if probe_walk and self.rounds_mode == "auto" and self.rounds_on:
@@ -254,6 +261,9 @@ class TrainStepGraph:
             self.stats["probed_live_tiles"] = live
             if live > self.ROUNDS_MAX_LIVE * tiles:
                 self.rounds_on = False
+            # (a probing re-build that follows a voided speculation -- `_recover` -- keeps both rounds until the next refinement)
+            self.front_only = self.rounds_on and live == 0 and self.speculate_front and not self._back_needed
+            self._back_needed = False
         self._live_sum = self._live_n = 0
         self._key = self._state_key()
         self._opacity_resets = getattr(m, "opacity_resets", 0)
@@ -320,6 +330,8 @@ class TrainStepGraph:
     ROUNDS_MIN_LISTED = 4_000_000   # "auto": below this the list stages are too short for a second round to pay
     ROUNDS_MIN_RATIO = 4.0          # ... and so they are when the frame lists less than this many entries per gradient row
     ROUNDS_MAX_LIVE = 0.05          # ... and rounds stay off where the front slab leaves more than this share of the tiles live
+    speculate_front = __import__('os').environ.get('GS_TG_FRONT_ONLY', '1') != '0'   # 0: "auto" never captures the front round alone
+    _back_needed = False
 
     def _alloc_rounds(self):
         """Depth rounds: the round block, the tiles' liveness / pixel states / sublist records between the rounds, the footprints
@@ -568,7 +580,7 @@ class TrainStepGraph:
             return
         self._ck(L.gs_round_split(self._st(), self.N, _p(b["depths"]), _p(b["tiles_per_gauss"]), self.round_fraction, _p(b["depth_hist"]),
                                    _p(b["rounds"])), "gs_round_split")
-        for phase in (1, 2):
+        for phase in ((4,) if self.front_only else (1, 2)):
             self._rounds_phase(phase)
             self._ck(L.gs_round_footprints(self._st(), self.N, self.tw, self.th, _p(b["bbox"]), _p(b["depths"]), _p(b["bbox_round"]),
                                             _p(b["tpg_round"])), "gs_round_footprints")
@@ -856,6 +868,9 @@ class TrainStepGraph:
         self.stats["overflows"] += 1
         self.stats["replayed_steps"] += len(redo)
         # (what did not fit, and into what: flags 1 = listed intersections, 2 = longest tile list, 4 / 8 = coarse bins, 16 = work units, 32 = rows)
+        if int(self.status[3]) & 64:   # GS_FLAG_BACK: a frame needed the back round the captured step does not hold
+            self._back_needed = True
+            self.stats["back_round_needed"] = self.stats.get("back_round_needed", 0) + 1
         self.stats.setdefault("overflow_log", []).append({
             "step": self.confirmed + 1, "flags": int(self.status[3]), "isects": n_isects, "longest_list": max_tile, "work_units": walk[0], "rows": walk[1],
             "capacities": [self.cap, self.cap_tile, self.cap_units, self.cap_rows]})
@@ -893,7 +908,8 @@ class TrainStepGraph:
                     capacity_isects=self.cap, capacity_tile_list=self.cap_tile, capacity_work_units=self.cap_units,
                     capacity_rows=self.cap_rows, probed_work_units=self.probed_walk[0], probed_rows=self.probed_walk[1],
                     seen_work_units=self.seen_units, seen_rows=self.seen_rows, steps=self.confirmed,
-                    graph=self.graph is not None, rounds=bool(self.rounds_on), round_fraction=self.round_fraction if self.rounds_on else None)
+                    graph=self.graph is not None, rounds=bool(self.rounds_on), round_fraction=self.round_fraction if self.rounds_on else None,
+                    front_round_alone=bool(self.rounds_on and self.front_only))
 
 
 class ViewParallelGraphStep(TrainStepGraph):

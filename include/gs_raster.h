@@ -56,6 +56,7 @@ extern "C" {
 #define GS_FLAG_COARSE_LIST 8 /* two-level binning: a bin list longer than coarse_list_cap */
 #define GS_FLAG_UNITS 16     /* training forward: the walk opened more work units than cap_units */
 #define GS_FLAG_ROWS 32      /* training forward: more gradient rows than cap_rows */
+#define GS_FLAG_BACK 64      /* depth rounds, phase 4: the front round left live tiles and no back round was enqueued */
 #define GS_FLAG_PEER 128     /* view-parallel step: another rank's guard was tripped (gs_guard_merge) */
 
 #define GS_OK 0
@@ -133,7 +134,11 @@ int gs_step_applied(void* stream, const int64_t* info_dev, int64_t* applied_dev)
  *   tile_rec[tiles*8] i32           training: lengths of the quadrant sublists and their part-filled work units (NULL: inference)
  * gs_blend_fwd in phase 1 clears the quadrant masks and the walk state and leaves the row-base scan to phase 2; render_colors /
  * render_alphas are complete after phase 2 (phase 1 writes every tile, phase 2 re-writes the tiles it resumes).  When the
- * front round leaves no live tile (rounds_dev[GS_ROUND_LIVE] == 0) the kernels of the back round return at once. */
+ * front round leaves no live tile (rounds_dev[GS_ROUND_LIVE] == 0) the kernels of the back round return at once.
+ *   phase 4 (front round ALONE, under a step guard)  the same calls as phase 1, speculating that the front round finishes the frame:
+ * gs_blend_fwd runs its row-base scan itself, and a tile that still has live pixels ORs GS_FLAG_BACK into the guard's flag word --
+ * the step is then void like one that outgrew a capacity (every kernel behind is a no-op), and the caller repeats it with both
+ * rounds.  What a captured step saves: the ~18 launches of a back round that has nothing to do. */
 #define GS_ROUND_BASE 0      /* list entries (= gradient-row slots) of the front round: the back round continues here */
 #define GS_ROUND_SPLIT 1     /* depth split as float bits: a Gaussian is in the front round when its depth bits are below */
 #define GS_ROUND_LIVE 2      /* tiles the front round left with live pixels */

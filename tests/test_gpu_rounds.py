@@ -392,3 +392,37 @@ def test_rounds_through_refinement_and_an_opacity_reset():
     for a, b in zip(ns_a, ns_b):
         assert abs(a - b) <= max(2, 0.002 * a), (ns_a, ns_b)
     assert abs(la - lb) <= 1e-3 * max(abs(la), 1e-6) + 1e-5, (la, lb)
+
+
+# ---- "auto": the captured step holds the front round alone and is voided by a frame that needs the back round ------------------
+def test_auto_captures_the_front_round_alone_and_recovers_when_a_frame_needs_more(monkeypatch):
+    """`rounds="auto"` on a scene whose front slab finishes every tile of the probed view: the graph holds the front round only
+    (no idle back round: `front_round_alone`).  Then a view arrives in which a quarter of the tiles see background only -- the
+    front round leaves them live: the step must void itself on the device (GS_FLAG_BACK), be found at the next poll and be replayed after a
+    re-build (which, on that view, turns rounds off) -- every step applied once, the end state the one-round runner's."""
+    monkeypatch.setattr(TrainStepGraph, "ROUNDS_MIN_LISTED", 1000)   # (the test scene lists 0.38 M entries, 2.2 per gradient row)
+    monkeypatch.setattr(TrainStepGraph, "ROUNDS_MIN_RATIO", 1.0)
+    dev, make, datas, gts = _setup("heavy")
+    far = dict(datas[0])
+    w2c = far["w2c"].clone()
+    w2c[0, 3] += 2.5   # (the scene slides to the right: a quarter of the tiles see background only)
+    far["w2c"] = w2c
+    (ma, oa), (mb, ob) = make(), make()
+    lc = LossComputer(0.2, clamp_input=True)
+    ra = TrainStepGraph(ma, oa, lc, datas[0], gts[0], check_every=4, rounds="off")
+    rb = TrainStepGraph(mb, ob, lc, datas[0], gts[0], check_every=4, rounds="auto", round_fraction=0.5)
+    rep = rb.report()
+    assert rep["rounds"] and rep["front_round_alone"], rep
+    for it in range(3):   # the speculation holds: same image and loss as one round
+        la = ra.step(datas[0], gts[0])["loss3"].clone(); ra.finish()
+        lb = rb.step(datas[0], gts[0])["loss3"].clone(); rb.finish()
+        assert torch.allclose(la, lb, rtol=1e-5, atol=1e-7), (it, la, lb)
+    assert rb.report()["overflows"] == 0
+    seq = [datas[0], far, datas[0], far, datas[0], datas[0]]
+    for d in seq:   # (the host keeps enqueueing behind the voided step)
+        ra.step(d, gts[0]); rb.step(d, gts[0])
+    ra.finish(); rb.finish()
+    rep = rb.report()
+    assert rep["steps"] == 3 + len(seq) and rep.get("back_round_needed", 0) >= 1 and not rep["front_round_alone"], rep
+    for k in ma.param_names:
+        _close(getattr(ma, k).detach(), getattr(mb, k).detach(), 2e-4, k)

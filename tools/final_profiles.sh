@@ -58,6 +58,14 @@ for c in "bench1M tight" "heavy2M gsplat_eager" "heavy2M tight" "S5 tight"; do t
 for a in "2 eager" "3 eager" "2 lazy"; do timeout 200 python tools/host_feed_probe.py $a 2>/dev/null; done > gpurun_out/${tag}_host_feed_probe.jsonl
 timeout 300 python tools/e2e_train.py 3000 both gpurun_out/${tag}_e2e.json > /dev/null 2>&1
 for c in "heavy2M tight" "heavy2M gsplat_eager" "heavy1M tight"; do timeout 300 python tools/lazy_bin_bound.py $c 2>/dev/null; done > gpurun_out/${tag}_lazy_bin_bound.jsonl
+# depth rounds: the captured step in one round / in two at several splits / as rounds="auto" picks (front round alone where the probe
+# finds no live tile), the forward fps through the eager seam, and the kernel traces of both forms at heavy 2 M
+for c in "heavy2M tight" "heavy1M tight" "heavy2M gsplat_eager" "heavy1M gsplat_eager" "S3 tight" "longlists tight" "heavy2Mwin tight"; do
+  timeout 300 python tools/rounds_time.py $c 0.0625,0.125,0.25 30 2>/dev/null | grep "^{"
+done > gpurun_out/${tag}_rounds_time.jsonl
+for c in "heavy2M tight" "heavy1M tight" "heavy2M gsplat" "heavy2Mwin tight" "bench1M tight"; do timeout 200 python tools/rounds_fps.py $c 60 2>/dev/null | grep "^{"; done > gpurun_out/${tag}_rounds_fps.jsonl
+timeout 300 bash tools/prof_cmd.sh ${tag}_rounds_heavy2m tools/rounds_time.py heavy2M tight auto,auto 40 > /dev/null 2>&1
+timeout 300 bash tools/prof_cmd.sh ${tag}_oneround_heavy2m tools/rounds_time.py heavy2M tight off,off 40 > /dev/null 2>&1
 # per-Gaussian criterion: fp32 sums / fp64 sums / fp64 sums + exact exp2 and division / fp32 oracle
 timeout 900 python tools/acc64_ab.py gpurun_out/${tag}_acc64_ab.json > gpurun_out/${tag}_acc64_ab.log 2>&1
 head -c 600 gpurun_out/${tag}_bench_line.json; echo; tail -3 gpurun_out/${tag}_bench.err
