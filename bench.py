@@ -42,7 +42,7 @@ CLOCK_HZ_NOMINAL = 2.4e9
 # (hipcc -S of csrc/gs_blend.hip, loop .LBB1_24): 208 VALU = 160 fma / mul / add / sub / min / DPP moves, 21 v_cmp, 19 v_cndmask,
 # 8 transcendentals (4 v_exp_f32 + 4 v_rcp_f32); 24 SALU and 2 LDS reads ride along
 BWD_LOOP_MIX = {"simple": 160, "cmp_cndmask": 40, "transcendental": 8}
-PROFILE_TAGS = ("r05", "r04", "r03", "r02", "r01")     # committed rocprofv3 summaries under profiles/, newest first
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02", "r01")     # committed rocprofv3 summaries under profiles/, newest first
 
 
 def parse_args(argv=None):

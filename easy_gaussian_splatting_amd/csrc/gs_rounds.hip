@@ -216,7 +216,8 @@ extern "C" int gs_round_footprints(void* stream, int64_t N, int tile_w, int tile
     const int W64 = (tile_w + 63) / 64;
     const size_t lds = sizeof(unsigned long long) * (size_t)W64 * tile_h;
     GS_REQUIRE(lds <= 60 * 1024, "tile grid too large for the live-tile bitmap in LDS");
-    const unsigned grid = (unsigned)std::min<int64_t>(1024, (N + kRoundThreads - 1) / kRoundThreads);
+    // (back round: every block builds the tile bitmap first -- th x W64 dependent byte gathers per wave --, so one block per CU)
+    const unsigned grid = (unsigned)std::min<int64_t>(R.phase == 2 ? 256 : 1024, (N + kRoundThreads - 1) / kRoundThreads);
     hipLaunchKernelGGL(round_footprints_kernel, dim3(grid), dim3(kRoundThreads), lds, (hipStream_t)stream, N, tile_w, tile_h, W64,
                        (const uint4*)bbox, depths, (const uint8_t*)R.live, R.blk, R.phase == 4 ? 1 : R.phase, (uint4*)bbox_round, tiles_per_gauss_round);
     GS_LAUNCH_CHECK("round_footprints_kernel");
