@@ -426,3 +426,75 @@ def test_auto_captures_the_front_round_alone_and_recovers_when_a_frame_needs_mor
     assert rep["steps"] == 3 + len(seq) and rep.get("back_round_needed", 0) >= 1 and not rep["front_round_alone"], rep
     for k in ma.param_names:
         _close(getattr(ma, k).detach(), getattr(mb, k).detach(), 2e-4, k)
+
+
+# GS_FUZZ_CASES=N widens the sweep (as tests/test_gpu_parity.py::test_randomised_configurations, whose scenes these are)
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("GS_FUZZ_CASES", "24"))))
+def test_randomised_configurations_in_two_rounds(case, monkeypatch):
+    """The randomised sweep of the parity suite (sizes, SH degree, stored K, background, splat scale, list mode, binning
+    pipeline), first camera, forward: two depth rounds at a drawn split == one round, bit for bit -- image, alphas and the
+    list arrays `meta` hands out."""
+    from easy_gaussian_splatting_amd import rendering
+    from test_gpu_parity import fuzz_case, to_dev
+    monkeypatch.setenv("GS_BINNING", ("tiles", "bins", "bins")[case % 3])
+    monkeypatch.setenv("GS_BINS_SHIFT", ("", "1", "2")[case % 3])
+    sc, (deg, W, H, use_bg, split, culling) = fuzz_case(case, 0)
+    t = to_dev(sc)
+    frac = (0.05, 0.125, 0.3, 0.6)[case % 4]
+    monkeypatch.setattr(rendering, "ROUND_FRACTION", frac)
+    colors = (t["shs"][:, :1].contiguous(), t["shs"][:, 1:].contiguous()) if split else t["shs"]
+    args = (t["means"], t["quats"], t["scales"], t["opacities"], colors, t["viewmats"][:1], t["Ks"][:1], W, H)
+    kw = dict(sh_degree=deg, packed=False, backgrounds=t["backgrounds"][:1] if use_bg else None, _tile_culling=culling)
+    with torch.no_grad():
+        rendering.reset_hints()
+        for _ in range(2):
+            img_a, al_a, meta_a = rendering.rasterization(*args, _rounds="off", **kw)
+        rendering.reset_hints()
+        for _ in range(2):
+            img_b, al_b, meta_b = rendering.rasterization(*args, _rounds="on", **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(img_a, img_b) and torch.equal(al_a, al_b), (case, frac)
+        for k in ("radii", "tiles_per_gauss", "isect_offsets", "flatten_ids"):
+            assert torch.equal(meta_a[k], meta_b[k]), (case, k)
+    rendering.reset_hints()
+
+
+@pytest.mark.parametrize("case", range(int(__import__("os").environ.get("GS_FUZZ_CASES", "24"))))
+def test_randomised_train_steps_in_two_rounds(case, monkeypatch):
+    """The same sweep through the captured train step: one step in two rounds (split drawn per case) against one step in one round
+    -- image, loss, sublist lengths, walk counters bitwise; every gradient to the rounding of another summation order."""
+    from test_gpu_parity import fuzz_case
+    monkeypatch.setenv("GS_BINNING", ("tiles", "bins", "bins")[case % 3])
+    monkeypatch.setenv("GS_BINS_SHIFT", ("", "1", "2")[case % 3])
+    sc, (deg, W, H, use_bg, split, culling) = fuzz_case(case, 0)
+    dev = torch.device("cuda:0")
+    T = torch.from_numpy
+    op = np.clip(sc["opacities"], 1e-3, 1 - 1e-3)
+    shs = T(sc["shs"])
+
+    def make():
+        m = GaussianModel(means=T(sc["means"]), log_scales=torch.log(T(sc["scales"])), quats=T(sc["quats"]),
+                          sh_0=shs[:, :1].contiguous(), sh_rest=shs[:, 1:].contiguous(),
+                          logit_opacities=T(np.log(op / (1 - op)).astype(np.float32)), sh_degree=deg,
+                          white_background=bool(np.all(sc["backgrounds"] == 1.0))).to(dev)
+        m.active_sh_degree = deg
+        m.tile_culling = {"gsplat": "gsplat", "tight": "tight", "gsplat_eager": "gsplat_eager"}[culling]
+        return m, build_optimizers(m, *LRS, fused="hip")
+
+    data = {"w2c": T(sc["viewmats"][0]).to(dev), "K": T(sc["Ks"][0]).to(dev), "width": W, "height": H}
+    gt = torch.rand((H, W, 3), generator=torch.Generator().manual_seed(case)).to(dev)
+    lc = LossComputer(0.2, clamp_input=True)
+    (ma, oa), (mb, ob) = make(), make()
+    ra = TrainStepGraph(ma, oa, lc, data, gt, use_graph=bool(case & 1), fuse_adam=False, rounds="off")
+    rb = TrainStepGraph(mb, ob, lc, data, gt, use_graph=bool(case & 1), fuse_adam=False, rounds="on", round_fraction=(0.05, 0.125, 0.3, 0.6)[case % 4])
+    oa_, ob_ = ra.step(), rb.step()
+    ra.finish(); rb.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(oa_["render_img"], ob_["render_img"]) and torch.equal(oa_["loss3"], ob_["loss3"]), case
+    assert torch.equal(ra.buf["qcnt"], rb.buf["qcnt"])
+    wa, wb = ra.buf["walk_state"][:8].tolist(), rb.buf["walk_state"][:8].tolist()
+    assert wa[0] == wb[0] and wa[3] == wb[3], (wa, wb)
+    _close(oa_["absgrad"], ob_["absgrad"], 2e-5, "absgrad")
+    for k, ga in ra.grads.items():
+        if ga is not None and ga.numel():
+            _close(ga, rb.grads[k], 2e-5, k)
