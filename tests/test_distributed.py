@@ -220,7 +220,7 @@ def _vp_worker(rank, world, port, out_dir):
 def test_view_parallel_step_equals_two_view_batch(tmp_path, world):
     """world = 8: BASELINE.json configs[3]'s rank count -- the 8-way all_gather_into_tensor layout, the rank-order sum over eight
     views, 1/8 folded into the optimizer step -- on gloo (the GPU twin is
-    tests/test_gpu_configs.py::test_config_s4_eight_ranks_equal_single_process)."""
+    tests/test_gpu_configs.py::test_config_s4_four_ranks_equal_single_process)."""
     from oracle import torch_oracle as TO
     port = _free_port()
     mp.spawn(_vp_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)

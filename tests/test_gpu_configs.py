@@ -285,20 +285,23 @@ def test_config_s4_sharded_views_equal_single_process(tmp_path):
     np.testing.assert_array_equal(r0["rad"], ref["rad"])
 
 
-# ---- configs[3] at its stated world size: 8 ranks, one view each
-N_S4X8, W_S4X8 = 200_000, 800
+# ---- configs[3] beyond two ranks: FOUR ranks, one view each (VERDICT r3 item 3b asked for the stated world size, 8; a GPU box
+# admits six processes on its card and the test runner is one of them, so the 8-rank exchange runs over gloo on the CPU --
+# tests/test_distributed.py, world 8 -- the R = 8 kernels in one process -- tests/test_gpu_view_parallel.py -- and this test
+# takes the widest world the card admits with room to spare)
+N_S4X8, W_S4X8, R_S4X8 = 200_000, 800, 4
 
 
 def _make_s4x8(device):
     from easy_gaussian_splatting_amd.model import build_optimizers
     from scenes import make_scene
-    sc = make_scene(N_S4X8, W_S4X8, W_S4X8, sh_degree=3, n_views=8, seed=42, extent=(3.0, 3.0, 3.0), scale_range=(0.003, 0.03),
+    sc = make_scene(N_S4X8, W_S4X8, W_S4X8, sh_degree=3, n_views=R_S4X8, seed=42, extent=(3.0, 3.0, 3.0), scale_range=(0.003, 0.03),
                     dist=8.0, white_bg=False)
     model = _model_from_scene(sc, device)
     opt = build_optimizers(model, *LRS, fused="hip")
     datas = [{"w2c": torch.from_numpy(sc["viewmats"][v]).to(device), "K": torch.from_numpy(sc["Ks"][v]).to(device),
-              "width": W_S4X8, "height": W_S4X8} for v in range(8)]
-    targets = [_target_image(W_S4X8, W_S4X8, 40 + v).float().to(device) for v in range(8)]
+              "width": W_S4X8, "height": W_S4X8} for v in range(R_S4X8)]
+    targets = [_target_image(W_S4X8, W_S4X8, 40 + v).float().to(device) for v in range(R_S4X8)]
     return model, opt, datas, targets
 
 
@@ -321,32 +324,33 @@ def _s4x8_worker(rank, world, port, out_dir):
         assert model.sh_0.grad is None and model.sh_rest.grad is None   # the factorised exchange: no dense SH gradient exists
         vp.step(datas[rank], out)
     torch.cuda.synchronize()
-    if rank in (0, 5, 7):
+    if rank in (0, 2, R_S4X8 - 1):
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), **_snapshot(model))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-def test_config_s4_eight_ranks_equal_single_process(tmp_path):
-    """The sharded 8-view batch at its stated world size: EIGHT ranks (gloo, sharing the one device of this box; RCCL
-    refuses two ranks on one GPU, the exchange code is backend-independent), one view each, ~200 k Gaussians at 800x800.
-    Exercises what two ranks cannot: the 8-way all_gather_into_tensor layout of the per-view colour gradients,
-    gs_sh_grad_views with R = 8, the rank-order sum, `1/8` folded into Adam.  Replicas bitwise identical; the update equals
-    ONE process that back-propagates all eight views and averages."""
+def test_config_s4_four_ranks_equal_single_process(tmp_path):
+    """A sharded view batch beyond two ranks: FOUR ranks (gloo, sharing the one device of this box; RCCL refuses two ranks
+    on one GPU, the exchange code is backend-independent; five processes on the card with the test runner, the box admits
+    six), one view each, ~200 k Gaussians at 800x800.  Exercises what two ranks cannot: the R-way all_gather_into_tensor
+    layout of the per-view colour gradients, gs_sh_grad_views with R > 2, the rank-order sum, `1/R` folded into Adam.
+    Replicas bitwise identical; the update equals ONE process that back-propagates all four views and averages."""
     from easy_gaussian_splatting_amd.loss import LossComputer
-    mp.spawn(_s4x8_worker, args=(8, _free_port(), str(tmp_path)), nprocs=8, join=True)
-    r0, r5, r7 = (np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in (0, 5, 7))
+    R = R_S4X8
+    mp.spawn(_s4x8_worker, args=(R, _free_port(), str(tmp_path)), nprocs=R, join=True)
+    r0, r5, r7 = (np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in (0, 2, R - 1))
     for k in r0.files:
-        np.testing.assert_array_equal(r0[k], r5[k], err_msg=f"replicas 0 / 5 diverged in {k}")
-        np.testing.assert_array_equal(r0[k], r7[k], err_msg=f"replicas 0 / 7 diverged in {k}")
+        np.testing.assert_array_equal(r0[k], r5[k], err_msg=f"replicas 0 / 2 diverged in {k}")
+        np.testing.assert_array_equal(r0[k], r7[k], err_msg=f"replicas 0 / {R - 1} diverged in {k}")
     d = dev()
     model, opt, datas, targets = _make_s4x8(d)
     lc = LossComputer(0.2, clamp_input=True)
     hw = float(W_S4X8)
     for _ in range(2):
         acc, gn, cnt, rad = None, 0.0, 0.0, None
-        for v in range(8):
+        for v in range(R):
             out = model(datas[v], clamp=False)
             lc.get_loss_dict(out["render_img"], targets[v])["total"].backward()
             radii = out["batch_radii"][0]
@@ -359,7 +363,7 @@ def test_config_s4_eight_ranks_equal_single_process(tmp_path):
             acc = gs if acc is None else [a + g for a, g in zip(acc, gs)]
             opt.zero_grad()
         for k, g in zip(model.param_names, acc):
-            getattr(model, k).grad = g / 8
+            getattr(model, k).grad = g / R
         opt.step()
         opt.zero_grad()
         model.grad_norm_accum += gn

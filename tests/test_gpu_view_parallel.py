@@ -414,7 +414,7 @@ def test_row_sums_record_and_in_place_bucket():
         run(_sh_grads="colors_pre", _view_payload=pay[:4 * N])
 
 
-@pytest.mark.parametrize("deg,R,K", [(3, 1, 16), (3, 3, 16), (1, 2, 16), (0, 2, 16), (0, 3, 1), (1, 2, 4)])
+@pytest.mark.parametrize("deg,R,K", [(3, 1, 16), (3, 3, 16), (3, 8, 16), (1, 2, 16), (0, 2, 16), (0, 3, 1), (1, 2, 4)])
 def test_sh_adam_views_equals_rebuild_plus_adam(deg, R, K):
     """`gs_sh_adam_views` (SH gradient of R views formed in LDS and applied by Adam in place, `max_radii` folded in) ==
     `gs_sh_grad_views` + `FusedAdam.step(only=SH, grad_scale=1/R)` + `torch.maximum`, bit for bit, over two steps."""
