@@ -55,7 +55,8 @@ SIGNATURES = {
     "gs_bins_lists": (_I, [_P, _I, _L, _I, _I, _I, _P, _P, _Z, _P, _L, _P, _P, _P, _P, _P, _P]),
     "gs_walk_state_ints": (_Z, [_L]),
     "gs_blend_fwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
-    "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_blend_bwd": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_unit_classes_ints": (_Z, [_L, _I, _I, _I]),
     "gs_project_bwd": (_I, [_P, _I, _L, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _F, _F,
                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "gs_row_sums": (_I, [_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),

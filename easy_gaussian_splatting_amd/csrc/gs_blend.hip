@@ -573,6 +573,10 @@ struct BlendBwdArgs {
     const uint8_t* qmask;
     const int32_t* row_base;
     int cap_units;
+    // fill classes (unit_classes_kernel), or nullptr: every unit runs as class 4 straight from unit_desc
+    const int32_t* cls_hdr;   // [kClsHdrInts]: units of class c at [c], c = 1 .. 4
+    const int4* cls_desc;     // class 4 at [0, cap_units), classes 3, 2, 1 behind it, cls_cap descriptors each
+    int cls_cap;
     const float *out_colors, *out_alphas, *v_colors, *v_alphas;
     float4* rows;   // [row pairs][3]
     const int64_t* guard;
@@ -581,7 +585,8 @@ struct BlendBwdArgs {
 
 constexpr int kBwdWaves = 4;
 constexpr int kPipeLanes = 8;                       // lanes per systolic pipeline (two pipelines share a 16-lane DPP row)
-constexpr int kPerLane = kUnit / kPipeLanes;        // 4 entries per lane
+constexpr int kPerLane = kUnit / kPipeLanes;        // 4 entries per lane in a full unit (bwd_wave<E>: E = 1 .. 4)
+static_assert(kPerLane == 4, "bwd_wave is instantiated for 1 .. 4 entries per lane");
 constexpr int kUnitsPerWave = 64 / kPipeLanes;      // 8
 // (Round 5 bounded half-quadrant -- 8 x 4 pixel -- work units with a timing build: -15 to -23 us for this kernel at the 1.55 x
 //  unit count they would have, before twice the rows in the row sum; not built.  HISTORY.md, profiles/r05_halfq_bound.txt.)
@@ -644,22 +649,12 @@ __device__ __forceinline__ void bwd_pair(EntryState& e, const float4 d0, const f
     P = Pn;
 }
 
-__global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBwdArgs a) {
-    __shared__ float4 sd0_all[kBwdWaves][kUnitsPerWave][64];   // 8 KB per wave: v_r, v_g, v_b, E of the unit's 64 pixels
-    __shared__ float2 sck_all[kBwdWaves][kUnitsPerWave][64];   // 4 KB per wave: checkpoint T, P = checkpoint colour . v
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pipe = lane / kPipeLanes, r = lane & (kPipeLanes - 1);
-    if (guard_tripped(a.guard)) return;
-    const int n_units = min(a.walk[kWalkUnits], a.cap_units);
-    const int unit = ((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave + pipe;
-    if (((int)blockIdx.x * kBwdWaves + wave) * kUnitsPerWave >= n_units) return;   // wave-uniform
-    GS_CLOCK_PROBE_SCOPE(2);
-    const bool valid = unit < n_units;
-    float4* sd0 = sd0_all[wave][pipe];
-    float2* sck = sck_all[wave][pipe];
-
-    int4 ud = make_int4(0, 0, 0, 0);
-    if (valid) ud = a.unit_desc[unit];
+// One wave of the backward: eight work units of ONE fill class E = entries per lane.  A unit of class E holds at most 8 E
+// entries -- full units and tails (the last, part-filled unit of a quadrant sublist) of 25-32 entries are class 4, tails of 1-8 /
+// 9-16 / 17-24 entries classes 1 / 2 / 3 -- and the systolic loop passes over 8 E entry slots per unit instead of all 32 (the
+// bench workload: 9 % of the slots of its 169 k units are empty, heavy-tailed footprints 16 %; tools/tail_stats.py).
+template <int E>
+__device__ __forceinline__ void bwd_wave(const BlendBwdArgs& a, const int4 ud, const bool valid, const int unit, float4* sd0, float2* sck, const int r) {
     const int tq = ud.x, su = ud.z;
     const bool first_unit = ud.y == 0;   // the sublist starts here: every pixel inside the image has T = 1, no colour yet
     const int t = tq >> 2, q = tq & 3;
@@ -675,14 +670,23 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
     // for each pixel's and each entry's loads before it issues the next ones -- 8 + 2 x 4 serialised round trips per wave in
     // front of a main loop of comparable length, with three waves per SIMD to hide them (round 3: 0.45 -> see DESIGN.md).
     // Out-of-range pixels / entries load from a clamped, valid address and are masked afterwards.
-    // batch 1: the sublist's length, this lane's four (flatten id, slot) pairs -- 32 contiguous bytes of the unit's block; pairs
+    // batch 1: the sublist's length, this lane's E (flatten id, slot) pairs -- 8 E contiguous bytes of the unit's block; pairs
     // past the end of the sublist are whatever the block held before -- and the quadrant's 64 pixels, 8 per lane of the pipeline
     const int n_sub = valid ? a.qcnt[tq] : 0;
-    int2 gs[kPerLane];
+    int2 gs[E];
     {
-        const int4* qp = reinterpret_cast<const int4*>(a.qlist + (size_t)su * kUnit + kPerLane * r);
-        const int4 g0 = qp[0], g1 = qp[1];
-        gs[0] = make_int2(g0.x, g0.y); gs[1] = make_int2(g0.z, g0.w); gs[2] = make_int2(g1.x, g1.y); gs[3] = make_int2(g1.z, g1.w);
+        const int2* qp2 = a.qlist + (size_t)su * kUnit + E * r;
+        if constexpr (E == 4) {
+            const int4* qp = reinterpret_cast<const int4*>(qp2);
+            const int4 g0 = qp[0], g1 = qp[1];
+            gs[0] = make_int2(g0.x, g0.y); gs[1] = make_int2(g0.z, g0.w); gs[2] = make_int2(g1.x, g1.y); gs[3] = make_int2(g1.z, g1.w);
+        } else if constexpr (E == 2) {
+            const int4 g0 = *reinterpret_cast<const int4*>(qp2);
+            gs[0] = make_int2(g0.x, g0.y); gs[1] = make_int2(g0.z, g0.w);
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) gs[i] = qp2[i];
+        }
     }
     constexpr int kPix = kUnitPixels / kPipeLanes;
     float l_vr[kPix], l_vg[kPix], l_vb[kPix], l_oa[kPix], l_cr[kPix], l_cg[kPix], l_cb[kPix], l_va[kPix];
@@ -700,11 +704,11 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         l_ck[i] = ckp[p];
     }
     // batch 2: the entries' packed records (addresses from batch 1), in flight while the pixels are staged
-    const int n_in = min(kUnit, n_sub - ud.y * kUnit);   // entries of the sublist that fall into this unit
-    float4 rq[kPerLane][3];
+    const int n_in = min(kPipeLanes * E, n_sub - ud.y * kUnit);   // entries of the sublist that fall into this unit (a unit of class E: <= 8 E)
+    float4 rq[E][3];
 #pragma unroll
-    for (int i = 0; i < kPerLane; ++i) {
-        const bool has = kPerLane * r + i < n_in;
+    for (int i = 0; i < E; ++i) {
+        const bool has = E * r + i < n_in;
         const float4* rp = a.rec + 3 * (size_t)(has ? gs[i].x : 0);
         rq[i][0] = rp[0]; rq[i][1] = rp[1]; rq[i][2] = rp[2];
     }
@@ -716,19 +720,19 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         const float Tf = 1.f - l_oa[i];
         const float va = a.v_alphas ? l_va[i] : 0.f;
         // E = T_final * v_alpha - render_colour . v_colour  (background terms cancel)
-        const float E = Tf * va - (l_cr[i] * vr + l_cg[i] * vg + l_cb[i] * vb);
+        const float Ev = Tf * va - (l_cr[i] * vr + l_cg[i] * vg + l_cb[i] * vb);
         // the unit's checkpoint: the pixel's state in front of its first entry (T < 0: finished or outside the image); the
         // first unit of a sublist starts from T = 1, nothing accumulated
         const float4 ck = first_unit ? make_float4(1.f, 0.f, 0.f, 0.f) : l_ck[i];
-        sd0[p] = inside ? make_float4(vr, vg, vb, E) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sd0[p] = inside ? make_float4(vr, vg, vb, Ev) : make_float4(0.f, 0.f, 0.f, 0.f);
         sck[p] = inside ? make_float2(ck.x, ck.y * vr + ck.z * vg + ck.w * vb) : make_float2(-1.f, 0.f);
     }
 
-    EntryState e[kPerLane];
-    int slot[kPerLane];
+    EntryState e[E];
+    int slot[E];
 #pragma unroll
-    for (int i = 0; i < kPerLane; ++i) {
-        const int en = kPerLane * r + i;
+    for (int i = 0; i < E; ++i) {
+        const int en = E * r + i;
         e[i].has = en < n_in;
         slot[i] = e[i].has ? gs[i].y : 0;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -757,7 +761,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
         T = act ? T : -1.f;   // pipeline fill / drain: nothing contributes
         GS_IF_CHECK(float D = dpp_row_shr1(D_out), Cn = dpp_row_shr1(C_out); if (r == 0) { D = ck.x; Cn = 0.f; } if (!act) { D = -1.f; Cn = 0.f; })
 #pragma unroll
-        for (int i = 0; i < kPerLane; ++i) {
+        for (int i = 0; i < E; ++i) {
             GS_IF_CHECK(const float T_before = T;)
             bwd_pair(e[i], d0, d1, T, P);
             GS_IF_CHECK(if (T > 0.f && T < T_before) { D = T; Cn += 1.f; })   // (contributed; the stop rule leaves T = -1 and D at the final value)
@@ -770,15 +774,15 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
     // the row of (slot, quadrant): the slot's first row (rows_before: a base per 16 slots + the masks of its predecessors in the
     // group) + the number of its existing rows in front of this quadrant.  Looked up HERE, not in the prologue: four 16-byte mask
     // loads in flight next to the records and the pixels cost the kernel its third wave per SIMD (178 VGPRs).
-    int row[kPerLane];
+    int row[E];
 #pragma unroll
-    for (int i = 0; i < kPerLane; ++i) {
+    for (int i = 0; i < E; ++i) {
         int m;
         row[i] = rows_before(a.row_base, a.qmask, slot[i], &m);
         row[i] += __popc((unsigned)m & ((1u << q) - 1u));
     }
 #pragma unroll
-    for (int i = 0; i < kPerLane; ++i) {
+    for (int i = 0; i < E; ++i) {
         if (e[i].has) {
             float4* rp = a.rows + (GS_ROW_FLOATS / 4) * (size_t)row[i];
             // v_opacity = sum vis * v_alpha = -sum(vs) / opacity   (vs = -opacity*vis*v_alpha)
@@ -788,6 +792,86 @@ __global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBw
             rp[2] = make_float4((float)e[i].s_r, (float)e[i].s_g, (float)e[i].s_b, 0.f);
         }
     }
+}
+
+// Groups the published work units by fill class in front of blend_bwd_kernel: cls[0, cap_units) class 4, then classes 3, 2, 1
+// in regions of cls_cap descriptors (a frame has at most one tail per quadrant sublist: 4 C tiles).  One atomic per block and
+// class (a returning same-address atomic per WAVE cost 0.19 ms at 31 k waves, HISTORY.md); the order inside a class is whatever
+// the blocks' atomics make it -- every unit writes rows of its own, no result depends on it.  .w = the unit's published index.
+constexpr int kClsHdrInts = 16, kClsThreads = 1024;
+__global__ __launch_bounds__(64) void unit_classes_clear_kernel(int32_t* __restrict__ hdr) {
+    if (threadIdx.x < kClsHdrInts) hdr[threadIdx.x] = 0;
+}
+__global__ __launch_bounds__(kClsThreads) void unit_classes_kernel(const int32_t* __restrict__ walk, const int4* __restrict__ unit_desc,
+                                                                   const int32_t* __restrict__ qcnt, int cap_units, int cls_cap,
+                                                                   int32_t* __restrict__ hdr, int4* __restrict__ cls, const int64_t* __restrict__ guard) {
+    __shared__ int s_cnt[kClsThreads / 64][4], s_base[kClsThreads / 64][4];
+    if (guard_tripped(guard)) return;
+    const int n_units = min(walk[kWalkUnits], cap_units);
+    if ((int)blockIdx.x * kClsThreads >= n_units) return;   // block-uniform
+    const int u = (int)blockIdx.x * kClsThreads + (int)threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int c = 0;
+    int4 ud = make_int4(0, 0, 0, 0);
+    if (u < n_units) {
+        ud = unit_desc[u];
+        const int n_in = min(kUnit, qcnt[ud.x] - ud.y * kUnit);
+        c = min(max((n_in + kPipeLanes - 1) / kPipeLanes, 1), 4);
+        ud.w = u;
+    }
+    unsigned long long m[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = __ballot(c == k + 1);
+    if (lane < 4) s_cnt[wave][lane] = (int)__popcll(lane == 0 ? m[0] : (lane == 1 ? m[1] : (lane == 2 ? m[2] : m[3])));
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        int tot = 0;
+        for (int w = 0; w < kClsThreads / 64; ++w) { s_base[w][threadIdx.x] = tot; tot += s_cnt[w][threadIdx.x]; }
+        const int base = tot ? atomicAdd(hdr + 1 + threadIdx.x, tot) : 0;
+        for (int w = 0; w < kClsThreads / 64; ++w) s_base[w][threadIdx.x] += base;
+    }
+    __syncthreads();
+    if (c) {
+        const unsigned long long mine = c == 1 ? m[0] : (c == 2 ? m[1] : (c == 3 ? m[2] : m[3]));
+        const int i = s_base[wave][c - 1] + (int)__popcll(mine & ((1ull << lane) - 1ull));
+        // (class 4 cannot outgrow cap_units; a tail region can only where the caller passed a cls_cap below 4 C tiles: dropped
+        //  descriptors would lose gradient rows, so gs_blend_bwd refuses such a cls_cap)
+        if (i < (c == 4 ? cap_units : cls_cap)) cls[(c == 4 ? 0 : cap_units + (3 - c) * cls_cap) + i] = ud;
+    }
+}
+
+__global__ __launch_bounds__(kBwdWaves * 64) void blend_bwd_kernel(const BlendBwdArgs a) {
+    __shared__ float4 sd0_all[kBwdWaves][kUnitsPerWave][64];   // 8 KB per wave: v_r, v_g, v_b, E of the unit's 64 pixels
+    __shared__ float2 sck_all[kBwdWaves][kUnitsPerWave][64];   // 4 KB per wave: checkpoint T, P = checkpoint colour . v
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pipe = lane / kPipeLanes, r = lane & (kPipeLanes - 1);
+    if (guard_tripped(a.guard)) return;
+    // the block's class and its place in it: class 4 over [0, cap_units) first (the longest waves), then 3, 2, 1
+    constexpr int kPerBlock = kBwdWaves * kUnitsPerWave;
+    int cls = 4, blk = (int)blockIdx.x, n_units, first = 0;
+    if (a.cls_hdr == nullptr) {
+        n_units = min(a.walk[kWalkUnits], a.cap_units);
+    } else {
+        const int b4 = (a.cap_units + kPerBlock - 1) / kPerBlock, bt = (a.cls_cap + kPerBlock - 1) / kPerBlock;
+        if (blk >= b4) {
+            const int k = (blk - b4) / bt;   // 0, 1, 2 -> class 3, 2, 1
+            cls = 3 - k; blk -= b4 + k * bt; first = a.cap_units + k * a.cls_cap;
+        }
+        n_units = min(a.cls_hdr[cls], cls == 4 ? a.cap_units : a.cls_cap);
+    }
+    const int in_class = (blk * kBwdWaves + wave) * kUnitsPerWave + pipe;
+    if ((blk * kBwdWaves + wave) * kUnitsPerWave >= n_units) return;   // wave-uniform
+    GS_CLOCK_PROBE_SCOPE(2);
+    const bool valid = in_class < n_units;
+    float4* sd0 = sd0_all[wave][pipe];
+    float2* sck = sck_all[wave][pipe];
+
+    int4 ud = make_int4(0, 0, 0, 0);
+    if (valid) ud = a.cls_hdr ? a.cls_desc[first + in_class] : a.unit_desc[in_class];
+    const int unit = a.cls_hdr ? ud.w : in_class;   // the unit's published index (the check build's arrays are indexed by it)
+    if (cls == 4) bwd_wave<4>(a, ud, valid, unit, sd0, sck, r);
+    else if (cls == 3) bwd_wave<3>(a, ud, valid, unit, sd0, sck, r);
+    else if (cls == 2) bwd_wave<2>(a, ud, valid, unit, sd0, sck, r);
+    else bwd_wave<1>(a, ud, valid, unit, sd0, sck, r);
 }
 
 }  // namespace gs
@@ -888,11 +972,23 @@ extern "C" int gs_blend_fwd(void* stream, int C, int width, int height, const fl
     return GS_OK;
 }
 
+// descriptors a tail region holds: one tail per quadrant sublist at most, rounded up to whole blocks of the backward
+static int64_t cls_region(int C, int width, int height) {
+    const int64_t tiles = (int64_t)((width + GS_TILE - 1) / GS_TILE) * ((height + GS_TILE - 1) / GS_TILE);
+    const int64_t per_block = kBwdWaves * kUnitsPerWave;
+    return (4 * (int64_t)C * tiles + per_block - 1) / per_block * per_block;
+}
+
+extern "C" size_t gs_unit_classes_ints(int64_t cap_units, int C, int width, int height) {
+    if (cap_units < 0 || C < 1 || width <= 0 || height <= 0) return 0;
+    return (size_t)kClsHdrInts + 4 * ((size_t)cap_units + 3 * (size_t)cls_region(C, width, height));
+}
+
 extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
                             const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_desc, int64_t cap_units,
                             const float* ckpt, const uint8_t* qmask, const int32_t* row_base, const int32_t* walk_state,
                             const float* render_colors, const float* render_alphas, const float* v_render_colors,
-                            const float* v_render_alphas, float* rows) {
+                            const float* v_render_alphas, float* rows, int32_t* unit_classes) {
     GS_REQUIRE(C >= 1 && width > 0 && height > 0 && cap_units >= 0 && cap_units < (1ll << 26), "C>=1, positive image size, 0 <= cap_units < 2^26");
     if (cap_units == 0) return GS_OK;
     GS_REQUIRE(rec && qlist && qcnt && unit_desc && ckpt && qmask && row_base && walk_state, "null list pointer");
@@ -911,7 +1007,22 @@ extern "C" int gs_blend_bwd(void* stream, int C, int width, int height, const fl
     a.guard = current_guard().info;
     GS_IF_CHECK(a.chk = g_bwd_check;)
     // one pipeline per work unit, eight per wave: the grid covers the capacity, waves past the published count return at once
-    const unsigned grid = (unsigned)((cap_units + kUnitsPerWave * kBwdWaves - 1) / (kUnitsPerWave * kBwdWaves));
+    unsigned grid = (unsigned)((cap_units + kUnitsPerWave * kBwdWaves - 1) / (kUnitsPerWave * kBwdWaves));
+    a.cls_hdr = nullptr; a.cls_desc = nullptr; a.cls_cap = 0;
+    if (unit_classes) {
+        // the units grouped by fill class first (16-byte aligned buffer of gs_unit_classes_ints int32: counters, then descriptors)
+        GS_REQUIRE(((uintptr_t)unit_classes & 15) == 0, "unit_classes must be 16-byte aligned");
+        a.cls_hdr = unit_classes; a.cls_desc = reinterpret_cast<const int4*>(unit_classes + kClsHdrInts);
+        a.cls_cap = (int)cls_region(C, width, height);
+        // (the counters are cleared by a launch, not by hipMemsetAsync: inside a captured step a memset node ahead of the kernel
+        //  that counts ended in GPU memory faults on this ROCm -- the eager sequence of the same calls did not)
+        hipLaunchKernelGGL(unit_classes_clear_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, unit_classes);
+        hipLaunchKernelGGL(unit_classes_kernel, dim3((unsigned)((cap_units + kClsThreads - 1) / kClsThreads)), dim3(kClsThreads), 0, (hipStream_t)stream,
+                           walk_state, a.unit_desc, qcnt, (int)cap_units, a.cls_cap, unit_classes, reinterpret_cast<int4*>(unit_classes + kClsHdrInts),
+                           a.guard);
+        GS_LAUNCH_CHECK("unit_classes_kernel");
+        grid += 3u * (unsigned)(a.cls_cap / (kUnitsPerWave * kBwdWaves));
+    }
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(grid), dim3(kBwdWaves * 64), 0, (hipStream_t)stream, a);
     GS_LAUNCH_CHECK("blend_bwd_kernel");
     return GS_OK;

@@ -24,6 +24,8 @@ from . import _native as nat
 from . import workspace as WS
 
 _TILE = nat.GS_TILE
+# GS_BWD_CLASSES=0: the blend backward takes its work units as the forward published them (A/B switch; the rows are the same bits)
+_BWD_CLASSES = os.environ.get("GS_BWD_CLASSES", "1") != "0"
 
 
 def _ptr(t: Optional[Tensor]) -> Optional[int]:
@@ -918,9 +920,11 @@ class _Rasterize(torch.autograd.Function):
             s["n_isects"], s["n_buckets"] = s["late"]["n_isects"], s["late"]["n_buckets"]
         P = lease.ptr
         n_rows = _settle_walk(s, cfg, render_colors, render_alphas)
+        # scratch for the backward's fill classes (gs_raster.h; a caching-allocator block, re-used stream-ordered)
+        ucls = torch.empty((int(L.gs_unit_classes_ints(lease.layout.cap_units, C, W, H)),), dtype=torch.int32, device=dev) if _BWD_CLASSES else None
         _stage("gs_blend_bwd", dev, lambda: nat.check(L.gs_blend_bwd(st, C, W, H, P(WS.REC), P(WS.QLIST), P(WS.QCNT),
                                  P(WS.UNIT_DESC), lease.layout.cap_units, P(WS.CKPT), P(WS.QMASK), P(WS.ROW_BASE), P(WS.WALK_STATE),
-                                 _ptr(render_colors), _ptr(render_alphas), _ptr(v_rc), _ptr(v_ra), P(WS.ROWS)), "gs_blend_bwd"))
+                                 _ptr(render_colors), _ptr(render_alphas), _ptr(v_rc), _ptr(v_ra), P(WS.ROWS), _ptr(ucls)), "gs_blend_bwd"))
         go = holder.grad_out or {}   # (`_grad_out`: caller-owned gradient tensors; autograd then receives None for those inputs)
         for k_, shp in (("means", (N, 3)), ("quats", (N, 4)), ("scales", (N, 3)), ("opacities", (N,)), ("grad_norm", (N,)), ("count", (N,))):
             if k_ in go and not (go[k_].shape == shp and go[k_].is_contiguous() and go[k_].dtype == torch.float32 and go[k_].device == dev):

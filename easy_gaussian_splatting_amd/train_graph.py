@@ -44,6 +44,7 @@ from torch import Tensor
 
 from . import _native as nat
 from .optim import FusedAdam
+from . import rendering
 from .rendering import _SH_JAC
 
 
@@ -325,6 +326,9 @@ class TrainStepGraph:
         b["ckpt"] = self._take("ckpt", (cu, 64, 4), torch.float32, shrink=True)
         b["qlist"] = self._take("qlist", (cu, nat.GS_UNIT, 2), torch.int32, shrink=True)
         b["unit_desc"] = self._take("unit_desc", (cu, 4), torch.int32, shrink=True)
+        # the backward's fill classes (gs_raster.h: gs_blend_bwd groups the units by how full they are); GS_BWD_CLASSES=0: off
+        b["unit_cls"] = (self._take("unit_cls", (int(nat.lib().gs_unit_classes_ints(cu, 1, self.W, self.H)),), torch.int32, shrink=True)
+                         if rendering._BWD_CLASSES else None)
         b["rows"] = self._take("rows", (cr, nat.GS_ROW_FLOATS), torch.float32, shrink=True)
 
     ROUNDS_MIN_LISTED = 4_000_000   # "auto": below this the list stages are too short for a second round to pay
@@ -622,7 +626,7 @@ class TrainStepGraph:
                                              _p(b["one"]), _p(b["v_render"])), "gs_l1_ssim_bwd_slots")
             self._ck(L.gs_blend_bwd(st, 1, W, H, _p(b["rec"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["unit_desc"]), self.cap_units,
                                      _p(b["ckpt"]), _p(b["qmask"]), _p(b["row_base"]), _p(b["walk_state"]),
-                                     _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"])),
+                                     _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"]), _p(b["unit_cls"])),
                       "gs_blend_bwd")
             b1, b2 = opt.defaults["betas"]
             if self.fuse_adam:
@@ -962,7 +966,7 @@ class ViewParallelGraphStep(TrainStepGraph):
                                              _p(b["one"]), _p(b["v_render"])), "gs_l1_ssim_bwd_slots")
             self._ck(L.gs_blend_bwd(st, 1, W, H, _p(b["rec"]), _p(b["qlist"]), _p(b["qcnt"]), _p(b["unit_desc"]), self.cap_units,
                                      _p(b["ckpt"]), _p(b["qmask"]), _p(b["row_base"]), _p(b["walk_state"]),
-                                     _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"])), "gs_blend_bwd")
+                                     _p(b["render_colors"]), _p(b["render_alphas"]), _p(b["v_render"]), None, _p(b["rows"]), _p(b["unit_cls"])), "gs_blend_bwd")
             sp = send.data_ptr()
             self._ck(L.gs_row_sums(st, 1, N, _p(b["radii"]), _p(b["colors_post"]), self._tpg(), _p(b["cum_tiles"]), _p(b["rows"]),
                                     _p(b["row_base"]), _p(b["qmask"]), _p(b["row_sums"]), sp, sp + 4 * 3 * N, float(max(H, W)), _p(b["viewmats"]),

@@ -359,12 +359,17 @@ int gs_blend_fwd(void* stream, int C, int width, int height, const float* rec,
  * systolic pipelines per wavefront, one GS_UNIT-entry work unit each; no atomics.  Writes one
  * 12-float row per (intersection, quadrant) some pixel took, at rows[(row_base[slot] + rank of the quadrant among the slot's
  * rows)*12]: (v_mx, v_my, |v_mx|, |v_my|, v_A, v_B, v_C, v_opacity, v_r, v_g, v_b, 0); rows[cap_rows*12].
- * The launch covers cap_units work units (pipelines past walk_state[GS_WALK_UNITS] return at once).  v_render_alphas may be NULL. */
+ * The launch covers cap_units work units (pipelines past walk_state[GS_WALK_UNITS] return at once).  v_render_alphas may be NULL.
+ * unit_classes (may be NULL): scratch of gs_unit_classes_ints(cap_units, C, width, height) int32, 16-byte aligned.  With it the
+ * call first groups the published units by FILL CLASS -- the last unit of a quadrant sublist is part-filled; units of at most 8 /
+ * 16 / 24 entries run 1 / 2 / 3 entries per lane instead of 4 -- and every wave takes eight units of one class.  Same rows,
+ * bit for bit (a unit writes rows of its own; the order units run in decides nothing). */
+size_t gs_unit_classes_ints(int64_t cap_units, int C, int width, int height);
 int gs_blend_bwd(void* stream, int C, int width, int height, const float* rec,
                  const int32_t* qlist, const int32_t* qcnt, const int32_t* unit_desc, int64_t cap_units,
                  const float* ckpt, const uint8_t* qmask, const int32_t* row_base, const int32_t* walk_state,
                  const float* render_colors, const float* render_alphas, const float* v_render_colors,
-                 const float* v_render_alphas, float* rows);
+                 const float* v_render_alphas, float* rows, int32_t* unit_classes);
 
 /* Row reduction + SH-bwd + P-bwd fused (replaces the atomics of the blend backward,
  * spherical_harmonics backward and fully_fused_projection backward).  Sums each Gaussian's rows

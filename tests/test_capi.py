@@ -71,8 +71,9 @@ def test_forward_and_backward_round_alpha_and_transmittance_with_the_same_instru
     trees = set()
     for name, ins in ks.items():
         slices = ISA.sigma_alpha_slices(ins)
-        # four (pixel, entry) evaluations per kernel body: the forward's four quadrants, the backward's four entries per lane
-        assert len(slices) == 4, (name, len(slices))
+        # (pixel, entry) evaluations per kernel body: the forward's four quadrants; the backward's entries per lane in its four
+        # fill classes, 4 + 3 + 2 + 1
+        assert len(slices) == (10 if "blend_bwd" in name else 4), (name, len(slices))
         for sl in slices:
             assert sl["neg"] and sl["alpha"], (name, sl)     # exp2(-sigma) feeding alpha = min(0.999, opacity * .)
             trees.add(sl["sigma"])
@@ -99,6 +100,11 @@ def test_loss_entries_refuse_images_beyond_their_32_bit_offsets(native):
 
 def test_identity_and_layout_queries(native):
     lib = native.lib()
+    # scratch of the blend backward's fill classes: 16 counters + 4 ints per descriptor -- cap_units of class 4, three tail regions
+    # of 4 C tiles each, rounded up to the 32 units a workgroup of the backward takes
+    assert lib.gs_unit_classes_ints(1000, 1, 1920, 1080) == 16 + 4 * (1000 + 3 * 32640)
+    assert lib.gs_unit_classes_ints(256, 2, 33, 17) == 16 + 4 * (256 + 3 * 64)
+    assert lib.gs_unit_classes_ints(-1, 1, 16, 16) == 0
     assert lib.gs_version() >= 100
     assert lib.gs_arch() == b"gfx950"
     assert 1 <= lib.gs_bin_groups(1) <= lib.gs_bin_groups(10**6) <= 256
