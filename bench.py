@@ -1091,8 +1091,9 @@ def run_rank(args) -> int:
                     "algorithmic_bytes": alg[dom], "n_isects_processed": n_isects,
                     "algorithmic_bytes_gsplat_lists": (40 + (88 if dom == "gs_blend_bwd" else 0)) * n_isects_ref + (24 if dom == "gs_blend_bwd" else 20) * H * W,
                     "avg_launch_ms": None if t_ms != t_ms else round(t_ms, 4),
-                    "avg_launch_ms_note": "HIP events around the kernel's launch in the eager step, on the launch stream (average over "
-                                          "the profiled steps; the launch gap of a single eager launch is inside the bracket)",
+                    "avg_launch_ms_note": "HIP events around the entry point's launches in the eager step, on the launch stream (average over "
+                                          "the profiled steps; the launch gaps of eager launches are inside the bracket; gs_blend_bwd = the "
+                                          "kernel + the two small launches that group its work units by fill class in front of it)",
                     "back_to_back_launch_ms": None if dom not in kernel_ms else round(kernel_ms[dom], 4),
                     # priced against HBM as the contract asks; the kernel's actual limiter is VALU issue (roofline_compute)
                     "limiter": "valu-issue"}
